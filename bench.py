@@ -1,0 +1,155 @@
+#!/usr/bin/env python3
+"""bench.py -- hot-path benchmark on MI355X (contract in the round prompt, section 4).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[2]): 50k spots x 3k genes x 5 time points => per time
+point N_t = 10k spots; the Sinkhorn coupling between consecutive time points is a 10k x 10k
+problem (latent dim 20, 10-component Gaussian-mixture latents, C = sqeuclidean / median, G = 1,
+default ot_config).  One bench "step" = ITERS_PER_STEP scaling iterations (one iteration = one
+update_a_b, ot_func.cpp:586-687: a row pass + a column pass over the I x J kernel matrix) of this
+rank's pair problem, inputs resident in HBM.  Pairs are independent, so ranks shard pairs with no
+data-path collective ("weak" scaling: one pair problem per rank).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+METRIC = "training steps/sec + Sinkhorn iters/sec, 50k spots x 3k genes x 5 timepoints"
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+ITERS_PER_STEP = 10
+OT_CFG = dict(lambda1=0.1, lambda2=5.0, epsilon=0.05, epsilon0=1.0, tolerance=1e-8, tau=1000.0,
+              batch_size=5, max_iter=10 ** 7)   # config.yaml:39-57
+
+
+def synthetic_latents(n, seed, centres=None, dim=20, k=10, sigma=0.3):
+    rng = np.random.default_rng(seed)
+    if centres is None:
+        centres = np.random.default_rng(1993).normal(size=(k, dim))
+    lab = rng.integers(0, k, size=n)
+    return centres[lab] + sigma * rng.normal(size=(n, dim))
+
+
+def cpu_baseline(I, J, budget_s=12.0):
+    """Oracle (plain-C port of ot_func.cpp, fp64, 1 thread) timed on the same I x J iteration.
+    Bounded sample: as many update_a_b iterations as fit in ~budget_s (at least 3)."""
+    from oracle import ot_oracle
+    rng = np.random.default_rng(0)
+    K = rng.uniform(0.01, 1.0, size=(I, J))
+    a, b = np.ones(I), np.ones(J)
+    dx, dy = np.ones(I) / I, np.ones(J) / J
+    p, q = np.ones(I), np.ones(J)
+    u, v = np.zeros(I), np.zeros(J)
+    eps, l1, l2 = 0.05, 0.1, 5.0
+    args = (a, b, K, dx, dy, p, q, u, v, l1, l2, l1 / (l1 + eps), l2 / (l2 + eps), eps)
+    ot_oracle.update_a_b(*args)   # touch pages
+    n, t0 = 0, time.perf_counter()
+    while True:
+        ot_oracle.update_a_b(*args)
+        n += 1
+        el = time.perf_counter() - t0
+        if (el > budget_s and n >= 3) or n >= 200:
+            break
+    return {"value": n / el, "unit": "iters/s", "cores": 1, "kind": "port",
+            "sample": f"{n} update_a_b iterations of one {I}x{J} fp64 problem, oracle/ot_oracle.c, 1 thread, {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--spots", type=int, default=10000, help="spots per time point (N_t)")
+    ap.add_argument("--storage", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    dev = f"cuda:{local_rank}"
+    torch.cuda.set_device(dev)
+
+    from spadot_amd.ot import OTSolver
+
+    I = J = args.spots
+    # rank r owns pair (t_r, t_r + 1): independent problems, no exchange step
+    x = synthetic_latents(I, seed=100 + rank)
+    y = synthetic_latents(J, seed=200 + rank)
+    solver = OTSolver(I, J, storage=args.storage, device=dev)
+    solver.set_cost_from_latents(x, y)
+    t0 = time.perf_counter()
+    info = solver.solve(OT_CFG)          # full 6-stage solve: leaves a converged, realistic state
+    torch.cuda.synchronize()
+    solve_s = time.perf_counter() - t0
+    total_iters = int(sum(info.stage_iters))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        solver.run_iterations(OT_CFG, OT_CFG["epsilon"], ITERS_PER_STEP, timed=False)
+    barrier()
+    t0 = time.perf_counter()
+    ev_ms = 0.0
+    for _ in range(args.steps):
+        ev_ms += solver.run_iterations(OT_CFG, OT_CFG["epsilon"], ITERS_PER_STEP, timed=True)
+    barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+
+    iters = args.steps * ITERS_PER_STEP
+    value = world * iters / el
+    esize = 4 if args.storage == "f32" else 8
+    # per-kernel live timing (HIP events on the solver's stream) for the roofline
+    kt = solver.time_kernels(OT_CFG, OT_CFG["epsilon"], reps=20)
+    ld = solver.ld
+    alg_bytes = float(I) * ld * esize          # one sweep of the I x ld kernel matrix per launch
+    dom = max(("row_pass", "col_pass"), key=lambda k: kt[k])
+    achieved = alg_bytes / (kt[dom] * 1e-3) / 1e9
+    out = {
+        "metric": METRIC, "value": value, "unit": "Sinkhorn iters/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.storage + " kernel matrix, f64 scalings/accumulation", "data": "synthetic",
+        "config": {"workload": f"cfg3: {I}x{J} Sinkhorn pair problem per GPU (50k spots x 3k genes x 5 tp => N_t=10k), "
+                               f"{ITERS_PER_STEP} scaling iterations per step", "storage": args.storage,
+                   "full_solve_s": solve_s, "full_solve_iters": total_iters,
+                   "event_ms_per_iter": ev_ms / iters},
+        "roofline": {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "alg_bytes_per_launch": alg_bytes,
+                     "kernel_ms": {k: v for k, v in kt.items()}},
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(I, J)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,87 @@
+"""ctypes loader for the in-tree HIP libraries.
+
+The product has no CPU path: a missing library is a hard error that tells the user how to
+build it (``python -m spadot_amd.csrc.build``); nothing here falls back to numpy/torch.
+"""
+import ctypes
+import os
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+_CACHE = {}
+
+
+class NativeLibraryMissing(RuntimeError):
+    pass
+
+
+def _load(name):
+    if name in _CACHE:
+        return _CACHE[name]
+    # torch bundles its own libamdhip64.so.7; importing it first makes this library bind to the
+    # SAME HIP runtime (same SONAME), so torch device pointers and streams are valid in our kernels.
+    import torch  # noqa: F401
+
+    path = os.path.join(_CSRC, name)
+    if not os.path.exists(path):
+        raise NativeLibraryMissing(
+            f"{path} is missing: build the HIP extension with `python -m spadot_amd.csrc.build` "
+            "(needs hipcc; cross-compiles for gfx950 without a GPU). There is no CPU fallback.")
+    lib = ctypes.CDLL(path)
+    _CACHE[name] = lib
+    return lib
+
+
+class OTConfig(ctypes.Structure):
+    """struct spadot_ot_config (include/spadot_ot.h)."""
+    _fields_ = [("lambda1", ctypes.c_double), ("lambda2", ctypes.c_double), ("epsilon", ctypes.c_double),
+                ("epsilon0", ctypes.c_double), ("tolerance", ctypes.c_double), ("tau", ctypes.c_double),
+                ("batch_size", ctypes.c_int), ("max_iter", ctypes.c_int)]
+
+
+class OTInfo(ctypes.Structure):
+    """struct spadot_ot_info (include/spadot_ot.h)."""
+    _fields_ = [("gap", ctypes.c_double), ("stage_iters", ctypes.c_int * 6), ("absorbs", ctypes.c_int),
+                ("gap_checks", ctypes.c_int)]
+
+
+def ot_lib():
+    """libspadot_ot.so with argtypes/restypes of include/spadot_ot.h part B set."""
+    lib = _load("libspadot_ot.so")
+    if getattr(lib, "_spadot_ready", False):
+        return lib
+    vp, ci, cd = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
+    lib.spadot_ot_version.restype = ctypes.c_char_p
+    lib.spadot_ot_create.argtypes = [ctypes.POINTER(vp), ci, ci, ci, vp]
+    lib.spadot_ot_create.restype = ci
+    lib.spadot_ot_destroy.argtypes = [vp]
+    lib.spadot_ot_destroy.restype = None
+    lib.spadot_ot_ld.argtypes = [vp]
+    lib.spadot_ot_ld.restype = ci
+    lib.spadot_ot_matrix_dev.argtypes = [vp, ci]
+    lib.spadot_ot_matrix_dev.restype = vp
+    lib.spadot_ot_vector_dev.argtypes = [vp, ci]
+    lib.spadot_ot_vector_dev.restype = vp
+    lib.spadot_ot_vector_host.argtypes = [vp, ci, vp]
+    lib.spadot_ot_vector_host.restype = ci
+    lib.spadot_ot_matrix_host.argtypes = [vp, ci, vp]
+    lib.spadot_ot_matrix_host.restype = ci
+    lib.spadot_ot_set_cost_dev.argtypes = [vp, vp, ci, ci]
+    lib.spadot_ot_set_cost_dev.restype = ci
+    lib.spadot_ot_set_cost_host.argtypes = [vp, vp]
+    lib.spadot_ot_set_cost_host.restype = ci
+    lib.spadot_ot_set_cost_from_latents_dev.argtypes = [vp, vp, vp, ci, ci]
+    lib.spadot_ot_set_cost_from_latents_dev.restype = ci
+    lib.spadot_ot_solve.argtypes = [vp, vp, ctypes.POINTER(OTConfig), ctypes.POINTER(OTInfo)]
+    lib.spadot_ot_solve.restype = ci
+    lib.spadot_ot_plan_dev.argtypes = [vp, vp, ci, ci]
+    lib.spadot_ot_plan_dev.restype = ci
+    lib.spadot_ot_plan_host.argtypes = [vp, vp]
+    lib.spadot_ot_plan_host.restype = ci
+    lib.spadot_ot_plan_rowsums_host.argtypes = [vp, vp]
+    lib.spadot_ot_plan_rowsums_host.restype = ci
+    lib.spadot_ot_run_iterations.argtypes = [vp, ctypes.POINTER(OTConfig), cd, ci, ctypes.POINTER(ctypes.c_float)]
+    lib.spadot_ot_run_iterations.restype = ci
+    lib.spadot_ot_time_kernels.argtypes = [vp, ctypes.POINTER(OTConfig), cd, ci, ctypes.POINTER(ctypes.c_float)]
+    lib.spadot_ot_time_kernels.restype = ci
+    lib._spadot_ready = True
+    return lib

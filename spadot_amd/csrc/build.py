@@ -1,0 +1,47 @@
+"""Builds the HIP libraries in-tree for gfx950 (hipcc cross-compiles without a GPU).
+
+    python -m spadot_amd.csrc.build [--force]
+
+One shared object per .hip translation unit, written next to its source so that it travels
+with the repository snapshot to the GPU box.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ARCH = "gfx950"
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+# source -> shared object
+TARGETS = {
+    "ot_sinkhorn.hip": "libspadot_ot.so",
+}
+
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", f"--offload-arch={ARCH}", "-Wno-unused-result"]
+
+
+def _stale(src, out, extra_deps):
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(d) > t for d in [src] + extra_deps if os.path.exists(d))
+
+
+def build_all(force=False, verbose=True):
+    inc = os.path.join(HERE, "..", "..", "include")
+    headers = [os.path.join(inc, f) for f in os.listdir(inc)] if os.path.isdir(inc) else []
+    built = []
+    for src, out in TARGETS.items():
+        s, o = os.path.join(HERE, src), os.path.join(HERE, out)
+        if force or _stale(s, o, headers):
+            cmd = [HIPCC] + FLAGS + ["-o", o, s]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        built.append(o)
+    return built
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv)

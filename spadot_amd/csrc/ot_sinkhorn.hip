@@ -1,0 +1,1296 @@
+// ot_sinkhorn.hip -- unbalanced entropic OT scaling iterations for MI355X (gfx950, wave64).
+//
+// What it replaces: /root/reference/SpaDOT/utils/OT_loss/ot_func.cpp (the C++ behind libot.so)
+// and the per-stage Python driver in ot_solvers.py:164-449.  See include/spadot_ot.h for the ABI.
+//
+// Data layout in HBM (one problem):
+//   C, K           I x ld row-major, element type T (double or float), ld = J rounded up to 64
+//                  elements; pad columns of K are kept at exactly 0 so row/column sums ignore them
+//   a,u,p,dx,...   fp64 vectors (length I or ld); scalings and every sum are fp64 in both modes
+//   part           nchunk x ld fp64 column partials (row-chunked column pass, fixed order => the
+//                  result is bitwise reproducible; no float atomics anywhere)
+//
+// Kernels (all HBM-bound; algorithmic bytes in DESIGN.md):
+//   k_row_pass   one wave per row, 16-byte loads, fp64 wave-shuffle reduction, fused a-update
+//   k_col_pass   256 threads x 16 bytes of one row per step, fp64 register accumulators per column
+//   k_col_fin    sums the chunk partials in order, fused b-update and tau flag
+//   k_absorb_*   u += eps ln a, v += eps ln b, K rebuilt from C; runs only when the tau flag is set
+//   k_drift / k_gap_*  convergence measures (ot_func.cpp:886-923)
+#include <hip/hip_runtime.h>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <type_traits>
+#include <vector>
+
+#include "../../include/spadot_ot.h"
+
+#define HIP_CHECK(expr)                                                                         \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess) {                                                                 \
+            fprintf(stderr, "libspadot_ot: HIP error %s at %s:%d (%s) -- there is no CPU path\n", \
+                    hipGetErrorString(_e), __FILE__, __LINE__, #expr);                          \
+            abort();                                                                            \
+        }                                                                                       \
+    } while (0)
+
+namespace {
+
+constexpr int WAVE = 64;
+constexpr int ROW_WAVES = 4;           // waves (= rows) per 256-thread block in row-oriented kernels
+constexpr int MAX_BATCH = 64;          // max scaling iterations per convergence check
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+template <typename T> struct Vec;
+template <> struct Vec<float>  { using type = float4;  static constexpr int N = 4; };
+template <> struct Vec<double> { using type = double2; static constexpr int N = 2; };
+
+template <typename T> __device__ __forceinline__ void unpack(const typename Vec<T>::type &v, double *o);
+template <> __device__ __forceinline__ void unpack<float>(const float4 &v, double *o) {
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+}
+template <> __device__ __forceinline__ void unpack<double>(const double2 &v, double *o) {
+    o[0] = v.x; o[1] = v.y;
+}
+template <typename T> __device__ __forceinline__ typename Vec<T>::type pack(const double *o);
+template <> __device__ __forceinline__ float4 pack<float>(const double *o) {
+    return make_float4((float)o[0], (float)o[1], (float)o[2], (float)o[3]);
+}
+template <> __device__ __forceinline__ double2 pack<double>(const double *o) {
+    return make_double2(o[0], o[1]);
+}
+
+__device__ __forceinline__ double wave_sum(double x) {
+#pragma unroll
+    for (int off = WAVE / 2; off > 0; off >>= 1) x += __shfl_down(x, off, WAVE);
+    return x;   // valid in lane 0
+}
+
+// Sum over a 256..1024-thread block; every thread gets the result.  `sh` needs 16 doubles.
+__device__ __forceinline__ double block_sum(double x, double *sh) {
+    x = wave_sum(x);
+    const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x >> 6;
+    const int nw = (blockDim.x + WAVE - 1) >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wid] = x;
+    __syncthreads();
+    double t = 0.0;
+    for (int k = 0; k < nw; k++) t += sh[k];   // fixed order
+    return t;
+}
+
+// ot_func.cpp:29-40: +-inf -> +-FLT_MAX (the float constant, for doubles too)
+__device__ __forceinline__ double clamp_inf(double x) {
+    if (isinf(x)) return x < 0 ? -(double)FLT_MAX : (double)FLT_MAX;
+    return x;
+}
+
+// ------------------------------------------------------------------------------------------
+// K = exp((u_i + v_j - C_ij)/eps) (ot_func.cpp:563-567, :802-806); pad columns written as 0.
+// `flag` (may be null): skip the whole launch unless *flag != 0 (device-side tau decision).
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_build_K(T *__restrict__ K, const T *__restrict__ C,
+                                                 const double *__restrict__ u,
+                                                 const double *__restrict__ v, double eps, int I,
+                                                 int J, int ld, const int *flag) {
+    if (flag && *flag == 0) return;
+    constexpr int V = Vec<T>::N;
+    using VT = typename Vec<T>::type;
+    const int j = (blockIdx.x * 256 + threadIdx.x) * V;
+    if (j >= ld) return;
+    double vv[V];
+#pragma unroll
+    for (int k = 0; k < V; k++) vv[k] = (j + k < J) ? v[j + k] : 0.0;
+    for (int i = blockIdx.y; i < I; i += gridDim.y) {
+        const double ui = u[i];
+        double c[V], o[V];
+        unpack<T>(*reinterpret_cast<const VT *>(C + (size_t)i * ld + j), c);
+#pragma unroll
+        for (int k = 0; k < V; k++) o[k] = (j + k < J) ? exp((ui + vv[k] - c[k]) / eps) : 0.0;
+        *reinterpret_cast<VT *>(K + (size_t)i * ld + j) = pack<T>(o);
+    }
+}
+
+// Kbar = exp(-C/eps) (ot_func.cpp:558-560), materialised only for the libot-compatible entry.
+template <typename T>
+__global__ __launch_bounds__(256) void k_build_Kbar(T *__restrict__ Kb, const T *__restrict__ C,
+                                                    double eps, int I, int J, int ld) {
+    constexpr int V = Vec<T>::N;
+    using VT = typename Vec<T>::type;
+    const int j = (blockIdx.x * 256 + threadIdx.x) * V;
+    if (j >= ld) return;
+    for (int i = blockIdx.y; i < I; i += gridDim.y) {
+        double c[V], o[V];
+        unpack<T>(*reinterpret_cast<const VT *>(C + (size_t)i * ld + j), c);
+#pragma unroll
+        for (int k = 0; k < V; k++) o[k] = (j + k < J) ? exp(-c[k] / eps) : 0.0;
+        *reinterpret_cast<VT *>(Kb + (size_t)i * ld + j) = pack<T>(o);
+    }
+}
+
+// Per-row sum of a matrix (MODE 0) or of exp(-C/eps) (MODE 1): out[i] = sum_j f(M_ij).
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void k_row_reduce(const T *__restrict__ M, double eps, int I,
+                                                    int J, int ld, double *__restrict__ out) {
+    constexpr int V = Vec<T>::N;
+    using VT = typename Vec<T>::type;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * ROW_WAVES + (threadIdx.x >> 6);
+    if (row >= I) return;
+    const T *r = M + (size_t)row * ld;
+    double acc = 0.0;
+    for (int j = lane * V; j < ld; j += WAVE * V) {
+        double c[V];
+        unpack<T>(*reinterpret_cast<const VT *>(r + j), c);
+#pragma unroll
+        for (int k = 0; k < V; k++)
+            if (j + k < J) acc += (MODE == 1) ? exp(-c[k] / eps) : c[k];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) out[row] = acc;
+}
+
+// out[slot] = sum_i x[i], one block, fixed order.
+__global__ __launch_bounds__(1024) void k_vec_sum(const double *__restrict__ x, int n,
+                                                  double *__restrict__ out, int slot) {
+    __shared__ double sh[16];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) acc += x[i];
+    acc = block_sum(acc, sh);
+    if (threadIdx.x == 0) out[slot] = acc;
+}
+
+// ------------------------------------------------------------------------------------------
+// Row pass (ot_func.cpp:610-636): s_i = sum_j K_ij w_j with w = b.dy, then
+//   old_a_i = a_i ; a_i = (p_i/s_i)^alpha1 * exp(-u_i/(lambda1+eps)) ; adx_i = a_i dx_i
+// One wave per row; lanes stride the row in 16-byte pieces (1 KiB per wave-instruction).
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_row_pass(const T *__restrict__ K,
+                                                  const double *__restrict__ w,
+                                                  double *__restrict__ a,
+                                                  double *__restrict__ old_a,
+                                                  double *__restrict__ adx,
+                                                  const double *__restrict__ p,
+                                                  const double *__restrict__ dx,
+                                                  const double *__restrict__ u, double alpha1,
+                                                  double inv_l1e, double tau, int I, int ld,
+                                                  int *flag) {
+    constexpr int V = Vec<T>::N;
+    using VT = typename Vec<T>::type;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * ROW_WAVES + (threadIdx.x >> 6);
+    if (row >= I) return;
+    const T *r = K + (size_t)row * ld;
+    double acc0 = 0.0, acc1 = 0.0;
+    int j = lane * V;
+    // two independent 16-byte loads in flight per lane per trip
+    for (; j + WAVE * V < ld; j += 2 * WAVE * V) {
+        double k0[V], k1[V];
+        unpack<T>(*reinterpret_cast<const VT *>(r + j), k0);
+        unpack<T>(*reinterpret_cast<const VT *>(r + j + WAVE * V), k1);
+#pragma unroll
+        for (int k = 0; k < V; k++) {
+            acc0 = fma(k0[k], w[j + k], acc0);
+            acc1 = fma(k1[k], w[j + WAVE * V + k], acc1);
+        }
+    }
+    if (j < ld) {
+        double k0[V];
+        unpack<T>(*reinterpret_cast<const VT *>(r + j), k0);
+#pragma unroll
+        for (int k = 0; k < V; k++) acc0 = fma(k0[k], w[j + k], acc0);
+    }
+    const double s = wave_sum(acc0 + acc1);
+    if (lane == 0) {
+        const double an = pow(p[row] / s, alpha1) * exp(-u[row] * inv_l1e);
+        old_a[row] = a[row];
+        a[row] = an;
+        adx[row] = an * dx[row];
+        if (an > tau) *flag = 1;    // benign race: every writer stores 1
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Column pass (ot_func.cpp:643-651): part[c][j] = sum_{i in chunk c} K_ij adx_i, rows ascending.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_col_pass(const T *__restrict__ K,
+                                                  const double *__restrict__ adx,
+                                                  double *__restrict__ part, int I, int ld,
+                                                  int rows_per_chunk) {
+    constexpr int V = Vec<T>::N;
+    using VT = typename Vec<T>::type;
+    const int j = (blockIdx.x * 256 + threadIdx.x) * V;
+    if (j >= ld) return;
+    const int i0 = blockIdx.y * rows_per_chunk;
+    const int i1 = min(I, i0 + rows_per_chunk);
+    double acc[V];
+#pragma unroll
+    for (int k = 0; k < V; k++) acc[k] = 0.0;
+    const T *base = K + j;
+    int i = i0;
+    for (; i + 4 <= i1; i += 4) {
+        VT r0 = *reinterpret_cast<const VT *>(base + (size_t)(i + 0) * ld);
+        VT r1 = *reinterpret_cast<const VT *>(base + (size_t)(i + 1) * ld);
+        VT r2 = *reinterpret_cast<const VT *>(base + (size_t)(i + 2) * ld);
+        VT r3 = *reinterpret_cast<const VT *>(base + (size_t)(i + 3) * ld);
+        const double x0 = adx[i], x1 = adx[i + 1], x2 = adx[i + 2], x3 = adx[i + 3];
+        double e0[V], e1[V], e2[V], e3[V];
+        unpack<T>(r0, e0); unpack<T>(r1, e1); unpack<T>(r2, e2); unpack<T>(r3, e3);
+#pragma unroll
+        for (int k = 0; k < V; k++) {
+            acc[k] = fma(e0[k], x0, acc[k]);
+            acc[k] = fma(e1[k], x1, acc[k]);
+            acc[k] = fma(e2[k], x2, acc[k]);
+            acc[k] = fma(e3[k], x3, acc[k]);
+        }
+    }
+    for (; i < i1; i++) {
+        double e0[V];
+        unpack<T>(*reinterpret_cast<const VT *>(base + (size_t)i * ld), e0);
+        const double x0 = adx[i];
+#pragma unroll
+        for (int k = 0; k < V; k++) acc[k] = fma(e0[k], x0, acc[k]);
+    }
+    double *o = part + (size_t)blockIdx.y * ld + j;
+#pragma unroll
+    for (int k = 0; k < V; k++) o[k] = acc[k];
+}
+
+// t_j = sum_c part[c][j];  old_b = b;  b_j = (q_j/t_j)^alpha2 exp(-v_j/(lambda2+eps));  w_j = b_j dy_j
+// (ot_func.cpp:657-668).  mode 1: only write t (used by the gap check).
+__global__ __launch_bounds__(256) void k_col_fin(const double *__restrict__ part, int nchunk,
+                                                 double *__restrict__ b,
+                                                 double *__restrict__ old_b,
+                                                 double *__restrict__ w,
+                                                 const double *__restrict__ q,
+                                                 const double *__restrict__ dy,
+                                                 const double *__restrict__ v, double alpha2,
+                                                 double inv_l2e, double tau, int J, int ld,
+                                                 int *flag, double *t_out, int mode) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= ld) return;
+    if (j >= J) { if (mode == 0) w[j] = 0.0; else t_out[j] = 0.0; return; }
+    double t = 0.0;
+    for (int c = 0; c < nchunk; c++) t += part[(size_t)c * ld + j];
+    if (mode == 1) { t_out[j] = t; return; }
+    const double bn = pow(q[j] / t, alpha2) * exp(-v[j] * inv_l2e);
+    old_b[j] = b[j];
+    b[j] = bn;
+    w[j] = bn * dy[j];
+    if (bn > tau) *flag = 1;
+}
+
+// tau-absorb, vector half (ot_func.cpp:792-814): runs only when *flag is set.
+__global__ __launch_bounds__(256) void k_absorb_vec(double *__restrict__ a, double *__restrict__ b,
+                                                    double *__restrict__ u, double *__restrict__ v,
+                                                    double *__restrict__ adx,
+                                                    double *__restrict__ w,
+                                                    const double *__restrict__ dx,
+                                                    const double *__restrict__ dy, double eps, int I,
+                                                    int J, const int *flag, int *absorb_count) {
+    if (*flag == 0) return;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < I) { u[t] = u[t] + eps * log(a[t]); a[t] = 1.0; adx[t] = dx[t]; }
+    if (t < J) { v[t] = v[t] + eps * log(b[t]); b[t] = 1.0; w[t] = dy[t]; }
+    if (t == 0) *absorb_count += 1;
+}
+
+// Stage transition (ot_solvers.py:249-260): absorb unconditionally, reset old_a/old_b too.
+__global__ __launch_bounds__(256) void k_stage_begin(double *a, double *b, double *old_a,
+                                                     double *old_b, double *u, double *v,
+                                                     double *adx, double *w, const double *dx,
+                                                     const double *dy, double eps_prev, int I, int J,
+                                                     int ld) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < I) { u[t] = u[t] + eps_prev * log(a[t]); a[t] = 1.0; old_a[t] = 1.0; adx[t] = dx[t]; }
+    if (t < J) { v[t] = v[t] + eps_prev * log(b[t]); b[t] = 1.0; old_b[t] = 1.0; w[t] = dy[t]; }
+    else if (t < ld) w[t] = 0.0;
+}
+
+// w = b.dy (pad 0), adx = a.dx -- used when a, b come from the caller (compat entry points).
+__global__ __launch_bounds__(256) void k_prep_vec(const double *a, const double *b, const double *dx,
+                                                  const double *dy, double *adx, double *w, int I,
+                                                  int J, int ld) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < I) adx[t] = a[t] * dx[t];
+    if (t < J) w[t] = b[t] * dy[t];
+    else if (t < ld) w[t] = 0.0;
+}
+
+// Dual-variable drift (ot_func.cpp:876-923, stages 0..4).  One block.
+//   ta = a e^{u/eps};  g1 = ||ta - old_a e^{u/eps}|| / (1 + ||ta||); likewise g2;  gap = std::max(g1,g2)
+__global__ __launch_bounds__(1024) void k_drift(const double *__restrict__ a,
+                                                const double *__restrict__ old_a,
+                                                const double *__restrict__ u,
+                                                const double *__restrict__ b,
+                                                const double *__restrict__ old_b,
+                                                const double *__restrict__ v, double eps, int I,
+                                                int J, double *scal) {
+    __shared__ double sh[16];
+    double d1 = 0, n1 = 0, d2 = 0, n2 = 0;
+    for (int i = threadIdx.x; i < I; i += blockDim.x) {
+        const double e = exp(u[i] / eps);
+        const double ta = a[i] * e;
+        const double t = ta - old_a[i] * e;
+        d1 += t * t;
+        n1 += ta * ta;
+    }
+    for (int j = threadIdx.x; j < J; j += blockDim.x) {
+        const double e = exp(v[j] / eps);
+        const double tb = b[j] * e;
+        const double t = tb - old_b[j] * e;
+        d2 += t * t;
+        n2 += tb * tb;
+    }
+    d1 = block_sum(d1, sh); n1 = block_sum(n1, sh);
+    d2 = block_sum(d2, sh); n2 = block_sum(n2, sh);
+    if (threadIdx.x == 0) {
+        const double g1 = sqrt(d1) / (1.0 + sqrt(n1));
+        const double g2 = sqrt(d2) / (1.0 + sqrt(n2));
+        scal[0] = (g1 < g2) ? g2 : g1;   // std::max(g1, g2): a NaN g1 wins (ot_func.cpp:922)
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Duality-gap row pass (ot_func.cpp:392-428, :481-483 folded into ONE sweep of K and C):
+// per row i with R_ij = K_ij a_i b_j (FROM_K) or R_ij read from a matrix:
+//   rt[0][i] = sum_j R dy_j     rt[1][i] = sum_j R clamp(ln R) - R
+//   rt[2][i] = sum_j R C_ij     rt[3][i] = sum_j R
+// and optionally R is written out (update_R, ot_func.cpp:570-584).
+// ------------------------------------------------------------------------------------------
+template <typename T, bool FROM_K>
+__global__ __launch_bounds__(256) void k_gap_rows(const T *__restrict__ KorR,
+                                                  const T *__restrict__ C,
+                                                  const double *__restrict__ a,
+                                                  const double *__restrict__ b,
+                                                  const double *__restrict__ dy,
+                                                  T *__restrict__ Rout, double *__restrict__ rt,
+                                                  int I, int J, int ld) {
+    constexpr int V = Vec<T>::N;
+    using VT = typename Vec<T>::type;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * ROW_WAVES + (threadIdx.x >> 6);
+    if (row >= I) return;
+    const T *kr = KorR + (size_t)row * ld;
+    const T *cr = C ? C + (size_t)row * ld : nullptr;
+    const double ai = FROM_K ? a[row] : 1.0;
+    double rs = 0, en = 0, co = 0, sr = 0;
+    for (int j = lane * V; j < ld; j += WAVE * V) {
+        double kv[V], cv[V], ro[V];
+        unpack<T>(*reinterpret_cast<const VT *>(kr + j), kv);
+        if (cr) unpack<T>(*reinterpret_cast<const VT *>(cr + j), cv);
+#pragma unroll
+        for (int k = 0; k < V; k++) {
+            double R = 0.0;
+            if (j + k < J) {
+                R = FROM_K ? kv[k] * ai * b[j + k] : kv[k];
+                rs += R * dy[j + k];
+                en += R * clamp_inf(log(R)) - R;
+                if (cr) co += R * cv[k];
+                sr += R;
+            }
+            ro[k] = R;
+        }
+        if (Rout) *reinterpret_cast<VT *>(Rout + (size_t)row * ld + j) = pack<T>(ro);
+    }
+    rs = wave_sum(rs); en = wave_sum(en); co = wave_sum(co); sr = wave_sum(sr);
+    if (lane == 0) {
+        rt[row] = rs; rt[(size_t)I + row] = en; rt[2 * (size_t)I + row] = co; rt[3 * (size_t)I + row] = sr;
+    }
+}
+
+// Gap finalisation, one block (ot_func.cpp:308-322, :340-355, :432-434, :485-489, :543).
+//   cs_j = col_scale ? b_j * t_j : t_j      (t = column pass with weights a.dx, or R^T dx directly)
+//   abar/bbar = a e^{u/eps}, b e^{v/eps} when `stabilised`, else a, b as given
+// scal[0]=gap scal[1]=primal scal[2]=dual.  scal[3] holds sum(Kbar) on entry.
+__global__ __launch_bounds__(1024) void k_gap_fin(const double *__restrict__ rt,
+                                                  const double *__restrict__ t,
+                                                  const double *__restrict__ a,
+                                                  const double *__restrict__ b,
+                                                  const double *__restrict__ u,
+                                                  const double *__restrict__ v,
+                                                  const double *__restrict__ p,
+                                                  const double *__restrict__ q,
+                                                  const double *__restrict__ dx,
+                                                  const double *__restrict__ dy, double eps,
+                                                  double l1, double l2, int I, int J, int col_scale,
+                                                  int stabilised, double *scal) {
+    __shared__ double sh[16];
+    double f1 = 0, en = 0, co = 0, sr = 0, c1 = 0, f2 = 0, c2 = 0;
+    for (int i = threadIdx.x; i < I; i += blockDim.x) {
+        const double x = rt[i];
+        f1 += dx[i] * (x * log(x / p[i]) - x + p[i]);
+        en += rt[(size_t)I + i];
+        co += rt[2 * (size_t)I + i];
+        sr += rt[3 * (size_t)I + i];
+        const double ab = stabilised ? a[i] * exp(u[i] / eps) : a[i];
+        c1 += (p[i] * dx[i]) * (exp((-eps * log(ab)) / l1) - 1.0);
+    }
+    for (int j = threadIdx.x; j < J; j += blockDim.x) {
+        const double x = col_scale ? b[j] * t[j] : t[j];
+        f2 += dy[j] * (x * log(x / q[j]) - x + q[j]);
+        const double bb = stabilised ? b[j] * exp(v[j] / eps) : b[j];
+        c2 += (q[j] * dy[j]) * (exp((-eps * log(bb)) / l2) - 1.0);
+    }
+    f1 = block_sum(f1, sh); en = block_sum(en, sh); co = block_sum(co, sh); sr = block_sum(sr, sh);
+    c1 = block_sum(c1, sh); f2 = block_sum(f2, sh); c2 = block_sum(c2, sh);
+    if (threadIdx.x == 0) {
+        const double skb = scal[3];
+        const double mn = (double)I * (double)J;
+        const double pri = l1 * f1 + l2 * f2 + (eps * (en + skb) + co) / mn;
+        const double dua = -(l1 * c1) - (l2 * c2) - eps * (sr - skb) / mn;
+        scal[1] = pri;
+        scal[2] = dua;
+        scal[0] = (pri - dua) / fabs(pri);
+    }
+}
+
+// plan = a_i K_ij b_j * scale  (ot_solvers.py:449 with scale = 1/J)
+template <typename T, typename TO>
+__global__ __launch_bounds__(256) void k_plan(const T *__restrict__ K, const double *__restrict__ a,
+                                              const double *__restrict__ b, double scale,
+                                              TO *__restrict__ out, int I, int J, int ld, int ldo) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= J) return;
+    const double bj = b[j];
+    for (int i = blockIdx.y; i < I; i += gridDim.y)
+        out[(size_t)i * ldo + j] = (TO)((double)K[(size_t)i * ld + j] * a[i] * bj * scale);
+}
+
+// dst (I x ldd, TD) <- src (I x lds, TS), columns < J; pad columns of dst <- 0
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void k_convert(const TS *__restrict__ src, int lds,
+                                                 TD *__restrict__ dst, int ldd, int I, int J) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= ldd) return;
+    for (int i = blockIdx.y; i < I; i += gridDim.y)
+        dst[(size_t)i * ldd + j] = (j < J) ? (TD)src[(size_t)i * lds + j] : (TD)0;
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Cost from latents (ot_solvers.py:101-103): D_ij = max(|x_i|^2 + |y_j|^2 - 2 x_i.y_j, 0), the
+// arithmetic of sklearn's euclidean_distances(squared=True); then C = D / median(D).
+// One thread owns one column j (y_j lives in registers), rows come in through uniform loads,
+// so the only HBM stream is the coalesced write of D.
+// ------------------------------------------------------------------------------------------
+constexpr int MAX_LATENT_DIM = 32;
+
+__global__ __launch_bounds__(256) void k_sqeuclid(const double *__restrict__ x,
+                                                  const double *__restrict__ y, int d, int I, int J,
+                                                  double *__restrict__ D, int rows_per_block) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const bool live = j < J;
+    double yj[MAX_LATENT_DIM];
+    double yy = 0.0;
+#pragma unroll
+    for (int k = 0; k < MAX_LATENT_DIM; k++) {
+        yj[k] = (live && k < d) ? y[(size_t)j * d + k] : 0.0;
+        yy += yj[k] * yj[k];
+    }
+    const int i0 = blockIdx.y * rows_per_block, i1 = min(I, i0 + rows_per_block);
+    for (int i = i0; i < i1; i++) {
+        const double *xi = x + (size_t)i * d;
+        double dot = 0.0, xx = 0.0;
+#pragma unroll
+        for (int k = 0; k < MAX_LATENT_DIM; k++) {
+            const double xv = (k < d) ? xi[k] : 0.0;
+            dot += xv * yj[k];
+            xx += xv * xv;
+        }
+        double v = -2.0 * dot;
+        v += xx;
+        v += yy;
+        if (live) D[(size_t)i * J + j] = v > 0.0 ? v : 0.0;
+    }
+}
+
+// Radix-select histogram: among keys whose bits above `shift+bits` equal `prefix`, count the
+// `bits`-bit digit at `shift`.  Non-negative doubles order like their bit patterns.
+__global__ __launch_bounds__(256) void k_select_hist(const unsigned long long *__restrict__ keys,
+                                                     size_t n, unsigned long long prefix, int shift,
+                                                     int bits, unsigned long long *__restrict__ hist) {
+    __shared__ unsigned int lh[4096];
+    for (int t = threadIdx.x; t < 4096; t += 256) lh[t] = 0;
+    __syncthreads();
+    const int hi = shift + bits;
+    const unsigned long long dmask = (1ull << bits) - 1ull;
+    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (size_t)gridDim.x * 256) {
+        const unsigned long long key = keys[t];
+        const bool match = (hi >= 64) ? true : ((key >> hi) == prefix);
+        if (match) atomicAdd(&lh[(key >> shift) & dmask], 1u);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 4096; t += 256)
+        if (lh[t]) atomicAdd(&hist[t], (unsigned long long)lh[t]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_scale_to_cost(const double *__restrict__ D, double denom,
+                                                       T *__restrict__ C, int I, int J, int ld) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= ld) return;
+    for (int i = blockIdx.y; i < I; i += gridDim.y)
+        C[(size_t)i * ld + j] = (j < J) ? (T)(D[(size_t)i * J + j] / denom) : (T)0;
+}
+
+__global__ void k_fill(double *x, double val, int n) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < n) x[t] = val;
+}
+
+}  // namespace
+
+// ============================================================================================
+// Host side
+// ============================================================================================
+struct spadot_ot_solver {
+    int I = 0, J = 0, ld = 0, storage = SPADOT_F64;
+    hipStream_t stream = nullptr;
+    void *C = nullptr, *K = nullptr;
+    // length-I vectors
+    double *a = nullptr, *old_a = nullptr, *u = nullptr, *p = nullptr, *dx = nullptr, *adx = nullptr;
+    // length-ld vectors
+    double *b = nullptr, *old_b = nullptr, *v = nullptr, *q = nullptr, *dy = nullptr, *w = nullptr,
+           *tcol = nullptr;
+    double *part = nullptr;    // nchunk x ld
+    double *rt = nullptr;      // 4 x I
+    double *scal = nullptr;    // 8 device scalars: gap, primal, dual, sumKbar, ...
+    int *flags = nullptr;      // MAX_BATCH + 1 ints (last = absorb counter)
+    double *h_scal = nullptr;  // pinned
+    int *h_flags = nullptr;    // pinned
+    int nchunk = 1, rows_per_chunk = 1;
+    double sum_kbar_eps = -1.0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    size_t elt() const { return storage == SPADOT_F32 ? 4 : 8; }
+};
+
+namespace {
+
+void *dmalloc(size_t bytes) {
+    void *p = nullptr;
+    HIP_CHECK(hipMalloc(&p, bytes ? bytes : 8));
+    return p;
+}
+
+dim3 grid_cols(const spadot_ot_solver *s, int V) {
+    return dim3((s->ld + 256 * V - 1) / (256 * V), (unsigned)std::min(s->I, 8192));
+}
+
+void require_device() {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        fprintf(stderr, "libspadot_ot: no HIP device available (%s); this library has no CPU path\n",
+                hipGetErrorString(e));
+        abort();
+    }
+}
+
+template <typename T> void launch_build_K(spadot_ot_solver *s, double eps, const int *flag) {
+    constexpr int V = Vec<T>::N;
+    hipLaunchKernelGGL(k_build_K<T>, grid_cols(s, V), dim3(256), 0, s->stream, (T *)s->K,
+                       (const T *)s->C, s->u, s->v, eps, s->I, s->J, s->ld, flag);
+}
+
+void build_K(spadot_ot_solver *s, double eps, const int *flag) {
+    if (s->storage == SPADOT_F32) launch_build_K<float>(s, eps, flag);
+    else launch_build_K<double>(s, eps, flag);
+}
+
+// scal[3] = sum exp(-C/eps) (or sum of a given Kbar matrix)
+template <typename T> void sum_kbar_T(spadot_ot_solver *s, const void *M, double eps, bool from_cost) {
+    dim3 g((s->I + ROW_WAVES - 1) / ROW_WAVES);
+    if (from_cost)
+        hipLaunchKernelGGL((k_row_reduce<T, 1>), g, dim3(256), 0, s->stream, (const T *)M, eps, s->I,
+                           s->J, s->ld, s->rt);
+    else
+        hipLaunchKernelGGL((k_row_reduce<T, 0>), g, dim3(256), 0, s->stream, (const T *)M, eps, s->I,
+                           s->J, s->ld, s->rt);
+    hipLaunchKernelGGL(k_vec_sum, dim3(1), dim3(1024), 0, s->stream, s->rt, s->I, s->scal, 3);
+}
+void sum_kbar(spadot_ot_solver *s, const void *M, double eps, bool from_cost) {
+    if (s->storage == SPADOT_F32) sum_kbar_T<float>(s, M, eps, from_cost);
+    else sum_kbar_T<double>(s, M, eps, from_cost);
+}
+
+struct IterParams { double eps, tau, l1, l2, al1, al2; };
+
+template <typename T> void one_iteration_T(spadot_ot_solver *s, const IterParams &P, int *flag) {
+    constexpr int V = Vec<T>::N;
+    const int I = s->I, J = s->J, ld = s->ld;
+    hipLaunchKernelGGL(k_row_pass<T>, dim3((I + ROW_WAVES - 1) / ROW_WAVES), dim3(256), 0, s->stream,
+                       (const T *)s->K, s->w, s->a, s->old_a, s->adx, s->p, s->dx, s->u, P.al1,
+                       1.0 / (P.l1 + P.eps), P.tau, I, ld, flag);
+    hipLaunchKernelGGL(k_col_pass<T>, dim3((ld + 256 * V - 1) / (256 * V), s->nchunk), dim3(256), 0,
+                       s->stream, (const T *)s->K, s->adx, s->part, I, ld, s->rows_per_chunk);
+    hipLaunchKernelGGL(k_col_fin, dim3((ld + 255) / 256), dim3(256), 0, s->stream, s->part, s->nchunk,
+                       s->b, s->old_b, s->w, s->q, s->dy, s->v, P.al2, 1.0 / (P.l2 + P.eps), P.tau,
+                       J, ld, flag, (double *)nullptr, 0);
+    const int mx = std::max(I, J);
+    hipLaunchKernelGGL(k_absorb_vec, dim3((mx + 255) / 256), dim3(256), 0, s->stream, s->a, s->b, s->u,
+                       s->v, s->adx, s->w, s->dx, s->dy, P.eps, I, J, flag, s->flags + MAX_BATCH);
+    launch_build_K<T>(s, P.eps, flag);
+}
+
+// `iters` scaling iterations with device-side tau decisions (ot_func.cpp:726-819), no host sync.
+void run_iterations(spadot_ot_solver *s, const IterParams &P, int iters) {
+    while (iters > 0) {
+        const int nb = std::min(iters, MAX_BATCH);
+        HIP_CHECK(hipMemsetAsync(s->flags, 0, sizeof(int) * MAX_BATCH, s->stream));
+        for (int t = 0; t < nb; t++) {
+            if (s->storage == SPADOT_F32) one_iteration_T<float>(s, P, s->flags + t);
+            else one_iteration_T<double>(s, P, s->flags + t);
+        }
+        iters -= nb;
+    }
+}
+
+double read_gap(spadot_ot_solver *s) {
+    HIP_CHECK(hipMemcpyAsync(s->h_scal, s->scal, sizeof(double) * 4, hipMemcpyDeviceToHost, s->stream));
+    HIP_CHECK(hipStreamSynchronize(s->stream));
+    HIP_CHECK(hipGetLastError());
+    return s->h_scal[0];
+}
+
+void drift_measure(spadot_ot_solver *s, double eps) {
+    hipLaunchKernelGGL(k_drift, dim3(1), dim3(1024), 0, s->stream, s->a, s->old_a, s->u, s->b, s->old_b,
+                       s->v, eps, s->I, s->J, s->scal);
+}
+
+// True primal-dual gap of the current (a, b, K) with R = a K b formed on the fly; scal[3] must
+// already hold sum(Kbar).  Rout (device, I x ld, storage type) may be null.
+template <typename T> void gap_measure_T(spadot_ot_solver *s, const IterParams &P, void *Rout) {
+    constexpr int V = Vec<T>::N;
+    const int I = s->I, J = s->J, ld = s->ld;
+    hipLaunchKernelGGL((k_gap_rows<T, true>), dim3((I + ROW_WAVES - 1) / ROW_WAVES), dim3(256), 0,
+                       s->stream, (const T *)s->K, (const T *)s->C, s->a, s->b, s->dy, (T *)Rout, s->rt,
+                       I, J, ld);
+    hipLaunchKernelGGL(k_col_pass<T>, dim3((ld + 256 * V - 1) / (256 * V), s->nchunk), dim3(256), 0,
+                       s->stream, (const T *)s->K, s->adx, s->part, I, ld, s->rows_per_chunk);
+    hipLaunchKernelGGL(k_col_fin, dim3((ld + 255) / 256), dim3(256), 0, s->stream, s->part, s->nchunk,
+                       (double *)nullptr, (double *)nullptr, (double *)nullptr, (const double *)nullptr,
+                       (const double *)nullptr, (const double *)nullptr, 0.0, 0.0, 0.0, J, ld,
+                       (int *)nullptr, s->tcol, 1);
+    hipLaunchKernelGGL(k_gap_fin, dim3(1), dim3(1024), 0, s->stream, s->rt, s->tcol, s->a, s->b, s->u,
+                       s->v, s->p, s->q, s->dx, s->dy, P.eps, P.l1, P.l2, I, J, 1, 1, s->scal);
+}
+void gap_measure(spadot_ot_solver *s, const IterParams &P, void *Rout) {
+    if (s->storage == SPADOT_F32) gap_measure_T<float>(s, P, Rout);
+    else gap_measure_T<double>(s, P, Rout);
+}
+
+// ot_func.cpp:830-930 on device state.  Returns the measure; *iters_done counts scaling iterations.
+// The reference's cur_iter bookkeeping (including its -1 quirk, :821-824 + :869) is kept on the host.
+double process_stage(spadot_ot_solver *s, const IterParams &P, bool last_stage, int batch_size,
+                     double threshold, int cur_iter, int max_iter, void *Rout, int *iters_done,
+                     int *checks) {
+    double gap = 1e100;
+    int done = 0, nchecks = 0;
+    while (gap > threshold) {
+        const int iters = last_stage ? batch_size : 5;
+        // step1_process: stops early (returning -1) once the counter reaches max_iter
+        int run = iters;
+        bool hit = false;
+        if (cur_iter + iters >= max_iter) {
+            run = std::max(1, std::min(iters, max_iter - cur_iter));
+            hit = true;
+        }
+        run_iterations(s, P, run);
+        done += run;
+        if (hit) {
+            printf("Reached max_iter with duality gap still above threshold. Returning");
+            cur_iter = -1;
+        } else {
+            cur_iter += iters;
+        }
+        if (last_stage) gap_measure(s, P, Rout);
+        else drift_measure(s, P.eps);
+        gap = read_gap(s);
+        nchecks++;
+    }
+    if (iters_done) *iters_done = done;
+    if (checks) *checks += nchecks;
+    return gap;
+}
+
+void choose_chunks(spadot_ot_solver *s) {
+    const int V = s->storage == SPADOT_F32 ? 4 : 2;
+    const int gx = (s->ld + 256 * V - 1) / (256 * V);
+    int want = std::max(1, 2048 / gx);              // ~2048 blocks = 8 per CU
+    want = std::min(want, std::max(1, s->I / 16));  // at least 16 rows per chunk
+    s->rows_per_chunk = (s->I + want - 1) / want;
+    s->nchunk = (s->I + s->rows_per_chunk - 1) / s->rows_per_chunk;
+}
+
+void upload_vec(spadot_ot_solver *s, double *dst, const double *src, int n) {
+    HIP_CHECK(hipMemcpyAsync(dst, src, sizeof(double) * n, hipMemcpyHostToDevice, s->stream));
+}
+void download_vec(spadot_ot_solver *s, double *dst, const double *src, int n) {
+    HIP_CHECK(hipMemcpyAsync(dst, src, sizeof(double) * n, hipMemcpyDeviceToHost, s->stream));
+}
+// host (m x n contiguous) <-> device (m x ld)
+template <typename T> void upload_mat(spadot_ot_solver *s, void *dst, const T *src) {
+    HIP_CHECK(hipMemsetAsync(dst, 0, (size_t)s->I * s->ld * sizeof(T), s->stream));
+    HIP_CHECK(hipMemcpy2DAsync(dst, (size_t)s->ld * sizeof(T), src, (size_t)s->J * sizeof(T),
+                               (size_t)s->J * sizeof(T), s->I, hipMemcpyHostToDevice, s->stream));
+}
+template <typename T> void download_mat(spadot_ot_solver *s, T *dst, const void *src) {
+    HIP_CHECK(hipMemcpy2DAsync(dst, (size_t)s->J * sizeof(T), src, (size_t)s->ld * sizeof(T),
+                               (size_t)s->J * sizeof(T), s->I, hipMemcpyDeviceToHost, s->stream));
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *spadot_ot_version(void) { return "spadot_ot 0.1 (gfx950)"; }
+
+int spadot_ot_create(spadot_ot_solver **out, int I, int J, int storage, void *stream) {
+    if (!out) return -22;
+    *out = nullptr;
+    if (I <= 0 || J <= 0 || (storage != SPADOT_F64 && storage != SPADOT_F32)) return -22;
+    require_device();
+    auto *s = new spadot_ot_solver();
+    s->I = I; s->J = J; s->storage = storage; s->stream = (hipStream_t)stream;
+    s->ld = round_up(J, 64);
+    choose_chunks(s);
+    const size_t mat = (size_t)I * s->ld * s->elt();
+    s->C = dmalloc(mat);
+    s->K = dmalloc(mat);
+    HIP_CHECK(hipMemsetAsync(s->C, 0, mat, s->stream));
+    HIP_CHECK(hipMemsetAsync(s->K, 0, mat, s->stream));
+    double *vi = (double *)dmalloc(sizeof(double) * 6 * (size_t)I);
+    s->a = vi; s->old_a = vi + I; s->u = vi + 2 * (size_t)I; s->p = vi + 3 * (size_t)I;
+    s->dx = vi + 4 * (size_t)I; s->adx = vi + 5 * (size_t)I;
+    const size_t L = s->ld;
+    double *vj = (double *)dmalloc(sizeof(double) * 7 * L);
+    s->b = vj; s->old_b = vj + L; s->v = vj + 2 * L; s->q = vj + 3 * L; s->dy = vj + 4 * L;
+    s->w = vj + 5 * L; s->tcol = vj + 6 * L;
+    HIP_CHECK(hipMemsetAsync(vi, 0, sizeof(double) * 6 * (size_t)I, s->stream));
+    HIP_CHECK(hipMemsetAsync(vj, 0, sizeof(double) * 7 * L, s->stream));
+    s->part = (double *)dmalloc(sizeof(double) * (size_t)s->nchunk * L);
+    s->rt = (double *)dmalloc(sizeof(double) * 4 * (size_t)I);
+    s->scal = (double *)dmalloc(sizeof(double) * 8);
+    s->flags = (int *)dmalloc(sizeof(int) * (MAX_BATCH + 1));
+    HIP_CHECK(hipMemsetAsync(s->scal, 0, sizeof(double) * 8, s->stream));
+    HIP_CHECK(hipMemsetAsync(s->flags, 0, sizeof(int) * (MAX_BATCH + 1), s->stream));
+    HIP_CHECK(hipHostMalloc((void **)&s->h_scal, sizeof(double) * 8, hipHostMallocDefault));
+    HIP_CHECK(hipHostMalloc((void **)&s->h_flags, sizeof(int) * (MAX_BATCH + 1), hipHostMallocDefault));
+    HIP_CHECK(hipEventCreate(&s->ev0));
+    HIP_CHECK(hipEventCreate(&s->ev1));
+    *out = s;
+    return 0;
+}
+
+void spadot_ot_destroy(spadot_ot_solver *s) {
+    if (!s) return;
+    (void)hipStreamSynchronize(s->stream);
+    void *dev[] = {s->C, s->K, s->a, s->b, s->part, s->rt, s->scal, s->flags};
+    for (void *p : dev) (void)hipFree(p);
+    (void)hipHostFree(s->h_scal); (void)hipHostFree(s->h_flags);
+    (void)hipEventDestroy(s->ev0); (void)hipEventDestroy(s->ev1);
+    delete s;
+}
+
+int spadot_ot_ld(const spadot_ot_solver *s) { return s ? s->ld : -22; }
+
+void *spadot_ot_matrix_dev(spadot_ot_solver *s, int which) {
+    if (!s) return nullptr;
+    return which == 0 ? s->C : (which == 1 ? s->K : nullptr);
+}
+
+double *spadot_ot_vector_dev(spadot_ot_solver *s, int which) {
+    if (!s) return nullptr;
+    switch (which) {
+        case 0: return s->a; case 1: return s->b; case 2: return s->u; case 3: return s->v;
+        case 4: return s->old_a; case 5: return s->old_b; default: return nullptr;
+    }
+}
+
+int spadot_ot_vector_host(spadot_ot_solver *s, int which, double *out) {
+    double *src = spadot_ot_vector_dev(s, which);
+    if (!src || !out) return -22;
+    const int n = (which == 0 || which == 2 || which == 4) ? s->I : s->J;
+    download_vec(s, out, src, n);
+    HIP_CHECK(hipStreamSynchronize(s->stream));
+    return 0;
+}
+
+int spadot_ot_matrix_host(spadot_ot_solver *s, int which, double *out) {
+    void *src = spadot_ot_matrix_dev(s, which);
+    if (!src || !out) return -22;
+    const size_t n = (size_t)s->I * s->J;
+    double *tmp = (double *)dmalloc(sizeof(double) * n);
+    dim3 g((s->J + 255) / 256, (unsigned)std::min(s->I, 8192));
+    if (s->storage == SPADOT_F32)
+        hipLaunchKernelGGL((k_convert<float, double>), g, dim3(256), 0, s->stream, (const float *)src, s->ld, tmp, s->J, s->I, s->J);
+    else
+        hipLaunchKernelGGL((k_convert<double, double>), g, dim3(256), 0, s->stream, (const double *)src, s->ld, tmp, s->J, s->I, s->J);
+    HIP_CHECK(hipMemcpyAsync(out, tmp, sizeof(double) * n, hipMemcpyDeviceToHost, s->stream));
+    HIP_CHECK(hipStreamSynchronize(s->stream));
+    HIP_CHECK(hipFree(tmp));
+    return 0;
+}
+
+int spadot_ot_set_cost_dev(spadot_ot_solver *s, const void *C_dev, int dtype, int ldc) {
+    if (!s || !C_dev || ldc < s->J) return -22;
+    dim3 g((s->ld + 255) / 256, (unsigned)std::min(s->I, 8192));
+    if (dtype == SPADOT_F64 && s->storage == SPADOT_F64)
+        hipLaunchKernelGGL((k_convert<double, double>), g, dim3(256), 0, s->stream, (const double *)C_dev, ldc, (double *)s->C, s->ld, s->I, s->J);
+    else if (dtype == SPADOT_F64 && s->storage == SPADOT_F32)
+        hipLaunchKernelGGL((k_convert<double, float>), g, dim3(256), 0, s->stream, (const double *)C_dev, ldc, (float *)s->C, s->ld, s->I, s->J);
+    else if (dtype == SPADOT_F32 && s->storage == SPADOT_F64)
+        hipLaunchKernelGGL((k_convert<float, double>), g, dim3(256), 0, s->stream, (const float *)C_dev, ldc, (double *)s->C, s->ld, s->I, s->J);
+    else if (dtype == SPADOT_F32 && s->storage == SPADOT_F32)
+        hipLaunchKernelGGL((k_convert<float, float>), g, dim3(256), 0, s->stream, (const float *)C_dev, ldc, (float *)s->C, s->ld, s->I, s->J);
+    else
+        return -22;
+    s->sum_kbar_eps = -1.0;
+    return 0;
+}
+
+int spadot_ot_set_cost_host(spadot_ot_solver *s, const double *C_host) {
+    if (!s || !C_host) return -22;
+    double *tmp = (double *)dmalloc(sizeof(double) * (size_t)s->I * s->J);
+    HIP_CHECK(hipMemcpyAsync(tmp, C_host, sizeof(double) * (size_t)s->I * s->J, hipMemcpyHostToDevice, s->stream));
+    int rc = spadot_ot_set_cost_dev(s, tmp, SPADOT_F64, s->J);
+    HIP_CHECK(hipStreamSynchronize(s->stream));
+    HIP_CHECK(hipFree(tmp));
+    return rc;
+}
+
+}  // extern "C"
+
+namespace {
+// k-th smallest (0-based) of n non-negative doubles on the device, exact, by 12-bit radix select.
+double select_kth(spadot_ot_solver *s, const double *D, size_t n, size_t k) {
+    unsigned long long *hist = (unsigned long long *)dmalloc(sizeof(unsigned long long) * 4096);
+    std::vector<unsigned long long> h(4096);
+    unsigned long long prefix = 0;
+    const int shifts[6] = {52, 40, 28, 16, 4, 0};
+    const int nbits[6] = {12, 12, 12, 12, 12, 4};
+    const int blocks = (int)std::min<size_t>(2048, (n + 255) / 256);
+    for (int pass = 0; pass < 6; pass++) {
+        HIP_CHECK(hipMemsetAsync(hist, 0, sizeof(unsigned long long) * 4096, s->stream));
+        hipLaunchKernelGGL(k_select_hist, dim3(blocks), dim3(256), 0, s->stream,
+                           (const unsigned long long *)D, n, prefix, shifts[pass], nbits[pass], hist);
+        HIP_CHECK(hipMemcpyAsync(h.data(), hist, sizeof(unsigned long long) * 4096, hipMemcpyDeviceToHost, s->stream));
+        HIP_CHECK(hipStreamSynchronize(s->stream));
+        const int nb = 1 << nbits[pass];
+        int bin = nb - 1;
+        for (int t = 0; t < nb; t++) {
+            if (k < h[t]) { bin = t; break; }
+            k -= h[t];
+        }
+        prefix = (prefix << nbits[pass]) | (unsigned long long)bin;
+    }
+    HIP_CHECK(hipFree(hist));
+    double out;
+    memcpy(&out, &prefix, sizeof(double));
+    return out;
+}
+}  // namespace
+
+extern "C" int spadot_ot_set_cost_from_latents_dev(spadot_ot_solver *s, const double *x_dev,
+                                                   const double *y_dev, int d, int divide_by_median) {
+    if (!s || !x_dev || !y_dev || d < 1 || d > MAX_LATENT_DIM) return -22;
+    const int I = s->I, J = s->J;
+    const size_t n = (size_t)I * J;
+    double *D = (double *)dmalloc(sizeof(double) * n);
+    const int rpb = 32;
+    hipLaunchKernelGGL(k_sqeuclid, dim3((J + 255) / 256, (I + rpb - 1) / rpb), dim3(256), 0, s->stream, x_dev,
+                       y_dev, d, I, J, D, rpb);
+    double denom = 1.0;
+    if (divide_by_median) {
+        // np.median: middle element, or the mean of the two middle elements
+        if (n & 1) denom = select_kth(s, D, n, n / 2);
+        else denom = (select_kth(s, D, n, n / 2 - 1) + select_kth(s, D, n, n / 2)) / 2.0;
+    }
+    dim3 g((s->ld + 255) / 256, (unsigned)std::min(I, 8192));
+    if (s->storage == SPADOT_F32)
+        hipLaunchKernelGGL(k_scale_to_cost<float>, g, dim3(256), 0, s->stream, D, denom, (float *)s->C, I, J, s->ld);
+    else
+        hipLaunchKernelGGL(k_scale_to_cost<double>, g, dim3(256), 0, s->stream, D, denom, (double *)s->C, I, J, s->ld);
+    HIP_CHECK(hipStreamSynchronize(s->stream));
+    HIP_CHECK(hipFree(D));
+    s->sum_kbar_eps = -1.0;
+    return 0;
+}
+
+extern "C" {
+
+// ot_solvers.py:164-449 with everything resident in HBM.
+int spadot_ot_solve(spadot_ot_solver *s, const double *G_host, const spadot_ot_config *cfg,
+                    spadot_ot_info *info) {
+    if (!s || !cfg) return -22;
+    const int I = s->I, J = s->J, ld = s->ld, S = 5;
+    if (cfg->batch_size < 1 || cfg->batch_size > MAX_BATCH * 64) return -22;
+    // p = G, q = mean(G), dx = 1/I, dy = 1/J (ot_solvers.py:220-227)
+    std::vector<double> g(I, 1.0);
+    if (G_host) memcpy(g.data(), G_host, sizeof(double) * I);
+    double gs = 0.0;
+    for (int i = 0; i < I; i++) gs += g[i];
+    upload_vec(s, s->p, g.data(), I);
+    HIP_CHECK(hipStreamSynchronize(s->stream));   // g is a host temporary
+    const int mx = std::max(I, ld);
+    dim3 gv((mx + 255) / 256);
+    hipLaunchKernelGGL(k_fill, dim3((I + 255) / 256), dim3(256), 0, s->stream, s->dx, 1.0 / I, I);
+    hipLaunchKernelGGL(k_fill, dim3((I + 255) / 256), dim3(256), 0, s->stream, s->u, 0.0, I);
+    hipLaunchKernelGGL(k_fill, dim3((I + 255) / 256), dim3(256), 0, s->stream, s->a, 1.0, I);
+    HIP_CHECK(hipMemsetAsync(s->b, 0, sizeof(double) * 7 * (size_t)ld, s->stream));
+    hipLaunchKernelGGL(k_fill, dim3((J + 255) / 256), dim3(256), 0, s->stream, s->dy, 1.0 / J, J);
+    hipLaunchKernelGGL(k_fill, dim3((J + 255) / 256), dim3(256), 0, s->stream, s->q, gs / I, J);
+    hipLaunchKernelGGL(k_fill, dim3((J + 255) / 256), dim3(256), 0, s->stream, s->b, 1.0, J);
+    HIP_CHECK(hipMemsetAsync(s->flags, 0, sizeof(int) * (MAX_BATCH + 1), s->stream));
+
+    const double f = exp(-log(cfg->epsilon) / S);
+    double eps_i = cfg->epsilon0 * f;
+    double gap = INFINITY;
+    spadot_ot_info rep;
+    memset(&rep, 0, sizeof(rep));
+    for (int e = 0; e <= S; e++) {
+        hipLaunchKernelGGL(k_stage_begin, gv, dim3(256), 0, s->stream, s->a, s->b, s->old_a, s->old_b,
+                           s->u, s->v, s->adx, s->w, s->dx, s->dy, eps_i, I, J, ld);
+        eps_i = eps_i / f;
+        IterParams P{eps_i, cfg->tau, cfg->lambda1, cfg->lambda2, cfg->lambda1 / (cfg->lambda1 + eps_i),
+                     cfg->lambda2 / (cfg->lambda2 + eps_i)};
+        const double thr = (e == S) ? cfg->tolerance : 1e-6;
+        build_K(s, eps_i, nullptr);
+        if (e == S) sum_kbar(s, s->C, eps_i, true);   // only the last stage's gap needs sum(Kbar)
+        gap = process_stage(s, P, e == S, cfg->batch_size, thr, 0, cfg->max_iter, nullptr,
+                            &rep.stage_iters[e], &rep.gap_checks);
+    }
+    HIP_CHECK(hipMemcpyAsync(s->h_flags, s->flags + MAX_BATCH, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    HIP_CHECK(hipStreamSynchronize(s->stream));
+    rep.absorbs = s->h_flags[0];
+    rep.gap = gap;
+    if (info) *info = rep;
+    return std::isnan(gap) ? 1 : 0;
+}
+
+int spadot_ot_plan_dev(spadot_ot_solver *s, void *plan_dev, int dtype, int ldp) {
+    if (!s || !plan_dev || ldp < s->J) return -22;
+    dim3 g((s->J + 255) / 256, (unsigned)std::min(s->I, 8192));
+    const double sc = 1.0 / s->J;
+    if (s->storage == SPADOT_F64 && dtype == SPADOT_F64)
+        hipLaunchKernelGGL((k_plan<double, double>), g, dim3(256), 0, s->stream, (const double *)s->K, s->a, s->b, sc, (double *)plan_dev, s->I, s->J, s->ld, ldp);
+    else if (s->storage == SPADOT_F64 && dtype == SPADOT_F32)
+        hipLaunchKernelGGL((k_plan<double, float>), g, dim3(256), 0, s->stream, (const double *)s->K, s->a, s->b, sc, (float *)plan_dev, s->I, s->J, s->ld, ldp);
+    else if (s->storage == SPADOT_F32 && dtype == SPADOT_F64)
+        hipLaunchKernelGGL((k_plan<float, double>), g, dim3(256), 0, s->stream, (const float *)s->K, s->a, s->b, sc, (double *)plan_dev, s->I, s->J, s->ld, ldp);
+    else if (s->storage == SPADOT_F32 && dtype == SPADOT_F32)
+        hipLaunchKernelGGL((k_plan<float, float>), g, dim3(256), 0, s->stream, (const float *)s->K, s->a, s->b, sc, (float *)plan_dev, s->I, s->J, s->ld, ldp);
+    else
+        return -22;
+    return 0;
+}
+
+int spadot_ot_plan_host(spadot_ot_solver *s, double *plan_host) {
+    if (!s || !plan_host) return -22;
+    double *tmp = (double *)dmalloc(sizeof(double) * (size_t)s->I * s->J);
+    int rc = spadot_ot_plan_dev(s, tmp, SPADOT_F64, s->J);
+    if (rc == 0)
+        HIP_CHECK(hipMemcpyAsync(plan_host, tmp, sizeof(double) * (size_t)s->I * s->J, hipMemcpyDeviceToHost, s->stream));
+    HIP_CHECK(hipStreamSynchronize(s->stream));
+    HIP_CHECK(hipFree(tmp));
+    return rc;
+}
+
+// rowsum_i = a_i * sum_j K_ij b_j / J  == (row pass with weights b) -- reuses k_gap_rows' rs slot
+int spadot_ot_plan_rowsums_host(spadot_ot_solver *s, double *rowsums_host) {
+    if (!s || !rowsums_host) return -22;
+    // dy-weighted row sums with dy := 1/J are exactly the plan's row sums
+    hipLaunchKernelGGL(k_fill, dim3((s->J + 255) / 256), dim3(256), 0, s->stream, s->tcol, 1.0 / s->J, s->J);
+    dim3 g((s->I + ROW_WAVES - 1) / ROW_WAVES);
+    if (s->storage == SPADOT_F32)
+        hipLaunchKernelGGL((k_gap_rows<float, true>), g, dim3(256), 0, s->stream, (const float *)s->K, (const float *)nullptr, s->a, s->b, s->tcol, (float *)nullptr, s->rt, s->I, s->J, s->ld);
+    else
+        hipLaunchKernelGGL((k_gap_rows<double, true>), g, dim3(256), 0, s->stream, (const double *)s->K, (const double *)nullptr, s->a, s->b, s->tcol, (double *)nullptr, s->rt, s->I, s->J, s->ld);
+    download_vec(s, rowsums_host, s->rt, s->I);
+    HIP_CHECK(hipStreamSynchronize(s->stream));
+    return 0;
+}
+
+int spadot_ot_run_iterations(spadot_ot_solver *s, const spadot_ot_config *cfg, double eps_stage,
+                             int iters, float *ms_out) {
+    if (!s || !cfg || iters < 0) return -22;
+    IterParams P{eps_stage, cfg->tau, cfg->lambda1, cfg->lambda2, cfg->lambda1 / (cfg->lambda1 + eps_stage),
+                 cfg->lambda2 / (cfg->lambda2 + eps_stage)};
+    HIP_CHECK(hipEventRecord(s->ev0, s->stream));
+    run_iterations(s, P, iters);
+    HIP_CHECK(hipEventRecord(s->ev1, s->stream));
+    if (ms_out) {
+        HIP_CHECK(hipEventSynchronize(s->ev1));
+        HIP_CHECK(hipEventElapsedTime(ms_out, s->ev0, s->ev1));
+    }
+    return 0;
+}
+
+// Per-kernel live timing: each kernel of one scaling iteration launched `reps` times back to back
+// between two HIP events on the solver's stream.  ms_out[0..3] = row pass, column pass, column
+// finalise, tau-absorb pair (flag clear => early exit) -- average milliseconds per launch.
+int spadot_ot_time_kernels(spadot_ot_solver *s, const spadot_ot_config *cfg, double eps_stage, int reps,
+                           float *ms_out) {
+    if (!s || !cfg || !ms_out || reps < 1) return -22;
+    IterParams P{eps_stage, cfg->tau, cfg->lambda1, cfg->lambda2, cfg->lambda1 / (cfg->lambda1 + eps_stage),
+                 cfg->lambda2 / (cfg->lambda2 + eps_stage)};
+    const int I = s->I, J = s->J, ld = s->ld;
+    const int V = s->storage == SPADOT_F32 ? 4 : 2;
+    HIP_CHECK(hipMemsetAsync(s->flags, 0, sizeof(int) * MAX_BATCH, s->stream));
+    int *flag = s->flags;
+    for (int which = 0; which < 4; which++) {
+        for (int phase = 0; phase < 2; phase++) {          // phase 0 = untimed warm-up
+            const int n = phase == 0 ? 2 : reps;
+            if (phase == 1) HIP_CHECK(hipEventRecord(s->ev0, s->stream));
+            for (int r = 0; r < n; r++) {
+                if (which == 0) {
+                    if (s->storage == SPADOT_F32)
+                        hipLaunchKernelGGL(k_row_pass<float>, dim3((I + ROW_WAVES - 1) / ROW_WAVES), dim3(256), 0, s->stream, (const float *)s->K, s->w, s->a, s->old_a, s->adx, s->p, s->dx, s->u, P.al1, 1.0 / (P.l1 + P.eps), P.tau, I, ld, flag);
+                    else
+                        hipLaunchKernelGGL(k_row_pass<double>, dim3((I + ROW_WAVES - 1) / ROW_WAVES), dim3(256), 0, s->stream, (const double *)s->K, s->w, s->a, s->old_a, s->adx, s->p, s->dx, s->u, P.al1, 1.0 / (P.l1 + P.eps), P.tau, I, ld, flag);
+                } else if (which == 1) {
+                    if (s->storage == SPADOT_F32)
+                        hipLaunchKernelGGL(k_col_pass<float>, dim3((ld + 256 * V - 1) / (256 * V), s->nchunk), dim3(256), 0, s->stream, (const float *)s->K, s->adx, s->part, I, ld, s->rows_per_chunk);
+                    else
+                        hipLaunchKernelGGL(k_col_pass<double>, dim3((ld + 256 * V - 1) / (256 * V), s->nchunk), dim3(256), 0, s->stream, (const double *)s->K, s->adx, s->part, I, ld, s->rows_per_chunk);
+                } else if (which == 2) {
+                    hipLaunchKernelGGL(k_col_fin, dim3((ld + 255) / 256), dim3(256), 0, s->stream, s->part, s->nchunk, s->b, s->old_b, s->w, s->q, s->dy, s->v, P.al2, 1.0 / (P.l2 + P.eps), P.tau, J, ld, flag, (double *)nullptr, 0);
+                } else {
+                    const int mx = std::max(I, J);
+                    hipLaunchKernelGGL(k_absorb_vec, dim3((mx + 255) / 256), dim3(256), 0, s->stream, s->a, s->b, s->u, s->v, s->adx, s->w, s->dx, s->dy, P.eps, I, J, s->flags + MAX_BATCH - 1, s->flags + MAX_BATCH);
+                    build_K(s, P.eps, s->flags + MAX_BATCH - 1);
+                }
+            }
+            if (phase == 1) {
+                HIP_CHECK(hipEventRecord(s->ev1, s->stream));
+                HIP_CHECK(hipEventSynchronize(s->ev1));
+                float ms = 0.f;
+                HIP_CHECK(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+                ms_out[which] = ms / reps;
+            }
+        }
+    }
+    return 0;
+}
+
+// ============================================================================================
+// PART A: libot.so-compatible entry points (host pointers).  Each call builds a temporary device
+// problem, runs the same kernels, and writes the mutated arrays back.
+// ============================================================================================
+}  // extern "C"
+
+namespace {
+struct Tmp {
+    spadot_ot_solver *s = nullptr;
+    Tmp(int m, int n, int storage) {
+        if (spadot_ot_create(&s, m, n, storage, nullptr) != 0) {
+            fprintf(stderr, "libspadot_ot: cannot create a %d x %d device problem\n", m, n);
+            abort();
+        }
+    }
+    ~Tmp() { spadot_ot_destroy(s); }
+};
+
+// float-vector helpers for the *_float entry points (vectors are widened to fp64 on the host)
+std::vector<double> widen(const float *x, int n) {
+    std::vector<double> o(n);
+    for (int i = 0; i < n; i++) o[i] = x[i];
+    return o;
+}
+
+template <typename T>
+void compat_update_k(T *K, T *K_, T *C, const double *u, const double *v, double eps, int m, int n) {
+    Tmp t(m, n, std::is_same<T, float>::value ? SPADOT_F32 : SPADOT_F64);
+    spadot_ot_solver *s = t.s;
+    upload_mat<T>(s, s->C, C);
+    upload_vec(s, s->u, u, m);
+    upload_vec(s, s->v, v, n);
+    void *kb = dmalloc((size_t)m * s->ld * sizeof(T));
+    constexpr int V = Vec<T>::N;
+    hipLaunchKernelGGL(k_build_Kbar<T>, grid_cols(s, V), dim3(256), 0, s->stream, (T *)kb, (const T *)s->C,
+                       eps, m, n, s->ld);
+    launch_build_K<T>(s, eps, nullptr);
+    download_mat<T>(s, K_, kb);
+    download_mat<T>(s, K, s->K);
+    HIP_CHECK(hipStreamSynchronize(s->stream));
+    HIP_CHECK(hipFree(kb));
+}
+
+template <typename T>
+void compat_update_R(T *R, T *K, const double *a, const double *b, int m, int n) {
+    Tmp t(m, n, std::is_same<T, float>::value ? SPADOT_F32 : SPADOT_F64);
+    spadot_ot_solver *s = t.s;
+    upload_mat<T>(s, s->K, K);
+    upload_vec(s, s->a, a, m);
+    upload_vec(s, s->b, b, n);
+    hipLaunchKernelGGL(k_fill, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->dy, 0.0, n);
+    hipLaunchKernelGGL((k_gap_rows<T, true>), dim3((m + ROW_WAVES - 1) / ROW_WAVES), dim3(256), 0, s->stream,
+                       (const T *)s->K, (const T *)nullptr, s->a, s->b, s->dy, (T *)s->C, s->rt, m, n, s->ld);
+    download_mat<T>(s, R, s->C);
+    HIP_CHECK(hipStreamSynchronize(s->stream));
+}
+
+// which: 0 = gap, 1 = primal, 2 = dual.  R given as a matrix; a, b are the (un-stabilised) scalings.
+template <typename T>
+double compat_gap(int which, T *C, T *Kbar, T *R, const double *dx, const double *dy, const double *p,
+                  const double *q, const double *a, const double *b, double eps, double l1, double l2,
+                  int m, int n) {
+    Tmp t(m, n, std::is_same<T, float>::value ? SPADOT_F32 : SPADOT_F64);
+    spadot_ot_solver *s = t.s;
+    constexpr int V = Vec<T>::N;
+    upload_mat<T>(s, s->C, C);
+    upload_mat<T>(s, s->K, Kbar);                 // K slot holds Kbar just long enough to sum it
+    sum_kbar(s, s->K, eps, false);
+    upload_mat<T>(s, s->K, R);                    // ... then holds R
+    upload_vec(s, s->dx, dx, m); upload_vec(s, s->dy, dy, n);
+    upload_vec(s, s->p, p, m);   upload_vec(s, s->q, q, n);
+    upload_vec(s, s->a, a, m);   upload_vec(s, s->b, b, n);
+    hipLaunchKernelGGL((k_gap_rows<T, false>), dim3((m + ROW_WAVES - 1) / ROW_WAVES), dim3(256), 0, s->stream,
+                       (const T *)s->K, (const T *)s->C, s->a, s->b, s->dy, (T *)nullptr, s->rt, m, n, s->ld);
+    // cs = R^T dx
+    hipLaunchKernelGGL(k_col_pass<T>, dim3((s->ld + 256 * V - 1) / (256 * V), s->nchunk), dim3(256), 0,
+                       s->stream, (const T *)s->K, s->dx, s->part, m, s->ld, s->rows_per_chunk);
+    hipLaunchKernelGGL(k_col_fin, dim3((s->ld + 255) / 256), dim3(256), 0, s->stream, s->part, s->nchunk,
+                       (double *)nullptr, (double *)nullptr, (double *)nullptr, (const double *)nullptr,
+                       (const double *)nullptr, (const double *)nullptr, 0.0, 0.0, 0.0, n, s->ld,
+                       (int *)nullptr, s->tcol, 1);
+    hipLaunchKernelGGL(k_gap_fin, dim3(1), dim3(1024), 0, s->stream, s->rt, s->tcol, s->a, s->b, s->u, s->v,
+                       s->p, s->q, s->dx, s->dy, eps, l1, l2, m, n, 0, 0, s->scal);
+    read_gap(s);
+    return s->h_scal[which];
+}
+}  // namespace
+
+extern "C" {
+
+void update_k_double(double *K, double *K_, double *C, double *u, double *v, double epsilon, int m, int n) {
+    compat_update_k<double>(K, K_, C, u, v, epsilon, m, n);
+}
+void update_k_float(float *K, float *K_, float *C, float *u, float *v, float epsilon, int m, int n) {
+    auto uu = widen(u, m), vv = widen(v, n);
+    compat_update_k<float>(K, K_, C, uu.data(), vv.data(), (double)epsilon, m, n);
+}
+void update_R_double(double *R, double *K, double *a, double *b, int m, int n) {
+    compat_update_R<double>(R, K, a, b, m, n);
+}
+void update_R_float(float *R, float *K, float *a, float *b, int m, int n) {
+    auto aa = widen(a, m), bb = widen(b, n);
+    compat_update_R<float>(R, K, aa.data(), bb.data(), m, n);
+}
+
+double primal_double(double *C, double *K, double *R, double *dx, double *dy, double *p, double *q,
+                     double *a, double *b, double epsilon, double lambda1, double lambda2, int m, int n) {
+    return compat_gap<double>(1, C, K, R, dx, dy, p, q, a, b, epsilon, lambda1, lambda2, m, n);
+}
+double dual_double(double *C, double *K, double *R, double *dx, double *dy, double *p, double *q,
+                   double *a, double *b, double epsilon, double lambda1, double lambda2, int m, int n) {
+    return compat_gap<double>(2, C, K, R, dx, dy, p, q, a, b, epsilon, lambda1, lambda2, m, n);
+}
+double compute_duality_gap_double(double *C, double *K, double *R, double *dx, double *dy, double *p,
+                                  double *q, double *a, double *b, double epsilon, double lambda1,
+                                  double lambda2, int m, int n) {
+    return compat_gap<double>(0, C, K, R, dx, dy, p, q, a, b, epsilon, lambda1, lambda2, m, n);
+}
+#define FLOAT_GAP(which)                                                                              \
+    auto dx_ = widen(dx, m), dy_ = widen(dy, n), p_ = widen(p, m), q_ = widen(q, n), a_ = widen(a, m), \
+         b_ = widen(b, n);                                                                            \
+    return (float)compat_gap<float>(which, C, K, R, dx_.data(), dy_.data(), p_.data(), q_.data(),     \
+                                    a_.data(), b_.data(), (double)epsilon, (double)lambda1,           \
+                                    (double)lambda2, m, n)
+float primal_float(float *C, float *K, float *R, float *dx, float *dy, float *p, float *q, float *a,
+                   float *b, float epsilon, float lambda1, float lambda2, int m, int n) { FLOAT_GAP(1); }
+float dual_float(float *C, float *K, float *R, float *dx, float *dy, float *p, float *q, float *a,
+                 float *b, float epsilon, float lambda1, float lambda2, int m, int n) { FLOAT_GAP(2); }
+float compute_duality_gap_float(float *C, float *K, float *R, float *dx, float *dy, float *p, float *q,
+                                float *a, float *b, float epsilon, float lambda1, float lambda2, int m,
+                                int n) { FLOAT_GAP(0); }
+#undef FLOAT_GAP
+
+float dummy_float(float *, float *, float *, float *, float *, float *, float *, float *, float *, float,
+                  float, float, int, int) { return 0; }
+double dummy_double(double *, double *, double *, double *, double *, double *, double *, double *,
+                    double *, double, double, double, int, int) { return 0; }
+
+}  // extern "C"
+
+namespace {
+// shared upload/download for step1_process_double / update_process_double
+void compat_load_state(spadot_ot_solver *s, double *a, double *b, double *old_a, double *old_b, double *K,
+                       double *C, double *dx, double *dy, double *p, double *q, double *u, double *v) {
+    const int m = s->I, n = s->J;
+    upload_mat<double>(s, s->C, C);
+    upload_mat<double>(s, s->K, K);
+    upload_vec(s, s->a, a, m); upload_vec(s, s->old_a, old_a, m); upload_vec(s, s->u, u, m);
+    upload_vec(s, s->p, p, m); upload_vec(s, s->dx, dx, m);
+    upload_vec(s, s->b, b, n); upload_vec(s, s->old_b, old_b, n); upload_vec(s, s->v, v, n);
+    upload_vec(s, s->q, q, n); upload_vec(s, s->dy, dy, n);
+    const int mx = std::max(m, s->ld);
+    hipLaunchKernelGGL(k_prep_vec, dim3((mx + 255) / 256), dim3(256), 0, s->stream, s->a, s->b, s->dx, s->dy,
+                       s->adx, s->w, m, n, s->ld);
+}
+void compat_store_state(spadot_ot_solver *s, double *a, double *b, double *old_a, double *old_b, double *K,
+                        double *u, double *v) {
+    const int m = s->I, n = s->J;
+    download_mat<double>(s, K, s->K);
+    download_vec(s, a, s->a, m); download_vec(s, old_a, s->old_a, m); download_vec(s, u, s->u, m);
+    download_vec(s, b, s->b, n); download_vec(s, old_b, s->old_b, n); download_vec(s, v, s->v, n);
+}
+}  // namespace
+
+extern "C" {
+
+int step1_process_double(double *a, double *b, double *old_a, double *old_b, double *K, double *C,
+                         double *dx, double *dy, double *p, double *q, double *u, double *v,
+                         int cur_iter, int max_iter, int iters, double tau, double lambda1,
+                         double lambda2, double alpha1, double alpha2, double epsilon, int m, int n) {
+    Tmp t(m, n, SPADOT_F64);
+    spadot_ot_solver *s = t.s;
+    compat_load_state(s, a, b, old_a, old_b, K, C, dx, dy, p, q, u, v);
+    IterParams P{epsilon, tau, lambda1, lambda2, alpha1, alpha2};
+    int run = iters, ret = cur_iter + iters;
+    if (iters > 0 && cur_iter + iters >= max_iter) {
+        run = std::max(1, std::min(iters, max_iter - cur_iter));
+        ret = -1;
+    }
+    run_iterations(s, P, run);
+    compat_store_state(s, a, b, old_a, old_b, K, u, v);
+    HIP_CHECK(hipStreamSynchronize(s->stream));
+    if (ret == -1) printf("Reached max_iter with duality gap still above threshold. Returning");
+    return ret;
+}
+
+double update_process_double(double *R, double *a, double *b, double *old_a, double *old_b, double *K,
+                             double *_K, double *C, double *dx, double *dy, double *p, double *q,
+                             double *u, double *v, int epsilon_scalings, int cur_epsilon_scaling,
+                             int batch_size, double epsilon, double threshold, double tau,
+                             double lambda1, double lambda2, double alpha1, double alpha2,
+                             int cur_iter, int max_iter, int m, int n) {
+    Tmp t(m, n, SPADOT_F64);
+    spadot_ot_solver *s = t.s;
+    const bool last = (cur_epsilon_scaling == epsilon_scalings);
+    void *Rdev = nullptr;
+    if (last) {
+        // sum(_K) from the caller's matrix: the K slot is free until the state is loaded
+        upload_mat<double>(s, s->K, _K);
+        sum_kbar(s, s->K, epsilon, false);
+        Rdev = dmalloc((size_t)m * s->ld * sizeof(double));
+    }
+    compat_load_state(s, a, b, old_a, old_b, K, C, dx, dy, p, q, u, v);
+    IterParams P{epsilon, tau, lambda1, lambda2, alpha1, alpha2};
+    const double gap = process_stage(s, P, last, batch_size, threshold, cur_iter, max_iter, Rdev, nullptr, nullptr);
+    compat_store_state(s, a, b, old_a, old_b, K, u, v);
+    if (last) download_mat<double>(s, R, Rdev);
+    HIP_CHECK(hipStreamSynchronize(s->stream));
+    if (Rdev) HIP_CHECK(hipFree(Rdev));
+    return gap;
+}
+
+}  // extern "C"

@@ -1,0 +1,173 @@
+"""Device-resident unbalanced-OT solver: thin Python handle over include/spadot_ot.h part B.
+
+Replaces the per-stage numpy/ctypes loop of the reference
+(/root/reference/SpaDOT/utils/OT_loss/ot_solvers.py:164-449) with one C call that keeps the
+cost matrix, the kernel matrix and the scalings in HBM for all six epsilon stages.
+torch is used only to own device memory and the stream.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from ._lib import OTConfig, OTInfo, ot_lib
+
+F64, F32 = 0, 1
+_TORCH_DT = {F64: torch.float64, F32: torch.float32}
+
+# keys of ot_config the solver reads (config.yaml:39-57 / ot_solvers.py:164-179)
+CONFIG_KEYS = ("lambda1", "lambda2", "epsilon", "epsilon0", "tolerance", "tau", "batch_size", "max_iter")
+
+
+def make_config(cfg):
+    c = OTConfig()
+    c.lambda1 = float(cfg["lambda1"]); c.lambda2 = float(cfg["lambda2"])
+    c.epsilon = float(cfg["epsilon"]); c.epsilon0 = float(cfg["epsilon0"])
+    c.tolerance = float(cfg["tolerance"]); c.tau = float(cfg["tau"])
+    c.batch_size = int(cfg["batch_size"]); c.max_iter = int(cfg["max_iter"])
+    return c
+
+
+class OTSolver:
+    """One I x J problem resident on `device`.  storage: 'f64' (reference arithmetic) or 'f32'
+    (fp32 cost/kernel matrices in HBM, fp64 scalings and accumulations)."""
+
+    def __init__(self, I, J, storage="f64", device="cuda:0", stream=None):
+        self.lib = ot_lib()
+        self.I, self.J = int(I), int(J)
+        self.storage = {"f64": F64, "f32": F32}[storage]
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("OTSolver needs a HIP device (torch device type 'cuda'); there is no CPU path")
+        torch.cuda.set_device(self.device)
+        self._stream = stream if stream is not None else torch.cuda.current_stream(self.device)
+        h = ctypes.c_void_p()
+        rc = self.lib.spadot_ot_create(ctypes.byref(h), self.I, self.J, self.storage,
+                                       ctypes.c_void_p(self._stream.cuda_stream))
+        if rc != 0 or not h:
+            raise RuntimeError(f"spadot_ot_create({I}, {J}) failed with {rc}")
+        self.h = h
+        self.ld = self.lib.spadot_ot_ld(self.h)
+        self.info = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.spadot_ot_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- cost ----
+    def set_cost(self, C):
+        """C: (I, J) numpy array or torch tensor (any device); row-major."""
+        if isinstance(C, np.ndarray):
+            C = np.ascontiguousarray(C, dtype=np.float64)
+            assert C.shape == (self.I, self.J)
+            rc = self.lib.spadot_ot_set_cost_host(self.h, C.ctypes.data_as(ctypes.c_void_p))
+        else:
+            C = C.to(self.device)
+            if C.dtype not in (torch.float64, torch.float32):
+                C = C.to(torch.float64)
+            C = C.contiguous()
+            assert tuple(C.shape) == (self.I, self.J)
+            dt = F64 if C.dtype == torch.float64 else F32
+            self._stream.wait_stream(torch.cuda.current_stream(self.device))
+            rc = self.lib.spadot_ot_set_cost_dev(self.h, ctypes.c_void_p(C.data_ptr()), dt, self.J)
+            self._keep = C  # alive until the conversion kernel has run
+        if rc != 0:
+            raise RuntimeError(f"set_cost failed with {rc}")
+
+    def set_cost_from_latents(self, x, y, divide_by_median=True):
+        """C = sqeuclidean(x, y) [/ median] computed on the device (ot_solvers.py:101-103)."""
+        x = torch.as_tensor(x).to(self.device, torch.float64).contiguous()
+        y = torch.as_tensor(y).to(self.device, torch.float64).contiguous()
+        assert x.shape[0] == self.I and y.shape[0] == self.J and x.shape[1] == y.shape[1]
+        self._stream.wait_stream(torch.cuda.current_stream(self.device))
+        rc = self.lib.spadot_ot_set_cost_from_latents_dev(
+            self.h, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()), int(x.shape[1]),
+            1 if divide_by_median else 0)
+        if rc != 0:
+            raise RuntimeError(f"set_cost_from_latents failed with {rc}")
+
+    # ---- solve ----
+    def solve(self, cfg, G=None):
+        """One whole solve.  Returns the OTInfo; raises like ot_solvers.py:446-447 on a NaN gap."""
+        c = make_config(cfg)
+        info = OTInfo()
+        gp = None
+        if G is not None:
+            g = np.ascontiguousarray(np.asarray(G, dtype=np.float64))
+            assert g.shape == (self.I,)
+            gp = g.ctypes.data_as(ctypes.c_void_p)
+        rc = self.lib.spadot_ot_solve(self.h, gp, ctypes.byref(c), ctypes.byref(info))
+        if rc < 0:
+            raise RuntimeError(f"spadot_ot_solve failed with {rc}")
+        self.info = info
+        if rc == 1:
+            raise RuntimeError("Overflow encountered in duality gap computation, please report this incident")
+        return info
+
+    def plan(self, out="numpy", dtype=None):
+        """Transport plan R/J.  out='numpy' -> fp64 ndarray (what the reference returns);
+        out='torch' -> device tensor in `dtype` (default: storage dtype), no host copy."""
+        if out == "numpy":
+            P = np.empty((self.I, self.J), dtype=np.float64)
+            rc = self.lib.spadot_ot_plan_host(self.h, P.ctypes.data_as(ctypes.c_void_p))
+            if rc != 0:
+                raise RuntimeError(f"plan_host failed with {rc}")
+            return P
+        dt = self.storage if dtype is None else {torch.float64: F64, torch.float32: F32}[dtype]
+        P = torch.empty((self.I, self.J), dtype=_TORCH_DT[dt], device=self.device)
+        rc = self.lib.spadot_ot_plan_dev(self.h, ctypes.c_void_p(P.data_ptr()), dt, self.J)
+        if rc != 0:
+            raise RuntimeError(f"plan_dev failed with {rc}")
+        torch.cuda.current_stream(self.device).wait_stream(self._stream)
+        return P
+
+    def plan_rowsums(self):
+        r = np.empty(self.I, dtype=np.float64)
+        rc = self.lib.spadot_ot_plan_rowsums_host(self.h, r.ctypes.data_as(ctypes.c_void_p))
+        if rc != 0:
+            raise RuntimeError(f"plan_rowsums failed with {rc}")
+        return r
+
+    def vector(self, name):
+        """Copy of a state vector ('a','b','u','v','old_a','old_b') as numpy fp64."""
+        idx = {"a": 0, "b": 1, "u": 2, "v": 3, "old_a": 4, "old_b": 5}[name]
+        n = self.I if name in ("a", "u", "old_a") else self.J
+        out = np.empty(n, dtype=np.float64)
+        rc = self.lib.spadot_ot_vector_host(self.h, idx, out.ctypes.data_as(ctypes.c_void_p))
+        if rc != 0:
+            raise RuntimeError(f"vector_host failed with {rc}")
+        return out
+
+    def matrix(self, name):
+        """Copy of the cost ('C') or kernel ('K') matrix as an (I, J) numpy fp64 array."""
+        out = np.empty((self.I, self.J), dtype=np.float64)
+        rc = self.lib.spadot_ot_matrix_host(self.h, {"C": 0, "K": 1}[name], out.ctypes.data_as(ctypes.c_void_p))
+        if rc != 0:
+            raise RuntimeError(f"matrix_host failed with {rc}")
+        return out
+
+    def run_iterations(self, cfg, eps_stage, iters, timed=True):
+        """Benchmark hook: `iters` scaling iterations, no checks.  Returns HIP-event ms (or None)."""
+        c = make_config(cfg)
+        ms = ctypes.c_float(0.0)
+        rc = self.lib.spadot_ot_run_iterations(self.h, ctypes.byref(c), float(eps_stage), int(iters),
+                                               ctypes.byref(ms) if timed else None)
+        if rc != 0:
+            raise RuntimeError(f"run_iterations failed with {rc}")
+        return ms.value if timed else None
+
+    def time_kernels(self, cfg, eps_stage, reps=20):
+        """Average HIP-event milliseconds per launch of each kernel of one scaling iteration."""
+        c = make_config(cfg)
+        ms = (ctypes.c_float * 4)()
+        rc = self.lib.spadot_ot_time_kernels(self.h, ctypes.byref(c), float(eps_stage), int(reps), ms)
+        if rc != 0:
+            raise RuntimeError(f"time_kernels failed with {rc}")
+        return {"row_pass": ms[0], "col_pass": ms[1], "col_fin": ms[2], "absorb_idle": ms[3]}
