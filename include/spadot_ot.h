@@ -112,6 +112,9 @@ void spadot_ot_destroy(spadot_ot_solver *s);
 /* Leading dimension (elements) of the solver's internal I x ld matrices, and raw device views of
  * its state for zero-copy consumers/tests.  which: 0=C 1=K ; vectors: 0=a 1=b 2=u 3=v 4=old_a 5=old_b */
 int spadot_ot_ld(const spadot_ot_solver *s);
+/* Fused single-sweep geometry: out[4] = {vectors per thread, rows per group, workgroups, rows per
+ * workgroup}; all 0 when the two-sweep kernels are in use. */
+void spadot_ot_fused_geometry(const spadot_ot_solver *s, int *out);
 void *spadot_ot_matrix_dev(spadot_ot_solver *s, int which);
 double *spadot_ot_vector_dev(spadot_ot_solver *s, int which);
 /* Host copy of one state vector (I or J doubles), synchronises the solver's stream. */
@@ -146,8 +149,9 @@ int spadot_ot_run_iterations(spadot_ot_solver *s, const spadot_ot_config *cfg, d
                              int iters, float *ms_out);
 
 /* Per-kernel live timing for the roofline: each kernel of one scaling iteration launched `reps` times
- * between two HIP events on the solver's stream.  ms_out[4] = average ms per launch of
- * {row pass, column pass, column finalise, idle tau-absorb pair}. */
+ * between two HIP events on the solver's stream.  ms_out[6] = average ms per launch of
+ * {row pass, column pass, column finalise, idle tau-absorb pair, fused single-sweep pass, fused
+ * column finalise}; the last two are 0 when the shape does not admit the fused path. */
 int spadot_ot_time_kernels(spadot_ot_solver *s, const spadot_ot_config *cfg, double eps_stage, int reps,
                            float *ms_out);
 

@@ -57,6 +57,8 @@ def ot_lib():
     lib.spadot_ot_destroy.restype = None
     lib.spadot_ot_ld.argtypes = [vp]
     lib.spadot_ot_ld.restype = ci
+    lib.spadot_ot_fused_geometry.argtypes = [vp, ctypes.POINTER(ci)]
+    lib.spadot_ot_fused_geometry.restype = None
     lib.spadot_ot_matrix_dev.argtypes = [vp, ci]
     lib.spadot_ot_matrix_dev.restype = vp
     lib.spadot_ot_vector_dev.argtypes = [vp, ci]

@@ -45,23 +45,26 @@ constexpr int MAX_BATCH = 64;          // max scaling iterations per convergence
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
+// 16-byte native vectors (ext_vector_type: usable as inline-asm "v" operands, unlike HIP's float4 struct)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
 template <typename T> struct Vec;
-template <> struct Vec<float>  { using type = float4;  static constexpr int N = 4; };
-template <> struct Vec<double> { using type = double2; static constexpr int N = 2; };
+template <> struct Vec<float>  { using type = f32x4; static constexpr int N = 4; };
+template <> struct Vec<double> { using type = f64x2; static constexpr int N = 2; };
 
 template <typename T> __device__ __forceinline__ void unpack(const typename Vec<T>::type &v, double *o);
-template <> __device__ __forceinline__ void unpack<float>(const float4 &v, double *o) {
+template <> __device__ __forceinline__ void unpack<float>(const f32x4 &v, double *o) {
     o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
 }
-template <> __device__ __forceinline__ void unpack<double>(const double2 &v, double *o) {
+template <> __device__ __forceinline__ void unpack<double>(const f64x2 &v, double *o) {
     o[0] = v.x; o[1] = v.y;
 }
 template <typename T> __device__ __forceinline__ typename Vec<T>::type pack(const double *o);
-template <> __device__ __forceinline__ float4 pack<float>(const double *o) {
-    return make_float4((float)o[0], (float)o[1], (float)o[2], (float)o[3]);
+template <> __device__ __forceinline__ f32x4 pack<float>(const double *o) {
+    return f32x4{(float)o[0], (float)o[1], (float)o[2], (float)o[3]};
 }
-template <> __device__ __forceinline__ double2 pack<double>(const double *o) {
-    return make_double2(o[0], o[1]);
+template <> __device__ __forceinline__ f64x2 pack<double>(const double *o) {
+    return f64x2{o[0], o[1]};
 }
 
 __device__ __forceinline__ double wave_sum(double x) {
@@ -81,6 +84,13 @@ __device__ __forceinline__ double block_sum(double x, double *sh) {
     double t = 0.0;
     for (int k = 0; k < nw; k++) t += sh[k];   // fixed order
     return t;
+}
+
+// (num/sum)^alpha * exp(-shift), the scaling update of ot_func.cpp:633-636 / :665-668, evaluated as
+// exp(alpha*log(num/sum) - shift): one log + one exp instead of pow + exp (same value to ~1e-15
+// relative; 0, inf and NaN propagate exactly as pow*exp does).
+__device__ __forceinline__ double scale_update(double num, double sum, double alpha, double shift) {
+    return exp(alpha * log(num / sum) - shift);
 }
 
 // ot_func.cpp:29-40: +-inf -> +-FLT_MAX (the float constant, for doubles too)
@@ -208,7 +218,7 @@ __global__ __launch_bounds__(256) void k_row_pass(const T *__restrict__ K,
     }
     const double s = wave_sum(acc0 + acc1);
     if (lane == 0) {
-        const double an = pow(p[row] / s, alpha1) * exp(-u[row] * inv_l1e);
+        const double an = scale_update(p[row], s, alpha1, u[row] * inv_l1e);
         old_a[row] = a[row];
         a[row] = an;
         adx[row] = an * dx[row];
@@ -280,7 +290,196 @@ __global__ __launch_bounds__(256) void k_col_fin(const double *__restrict__ part
     double t = 0.0;
     for (int c = 0; c < nchunk; c++) t += part[(size_t)c * ld + j];
     if (mode == 1) { t_out[j] = t; return; }
-    const double bn = pow(q[j] / t, alpha2) * exp(-v[j] * inv_l2e);
+    const double bn = scale_update(q[j], t, alpha2, v[j] * inv_l2e);
+    old_b[j] = b[j];
+    b[j] = bn;
+    w[j] = bn * dy[j];
+    if (bn > tau) *flag = 1;
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Fused scaling pass: ONE sweep of K per iteration instead of two.
+// A 512-thread workgroup owns a band of rows and the whole row width.  For R rows at a time the
+// band's elements sit in registers (VPT 16-byte vectors per thread per row): the workgroup
+//   1. dots them with w = b.dy (staged once in LDS)           -> s_i        (ot_func.cpp:610-619)
+//   2. lets R threads finish a_i = (p_i/s_i)^alpha1 e^{-u_i/(lambda1+eps)}   (ot_func.cpp:633-636)
+//   3. adds K_ij * a_i dx_i into per-thread fp64 column accumulators        (ot_func.cpp:643-651)
+// while the next R rows are already in flight into the second register buffer.  Column partials go
+// to part[block][j]; k_col_fin2 sums them in block order (deterministic) and updates b.
+// Algorithmic HBM bytes per launch: I*ld*sizeof(T) (+ nblk*ld*8 partials).
+// ------------------------------------------------------------------------------------------
+constexpr int FUSED_THREADS = 512;   // 8 waves = 2 per SIMD: one workgroup per CU may use 256 VGPRs
+
+template <typename T, int VPT, int R>
+struct FusedRows {
+    using VT = typename Vec<T>::type;
+    VT v[R][VPT];
+};
+
+// Unconditional loads: rows past the band re-read its last row (their a.dx weight is forced to 0) and
+// vector slots past ld re-read the row's last vector (their w entries in LDS are 0 and their column
+// accumulators are never stored), so the sweep has no divergent branches.
+template <typename T, int VPT, int R>
+__device__ __forceinline__ void fused_load(FusedRows<T, VPT, R> &buf, const T *__restrict__ K, int row0,
+                                           int row_end, int ld, int tid) {
+    constexpr int V = Vec<T>::N;
+    using VT = typename Vec<T>::type;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int row = min(row0 + r, row_end - 1);
+        const T *base = K + (size_t)row * ld;
+#pragma unroll
+        for (int k = 0; k < VPT; k++) {
+            const int j = min((tid + k * FUSED_THREADS) * V, ld - V);
+            buf.v[r][k] = *reinterpret_cast<const VT *>(base + j);
+        }
+    }
+}
+
+template <typename T, int VPT, int R>
+__device__ __forceinline__ void fused_group(FusedRows<T, VPT, R> &buf, int row0, int row_end,
+                                            const double *wl, double *red, double *arow,
+                                            double *colacc, double *__restrict__ a,
+                                            double *__restrict__ old_a, double *__restrict__ adx,
+                                            const double *__restrict__ p,
+                                            const double *__restrict__ dx,
+                                            const double *__restrict__ u, double alpha1,
+                                            double inv_l1e, double tau, int ld, int *flag) {
+    constexpr int V = Vec<T>::N;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    double s[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) s[r] = 0.0;
+#pragma unroll
+    for (int k = 0; k < VPT; k++) {
+        const int j = (tid + k * FUSED_THREADS) * V;
+        double wv[V];
+#pragma unroll
+        for (int e = 0; e < V; e++) wv[e] = wl[j + e];     // 0 beyond ld (LDS image is padded)
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            double kv[V];
+            unpack<T>(buf.v[r][k], kv);
+#pragma unroll
+            for (int e = 0; e < V; e++) s[r] = fma(kv[e], wv[e], s[r]);
+        }
+    }
+    // keep the band in its storage type across the barriers: without this the compiler keeps the
+    // widened fp64 copies of an fp32 band live for the accumulate phase (2x the registers)
+#pragma unroll
+    for (int r = 0; r < R; r++)
+#pragma unroll
+        for (int k = 0; k < VPT; k++) asm volatile("" : "+v"(buf.v[r][k]));
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        s[r] = wave_sum(s[r]);
+        if (lane == 0) red[wid * R + r] = s[r];
+    }
+    __syncthreads();
+    if (tid < R) {
+        const int row = row0 + tid;
+        double x = 0.0;
+        if (row < row_end) {
+            double t = 0.0;
+#pragma unroll
+            for (int wv = 0; wv < FUSED_THREADS / 64; wv++) t += red[wv * R + tid];
+            const double an = scale_update(p[row], t, alpha1, u[row] * inv_l1e);
+            old_a[row] = a[row];
+            a[row] = an;
+            x = an * dx[row];
+            adx[row] = x;
+            if (an > tau) *flag = 1;
+        }
+        arow[tid] = x;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const double x = arow[r];
+#pragma unroll
+        for (int k = 0; k < VPT; k++) {
+            double kv[V];
+            unpack<T>(buf.v[r][k], kv);
+#pragma unroll
+            for (int e = 0; e < V; e++) colacc[k * V + e] = fma(kv[e], x, colacc[k * V + e]);
+        }
+    }
+}
+
+template <typename T, int VPT, int R>
+__global__ __launch_bounds__(FUSED_THREADS) void k_fused_pass(
+    const T *__restrict__ K, const double *__restrict__ w, double *__restrict__ a,
+    double *__restrict__ old_a, double *__restrict__ adx, const double *__restrict__ p,
+    const double *__restrict__ dx, const double *__restrict__ u, double alpha1, double inv_l1e,
+    double tau, double *__restrict__ part, int I, int ld, int rows_per_block, int *flag) {
+    constexpr int V = Vec<T>::N;
+    extern __shared__ double smem[];
+    constexpr int WPAD = VPT * FUSED_THREADS * V;    // w image padded with zeros to the register tile
+    double *wl = smem;                       // WPAD doubles
+    double *red = smem + WPAD;               // (FUSED_THREADS/64) * R
+    double *arow = red + (FUSED_THREADS / 64) * R;   // R
+    const int tid = threadIdx.x;
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(I, r0 + rows_per_block);
+    FusedRows<T, VPT, R> bufA, bufB;
+    fused_load<T, VPT, R>(bufA, K, r0, r1, ld, tid);
+    for (int j = tid; j < WPAD; j += FUSED_THREADS) wl[j] = (j < ld) ? w[j] : 0.0;
+    double colacc[VPT * V];
+#pragma unroll
+    for (int k = 0; k < VPT * V; k++) colacc[k] = 0.0;
+    __syncthreads();
+    for (int g = r0; g < r1; g += 2 * R) {
+        fused_load<T, VPT, R>(bufB, K, g + R, r1, ld, tid);          // rows >= r1: clamped, weight 0
+        fused_group<T, VPT, R>(bufA, g, r1, wl, red, arow, colacc, a, old_a, adx, p, dx, u, alpha1,
+                               inv_l1e, tau, ld, flag);
+        if (g + R < r1) {
+            fused_load<T, VPT, R>(bufA, K, g + 2 * R, r1, ld, tid);
+            fused_group<T, VPT, R>(bufB, g + R, r1, wl, red, arow, colacc, a, old_a, adx, p, dx, u,
+                                   alpha1, inv_l1e, tau, ld, flag);
+        }
+    }
+    double *o = part + (size_t)blockIdx.x * ld;
+#pragma unroll
+    for (int k = 0; k < VPT; k++) {
+        const int j = (tid + k * FUSED_THREADS) * V;
+        if (j < ld) {
+#pragma unroll
+            for (int e = 0; e < V; e++) o[j + e] = colacc[k * V + e];
+        }
+    }
+}
+
+// Column finalise for many partial rows: 64 columns x 16 partial-groups per block; partials are
+// summed in ascending block order within a group and groups in ascending order (deterministic).
+// mode 0: b update (ot_func.cpp:657-668) ; mode 1: t_out[j] = sum only.
+__global__ __launch_bounds__(1024) void k_col_fin2(const double *__restrict__ part, int npart,
+                                                   double *__restrict__ b,
+                                                   double *__restrict__ old_b,
+                                                   double *__restrict__ w,
+                                                   const double *__restrict__ q,
+                                                   const double *__restrict__ dy,
+                                                   const double *__restrict__ v, double alpha2,
+                                                   double inv_l2e, double tau, int J, int ld,
+                                                   int *flag, double *t_out, int mode) {
+    __shared__ double sh[16][65];
+    const int cx = threadIdx.x & 63, gy = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + cx;
+    double t = 0.0;
+    if (j < ld) {
+        const int per = (npart + 15) / 16;
+        const int c0 = gy * per, c1 = min(npart, c0 + per);
+        for (int c = c0; c < c1; c++) t += part[(size_t)c * ld + j];
+    }
+    sh[gy][cx] = t;
+    __syncthreads();
+    if (gy != 0 || j >= ld) return;
+    t = 0.0;
+#pragma unroll
+    for (int g = 0; g < 16; g++) t += sh[g][cx];
+    if (j >= J) { if (mode == 0) w[j] = 0.0; else t_out[j] = 0.0; return; }
+    if (mode == 1) { t_out[j] = t; return; }
+    const double bn = scale_update(q[j], t, alpha2, v[j] * inv_l2e);
     old_b[j] = b[j];
     b[j] = bn;
     w[j] = bn * dy[j];
@@ -567,6 +766,9 @@ struct spadot_ot_solver {
     double *h_scal = nullptr;  // pinned
     int *h_flags = nullptr;    // pinned
     int nchunk = 1, rows_per_chunk = 1;
+    // fused single-sweep pass (k_fused_pass): 0 = not applicable for this shape
+    int fused_vpt = 0, fused_r = 0, fused_blocks = 0, fused_rows_per_block = 0;
+    size_t fused_lds = 0;
     double sum_kbar_eps = -1.0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     size_t elt() const { return storage == SPADOT_F32 ? 4 : 8; }
@@ -581,7 +783,11 @@ void *dmalloc(size_t bytes) {
 }
 
 dim3 grid_cols(const spadot_ot_solver *s, int V) {
-    return dim3((s->ld + 256 * V - 1) / (256 * V), (unsigned)std::min(s->I, 8192));
+    // rows are strided over gridDim.y: ~2k blocks fill the chip, and a launch that exits on a clear
+    // tau flag stays cheap
+    const int gx = (s->ld + 256 * V - 1) / (256 * V);
+    const int gy = std::max(1, std::min(s->I, 2048 / gx));
+    return dim3(gx, (unsigned)gy);
 }
 
 void require_device() {
@@ -623,9 +829,56 @@ void sum_kbar(spadot_ot_solver *s, const void *M, double eps, bool from_cost) {
 
 struct IterParams { double eps, tau, l1, l2, al1, al2; };
 
+template <typename T, int VPT, int R>
+void launch_fused(spadot_ot_solver *s, const IterParams &P, int *flag) {
+    static bool attr_set = false;
+    auto kern = k_fused_pass<T, VPT, R>;
+    if (!attr_set) {
+        HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(s->fused_blocks), dim3(FUSED_THREADS), s->fused_lds, s->stream,
+                       (const T *)s->K, s->w, s->a, s->old_a, s->adx, s->p, s->dx, s->u, P.al1,
+                       1.0 / (P.l1 + P.eps), P.tau, s->part, s->I, s->ld, s->fused_rows_per_block, flag);
+}
+
+template <typename T> void fused_pass_T(spadot_ot_solver *s, const IterParams &P, int *flag);
+#define FUSED_CASE(T, VPT, R) case VPT: launch_fused<T, VPT, R>(s, P, flag); break;
+template <> void fused_pass_T<float>(spadot_ot_solver *s, const IterParams &P, int *flag) {
+    switch (s->fused_vpt) {
+        FUSED_CASE(float, 1, 2) FUSED_CASE(float, 2, 2) FUSED_CASE(float, 3, 2) FUSED_CASE(float, 4, 2)
+        FUSED_CASE(float, 5, 2) FUSED_CASE(float, 6, 1) FUSED_CASE(float, 7, 1) FUSED_CASE(float, 8, 1)
+        default: abort();
+    }
+}
+template <> void fused_pass_T<double>(spadot_ot_solver *s, const IterParams &P, int *flag) {
+    switch (s->fused_vpt) {
+        FUSED_CASE(double, 1, 2) FUSED_CASE(double, 2, 2) FUSED_CASE(double, 3, 2) FUSED_CASE(double, 4, 2)
+        FUSED_CASE(double, 5, 2) FUSED_CASE(double, 6, 2) FUSED_CASE(double, 7, 1) FUSED_CASE(double, 8, 1)
+        FUSED_CASE(double, 9, 1) FUSED_CASE(double, 10, 1) FUSED_CASE(double, 11, 1) FUSED_CASE(double, 12, 1)
+        default: abort();
+    }
+}
+#undef FUSED_CASE
+
+void absorb_if_flagged(spadot_ot_solver *s, const IterParams &P, int *flag) {
+    const int mx = std::max(s->I, s->J);
+    hipLaunchKernelGGL(k_absorb_vec, dim3((mx + 255) / 256), dim3(256), 0, s->stream, s->a, s->b, s->u,
+                       s->v, s->adx, s->w, s->dx, s->dy, P.eps, s->I, s->J, flag, s->flags + MAX_BATCH);
+    build_K(s, P.eps, flag);
+}
+
 template <typename T> void one_iteration_T(spadot_ot_solver *s, const IterParams &P, int *flag) {
     constexpr int V = Vec<T>::N;
     const int I = s->I, J = s->J, ld = s->ld;
+    if (s->fused_vpt > 0) {
+        fused_pass_T<T>(s, P, flag);
+        hipLaunchKernelGGL(k_col_fin2, dim3((ld + 63) / 64), dim3(1024), 0, s->stream, s->part,
+                           s->fused_blocks, s->b, s->old_b, s->w, s->q, s->dy, s->v, P.al2,
+                           1.0 / (P.l2 + P.eps), P.tau, J, ld, flag, (double *)nullptr, 0);
+        absorb_if_flagged(s, P, flag);
+        return;
+    }
     hipLaunchKernelGGL(k_row_pass<T>, dim3((I + ROW_WAVES - 1) / ROW_WAVES), dim3(256), 0, s->stream,
                        (const T *)s->K, s->w, s->a, s->old_a, s->adx, s->p, s->dx, s->u, P.al1,
                        1.0 / (P.l1 + P.eps), P.tau, I, ld, flag);
@@ -634,10 +887,7 @@ template <typename T> void one_iteration_T(spadot_ot_solver *s, const IterParams
     hipLaunchKernelGGL(k_col_fin, dim3((ld + 255) / 256), dim3(256), 0, s->stream, s->part, s->nchunk,
                        s->b, s->old_b, s->w, s->q, s->dy, s->v, P.al2, 1.0 / (P.l2 + P.eps), P.tau,
                        J, ld, flag, (double *)nullptr, 0);
-    const int mx = std::max(I, J);
-    hipLaunchKernelGGL(k_absorb_vec, dim3((mx + 255) / 256), dim3(256), 0, s->stream, s->a, s->b, s->u,
-                       s->v, s->adx, s->w, s->dx, s->dy, P.eps, I, J, flag, s->flags + MAX_BATCH);
-    launch_build_K<T>(s, P.eps, flag);
+    absorb_if_flagged(s, P, flag);
 }
 
 // `iters` scaling iterations with device-side tau decisions (ot_func.cpp:726-819), no host sync.
@@ -730,6 +980,33 @@ void choose_chunks(spadot_ot_solver *s) {
     s->nchunk = (s->I + s->rows_per_chunk - 1) / s->rows_per_chunk;
 }
 
+// Fused single-sweep pass is used when a row fits the register budget of one 1024-thread workgroup
+// and w fits LDS; SPADOT_OT_NO_FUSED=1 forces the two-sweep kernels (A/B runs, fallback tests).
+void choose_fused(spadot_ot_solver *s) {
+    s->fused_vpt = 0;
+    const char *off = getenv("SPADOT_OT_NO_FUSED");
+    if (off && off[0] == '1') return;
+    const int V = s->storage == SPADOT_F32 ? 4 : 2;
+    const int vpt = (s->ld + V * FUSED_THREADS - 1) / (V * FUSED_THREADS);
+    const int max_vpt = s->storage == SPADOT_F32 ? 8 : 12;
+    if (vpt > max_vpt) return;
+    const int R = vpt <= (s->storage == SPADOT_F32 ? 5 : 6) ? 2 : 1;     // must match the FUSED_CASE table
+    const size_t lds = sizeof(double) * ((size_t)vpt * FUSED_THREADS * V + (FUSED_THREADS / 64) * R + R);
+    if (lds > 160 * 1024) return;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            cus = prop.multiProcessorCount;
+    }
+    int blocks = std::max(1, std::min(cus, (s->I + 2 * R - 1) / (2 * R)));
+    int rpb = (s->I + blocks - 1) / blocks;
+    rpb = round_up(rpb, R);
+    blocks = (s->I + rpb - 1) / rpb;
+    s->fused_vpt = vpt; s->fused_r = R; s->fused_blocks = blocks; s->fused_rows_per_block = rpb;
+    s->fused_lds = lds;
+}
+
 void upload_vec(spadot_ot_solver *s, double *dst, const double *src, int n) {
     HIP_CHECK(hipMemcpyAsync(dst, src, sizeof(double) * n, hipMemcpyHostToDevice, s->stream));
 }
@@ -762,6 +1039,7 @@ int spadot_ot_create(spadot_ot_solver **out, int I, int J, int storage, void *st
     s->I = I; s->J = J; s->storage = storage; s->stream = (hipStream_t)stream;
     s->ld = round_up(J, 64);
     choose_chunks(s);
+    choose_fused(s);
     const size_t mat = (size_t)I * s->ld * s->elt();
     s->C = dmalloc(mat);
     s->K = dmalloc(mat);
@@ -776,7 +1054,7 @@ int spadot_ot_create(spadot_ot_solver **out, int I, int J, int storage, void *st
     s->w = vj + 5 * L; s->tcol = vj + 6 * L;
     HIP_CHECK(hipMemsetAsync(vi, 0, sizeof(double) * 6 * (size_t)I, s->stream));
     HIP_CHECK(hipMemsetAsync(vj, 0, sizeof(double) * 7 * L, s->stream));
-    s->part = (double *)dmalloc(sizeof(double) * (size_t)s->nchunk * L);
+    s->part = (double *)dmalloc(sizeof(double) * (size_t)std::max(s->nchunk, s->fused_blocks) * L);
     s->rt = (double *)dmalloc(sizeof(double) * 4 * (size_t)I);
     s->scal = (double *)dmalloc(sizeof(double) * 8);
     s->flags = (int *)dmalloc(sizeof(int) * (MAX_BATCH + 1));
@@ -801,6 +1079,11 @@ void spadot_ot_destroy(spadot_ot_solver *s) {
 }
 
 int spadot_ot_ld(const spadot_ot_solver *s) { return s ? s->ld : -22; }
+
+void spadot_ot_fused_geometry(const spadot_ot_solver *s, int *out) {
+    if (!s || !out) return;
+    out[0] = s->fused_vpt; out[1] = s->fused_r; out[2] = s->fused_blocks; out[3] = s->fused_rows_per_block;
+}
 
 void *spadot_ot_matrix_dev(spadot_ot_solver *s, int which) {
     if (!s) return nullptr;
@@ -1036,7 +1319,8 @@ int spadot_ot_run_iterations(spadot_ot_solver *s, const spadot_ot_config *cfg, d
 
 // Per-kernel live timing: each kernel of one scaling iteration launched `reps` times back to back
 // between two HIP events on the solver's stream.  ms_out[0..3] = row pass, column pass, column
-// finalise, tau-absorb pair (flag clear => early exit) -- average milliseconds per launch.
+// finalise, tau-absorb pair (flag clear => early exit), and -- when the shape allows the fused
+// single-sweep path -- ms_out[4] = fused pass, ms_out[5] = its column finalise (else 0).
 int spadot_ot_time_kernels(spadot_ot_solver *s, const spadot_ot_config *cfg, double eps_stage, int reps,
                            float *ms_out) {
     if (!s || !cfg || !ms_out || reps < 1) return -22;
@@ -1046,7 +1330,9 @@ int spadot_ot_time_kernels(spadot_ot_solver *s, const spadot_ot_config *cfg, dou
     const int V = s->storage == SPADOT_F32 ? 4 : 2;
     HIP_CHECK(hipMemsetAsync(s->flags, 0, sizeof(int) * MAX_BATCH, s->stream));
     int *flag = s->flags;
-    for (int which = 0; which < 4; which++) {
+    ms_out[4] = ms_out[5] = 0.f;
+    for (int which = 0; which < 6; which++) {
+        if (which >= 4 && s->fused_vpt == 0) continue;
         for (int phase = 0; phase < 2; phase++) {          // phase 0 = untimed warm-up
             const int n = phase == 0 ? 2 : reps;
             if (phase == 1) HIP_CHECK(hipEventRecord(s->ev0, s->stream));
@@ -1063,10 +1349,13 @@ int spadot_ot_time_kernels(spadot_ot_solver *s, const spadot_ot_config *cfg, dou
                         hipLaunchKernelGGL(k_col_pass<double>, dim3((ld + 256 * V - 1) / (256 * V), s->nchunk), dim3(256), 0, s->stream, (const double *)s->K, s->adx, s->part, I, ld, s->rows_per_chunk);
                 } else if (which == 2) {
                     hipLaunchKernelGGL(k_col_fin, dim3((ld + 255) / 256), dim3(256), 0, s->stream, s->part, s->nchunk, s->b, s->old_b, s->w, s->q, s->dy, s->v, P.al2, 1.0 / (P.l2 + P.eps), P.tau, J, ld, flag, (double *)nullptr, 0);
+                } else if (which == 3) {
+                    absorb_if_flagged(s, P, s->flags + MAX_BATCH - 1);
+                } else if (which == 4) {
+                    if (s->storage == SPADOT_F32) fused_pass_T<float>(s, P, flag);
+                    else fused_pass_T<double>(s, P, flag);
                 } else {
-                    const int mx = std::max(I, J);
-                    hipLaunchKernelGGL(k_absorb_vec, dim3((mx + 255) / 256), dim3(256), 0, s->stream, s->a, s->b, s->u, s->v, s->adx, s->w, s->dx, s->dy, P.eps, I, J, s->flags + MAX_BATCH - 1, s->flags + MAX_BATCH);
-                    build_K(s, P.eps, s->flags + MAX_BATCH - 1);
+                    hipLaunchKernelGGL(k_col_fin2, dim3((ld + 63) / 64), dim3(1024), 0, s->stream, s->part, s->fused_blocks, s->b, s->old_b, s->w, s->q, s->dy, s->v, P.al2, 1.0 / (P.l2 + P.eps), P.tau, J, ld, flag, (double *)nullptr, 0);
                 }
             }
             if (phase == 1) {

@@ -166,8 +166,14 @@ class OTSolver:
     def time_kernels(self, cfg, eps_stage, reps=20):
         """Average HIP-event milliseconds per launch of each kernel of one scaling iteration."""
         c = make_config(cfg)
-        ms = (ctypes.c_float * 4)()
+        ms = (ctypes.c_float * 6)()
         rc = self.lib.spadot_ot_time_kernels(self.h, ctypes.byref(c), float(eps_stage), int(reps), ms)
         if rc != 0:
             raise RuntimeError(f"time_kernels failed with {rc}")
-        return {"row_pass": ms[0], "col_pass": ms[1], "col_fin": ms[2], "absorb_idle": ms[3]}
+        return {"row_pass": ms[0], "col_pass": ms[1], "col_fin": ms[2], "absorb_idle": ms[3],
+                "fused_pass": ms[4], "fused_col_fin": ms[5]}
+
+    def fused_geometry(self):
+        g = (ctypes.c_int * 4)()
+        self.lib.spadot_ot_fused_geometry(self.h, g)
+        return {"vpt": g[0], "rows_per_group": g[1], "workgroups": g[2], "rows_per_workgroup": g[3]}
