@@ -1,0 +1,128 @@
+/*
+ * spadot_model.h -- C-ABI of libspadot_model.so: the hand-written HIP kernels (gfx950) behind the
+ * model side of SpaDOT's training step.  All pointers are DEVICE pointers unless named *_host;
+ * `stream` is a hipStream_t passed as void*; every function returns 0 or a negative errno-style
+ * code and only ENQUEUES work (no host synchronisation).  No torch types appear here; the Python
+ * host (spadot_amd/model) passes tensor.data_ptr() values.
+ *
+ * Reference interfaces replaced (all under /root/reference/SpaDOT):
+ *   spadot_gat_*       torch_geometric GATConv's edge phase as called at model/encoder.py:56-58
+ *                      (scatter-softmax over incoming edges + weighted scatter-add)
+ *   spadot_kernel_matrix   model/svgp.py:110-125 (Kernel.forward: cdist + Gaussian/Cauchy/Quadratic)
+ *   spadot_rowdot_*    the diag(A B^T) pattern of svgp.py:80, :98 and the trace identity replacing
+ *                      the (b,m,m) tensor of svgp.py:99-101
+ *   spadot_elbo_*      the scalar reductions of svgp.py:102-104 and model/SpaDOT.py:67-77,:125-142
+ *   spadot_vae_*       model/SpaDOT.py:78-93 (reparameterisation, GAT KL, reconstruction, alignment)
+ *   spadot_kmeans_*    utils/_train_utils.py:240-253 (loss) and sklearn KMeans.predict (labels, :266-269)
+ *   spadot_adamw_*     utils/_train_utils.py:214-217 (clip_grad_norm_(0.3) + AdamW.step)
+ */
+#ifndef SPADOT_MODEL_H
+#define SPADOT_MODEL_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { SPADOT_DT_F32 = 0, SPADOT_DT_BF16 = 1, SPADOT_DT_F64 = 2 };
+enum { SPADOT_KERNEL_GAUSSIAN = 0, SPADOT_KERNEL_CAUCHY = 1, SPADOT_KERNEL_QUADRATIC = 2 };
+
+const char *spadot_model_version(void);
+
+/* ---------------------------------------------------------------- GAT edge phase
+ * Graph in CSR by TARGET node: rowptr[n+1], col[E] = source node of each incoming edge (self loops
+ * already present exactly once per node, as GATConv(add_self_loops=True) leaves them).
+ * h: [n, H*C] features after the layer's linear map (dtype = SPADOT_DT_F32 or _BF16);
+ * s_src, s_dst: [n, H] fp32 attention logits (h . att_src, h . att_dst per head).
+ *
+ * forward:  e_ij = leaky_relu(s_src[j] + s_dst[i], 0.2); alpha = softmax over incoming edges of i
+ *           (exp(e - max) / (sum + 1e-16)); agg_i = sum_j alpha_ij h_j
+ *           concat != 0: out[i, H*C] = act(agg + bias[H*C])      (act = leaky_relu(0.01) if act != 0)
+ *           concat == 0: out[i, C]   = act(mean_h agg + bias[C])
+ *           alpha_out [E, H] fp32 is kept for the backward pass.
+ */
+int spadot_gat_forward(const void *h, int dtype, const float *s_src, const float *s_dst,
+                       const int *rowptr, const int *col, const float *bias, int n, int H, int C,
+                       int concat, int act, void *out, float *alpha_out, void *stream);
+
+/* backward, target-side half: from g_out (gradient w.r.t. `out`, same shape/dtype as out) and the
+ * saved forward tensors computes
+ *   g_pre [n, H*C] (dtype) = gradient w.r.t. agg (activation and head-mean undone)
+ *   dz    [E, H] fp32      = gradient w.r.t. the pre-leaky logits s_src[j] + s_dst[i]
+ *   ds_dst[n, H] fp32      = sum over incoming edges of dz
+ */
+int spadot_gat_backward_target(const void *g_out, const void *out, const void *h, int dtype,
+                               const float *s_src, const float *s_dst, const float *alpha,
+                               const int *rowptr, const int *col, int n, int H, int C, int concat,
+                               int act, void *g_pre, float *dz, float *ds_dst, void *stream);
+
+/* backward, source-side half (no atomics): transposed CSR rowptr_t[n+1], col_t[E] = TARGET of each
+ * outgoing edge, eid_t[E] = position of that edge in the target-ordered arrays (alpha, dz).
+ *   dh[j]     = sum_{j->i} alpha_ij g_pre[i]      [n, H*C] (dtype)
+ *   ds_src[j] = sum_{j->i} dz_ij                  [n, H] fp32
+ */
+int spadot_gat_backward_source(const void *g_pre, int dtype, const float *alpha, const float *dz,
+                               const int *rowptr_t, const int *col_t, const int *eid_t, int n, int H,
+                               int C, void *dh, float *ds_src, void *stream);
+
+/* ---------------------------------------------------------------- SVGP pieces */
+
+/* K[i,j] = k(|x_i - z_j|^2 / scale), x [n,d], z [m,d], K [n,m]; dtype F32 or F64 for all three.
+ * Gaussian exp(-d2/scale); Cauchy 1/(1+d2/scale); Quadratic 1 - d2/(d2+scale)  (svgp.py:116-124). */
+int spadot_kernel_matrix(const void *x, const void *z, int n, int m, int d, double scale, int kind,
+                         int dtype, void *K, void *stream);
+
+/* Batched row-wise dot products: out[l, i] = sum_k A[l, i, k] * B[i, k]   (A [L,n,m], B [n,m]).
+ * dtype F32 or F64. */
+int spadot_rowdot_forward(const void *A, const void *B, int L, int n, int m, int dtype, void *out,
+                          void *stream);
+/* gA[l,i,k] = g[l,i] * B[i,k]   (B is a constant of the step: no gradient) */
+int spadot_rowdot_backward(const void *g, const void *B, int L, int n, int m, int dtype, void *gA,
+                           void *stream);
+
+/* ELBO scalar reductions over a [b, L] batch (row-major, L latent dims):
+ *   l3 = -0.5 * sum_{i,l} [ (ktilde_i + tr_{i,l}) / var_{i,l} + log var_{i,l} + log(2 pi)
+ *                           + (mu_{i,l} - mv_{i,l})^2 / var_{i,l} ]                (svgp.py:97-104)
+ *   ce = sum_{i,l} -0.5 * [ log(2 pi) + log var + (pv + pm^2 - 2 pm mu + mu^2) / var ]  (SpaDOT.py:125-142)
+ * out2[0] = l3, out2[1] = ce (fp64 accumulators written as `dtype`).
+ * inputs: mu, var (encoder mean / variance), mv (K_nm K_mm^-1 mu_hat), tr (trace term), pm, pv
+ * (posterior mean / variance): all [b, L]; ktilde [b]. */
+int spadot_elbo_forward(const void *mu, const void *var, const void *mv, const void *tr, const void *pm,
+                        const void *pv, const void *ktilde, int b, int L, int dtype, void *out2,
+                        void *stream);
+/* element-wise gradients given g2 = (dLoss/dl3, dLoss/dce) on the device: g_mu, g_var, g_mv, g_tr, g_pm,
+ * g_pv, each [b, L]. */
+int spadot_elbo_backward(const void *g2, const void *mu, const void *var, const void *mv, const void *tr,
+                         const void *pm, const void *pv, const void *ktilde, int b, int L, int dtype,
+                         void *g_mu, void *g_var, void *g_mv, void *g_tr, void *g_pm, void *g_pv,
+                         void *stream);
+
+/* ---------------------------------------------------------------- VAE head losses (SpaDOT.py:78-93)
+ * out1[0] = inv_scale * sum_k (y[k] - yhat[k])^2 over `count` elements (recon: inv_scale = 1/G),
+ * deterministic two-stage reduction through `scratch` (>= 2048 doubles).
+ * backward writes g_yhat[k] = -2 inv_scale (y[k] - yhat[k]) * g1[0]. */
+int spadot_sqerr_forward(const void *y, const void *yhat, long long count, double inv_scale, int dtype,
+                         double *scratch, void *out1, void *stream);
+int spadot_sqerr_backward(const void *g1, const void *y, const void *yhat, long long count,
+                          double inv_scale, int dtype, void *g_yhat, void *stream);
+
+/* ---------------------------------------------------------------- k-means glue */
+/* labels[i] = argmin_c |x_i - c_c|^2 (first minimum wins), x [n,d], centers [k,d], int32 labels.
+ * Distances are accumulated in fp64 whatever `dtype` (F32/F64) the inputs have. */
+int spadot_kmeans_assign(const void *x, const void *centers, int n, int k, int d, int dtype, int *labels,
+                         void *stream);
+
+/* ---------------------------------------------------------------- optimiser (one flat fp32 buffer)
+ * sumsq[0] = sum g^2 over `count` gradients (deterministic two-stage reduction; scratch >= 2048 doubles). */
+int spadot_grad_sumsq(const float *grad, long long count, double *scratch, float *sumsq, void *stream);
+/* clip_grad_norm_(max_norm) folded into AdamW (torch semantics: decoupled weight decay, bias
+ * correction, eps outside the sqrt):  coef = min(1, max_norm / (sqrt(sumsq) + 1e-6)); g = coef * grad;
+ * p -= lr*wd*p; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr/(1-b1^t) * m / (sqrt(v/(1-b2^t)) + eps).
+ * sumsq is read on the device (no host round trip). */
+int spadot_adamw_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
+                      const float *sumsq, long long count, double lr, double beta1, double beta2,
+                      double eps, double weight_decay, double max_norm, int step, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPADOT_MODEL_H */

@@ -165,11 +165,11 @@ def main():
     ref.zero_grad()
     loss.backward()
     for name, p in ref.named_parameters():
-        comp["grad/" + name] = p.grad.detach().numpy() if p.grad is not None else np.zeros(0)
+        comp["grad/" + name] = p.grad.detach().numpy().copy() if p.grad is not None else np.zeros(0)
     # running statistics after that ONE train-mode forward (momentum 0.1, unbiased batch variance)
     for kk, v in ref.state_dict().items():
         if "running" in kk or "num_batches" in kk:
-            comp["sd_after/" + kk] = v.detach().numpy()
+            comp["sd_after/" + kk] = v.detach().numpy().copy()   # state_dict() aliases the live buffers
     # encoder / decoder alone, train + eval
     ref.load_state_dict(sd0)
     ref.train()

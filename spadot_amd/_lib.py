@@ -87,3 +87,33 @@ def ot_lib():
     lib.spadot_ot_time_kernels.restype = ci
     lib._spadot_ready = True
     return lib
+
+
+def model_lib():
+    """libspadot_model.so with argtypes/restypes of include/spadot_model.h set."""
+    lib = _load("libspadot_model.so")
+    if getattr(lib, "_spadot_ready", False):
+        return lib
+    vp, ci, cd, ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_longlong
+    lib.spadot_model_version.restype = ctypes.c_char_p
+    sig = {
+        "spadot_gat_forward": [vp, ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp, vp],
+        "spadot_gat_backward_target": [vp, vp, vp, ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp],
+        "spadot_gat_backward_source": [vp, ci, vp, vp, vp, vp, vp, ci, ci, ci, vp, vp, vp],
+        "spadot_kernel_matrix": [vp, vp, ci, ci, ci, cd, ci, ci, vp, vp],
+        "spadot_rowdot_forward": [vp, vp, ci, ci, ci, ci, vp, vp],
+        "spadot_rowdot_backward": [vp, vp, ci, ci, ci, ci, vp, vp],
+        "spadot_elbo_forward": [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp, vp],
+        "spadot_elbo_backward": [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp],
+        "spadot_sqerr_forward": [vp, vp, ll, cd, ci, vp, vp, vp],
+        "spadot_sqerr_backward": [vp, vp, vp, ll, cd, ci, vp, vp],
+        "spadot_kmeans_assign": [vp, vp, ci, ci, ci, ci, vp, vp],
+        "spadot_grad_sumsq": [vp, ll, vp, vp, vp],
+        "spadot_adamw_step": [vp, vp, vp, vp, vp, ll, cd, cd, cd, cd, cd, cd, ci, vp],
+    }
+    for name, args in sig.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = ci
+    lib._spadot_ready = True
+    return lib

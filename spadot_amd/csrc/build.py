@@ -16,9 +16,10 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # source -> shared object
 TARGETS = {
     "ot_sinkhorn.hip": "libspadot_ot.so",
+    "model_kernels.hip": "libspadot_model.so",
 }
 
-FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", f"--offload-arch={ARCH}", "-Wno-unused-result"]
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", f"--offload-arch={ARCH}", "-Wno-unused-result", "-Wno-pass-failed"]
 
 
 def _stale(src, out, extra_deps):

@@ -1,0 +1,704 @@
+// model_kernels.hip -- hand-written HIP kernels (gfx950, wave64) for the model side of the SpaDOT
+// training step.  ABI and reference citations: include/spadot_model.h.
+//
+// GAT edge phase (the memory-bound part of the step): one 256-thread workgroup per target node,
+// wave w owns heads w, w+4, ...; the 64 lanes of a wave split the C channels of a head, so a row
+// gather h[j, head, :] is one or two coalesced wave-wide loads.  Softmax statistics are wave
+// shuffles; the weighted sum is register-accumulated in fp32; no atomics anywhere (the source-side
+// gradient uses the transposed CSR instead of scatter-add), so results are bitwise reproducible.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+
+#include "../../include/spadot_model.h"
+
+namespace {
+
+constexpr int WAVE = 64;
+constexpr float ATT_SLOPE = 0.2f;    // GATConv negative_slope
+constexpr float ACT_SLOPE = 0.01f;   // F.leaky_relu default (encoder.py:56-57)
+
+template <typename T> __device__ __forceinline__ float ld(const T *p);
+template <> __device__ __forceinline__ float ld<float>(const float *p) { return *p; }
+template <> __device__ __forceinline__ float ld<__bf16>(const __bf16 *p) { return (float)*p; }
+template <typename T> __device__ __forceinline__ void st(T *p, float v);
+template <> __device__ __forceinline__ void st<float>(float *p, float v) { *p = v; }
+template <> __device__ __forceinline__ void st<__bf16>(__bf16 *p, float v) { *p = (__bf16)v; }
+
+// VEC consecutive elements -> fp32 registers (16-byte / 8-byte vector access when VEC == 4)
+template <typename T, int VEC> __device__ __forceinline__ void ldv(const T *p, float *o) {
+    if constexpr (VEC == 4 && sizeof(T) == 4) {
+        const float4 v = *reinterpret_cast<const float4 *>(p);
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    } else if constexpr (VEC == 4 && sizeof(T) == 2) {
+        const uint2 v = *reinterpret_cast<const uint2 *>(p);
+        o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+        o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+    } else {
+#pragma unroll
+        for (int k = 0; k < VEC; k++) o[k] = ld<T>(p + k);
+    }
+}
+template <typename T, int VEC> __device__ __forceinline__ void stv(T *p, const float *o) {
+    if constexpr (VEC == 4 && sizeof(T) == 4) {
+        *reinterpret_cast<float4 *>(p) = make_float4(o[0], o[1], o[2], o[3]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < VEC; k++) st<T>(p + k, o[k]);
+    }
+}
+
+__device__ __forceinline__ float wave_sum_f(float x) {
+#pragma unroll
+    for (int off = WAVE / 2; off > 0; off >>= 1) x += __shfl_xor(x, off, WAVE);
+    return x;   // all lanes
+}
+__device__ __forceinline__ float wave_max_f(float x) {
+#pragma unroll
+    for (int off = WAVE / 2; off > 0; off >>= 1) x = fmaxf(x, __shfl_xor(x, off, WAVE));
+    return x;
+}
+__device__ __forceinline__ double wave_sum_d(double x) {
+#pragma unroll
+    for (int off = WAVE / 2; off > 0; off >>= 1) x += __shfl_xor(x, off, WAVE);
+    return x;
+}
+__device__ __forceinline__ double block_sum_d(double x, double *sh) {
+    x = wave_sum_d(x);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wid] = x;
+    __syncthreads();
+    double t = 0.0;
+    for (int k = 0; k < nw; k++) t += sh[k];
+    return t;
+}
+
+__device__ __forceinline__ float leaky(float z, float slope) { return z > 0.f ? z : slope * z; }
+
+// ------------------------------------------------------------------------------------------
+// GAT forward.  NITER*64*VEC >= C; lane owns channels {(it*64 + lane)*VEC + k}.
+// ------------------------------------------------------------------------------------------
+template <typename T, int VEC, int NITER>
+__global__ __launch_bounds__(256) void k_gat_fwd(const T *__restrict__ h, const float *__restrict__ s_src,
+                                                 const float *__restrict__ s_dst,
+                                                 const int *__restrict__ rowptr,
+                                                 const int *__restrict__ col,
+                                                 const float *__restrict__ bias, int n, int H, int C,
+                                                 int concat, int act, T *__restrict__ out,
+                                                 float *__restrict__ alpha_out) {
+    extern __shared__ float smem[];   // mean mode: 4 * C floats
+    const int i = blockIdx.x;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int p0 = rowptr[i], deg = rowptr[i + 1] - p0;
+    const size_t HC = (size_t)H * C;
+    float macc[NITER][VEC];           // head-mean accumulator (concat == 0)
+#pragma unroll
+    for (int it = 0; it < NITER; it++)
+#pragma unroll
+        for (int k = 0; k < VEC; k++) macc[it][k] = 0.f;
+
+    for (int hd = wid; hd < H; hd += 4) {
+        const float sd = s_dst[(size_t)i * H + hd];
+        // softmax statistics over the incoming edges (exp(e - max) / (sum + 1e-16))
+        float m = -INFINITY;
+        for (int t = lane; t < deg; t += WAVE)
+            m = fmaxf(m, leaky(s_src[(size_t)col[p0 + t] * H + hd] + sd, ATT_SLOPE));
+        m = wave_max_f(m);
+        float ssum = 0.f;
+        for (int t = lane; t < deg; t += WAVE)
+            ssum += __expf(leaky(s_src[(size_t)col[p0 + t] * H + hd] + sd, ATT_SLOPE) - m);
+        ssum = wave_sum_f(ssum) + 1e-16f;
+
+        float acc[NITER][VEC];
+#pragma unroll
+        for (int it = 0; it < NITER; it++)
+#pragma unroll
+            for (int k = 0; k < VEC; k++) acc[it][k] = 0.f;
+        for (int base = 0; base < deg; base += WAVE) {
+            const int t = base + lane;
+            int j = 0;
+            float a = 0.f;
+            if (t < deg) {
+                j = col[p0 + t];
+                a = __expf(leaky(s_src[(size_t)j * H + hd] + sd, ATT_SLOPE) - m) / ssum;
+                alpha_out[(size_t)(p0 + t) * H + hd] = a;
+            }
+            const int cnt = min(WAVE, deg - base);
+#pragma unroll 4
+            for (int q = 0; q < cnt; q++) {
+                const int jj = __shfl(j, q, WAVE);
+                const float aa = __shfl(a, q, WAVE);
+                const T *row = h + (size_t)jj * HC + (size_t)hd * C;
+#pragma unroll
+                for (int it = 0; it < NITER; it++) {
+                    const int c = (it * WAVE + lane) * VEC;
+                    if (c < C) {
+                        float v[VEC];
+                        ldv<T, VEC>(row + c, v);
+#pragma unroll
+                        for (int k = 0; k < VEC; k++) acc[it][k] = fmaf(aa, v[k], acc[it][k]);
+                    }
+                }
+            }
+        }
+        if (concat) {
+#pragma unroll
+            for (int it = 0; it < NITER; it++) {
+                const int c = (it * WAVE + lane) * VEC;
+                if (c < C) {
+                    float o[VEC];
+#pragma unroll
+                    for (int k = 0; k < VEC; k++) {
+                        const float v = acc[it][k] + bias[(size_t)hd * C + c + k];
+                        o[k] = act ? leaky(v, ACT_SLOPE) : v;
+                    }
+                    stv<T, VEC>(out + (size_t)i * HC + (size_t)hd * C + c, o);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < NITER; it++)
+#pragma unroll
+                for (int k = 0; k < VEC; k++) macc[it][k] += acc[it][k];
+        }
+    }
+    if (!concat) {
+#pragma unroll
+        for (int it = 0; it < NITER; it++) {
+            const int c = (it * WAVE + lane) * VEC;
+            if (c < C)
+#pragma unroll
+                for (int k = 0; k < VEC; k++) smem[wid * C + c + k] = macc[it][k];
+        }
+        __syncthreads();
+        if (wid == 0) {
+#pragma unroll
+            for (int it = 0; it < NITER; it++) {
+                const int c = (it * WAVE + lane) * VEC;
+                if (c < C) {
+                    float o[VEC];
+#pragma unroll
+                    for (int k = 0; k < VEC; k++) {
+                        const float v = (smem[c + k] + smem[C + c + k] + smem[2 * C + c + k] + smem[3 * C + c + k]) / (float)H
+                                        + bias[c + k];
+                        o[k] = act ? leaky(v, ACT_SLOPE) : v;
+                    }
+                    stv<T, VEC>(out + (size_t)i * C + c, o);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// GAT backward, target side: g_pre, dz (per edge, per head), ds_dst.
+// ------------------------------------------------------------------------------------------
+template <typename T, int VEC, int NITER>
+__global__ __launch_bounds__(256) void k_gat_bwd_target(
+    const T *__restrict__ g_out, const T *__restrict__ out, const T *__restrict__ h,
+    const float *__restrict__ s_src, const float *__restrict__ s_dst, const float *__restrict__ alpha,
+    const int *__restrict__ rowptr, const int *__restrict__ col, int n, int H, int C, int concat, int act,
+    T *__restrict__ g_pre, float *__restrict__ dz, float *__restrict__ ds_dst) {
+    const int i = blockIdx.x;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int p0 = rowptr[i], deg = rowptr[i + 1] - p0;
+    const size_t HC = (size_t)H * C;
+    for (int hd = wid; hd < H; hd += 4) {
+        float g[NITER][VEC];
+#pragma unroll
+        for (int it = 0; it < NITER; it++) {
+            const int c = (it * WAVE + lane) * VEC;
+#pragma unroll
+            for (int k = 0; k < VEC; k++) g[it][k] = 0.f;
+            if (c < C) {
+                float go[VEC], oo[VEC];
+                const size_t off = concat ? (size_t)i * HC + (size_t)hd * C + c : (size_t)i * C + c;
+                ldv<T, VEC>(g_out + off, go);
+                if (act) ldv<T, VEC>(out + off, oo);
+#pragma unroll
+                for (int k = 0; k < VEC; k++) {
+                    float v = go[k];
+                    if (act && !(oo[k] > 0.f)) v *= ACT_SLOPE;
+                    g[it][k] = concat ? v : v / (float)H;
+                }
+                stv<T, VEC>(g_pre + (size_t)i * HC + (size_t)hd * C + c, g[it]);
+            }
+        }
+        const float sd = s_dst[(size_t)i * H + hd];
+        // phase 1: d(alpha) per edge (parked in dz), and sum_k alpha_k d(alpha_k)
+        float dsum = 0.f;
+        for (int base = 0; base < deg; base += WAVE) {
+            const int t = base + lane;
+            const int j = (t < deg) ? col[p0 + t] : 0;
+            const int cnt = min(WAVE, deg - base);
+            float da = 0.f;
+            for (int q = 0; q < cnt; q++) {
+                const int jj = __shfl(j, q, WAVE);
+                const T *row = h + (size_t)jj * HC + (size_t)hd * C;
+                float part = 0.f;
+#pragma unroll
+                for (int it = 0; it < NITER; it++) {
+                    const int c = (it * WAVE + lane) * VEC;
+                    if (c < C) {
+                        float v[VEC];
+                        ldv<T, VEC>(row + c, v);
+#pragma unroll
+                        for (int k = 0; k < VEC; k++) part = fmaf(g[it][k], v[k], part);
+                    }
+                }
+                part = wave_sum_f(part);
+                if (lane == q) da = part;
+            }
+            if (t < deg) {
+                const float a = alpha[(size_t)(p0 + t) * H + hd];
+                dsum += a * da;
+                dz[(size_t)(p0 + t) * H + hd] = da;
+            }
+        }
+        dsum = wave_sum_f(dsum);
+        // phase 2: softmax + leaky backward
+        float dsd = 0.f;
+        for (int t = lane; t < deg; t += WAVE) {
+            const size_t e = (size_t)(p0 + t) * H + hd;
+            const float a = alpha[e];
+            const float z = s_src[(size_t)col[p0 + t] * H + hd] + sd;
+            const float d = a * (dz[e] - dsum) * (z > 0.f ? 1.f : ATT_SLOPE);
+            dz[e] = d;
+            dsd += d;
+        }
+        dsd = wave_sum_f(dsd);
+        if (lane == 0) ds_dst[(size_t)i * H + hd] = dsd;
+    }
+}
+
+// GAT backward, source side: gather over OUTGOING edges (transposed CSR).
+template <typename T, int VEC, int NITER>
+__global__ __launch_bounds__(256) void k_gat_bwd_source(
+    const T *__restrict__ g_pre, const float *__restrict__ alpha, const float *__restrict__ dz,
+    const int *__restrict__ rowptr_t, const int *__restrict__ col_t, const int *__restrict__ eid_t, int n,
+    int H, int C, T *__restrict__ dh, float *__restrict__ ds_src) {
+    const int j = blockIdx.x;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int p0 = rowptr_t[j], deg = rowptr_t[j + 1] - p0;
+    const size_t HC = (size_t)H * C;
+    for (int hd = wid; hd < H; hd += 4) {
+        float acc[NITER][VEC];
+#pragma unroll
+        for (int it = 0; it < NITER; it++)
+#pragma unroll
+            for (int k = 0; k < VEC; k++) acc[it][k] = 0.f;
+        float sds = 0.f;
+        for (int base = 0; base < deg; base += WAVE) {
+            const int t = base + lane;
+            int i = 0;
+            float a = 0.f;
+            if (t < deg) {
+                i = col_t[p0 + t];
+                const size_t e = (size_t)eid_t[p0 + t] * H + hd;
+                a = alpha[e];
+                sds += dz[e];
+            }
+            const int cnt = min(WAVE, deg - base);
+#pragma unroll 4
+            for (int q = 0; q < cnt; q++) {
+                const int ii = __shfl(i, q, WAVE);
+                const float aa = __shfl(a, q, WAVE);
+                const T *row = g_pre + (size_t)ii * HC + (size_t)hd * C;
+#pragma unroll
+                for (int it = 0; it < NITER; it++) {
+                    const int c = (it * WAVE + lane) * VEC;
+                    if (c < C) {
+                        float v[VEC];
+                        ldv<T, VEC>(row + c, v);
+#pragma unroll
+                        for (int k = 0; k < VEC; k++) acc[it][k] = fmaf(aa, v[k], acc[it][k]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NITER; it++) {
+            const int c = (it * WAVE + lane) * VEC;
+            if (c < C) stv<T, VEC>(dh + (size_t)j * HC + (size_t)hd * C + c, acc[it]);
+        }
+        sds = wave_sum_f(sds);
+        if (lane == 0) ds_src[(size_t)j * H + hd] = sds;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Kernel matrix (svgp.py:110-125)
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_kernel_matrix(const T *__restrict__ x, const T *__restrict__ z,
+                                                       int n, int m, int d, double scale, int kind,
+                                                       T *__restrict__ K) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= m || i >= n) return;
+    double d2 = 0.0;
+    for (int k = 0; k < d; k++) {
+        const double t = (double)x[(size_t)i * d + k] - (double)z[(size_t)j * d + k];
+        d2 += t * t;
+    }
+    double r;
+    if (kind == SPADOT_KERNEL_GAUSSIAN) r = exp(-d2 / scale);
+    else if (kind == SPADOT_KERNEL_CAUCHY) r = 1.0 / (1.0 + d2 / scale);
+    else r = 1.0 - d2 / (d2 + scale);
+    K[(size_t)i * m + j] = (T)r;
+}
+
+// out[l,i] = sum_k A[l,i,k] B[i,k] : one wave per (l,i)
+template <typename T>
+__global__ __launch_bounds__(256) void k_rowdot_fwd(const T *__restrict__ A, const T *__restrict__ B, int L,
+                                                    int n, int m, T *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= (long long)L * n) return;
+    const int i = (int)(r % n);
+    const T *a = A + (size_t)r * m, *b = B + (size_t)i * m;
+    double acc = 0.0;
+    for (int k = lane; k < m; k += WAVE) acc += (double)a[k] * (double)b[k];
+    acc = wave_sum_d(acc);
+    if (lane == 0) out[r] = (T)acc;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_rowdot_bwd(const T *__restrict__ g, const T *__restrict__ B, int L,
+                                                    int n, int m, T *__restrict__ gA) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long tot = (long long)L * n * m;
+    if (idx >= tot) return;
+    const long long r = idx / m;
+    const int k = (int)(idx % m), i = (int)(r % n);
+    gA[idx] = (T)((double)g[r] * (double)B[(size_t)i * m + k]);
+}
+
+constexpr double LOG_2PI = 1.8378770664093453;   // SpaDOT.py:138
+
+template <typename T>
+__global__ __launch_bounds__(1024) void k_elbo_fwd(const T *mu, const T *var, const T *mv, const T *tr,
+                                                   const T *pm, const T *pv, const T *kt, int b, int L,
+                                                   T *out2) {
+    __shared__ double sh[16];
+    double l3 = 0.0, ce = 0.0;
+    const int tot = b * L;
+    for (int e = threadIdx.x; e < tot; e += blockDim.x) {
+        const int i = e / L;
+        const double v = var[e], m_ = mu[e], d = m_ - (double)mv[e];
+        l3 += ((double)kt[i] + (double)tr[e]) / v + log(v) + LOG_2PI + d * d / v;
+        const double p = pm[e];
+        ce += LOG_2PI + log(v) + ((double)pv[e] + p * p - 2.0 * p * m_ + m_ * m_) / v;
+    }
+    l3 = block_sum_d(l3, sh);
+    ce = block_sum_d(ce, sh);
+    if (threadIdx.x == 0) { out2[0] = (T)(-0.5 * l3); out2[1] = (T)(-0.5 * ce); }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_elbo_bwd(const T *g2, const T *mu, const T *var, const T *mv,
+                                                  const T *tr, const T *pm, const T *pv, const T *kt, int b,
+                                                  int L, T *g_mu, T *g_var, T *g_mv, T *g_tr, T *g_pm,
+                                                  T *g_pv) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= b * L) return;
+    const int i = e / L;
+    const double gl = -0.5 * (double)g2[0], gc = -0.5 * (double)g2[1];
+    const double v = var[e], m_ = mu[e], d = m_ - (double)mv[e], p = pm[e];
+    const double q = (double)pv[e] + p * p - 2.0 * p * m_ + m_ * m_;
+    const double a3 = (double)kt[i] + (double)tr[e];
+    g_mu[e] = (T)(gl * (2.0 * d / v) + gc * ((2.0 * m_ - 2.0 * p) / v));
+    g_var[e] = (T)(gl * (-a3 / (v * v) + 1.0 / v - d * d / (v * v)) + gc * (1.0 / v - q / (v * v)));
+    g_mv[e] = (T)(gl * (-2.0 * d / v));
+    g_tr[e] = (T)(gl / v);
+    g_pm[e] = (T)(gc * ((2.0 * p - 2.0 * m_) / v));
+    g_pv[e] = (T)(gc / v);
+}
+
+// sum of squared differences, two-stage
+template <typename T>
+__global__ __launch_bounds__(256) void k_sqerr_part(const T *__restrict__ y, const T *__restrict__ yh,
+                                                    long long count, double *__restrict__ part) {
+    __shared__ double sh[16];
+    double acc = 0.0;
+    for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < count; k += (long long)gridDim.x * 256) {
+        const double d = (double)y[k] - (double)yh[k];
+        acc += d * d;
+    }
+    acc = block_sum_d(acc, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = acc;
+}
+template <typename T>
+__global__ __launch_bounds__(1024) void k_final_sum(const double *__restrict__ part, int nparts, double scale,
+                                                    T *__restrict__ out) {
+    __shared__ double sh[16];
+    double acc = 0.0;
+    for (int k = threadIdx.x; k < nparts; k += blockDim.x) acc += part[k];
+    acc = block_sum_d(acc, sh);
+    if (threadIdx.x == 0) out[0] = (T)(acc * scale);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_sqerr_bwd(const T *g1, const T *__restrict__ y,
+                                                   const T *__restrict__ yh, long long count, double inv_scale,
+                                                   T *__restrict__ gy) {
+    const double c = -2.0 * inv_scale * (double)g1[0];
+    for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < count; k += (long long)gridDim.x * 256)
+        gy[k] = (T)(c * ((double)y[k] - (double)yh[k]));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_kmeans_assign(const T *__restrict__ x, const T *__restrict__ cen,
+                                                       int n, int kc, int d, int *__restrict__ labels) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double best = INFINITY;
+    int arg = 0;
+    for (int c = 0; c < kc; c++) {
+        double s = 0.0;
+        for (int k = 0; k < d; k++) {
+            const double t = (double)x[(size_t)i * d + k] - (double)cen[(size_t)c * d + k];
+            s += t * t;
+        }
+        if (s < best) { best = s; arg = c; }
+    }
+    labels[i] = arg;
+}
+
+__global__ __launch_bounds__(256) void k_sumsq_part(const float *__restrict__ g, long long count,
+                                                    double *__restrict__ part) {
+    __shared__ double sh[16];
+    double acc = 0.0;
+    const long long n4 = count / 4;
+    const float4 *g4 = reinterpret_cast<const float4 *>(g);
+    for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < n4; k += (long long)gridDim.x * 256) {
+        const float4 v = g4[k];
+        acc += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    }
+    if (blockIdx.x == 0)
+        for (long long k = n4 * 4 + threadIdx.x; k < count; k += 256) acc += (double)g[k] * g[k];
+    acc = block_sum_d(acc, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = acc;
+}
+
+__global__ __launch_bounds__(256) void k_adamw(float *__restrict__ p, const float *__restrict__ g,
+                                               float *__restrict__ m, float *__restrict__ v,
+                                               const float *__restrict__ sumsq, long long count, float lr,
+                                               float b1, float b2, float eps, float wd, float max_norm,
+                                               float bc1, float bc2_sqrt) {
+    const float total = sqrtf(sumsq[0]);
+    const float coef = fminf(1.f, max_norm / (total + 1e-6f));
+    for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < count; k += (long long)gridDim.x * 256) {
+        const float gg = g[k] * coef;
+        float pp = p[k] * (1.f - lr * wd);
+        const float mm = m[k] + (gg - m[k]) * (1.f - b1);      // lerp_(grad, 1 - beta1)
+        const float vv = v[k] * b2 + gg * gg * (1.f - b2);
+        const float denom = sqrtf(vv) / bc2_sqrt + eps;
+        pp -= (lr / bc1) * (mm / denom);
+        p[k] = pp; m[k] = mm; v[k] = vv;
+    }
+}
+
+int pick_gat(int C, int &vec, int &niter) {
+    if (C % 256 == 0 && C / 256 <= 4) { vec = 4; niter = C / 256; return 0; }
+    if (C <= 512) { vec = 1; niter = (C + 63) / 64; return 0; }
+    return -22;
+}
+
+}  // namespace
+
+#define GAT_DISPATCH(KERNEL, T, ...)                                                            \
+    do {                                                                                        \
+        if (vec == 4 && niter == 1) hipLaunchKernelGGL((KERNEL<T, 4, 1>), __VA_ARGS__);          \
+        else if (vec == 4 && niter == 2) hipLaunchKernelGGL((KERNEL<T, 4, 2>), __VA_ARGS__);     \
+        else if (vec == 4 && niter == 3) hipLaunchKernelGGL((KERNEL<T, 4, 3>), __VA_ARGS__);     \
+        else if (vec == 4 && niter == 4) hipLaunchKernelGGL((KERNEL<T, 4, 4>), __VA_ARGS__);     \
+        else if (niter == 1) hipLaunchKernelGGL((KERNEL<T, 1, 1>), __VA_ARGS__);                 \
+        else if (niter == 2) hipLaunchKernelGGL((KERNEL<T, 1, 2>), __VA_ARGS__);                 \
+        else if (niter <= 4) hipLaunchKernelGGL((KERNEL<T, 1, 4>), __VA_ARGS__);                 \
+        else hipLaunchKernelGGL((KERNEL<T, 1, 8>), __VA_ARGS__);                                 \
+    } while (0)
+
+extern "C" {
+
+const char *spadot_model_version(void) { return "spadot_model 0.1 (gfx950)"; }
+
+int spadot_gat_forward(const void *h, int dtype, const float *s_src, const float *s_dst, const int *rowptr,
+                       const int *col, const float *bias, int n, int H, int C, int concat, int act, void *out,
+                       float *alpha_out, void *stream) {
+    int vec, niter;
+    if (n <= 0 || H <= 0 || pick_gat(C, vec, niter)) return -22;
+    if (!concat && H > 4) return -22;   // head-mean reduces over the workgroup's 4 waves
+    hipStream_t st_ = (hipStream_t)stream;
+    const size_t lds = concat ? 0 : sizeof(float) * 4 * (size_t)C;
+    if (dtype == SPADOT_DT_F32)
+        GAT_DISPATCH(k_gat_fwd, float, dim3(n), dim3(256), lds, st_, (const float *)h, s_src, s_dst, rowptr, col,
+                     bias, n, H, C, concat, act, (float *)out, alpha_out);
+    else if (dtype == SPADOT_DT_BF16)
+        GAT_DISPATCH(k_gat_fwd, __bf16, dim3(n), dim3(256), lds, st_, (const __bf16 *)h, s_src, s_dst, rowptr, col,
+                     bias, n, H, C, concat, act, (__bf16 *)out, alpha_out);
+    else
+        return -22;
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+int spadot_gat_backward_target(const void *g_out, const void *out, const void *h, int dtype, const float *s_src,
+                               const float *s_dst, const float *alpha, const int *rowptr, const int *col, int n,
+                               int H, int C, int concat, int act, void *g_pre, float *dz, float *ds_dst,
+                               void *stream) {
+    int vec, niter;
+    if (n <= 0 || H <= 0 || pick_gat(C, vec, niter)) return -22;
+    hipStream_t st_ = (hipStream_t)stream;
+    if (dtype == SPADOT_DT_F32)
+        GAT_DISPATCH(k_gat_bwd_target, float, dim3(n), dim3(256), 0, st_, (const float *)g_out, (const float *)out,
+                     (const float *)h, s_src, s_dst, alpha, rowptr, col, n, H, C, concat, act, (float *)g_pre, dz,
+                     ds_dst);
+    else if (dtype == SPADOT_DT_BF16)
+        GAT_DISPATCH(k_gat_bwd_target, __bf16, dim3(n), dim3(256), 0, st_, (const __bf16 *)g_out, (const __bf16 *)out,
+                     (const __bf16 *)h, s_src, s_dst, alpha, rowptr, col, n, H, C, concat, act, (__bf16 *)g_pre, dz,
+                     ds_dst);
+    else
+        return -22;
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+int spadot_gat_backward_source(const void *g_pre, int dtype, const float *alpha, const float *dz,
+                               const int *rowptr_t, const int *col_t, const int *eid_t, int n, int H, int C,
+                               void *dh, float *ds_src, void *stream) {
+    int vec, niter;
+    if (n <= 0 || H <= 0 || pick_gat(C, vec, niter)) return -22;
+    hipStream_t st_ = (hipStream_t)stream;
+    if (dtype == SPADOT_DT_F32)
+        GAT_DISPATCH(k_gat_bwd_source, float, dim3(n), dim3(256), 0, st_, (const float *)g_pre, alpha, dz, rowptr_t,
+                     col_t, eid_t, n, H, C, (float *)dh, ds_src);
+    else if (dtype == SPADOT_DT_BF16)
+        GAT_DISPATCH(k_gat_bwd_source, __bf16, dim3(n), dim3(256), 0, st_, (const __bf16 *)g_pre, alpha, dz, rowptr_t,
+                     col_t, eid_t, n, H, C, (__bf16 *)dh, ds_src);
+    else
+        return -22;
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+#define FP_DISPATCH(dtype, CALL_F32, CALL_F64) \
+    do { if ((dtype) == SPADOT_DT_F32) { CALL_F32; } else if ((dtype) == SPADOT_DT_F64) { CALL_F64; } else return -22; } while (0)
+
+int spadot_kernel_matrix(const void *x, const void *z, int n, int m, int d, double scale, int kind, int dtype,
+                         void *K, void *stream) {
+    if (n <= 0 || m <= 0 || d <= 0 || kind < 0 || kind > 2 || n > 65535 * 64) return -22;
+    hipStream_t st_ = (hipStream_t)stream;
+    // rows go through gridDim.y in slabs of <= 65535
+    for (int r0 = 0; r0 < n; r0 += 65535) {
+        const int rows = n - r0 < 65535 ? n - r0 : 65535;
+        dim3 g((m + 255) / 256, rows);
+        FP_DISPATCH(dtype,
+                    hipLaunchKernelGGL(k_kernel_matrix<float>, g, dim3(256), 0, st_, (const float *)x + (size_t)r0 * d, (const float *)z, rows, m, d, scale, kind, (float *)K + (size_t)r0 * m),
+                    hipLaunchKernelGGL(k_kernel_matrix<double>, g, dim3(256), 0, st_, (const double *)x + (size_t)r0 * d, (const double *)z, rows, m, d, scale, kind, (double *)K + (size_t)r0 * m));
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+int spadot_rowdot_forward(const void *A, const void *B, int L, int n, int m, int dtype, void *out, void *stream) {
+    if (L <= 0 || n <= 0 || m <= 0) return -22;
+    hipStream_t st_ = (hipStream_t)stream;
+    const long long rows = (long long)L * n;
+    dim3 g((unsigned)((rows + 3) / 4));
+    FP_DISPATCH(dtype,
+                hipLaunchKernelGGL(k_rowdot_fwd<float>, g, dim3(256), 0, st_, (const float *)A, (const float *)B, L, n, m, (float *)out),
+                hipLaunchKernelGGL(k_rowdot_fwd<double>, g, dim3(256), 0, st_, (const double *)A, (const double *)B, L, n, m, (double *)out));
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+int spadot_rowdot_backward(const void *g_, const void *B, int L, int n, int m, int dtype, void *gA, void *stream) {
+    if (L <= 0 || n <= 0 || m <= 0) return -22;
+    hipStream_t st_ = (hipStream_t)stream;
+    const long long tot = (long long)L * n * m;
+    dim3 g((unsigned)((tot + 255) / 256));
+    FP_DISPATCH(dtype,
+                hipLaunchKernelGGL(k_rowdot_bwd<float>, g, dim3(256), 0, st_, (const float *)g_, (const float *)B, L, n, m, (float *)gA),
+                hipLaunchKernelGGL(k_rowdot_bwd<double>, g, dim3(256), 0, st_, (const double *)g_, (const double *)B, L, n, m, (double *)gA));
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+int spadot_elbo_forward(const void *mu, const void *var, const void *mv, const void *tr, const void *pm,
+                        const void *pv, const void *ktilde, int b, int L, int dtype, void *out2, void *stream) {
+    if (b <= 0 || L <= 0) return -22;
+    hipStream_t st_ = (hipStream_t)stream;
+    FP_DISPATCH(dtype,
+                hipLaunchKernelGGL(k_elbo_fwd<float>, dim3(1), dim3(1024), 0, st_, (const float *)mu, (const float *)var, (const float *)mv, (const float *)tr, (const float *)pm, (const float *)pv, (const float *)ktilde, b, L, (float *)out2),
+                hipLaunchKernelGGL(k_elbo_fwd<double>, dim3(1), dim3(1024), 0, st_, (const double *)mu, (const double *)var, (const double *)mv, (const double *)tr, (const double *)pm, (const double *)pv, (const double *)ktilde, b, L, (double *)out2));
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+int spadot_elbo_backward(const void *g2, const void *mu, const void *var, const void *mv, const void *tr,
+                         const void *pm, const void *pv, const void *ktilde, int b, int L, int dtype, void *g_mu,
+                         void *g_var, void *g_mv, void *g_tr, void *g_pm, void *g_pv, void *stream) {
+    if (b <= 0 || L <= 0) return -22;
+    hipStream_t st_ = (hipStream_t)stream;
+    dim3 g((b * L + 255) / 256);
+    FP_DISPATCH(dtype,
+                hipLaunchKernelGGL(k_elbo_bwd<float>, g, dim3(256), 0, st_, (const float *)g2, (const float *)mu, (const float *)var, (const float *)mv, (const float *)tr, (const float *)pm, (const float *)pv, (const float *)ktilde, b, L, (float *)g_mu, (float *)g_var, (float *)g_mv, (float *)g_tr, (float *)g_pm, (float *)g_pv),
+                hipLaunchKernelGGL(k_elbo_bwd<double>, g, dim3(256), 0, st_, (const double *)g2, (const double *)mu, (const double *)var, (const double *)mv, (const double *)tr, (const double *)pm, (const double *)pv, (const double *)ktilde, b, L, (double *)g_mu, (double *)g_var, (double *)g_mv, (double *)g_tr, (double *)g_pm, (double *)g_pv));
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+int spadot_sqerr_forward(const void *y, const void *yhat, long long count, double inv_scale, int dtype,
+                         double *scratch, void *out1, void *stream) {
+    if (count <= 0 || !scratch) return -22;
+    hipStream_t st_ = (hipStream_t)stream;
+    const int nb = (int)((count + 255) / 256 < 2048 ? (count + 255) / 256 : 2048);
+    FP_DISPATCH(dtype,
+                { hipLaunchKernelGGL(k_sqerr_part<float>, dim3(nb), dim3(256), 0, st_, (const float *)y, (const float *)yhat, count, scratch);
+                  hipLaunchKernelGGL(k_final_sum<float>, dim3(1), dim3(1024), 0, st_, scratch, nb, inv_scale, (float *)out1); },
+                { hipLaunchKernelGGL(k_sqerr_part<double>, dim3(nb), dim3(256), 0, st_, (const double *)y, (const double *)yhat, count, scratch);
+                  hipLaunchKernelGGL(k_final_sum<double>, dim3(1), dim3(1024), 0, st_, scratch, nb, inv_scale, (double *)out1); });
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+int spadot_sqerr_backward(const void *g1, const void *y, const void *yhat, long long count, double inv_scale,
+                          int dtype, void *g_yhat, void *stream) {
+    if (count <= 0) return -22;
+    hipStream_t st_ = (hipStream_t)stream;
+    const int nb = (int)((count + 255) / 256 < 4096 ? (count + 255) / 256 : 4096);
+    FP_DISPATCH(dtype,
+                hipLaunchKernelGGL(k_sqerr_bwd<float>, dim3(nb), dim3(256), 0, st_, (const float *)g1, (const float *)y, (const float *)yhat, count, inv_scale, (float *)g_yhat),
+                hipLaunchKernelGGL(k_sqerr_bwd<double>, dim3(nb), dim3(256), 0, st_, (const double *)g1, (const double *)y, (const double *)yhat, count, inv_scale, (double *)g_yhat));
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+int spadot_kmeans_assign(const void *x, const void *centers, int n, int k, int d, int dtype, int *labels,
+                         void *stream) {
+    if (n <= 0 || k <= 0 || d <= 0) return -22;
+    hipStream_t st_ = (hipStream_t)stream;
+    dim3 g((n + 255) / 256);
+    FP_DISPATCH(dtype,
+                hipLaunchKernelGGL(k_kmeans_assign<float>, g, dim3(256), 0, st_, (const float *)x, (const float *)centers, n, k, d, labels),
+                hipLaunchKernelGGL(k_kmeans_assign<double>, g, dim3(256), 0, st_, (const double *)x, (const double *)centers, n, k, d, labels));
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+int spadot_grad_sumsq(const float *grad, long long count, double *scratch, float *sumsq, void *stream) {
+    if (count <= 0 || !scratch) return -22;
+    if (((uintptr_t)grad & 15) != 0) return -22;   // float4 path needs 16-byte alignment
+    hipStream_t st_ = (hipStream_t)stream;
+    const long long want = (count / 4 + 255) / 256;
+    const int nb = (int)(want < 1 ? 1 : (want < 2048 ? want : 2048));
+    hipLaunchKernelGGL(k_sumsq_part, dim3(nb), dim3(256), 0, st_, grad, count, scratch);
+    hipLaunchKernelGGL(k_final_sum<float>, dim3(1), dim3(1024), 0, st_, scratch, nb, 1.0, sumsq);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+int spadot_adamw_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, const float *sumsq,
+                      long long count, double lr, double beta1, double beta2, double eps, double weight_decay,
+                      double max_norm, int step, void *stream) {
+    if (count <= 0 || step < 1) return -22;
+    hipStream_t st_ = (hipStream_t)stream;
+    const long long want = (count + 255) / 256;
+    const int nb = (int)(want < 4096 ? want : 4096);
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
+    hipLaunchKernelGGL(k_adamw, dim3(nb), dim3(256), 0, st_, param, grad, exp_avg, exp_avg_sq, sumsq, count,
+                       (float)lr, (float)beta1, (float)beta2, (float)eps, (float)weight_decay, (float)max_norm,
+                       (float)bc1, (float)sqrt(bc2));
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+}  // extern "C"

@@ -1,0 +1,106 @@
+"""Spatial graph and mini-batch construction for the GAT branch (host side, one-off per run).
+
+Replaces, without the dense N_t x N_t adjacency the reference builds:
+  _Cal_Spatial_Net                /root/reference/SpaDOT/utils/_utils.py:52-100
+  dense_to_sparse + NeighborLoader(num_neighbors=[f, f], batch_size=512, subgraph_type="induced")
+                                  /root/reference/SpaDOT/utils/_train_utils.py:69-85
+The loader is not shuffled in the reference, so its batches are the same every epoch: they are built
+once here (node ids + CSR in both directions) and kept on the device.
+"""
+import numpy as np
+import torch
+
+from .ops import BatchGraph
+
+
+def knn_graph(coords, k_cutoff, max_neigh=30):
+    """Directed edges i -> j for j among the k_cutoff nearest neighbours of i (self excluded), plus one
+    self loop per node (_utils.py:66-100: kNN over max_neigh+1 candidates, columns 1..k_cutoff kept;
+    `G + eye`).  Returns int64 edge_index [2, E], row 0 = source i, row 1 = target j, sorted row-major
+    like dense_to_sparse of the reference's adjacency."""
+    from sklearn.neighbors import NearestNeighbors
+    coords = np.asarray(coords, dtype=np.float64)
+    n = coords.shape[0]
+    kk = min(max_neigh + 1, n)
+    _, idx = NearestNeighbors(n_neighbors=kk, algorithm="auto").fit(coords).kneighbors(coords)
+    nb = idx[:, 1:k_cutoff + 1]
+    src = np.repeat(np.arange(n, dtype=np.int64), nb.shape[1])
+    dst = nb.reshape(-1).astype(np.int64)
+    keep = src != dst          # a duplicate point can return another index first; self loops are added once below
+    src = np.concatenate([src[keep], np.arange(n, dtype=np.int64)])
+    dst = np.concatenate([dst[keep], np.arange(n, dtype=np.int64)])
+    key = np.unique(src * n + dst)
+    return np.stack([key // n, key % n])
+
+
+def _csr_both(src, dst, n):
+    """CSR by target and its transpose for an edge list that already has exactly one self loop per node."""
+    order = np.argsort(dst, kind="stable")
+    col = src[order].astype(np.int32)
+    tgt = dst[order]
+    rowptr = np.zeros(n + 1, dtype=np.int32)
+    np.cumsum(np.bincount(tgt, minlength=n), out=rowptr[1:])
+    perm = np.argsort(col, kind="stable").astype(np.int32)
+    col_t = tgt[perm].astype(np.int32)
+    rowptr_t = np.zeros(n + 1, dtype=np.int32)
+    np.cumsum(np.bincount(col, minlength=n), out=rowptr_t[1:])
+    return rowptr, col, rowptr_t, col_t, perm
+
+
+def build_batch_graph(edge_index, n, device):
+    """edge_index [2, E] (source, target) -> BatchGraph with GATConv's self-loop convention applied
+    (existing self loops dropped, one per node appended: SURVEY App. A)."""
+    ei = edge_index.cpu().numpy() if isinstance(edge_index, torch.Tensor) else np.asarray(edge_index)
+    src, dst = ei[0].astype(np.int64), ei[1].astype(np.int64)
+    keep = src != dst
+    loops = np.arange(n, dtype=np.int64)
+    src = np.concatenate([src[keep], loops])
+    dst = np.concatenate([dst[keep], loops])
+    parts = _csr_both(src, dst, n)
+    return BatchGraph(n, *(torch.from_numpy(np.ascontiguousarray(p)).to(device) for p in parts))
+
+
+def induced_batch(edge_index, n_nodes, seeds, hops=2):
+    """Seeds + their `hops`-hop in-neighbourhood (sources of edges pointing at the frontier), seeds
+    first; edges = every original edge with both ends inside (NeighborLoader 'induced', fan-out >=
+    in-degree: SURVEY App. B).  Returns (n_id int64 [n_sub], sub_edge_index int64 [2, E_sub])."""
+    ei = edge_index.cpu().numpy() if isinstance(edge_index, torch.Tensor) else np.asarray(edge_index)
+    src, dst = ei[0], ei[1]
+    seen = np.zeros(n_nodes, dtype=bool)
+    seeds = np.asarray(seeds, dtype=np.int64)
+    seen[seeds] = True
+    n_id = [seeds]
+    frontier_mask = seen.copy()
+    for _ in range(hops):
+        hit = frontier_mask[dst]
+        cand = np.unique(src[hit])
+        new = cand[~seen[cand]]
+        seen[new] = True
+        n_id.append(new)
+        frontier_mask = np.zeros(n_nodes, dtype=bool)
+        frontier_mask[new] = True
+    n_id = np.concatenate(n_id)
+    relabel = np.full(n_nodes, -1, dtype=np.int64)
+    relabel[n_id] = np.arange(n_id.size)
+    keep = seen[src] & seen[dst]
+    return n_id, np.stack([relabel[src[keep]], relabel[dst[keep]]])
+
+
+class Batch:
+    """One precomputed training batch of a time point (what the reference's loader yields each epoch)."""
+
+    def __init__(self, n_id, graph, batch_size):
+        self.n_id = n_id            # int64 device tensor, seeds first
+        self.graph = graph          # BatchGraph on the device
+        self.batch_size = int(batch_size)
+
+
+def precompute_batches(edge_index, n_nodes, batch_size, device, hops=2):
+    """All batches of one time point in loader order (consecutive seed blocks, last one partial)."""
+    out = []
+    for s in range(0, n_nodes, batch_size):
+        seeds = np.arange(s, min(n_nodes, s + batch_size))
+        n_id, sub = induced_batch(edge_index, n_nodes, seeds, hops)
+        g = build_batch_graph(sub, n_id.size, device)
+        out.append(Batch(torch.from_numpy(n_id).to(device), g, seeds.size))
+    return out

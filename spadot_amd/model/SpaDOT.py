@@ -1,0 +1,93 @@
+"""Composite model: mirror of /root/reference/SpaDOT/model/SpaDOT.py (same constructor, forward and
+all_latent_samples signatures, same attribute and state_dict names).
+
+model_config additions understood here (all optional): 'compute_dtype' (torch.float32 | torch.bfloat16)
+for the GAT branch and the big linears; parameters are fp32, the SVGP m x m algebra is fp64
+(see model/svgp.py).  model_config['dtype'] of the reference (float64) is accepted and ignored for
+parameters: this path is an fp32/bf16 device path with stated tolerances (tests/test_model_gpu.py).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..ops import BatchGraph, sqerr_sum
+from .decoder import Decoder
+from .encoder import GATEncoder, SVGPEncoder
+from .svgp import SVGP
+
+
+class SpaDOT(nn.Module):
+    def __init__(self, model_config, dataloader_dict):
+        super().__init__()
+        self.input_dim = model_config["input_dim"]
+        self.SVGP_z_dim = model_config["z_dim"] // 2
+        self.GAT_z_dim = model_config["z_dim"] // 2
+        self.dtype = torch.float32
+        self.compute_dtype = model_config.get("compute_dtype", torch.float32)
+        self.device = torch.device(model_config["device"])
+
+        self.SVGPEncoder = SVGPEncoder(input_dim=self.input_dim, SVGP_z_dim=self.SVGP_z_dim,
+                                       hidden_dims=model_config["svgp_encoder_layers"])
+        self.GATEncoder = GATEncoder(input_dim=self.input_dim, GAT_z_dim=self.GAT_z_dim,
+                                     hidden_dim=model_config["gat_encoder_hidden"],
+                                     num_heads=model_config["gat_attention_heads"],
+                                     compute_dtype=self.compute_dtype)
+        self.decoder = Decoder(input_dim=self.input_dim, z_dim=self.SVGP_z_dim + self.GAT_z_dim,
+                               decoder_layers=model_config["decoder_layers"])
+        self.svgp_dict = nn.ModuleDict({
+            str(tp): SVGP(model_config=model_config, inducing_points=dataloader_dict["inducing_points"][tp],
+                          N_train=dataloader_dict["N_train"][tp])
+            for tp in model_config["timepoints"]})
+        # K-means / OT state (plain attributes, not in the state_dict: SpaDOT.py:47-50)
+        self.gammas = {}
+        self.kmeans_center_dict = {}
+        self.kmeans_cluster_dict = {}
+        self.kmeans_index_dict = {}
+
+    def forward(self, x, y, edge_index, tp, batch_size, noise=None, batch_key=None):
+        """x: coordinates [n_sub, 2]; y: expression [n_sub, G]; edge_index: BatchGraph (or [2, E] tensor);
+        the first `batch_size` rows are the seeds.  Returns (recon, SVGP_KL, GAT_KL, alignment,
+        final_latent) like SpaDOT.py:52-94.  `noise` = (eps_svgp, eps_gat), each [b, L], replaces the
+        two torch.randn_like draws (SpaDOT.py:78,83) for parity tests; `batch_key` lets the SVGP cache
+        the coordinate-only constants of a recurring batch."""
+        b = batch_size
+        svgp = self.svgp_dict[str(tp)]
+        yb = y[:b]
+        q_mu, q_var = self.SVGPEncoder(yb.float())
+        bc = svgp.batch_constants(x[:b], key=batch_key)
+        p_m, p_v, l3_sum, kl_sum, ce = svgp.elbo_terms(bc, q_mu, q_var)
+        inside_elbo = l3_sum - (b / float(svgp.N_train)) * kl_sum
+        diff = ce - inside_elbo
+        # sign trick of SpaDOT.py:76-77 without the host round trip: -(|diff|) either way
+        SVGP_KL = -torch.abs(diff) / self.SVGP_z_dim
+        eps_s = torch.randn_like(p_m) if noise is None else noise[0].to(p_m.dtype)
+        SVGP_latent = (p_m + eps_s * torch.sqrt(p_v)).float()
+
+        g_mu, g_var = self.GATEncoder(y, edge_index, rows=b)
+        eps_g = torch.randn_like(g_mu) if noise is None else noise[1].to(g_mu.dtype)
+        GAT_latent = g_mu + eps_g * torch.sqrt(g_var)
+        GAT_KL = -0.5 * torch.sum(1 + torch.log(g_var) - g_mu.pow(2) - g_var) / self.GAT_z_dim
+
+        final_latent = torch.cat([SVGP_latent, GAT_latent], dim=1)
+        recon_loss = sqerr_sum(yb.float(), self.decoder(final_latent), 1.0 / self.input_dim)
+        alignment_loss = F.mse_loss(SVGP_latent.norm(dim=1) / self.SVGP_z_dim,
+                                    GAT_latent.norm(dim=1) / self.GAT_z_dim, reduction="sum")
+        return recon_loss, SVGP_KL.float(), GAT_KL, alignment_loss, final_latent
+
+    def all_latent_samples(self, X, Y, edge_index, tp, as_numpy=True):
+        """Posterior means of the whole time point (SpaDOT.py:96-123); no N_t x N_t intermediates."""
+        X = torch.as_tensor(X).to(self.device)
+        Y = torch.as_tensor(Y).to(self.device)
+        if not isinstance(edge_index, BatchGraph):
+            edge_index = torch.as_tensor(edge_index)
+        svgp = self.svgp_dict[str(tp)]
+        q_mu, q_var = self.SVGPEncoder(Y.float())
+        bc = svgp.batch_constants(X, key=("all", str(tp)))
+        p_m, _, _ = svgp.posterior(bc, q_mu, q_var)
+        g_mu, _ = self.GATEncoder(Y, edge_index)
+        lat = torch.cat((p_m.float(), g_mu), dim=1)
+        return lat.detach().cpu().numpy() if as_numpy else lat.detach()
+
+    def _gauss_cross_entropy(self, mu1, var1, mu2, var2):
+        """SpaDOT.py:125-142 (element-wise; the summed form is fused into ops.elbo_reduce)."""
+        return -0.5 * (1.8378770664093453 + torch.log(var2) + (var1 + mu1 ** 2 - 2 * mu1 * mu2 + mu2 ** 2) / var2)

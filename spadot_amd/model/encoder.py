@@ -1,0 +1,96 @@
+"""Encoders: mirror of /root/reference/SpaDOT/model/encoder.py (same class names, constructor
+arguments and state_dict keys).
+
+GATConv here is this package's own layer (torch_geometric is not a dependency): the dense map
+x -> h = x W^T and the attention logits are library GEMMs on MFMA; the edge phase (scatter-softmax
+over incoming edges + weighted scatter-add, bias, activation, head concat/mean) is ONE hand-written
+HIP kernel forward and two backward (spadot_amd.ops.gat_edge).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..graph import build_batch_graph
+from ..ops import BatchGraph, gat_edge
+
+
+class SVGPEncoder(nn.Module):
+    """encoder.py:7-34: [Linear, BatchNorm1d, LeakyReLU] per hidden size, then Linear -> (mu, var)."""
+
+    def __init__(self, input_dim, SVGP_z_dim, hidden_dims):
+        super().__init__()
+        layers = [input_dim] + list(hidden_dims)
+        net = []
+        for i in range(1, len(layers)):
+            lin = nn.Linear(layers[i - 1], layers[i])
+            nn.init.xavier_uniform_(lin.weight)
+            net += [lin, nn.BatchNorm1d(layers[i]), nn.LeakyReLU()]
+        self.SVGP_encoder_net = nn.Sequential(*net)
+        self.SVGP_fc = nn.Linear(hidden_dims[-1], SVGP_z_dim * 2)
+        nn.init.xavier_uniform_(self.SVGP_fc.weight)
+
+    def forward(self, x):
+        h = self.SVGP_encoder_net(x)
+        mu, logvar = torch.chunk(self.SVGP_fc(h), 2, dim=1)
+        return mu, torch.exp(logvar)
+
+
+class GATConv(nn.Module):
+    """Graph attention layer with torch_geometric.nn.GATConv's parameters (lin.weight [H*C, in] without
+    bias, att_src/att_dst [1, H, C], bias [H*C] or [C]) and forward semantics:
+    negative_slope 0.2, self loops re-added, softmax over incoming edges, concat or head mean.
+
+    forward(x, graph, act=False): `graph` is a BatchGraph (CSR both ways, on the device) or an
+    edge_index tensor [2, E] (converted on the fly).  `act` fuses the following leaky_relu(0.01) of
+    encoder.py:56-57 into the kernel's epilogue.  `compute_dtype` (fp32 or bf16) is the dtype of h and
+    of the layer's output; parameters stay fp32."""
+
+    def __init__(self, in_channels, out_channels, heads=1, concat=True, compute_dtype=torch.float32):
+        super().__init__()
+        self.in_channels, self.out_channels, self.heads, self.concat = in_channels, out_channels, heads, concat
+        self.compute_dtype = compute_dtype
+        self.lin = nn.Linear(in_channels, heads * out_channels, bias=False)
+        self.att_src = nn.Parameter(torch.empty(1, heads, out_channels))
+        self.att_dst = nn.Parameter(torch.empty(1, heads, out_channels))
+        self.bias = nn.Parameter(torch.zeros(heads * out_channels if concat else out_channels))
+        nn.init.xavier_uniform_(self.lin.weight)     # PyG: glorot on lin and att; zeros on bias
+        nn.init.xavier_uniform_(self.att_src)
+        nn.init.xavier_uniform_(self.att_dst)
+
+    def forward(self, x, graph, act=False):
+        H, C = self.heads, self.out_channels
+        if not isinstance(graph, BatchGraph):
+            graph = build_batch_graph(graph, x.shape[0], x.device)
+        cd = self.compute_dtype
+        W = self.lin.weight
+        xc = x.to(cd)
+        h = F.linear(xc, W.to(cd))                                   # [n, H*C]  (MFMA GEMM)
+        # logits without re-reading h: s = h.att = x (W_h^T att_h)    [n, H] each
+        Wh = W.view(H, C, self.in_channels)
+        w_att = torch.cat([torch.einsum("hci,hc->hi", Wh, self.att_src[0]),
+                           torch.einsum("hci,hc->hi", Wh, self.att_dst[0])], dim=0)      # [2H, in]
+        s = F.linear(xc, w_att.to(cd)).float()
+        return gat_edge(h, s[:, :H], s[:, H:], self.bias, graph, H, C, self.concat, act)
+
+
+class GATEncoder(nn.Module):
+    """encoder.py:37-61."""
+
+    def __init__(self, input_dim, GAT_z_dim, hidden_dim=512, num_heads=4, compute_dtype=torch.float32):
+        super().__init__()
+        self.gat1 = GATConv(input_dim, hidden_dim, heads=num_heads, concat=True, compute_dtype=compute_dtype)
+        self.gat2 = GATConv(hidden_dim * num_heads, hidden_dim, heads=num_heads, concat=True, compute_dtype=compute_dtype)
+        self.gat3 = GATConv(hidden_dim * num_heads, hidden_dim, heads=num_heads, concat=False, compute_dtype=compute_dtype)
+        self.GAT_fc = nn.Linear(hidden_dim, GAT_z_dim * 2)
+        nn.init.xavier_uniform_(self.GAT_fc.weight)
+
+    def forward(self, x, edge_index, rows=None):
+        """`rows` (optional int): only the first `rows` nodes of the output are needed (the seeds)."""
+        h = self.gat1(x, edge_index, act=True)
+        h = self.gat2(h, edge_index, act=True)
+        h = self.gat3(h, edge_index, act=False)
+        if rows is not None:
+            h = h[:rows]
+        z = self.GAT_fc(h.float())
+        mu, logvar = torch.chunk(z, 2, dim=1)
+        return mu, torch.exp(logvar)

@@ -1,0 +1,273 @@
+"""Autograd bindings of the hand-written HIP kernels in libspadot_model.so (include/spadot_model.h).
+
+torch owns device memory, streams and the autograd tape; every numeric op below is a HIP kernel
+reached through the C-ABI with raw device pointers.  There is no CPU implementation: calling any of
+these with CPU tensors, or without the built library, raises.
+"""
+import ctypes
+
+import torch
+
+from ._lib import model_lib
+
+DT_F32, DT_BF16, DT_F64 = 0, 1, 2
+_DT = {torch.float32: DT_F32, torch.bfloat16: DT_BF16, torch.float64: DT_F64}
+KERNEL_KINDS = {"Gaussian": 0, "Cauchy": 1, "Quadratic": 2}
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("spadot_amd ops run on the MI355X only (got a CPU tensor); there is no CPU path")
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed with {rc}")
+
+
+# ----------------------------------------------------------------------------- graph container
+
+class BatchGraph:
+    """CSR (by target) + transposed CSR (by source) of one induced batch graph, on the device.
+    Built once per batch by spadot_amd.graph.build_batch_graph; self loops are already in the GATConv
+    convention (exactly one per node)."""
+
+    def __init__(self, n, rowptr, col, rowptr_t, col_t, eid_t):
+        self.n = int(n)
+        self.rowptr, self.col = rowptr, col
+        self.rowptr_t, self.col_t, self.eid_t = rowptr_t, col_t, eid_t
+        self.E = int(col.numel())
+
+    def to(self, device):
+        return BatchGraph(self.n, *(t.to(device) for t in (self.rowptr, self.col, self.rowptr_t, self.col_t, self.eid_t)))
+
+
+# ----------------------------------------------------------------------------- GAT edge phase
+
+class _GATEdge(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, s_src, s_dst, bias, graph, H, C, concat, act):
+        _need_cuda(h, s_src, s_dst, bias)
+        lib = model_lib()
+        h = h.contiguous()
+        s_src = s_src.contiguous().float()
+        s_dst = s_dst.contiguous().float()
+        bias_f = bias.contiguous().float()
+        n = graph.n
+        assert h.shape == (n, H * C), (h.shape, n, H, C)
+        out = torch.empty((n, H * C if concat else C), dtype=h.dtype, device=h.device)
+        alpha = torch.empty((graph.E, H), dtype=torch.float32, device=h.device)
+        _check(lib.spadot_gat_forward(_p(h), _DT[h.dtype], _p(s_src), _p(s_dst), _p(graph.rowptr), _p(graph.col),
+                                      _p(bias_f), n, H, C, int(concat), int(act), _p(out), _p(alpha), _stream()),
+               "spadot_gat_forward")
+        ctx.save_for_backward(h, s_src, s_dst, out, alpha)
+        ctx.graph, ctx.H, ctx.C, ctx.concat, ctx.act = graph, H, C, concat, act
+        ctx.bias_dtype = bias.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        lib = model_lib()
+        h, s_src, s_dst, out, alpha = ctx.saved_tensors
+        graph, H, C = ctx.graph, ctx.H, ctx.C
+        n = graph.n
+        g_out = g_out.contiguous().to(h.dtype)
+        g_pre = torch.empty((n, H * C), dtype=h.dtype, device=h.device)
+        dz = torch.empty((graph.E, H), dtype=torch.float32, device=h.device)
+        ds_dst = torch.empty((n, H), dtype=torch.float32, device=h.device)
+        _check(lib.spadot_gat_backward_target(_p(g_out), _p(out), _p(h), _DT[h.dtype], _p(s_src), _p(s_dst), _p(alpha),
+                                              _p(graph.rowptr), _p(graph.col), n, H, C, int(ctx.concat), int(ctx.act),
+                                              _p(g_pre), _p(dz), _p(ds_dst), _stream()), "spadot_gat_backward_target")
+        dh = torch.empty_like(h)
+        ds_src = torch.empty((n, H), dtype=torch.float32, device=h.device)
+        _check(lib.spadot_gat_backward_source(_p(g_pre), _DT[h.dtype], _p(alpha), _p(dz), _p(graph.rowptr_t),
+                                              _p(graph.col_t), _p(graph.eid_t), n, H, C, _p(dh), _p(ds_src), _stream()),
+               "spadot_gat_backward_source")
+        gp = g_pre.float()
+        dbias = gp.sum(dim=0) if ctx.concat else gp.view(n, H, C).sum(dim=(0, 1))
+        return dh, ds_src, ds_dst, dbias.to(ctx.bias_dtype), None, None, None, None, None
+
+
+def gat_edge(h, s_src, s_dst, bias, graph, heads, channels, concat=True, act=False):
+    """Edge phase of one GATConv layer (+ bias, optional leaky_relu(0.01), head concat/mean)."""
+    return _GATEdge.apply(h, s_src, s_dst, bias, graph, heads, channels, concat, act)
+
+
+# ----------------------------------------------------------------------------- SVGP pieces
+
+def kernel_matrix(x, z, kernel_type="Gaussian", scale=0.1):
+    """K(x, z) of svgp.py:110-125 as a HIP kernel; x [n,d], z [m,d] (fp32 or fp64), no gradient
+    (coordinates and inducing points are not trainable: svgp.py:24-30)."""
+    _need_cuda(x, z)
+    x, z = x.contiguous(), z.contiguous().to(x.dtype)
+    K = torch.empty((x.shape[0], z.shape[0]), dtype=x.dtype, device=x.device)
+    _check(model_lib().spadot_kernel_matrix(_p(x), _p(z), x.shape[0], z.shape[0], x.shape[1], float(scale),
+                                            KERNEL_KINDS[kernel_type], _DT[x.dtype], _p(K), _stream()),
+           "spadot_kernel_matrix")
+    return K
+
+
+class _RowDot(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, A, B):
+        _need_cuda(A, B)
+        A, B = A.contiguous(), B.contiguous()
+        L, n, m = A.shape
+        out = torch.empty((L, n), dtype=A.dtype, device=A.device)
+        _check(model_lib().spadot_rowdot_forward(_p(A), _p(B), L, n, m, _DT[A.dtype], _p(out), _stream()),
+               "spadot_rowdot_forward")
+        ctx.save_for_backward(B)
+        ctx.shape = (L, n, m)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (B,) = ctx.saved_tensors
+        L, n, m = ctx.shape
+        g = g.contiguous()
+        gA = torch.empty((L, n, m), dtype=g.dtype, device=g.device)
+        _check(model_lib().spadot_rowdot_backward(_p(g), _p(B), L, n, m, _DT[g.dtype], _p(gA), _stream()),
+               "spadot_rowdot_backward")
+        return gA, None
+
+
+def rowdot(A, B):
+    """out[l, i] = sum_k A[l, i, k] * B[i, k]  (B constant)."""
+    return _RowDot.apply(A, B)
+
+
+class _ELBO(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mu, var, mv, tr, pm, pv, ktilde):
+        ts = [t.contiguous() for t in (mu, var, mv, tr, pm, pv, ktilde)]
+        _need_cuda(*ts)
+        b, L = ts[0].shape
+        out = torch.empty(2, dtype=ts[0].dtype, device=ts[0].device)
+        _check(model_lib().spadot_elbo_forward(*(_p(t) for t in ts), b, L, _DT[ts[0].dtype], _p(out), _stream()),
+               "spadot_elbo_forward")
+        ctx.save_for_backward(*ts)
+        return out
+
+    @staticmethod
+    def backward(ctx, g2):
+        ts = ctx.saved_tensors
+        b, L = ts[0].shape
+        g2 = g2.contiguous()
+        outs = [torch.empty_like(ts[0]) for _ in range(6)]
+        _check(model_lib().spadot_elbo_backward(_p(g2), *(_p(t) for t in ts), b, L, _DT[ts[0].dtype],
+                                                *(_p(o) for o in outs), _stream()), "spadot_elbo_backward")
+        return (*outs, None)
+
+
+def elbo_reduce(mu, var, mv, tr, pm, pv, ktilde):
+    """(l3_sum, ce_sum) of svgp.py:97-104 and SpaDOT.py:125-142 over a [b, L] batch."""
+    out = _ELBO.apply(mu, var, mv, tr, pm, pv, ktilde)
+    return out[0], out[1]
+
+
+_scratch = {}
+
+
+def _get_scratch(device):
+    key = str(device)
+    if key not in _scratch:
+        _scratch[key] = torch.empty(4096, dtype=torch.float64, device=device)
+    return _scratch[key]
+
+
+class _SqErr(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, yhat, inv_scale):
+        _need_cuda(y, yhat)
+        y, yhat = y.contiguous(), yhat.contiguous()
+        assert y.shape == yhat.shape and y.dtype == yhat.dtype
+        out = torch.empty(1, dtype=y.dtype, device=y.device)
+        _check(model_lib().spadot_sqerr_forward(_p(y), _p(yhat), y.numel(), float(inv_scale), _DT[y.dtype],
+                                                _p(_get_scratch(y.device)), _p(out), _stream()), "spadot_sqerr_forward")
+        ctx.save_for_backward(y, yhat)
+        ctx.inv_scale = float(inv_scale)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        y, yhat = ctx.saved_tensors
+        g1 = g.reshape(1).contiguous().to(y.dtype)
+        gy = torch.empty_like(yhat)
+        _check(model_lib().spadot_sqerr_backward(_p(g1), _p(y), _p(yhat), y.numel(), ctx.inv_scale, _DT[y.dtype],
+                                                 _p(gy), _stream()), "spadot_sqerr_backward")
+        return None, gy, None
+
+
+def sqerr_sum(y, yhat, inv_scale):
+    """inv_scale * sum (y - yhat)^2 (SpaDOT.py:89 with inv_scale = 1/input_dim); gradient to yhat only."""
+    return _SqErr.apply(y, yhat, inv_scale)
+
+
+def kmeans_assign(x, centers):
+    """int32 labels = nearest centre (fp64 distance accumulation, first minimum wins)."""
+    _need_cuda(x, centers)
+    x = x.contiguous()
+    centers = centers.contiguous().to(x.dtype)
+    labels = torch.empty(x.shape[0], dtype=torch.int32, device=x.device)
+    _check(model_lib().spadot_kmeans_assign(_p(x), _p(centers), x.shape[0], centers.shape[0], x.shape[1],
+                                            _DT[x.dtype], _p(labels), _stream()), "spadot_kmeans_assign")
+    return labels
+
+
+# ----------------------------------------------------------------------------- optimiser
+
+class FlatAdamW:
+    """clip_grad_norm_(max_norm) + AdamW.step (_train_utils.py:214-217) as two HIP kernels over ONE
+    flat fp32 parameter buffer.  Parameters of `module` are re-pointed into the flat buffer (so the
+    gradient all-reduce of the data-parallel path is a single collective over `flat_grad`)."""
+
+    def __init__(self, params, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_norm=0.3):
+        params = [p for p in params if p.requires_grad]
+        assert params and all(p.is_cuda and p.dtype == torch.float32 for p in params), \
+            "FlatAdamW needs fp32 parameters on the MI355X"
+        dev = params[0].device
+        sizes = [p.numel() for p in params]
+        # 16-byte aligned segments so every view supports vector access
+        offs, tot = [], 0
+        for s in sizes:
+            offs.append(tot)
+            tot += (s + 3) // 4 * 4
+        self.flat_param = torch.zeros(tot, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(tot, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(tot, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(tot, dtype=torch.float32, device=dev)
+        self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.scratch = torch.empty(4096, dtype=torch.float64, device=dev)
+        for p, o, s in zip(params, offs, sizes):
+            self.flat_param[o:o + s].copy_(p.data.reshape(-1))
+            p.data = self.flat_param[o:o + s].view_as(p.data)
+            p.grad = self.flat_grad[o:o + s].view_as(p.data)
+        self.params, self.count = params, tot
+        self.lr, self.betas, self.eps, self.weight_decay, self.max_norm = lr, betas, eps, weight_decay, max_norm
+        self.t = 0
+
+    def zero_grad(self):
+        self.flat_grad.zero_()
+
+    def grad_norm_sq(self):
+        """Device scalar: squared global gradient norm (deterministic reduction)."""
+        _check(model_lib().spadot_grad_sumsq(_p(self.flat_grad), self.count, _p(self.scratch), _p(self.sumsq),
+                                             _stream()), "spadot_grad_sumsq")
+        return self.sumsq
+
+    def step(self):
+        self.t += 1
+        self.grad_norm_sq()
+        _check(model_lib().spadot_adamw_step(_p(self.flat_param), _p(self.flat_grad), _p(self.exp_avg),
+                                             _p(self.exp_avg_sq), _p(self.sumsq), self.count, self.lr, self.betas[0],
+                                             self.betas[1], self.eps, self.weight_decay, self.max_norm, self.t,
+                                             _stream()), "spadot_adamw_step")

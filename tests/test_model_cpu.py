@@ -1,0 +1,74 @@
+"""CPU: host-side model logic that needs no kernel launch -- state_dict layout, graph/batch construction."""
+import numpy as np
+import torch
+
+from conftest import load_golden
+from oracle import model_oracle as mo
+
+
+def _cfg(g, device="cpu"):
+    return dict(input_dim=g["Y"].shape[1], z_dim=20, device=device, svgp_encoder_layers=[24, 12],
+                gat_encoder_hidden=8, gat_attention_heads=int(g["heads"]), decoder_layers=[12, 24],
+                kernel_type="Gaussian", kernel_scale=0.1, timepoints=[0, 1])
+
+
+def test_state_dict_keys_and_shapes_match_reference():
+    from spadot_amd.model import SpaDOT
+    g = load_golden("model_composite.npz")
+    m = SpaDOT.SpaDOT(_cfg(g), {"inducing_points": {0: g["ind0"], 1: g["ind1"]},
+                                "N_train": {0: float(g["N_train0"]), 1: float(g["N_train1"])}})
+    ref = {k[3:]: g[k].shape for k in g.files if k.startswith("sd/")}
+    mine = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert set(mine) == set(ref)
+    for k in ref:
+        assert mine[k] == tuple(ref[k]), k
+    # the reference's fp64 checkpoint loads (values are cast to this path's fp32 parameters)
+    m.load_state_dict({k[3:]: torch.as_tensor(g[k]) for k in g.files if k.startswith("sd/")})
+
+
+def test_knn_graph_matches_oracle_and_reference_edge_counts():
+    from spadot_amd.graph import knn_graph
+    rng = np.random.default_rng(0)
+    for n, k in [(150, 6), (747, 6), (500, 12)]:
+        c = rng.uniform(0, 30, size=(n, 2))
+        ei = knn_graph(c, k)
+        np.testing.assert_array_equal(ei, mo.knn_graph(c, k).numpy())
+        assert ei.shape[1] == n * (k + 1)          # n*k directed edges + n self loops
+    # ChickenHeart notebook: 747 spots, k=6 -> 4482 kNN edges (examples/ChickenHeart.ipynb:221-230)
+    assert knn_graph(rng.uniform(size=(747, 2)), 6).shape[1] - 747 == 4482
+
+
+def test_induced_batches_match_oracle_and_fixture():
+    from spadot_amd.graph import induced_batch
+    g = load_golden("model_composite.npz")
+    n = g["X"].shape[0]
+    n_id, sub = induced_batch(g["edge_index"], n, np.arange(int(g["batch_size"])))
+    np.testing.assert_array_equal(n_id, g["n_id"])
+    np.testing.assert_array_equal(sub, g["sub_edge_index"])
+    # a local (grid-ordered) graph gives a batch much smaller than the time point
+    side = 40
+    xy = np.stack(np.meshgrid(np.arange(side), np.arange(side)), -1).reshape(-1, 2).astype(float)
+    from spadot_amd.graph import knn_graph
+    ei = knn_graph(xy + 0.01 * np.random.default_rng(1).normal(size=xy.shape), 6)
+    n_id2, sub2 = induced_batch(ei, side * side, np.arange(64))
+    o_id, o_sub = mo.induced_batch(torch.as_tensor(ei), side * side, np.arange(64))
+    np.testing.assert_array_equal(n_id2, o_id.numpy())
+    np.testing.assert_array_equal(sub2, o_sub.numpy())
+    assert 64 < n_id2.size < side * side // 2
+
+
+def test_csr_round_trip():
+    from spadot_amd.graph import _csr_both
+    rng = np.random.default_rng(2)
+    n = 50
+    src = rng.integers(0, n, 400); dst = rng.integers(0, n, 400)
+    keep = src != dst
+    src = np.concatenate([src[keep], np.arange(n)]); dst = np.concatenate([dst[keep], np.arange(n)])
+    rowptr, col, rowptr_t, col_t, eid_t = _csr_both(src, dst, n)
+    # target-ordered edges
+    tgt = np.repeat(np.arange(n), np.diff(rowptr))
+    assert sorted(zip(col.tolist(), tgt.tolist())) == sorted(zip(src.tolist(), dst.tolist()))
+    # transposed view enumerates the same edges, eid_t points back into the target order
+    s_t = np.repeat(np.arange(n), np.diff(rowptr_t))
+    np.testing.assert_array_equal(col[eid_t], s_t)
+    np.testing.assert_array_equal(tgt[eid_t], col_t)

@@ -1,0 +1,260 @@
+"""GPU parity tests for the model side: HIP kernels (through the C-ABI of libspadot_model.so) and the
+model mirror vs the fp64 CPU oracle and the reference-generated golden vectors.
+
+Stated tolerances (reference fp64 CPU vs this fp32 device path): single forward from
+identical weights/batch/noise -- latent embeddings and loss terms rtol 1e-4 / atol 1e-5; SVGP
+posterior (fp64 on the device) rtol 1e-6; bf16 storage relaxes latents to rtol 2e-2; integer
+cluster labels exact."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import model_oracle as mo
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+F64 = torch.float64
+
+
+def T(x, dtype=F64):
+    return torch.as_tensor(np.asarray(x), dtype=dtype)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from spadot_amd import ops
+    return ops
+
+
+def _graph(ei, n):
+    from spadot_amd.graph import build_batch_graph
+    return build_batch_graph(ei, n, DEV)
+
+
+# ------------------------------------------------------------------ GAT edge phase
+
+@pytest.mark.parametrize("H,C,concat,act", [(4, 8, True, True), (4, 8, False, False), (4, 512, True, True),
+                                           (4, 512, False, False), (2, 96, True, False), (3, 256, True, True)])
+def test_gat_edge_forward_backward_vs_oracle(ops, H, C, concat, act):
+    rng = np.random.default_rng(H * 1000 + C)
+    n, k = 97, 7
+    coords = rng.uniform(size=(n, 2))
+    ei = mo.knn_graph(coords, k)
+    # add a hub (in-degree > 64 exercises the multi-chunk path) and drop its duplicates
+    extra = np.stack([np.arange(n), np.full(n, 5)])
+    ei = torch.as_tensor(np.unique(np.concatenate([ei.numpy(), extra], axis=1), axis=1))
+    fin = 24
+    x = T(rng.normal(size=(n, fin)))
+    W = T(rng.normal(size=(H * C, fin)) / np.sqrt(fin))
+    a_s = T(rng.normal(size=(1, H, C)) * 0.3); a_d = T(rng.normal(size=(1, H, C)) * 0.3)
+    bias = T(rng.normal(size=(H * C if concat else C)) * 0.1)
+    # oracle (fp64, autograd through the plain formulas)
+    xo, Wo, aso, ado, bo = (t.clone().requires_grad_(True) for t in (x, W, a_s, a_d, bias))
+    out_o = mo.gat_conv(xo, ei, Wo, aso, ado, bo, H, concat)
+    if act:
+        out_o = mo.leaky_relu(out_o)
+    gsel = T(rng.normal(size=tuple(out_o.shape)))
+    (out_o * gsel).sum().backward()
+    # device: same decomposition as spadot_amd.model.encoder.GATConv
+    g = _graph(ei, n)
+    xd, Wd, asd, add_, bd = (t.to(DEV, torch.float32).requires_grad_(True) for t in (x, W, a_s, a_d, bias))
+    h = xd @ Wd.T
+    Wh = Wd.view(H, C, fin)
+    s_src = xd @ torch.einsum("hci,hc->hi", Wh, asd[0]).T
+    s_dst = xd @ torch.einsum("hci,hc->hi", Wh, add_[0]).T
+    out_d = ops.gat_edge(h, s_src, s_dst, bd, g, H, C, concat, act)
+    (out_d * gsel.to(DEV, torch.float32)).sum().backward()
+    np.testing.assert_allclose(out_d.detach().cpu().numpy(), out_o.detach().numpy(), rtol=1e-4, atol=1e-5)
+    for name, d, o in (("x", xd, xo), ("W", Wd, Wo), ("att_src", asd, aso), ("att_dst", add_, ado), ("bias", bd, bo)):
+        ref = o.grad.numpy()
+        np.testing.assert_allclose(d.grad.cpu().numpy(), ref, rtol=2e-3, atol=2e-4 * np.abs(ref).max(), err_msg=name)
+
+
+def test_gat_edge_bf16_storage(ops):
+    rng = np.random.default_rng(3)
+    n, H, C = 64, 4, 512
+    ei = mo.knn_graph(rng.uniform(size=(n, 2)), 6)
+    g = _graph(ei, n)
+    h = T(rng.normal(size=(n, H * C)), torch.float32).to(DEV)
+    s1 = T(rng.normal(size=(n, H)), torch.float32).to(DEV); s2 = T(rng.normal(size=(n, H)), torch.float32).to(DEV)
+    bias = torch.zeros(H * C, device=DEV)
+    o32 = ops.gat_edge(h, s1, s2, bias, g, H, C, True, True)
+    o16 = ops.gat_edge(h.bfloat16(), s1, s2, bias, g, H, C, True, True)
+    assert o16.dtype == torch.bfloat16
+    np.testing.assert_allclose(o16.float().cpu().numpy(), o32.cpu().numpy(), rtol=2e-2, atol=2e-2)
+
+
+# ------------------------------------------------------------------ SVGP pieces
+
+@pytest.mark.parametrize("tag", ["s", "l"])
+def test_kernel_matrix_and_svgp_match_reference(ops, tag):
+    from spadot_amd.model.svgp import SVGP
+    g = load_golden("model_svgp.npz")
+    x, z = T(g[f"{tag}_x"]).to(DEV), T(g[f"{tag}_z"]).to(DEV)
+    for kt in ("Gaussian", "Cauchy", "Quadratic"):
+        K = ops.kernel_matrix(x, z, kt, 0.1)
+        np.testing.assert_allclose(K.cpu().numpy(), g[f"{tag}_K_{kt}"], rtol=1e-12, atol=1e-15)
+        K32 = ops.kernel_matrix(x.float(), z.float(), kt, 0.1)
+        np.testing.assert_allclose(K32.cpu().numpy(), g[f"{tag}_K_{kt}"], rtol=2e-5, atol=1e-7)
+    cfg = dict(device=DEV, kernel_type="Gaussian", kernel_scale=0.1)
+    sv = SVGP(cfg, g[f"{tag}_z"], float(g[f"{tag}_N_train"]))
+    y, noise = T(g[f"{tag}_y"]).to(DEV), T(g[f"{tag}_noise"]).to(DEV)
+    mean, B, mu_hat, A_hat = sv.approximate_posterior_params(x, x, y, noise)
+    # fp64 on the device; two jittered inverses (cond ~1e6) -> 1e-6
+    np.testing.assert_allclose(mean.cpu().numpy(), g[f"{tag}_mean"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(B.cpu().numpy(), g[f"{tag}_B"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(mu_hat.cpu().numpy(), g[f"{tag}_mu_hat"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(A_hat.cpu().numpy(), g[f"{tag}_A_hat"], rtol=1e-6, atol=1e-9)
+    l3, kl = sv.variational_loss(x, y, noise, mu_hat, A_hat)
+    assert float(l3) == pytest.approx(float(g[f"{tag}_l3"]), rel=1e-7)
+    assert float(kl) == pytest.approx(float(g[f"{tag}_kl"]), rel=1e-7)
+    xt = T(g[f"{tag}_xt"]).to(DEV)
+    mean_t, B_t, _, _ = sv.approximate_posterior_params(xt, x, y, noise)
+    np.testing.assert_allclose(mean_t.cpu().numpy(), g[f"{tag}_mean_t"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(B_t.cpu().numpy(), g[f"{tag}_B_t"], rtol=1e-6, atol=1e-9)
+
+
+def test_reduction_kernels_gradients_vs_torch(ops):
+    """rowdot / elbo_reduce / sqerr_sum: values and gradients against the same formulas in plain torch fp64."""
+    rng = np.random.default_rng(4)
+    L, n, m, b = 3, 37, 21, 37
+    A = T(rng.normal(size=(L, n, m))).to(DEV).requires_grad_(True)
+    B = T(rng.normal(size=(n, m))).to(DEV)
+    out = ops.rowdot(A, B)
+    ref = (A.detach() * B[None]).sum(-1)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.cpu().numpy(), rtol=1e-12)
+    w = T(rng.normal(size=(L, n))).to(DEV)
+    (out * w).sum().backward()
+    np.testing.assert_allclose(A.grad.cpu().numpy(), (w[:, :, None] * B[None]).cpu().numpy(), rtol=1e-12)
+
+    names = ("mu", "var", "mv", "tr", "pm", "pv")
+    vals = {k: T(rng.normal(size=(b, L))).to(DEV) for k in names}
+    vals["var"] = vals["var"].abs() + 0.3; vals["pv"] = vals["pv"].abs() + 0.1
+    kt = T(rng.uniform(size=b)).to(DEV)
+    leaf = {k: v.clone().requires_grad_(True) for k, v in vals.items()}
+    l3, ce = ops.elbo_reduce(*(leaf[k] for k in names), kt)
+    (2.0 * l3 - 0.7 * ce).backward()
+    ref = {k: v.clone().requires_grad_(True) for k, v in vals.items()}
+    l3r = -0.5 * ((kt[:, None] + ref["tr"]) / ref["var"] + torch.log(ref["var"]) + np.log(2 * np.pi)
+                  + (ref["mu"] - ref["mv"]) ** 2 / ref["var"]).sum()
+    cer = mo.gauss_cross_entropy(ref["pm"], ref["pv"], ref["mu"], ref["var"]).sum()
+    (2.0 * l3r - 0.7 * cer).backward()
+    assert float(l3) == pytest.approx(float(l3r), rel=1e-12) and float(ce) == pytest.approx(float(cer), rel=1e-12)
+    for k in names:
+        np.testing.assert_allclose(leaf[k].grad.cpu().numpy(), ref[k].grad.cpu().numpy(), rtol=1e-10, atol=1e-12, err_msg=k)
+
+    y = T(rng.normal(size=(50, 33)), torch.float32).to(DEV)
+    yh = T(rng.normal(size=(50, 33)), torch.float32).to(DEV).requires_grad_(True)
+    r = ops.sqerr_sum(y, yh, 1.0 / 33)
+    (3.0 * r).backward()
+    assert float(r) == pytest.approx(float(((y - yh.detach()) ** 2).sum() / 33), rel=1e-6)
+    np.testing.assert_allclose(yh.grad.cpu().numpy(), (3.0 * -2.0 / 33 * (y - yh.detach())).cpu().numpy(), rtol=1e-6)
+
+
+# ------------------------------------------------------------------ composite model
+
+def _model(g, compute_dtype=torch.float32):
+    from spadot_amd.model import SpaDOT
+    cfg = dict(input_dim=g["Y"].shape[1], z_dim=20, device=DEV, svgp_encoder_layers=[24, 12],
+               gat_encoder_hidden=8, gat_attention_heads=int(g["heads"]), decoder_layers=[12, 24],
+               kernel_type="Gaussian", kernel_scale=0.1, timepoints=[0, 1], compute_dtype=compute_dtype)
+    m = SpaDOT.SpaDOT(cfg, {"inducing_points": {0: g["ind0"], 1: g["ind1"]},
+                            "N_train": {0: float(g["N_train0"]), 1: float(g["N_train1"])}}).to(DEV)
+    m.load_state_dict({k[3:]: torch.as_tensor(g[k]) for k in g.files if k.startswith("sd/")})
+    return m
+
+
+def test_composite_forward_and_gradients_match_reference(ops):
+    g = load_golden("model_composite.npz")
+    m = _model(g)
+    m.train()
+    b = int(g["batch_size"])
+    n_id = torch.as_tensor(g["n_id"])
+    xb = T(g["X"])[n_id].to(DEV)
+    yb = T(g["Y"], torch.float32)[n_id].to(DEV)
+    graph = _graph(g["sub_edge_index"], n_id.numel())
+    noise = (T(g["noise_svgp"]).to(DEV), T(g["noise_gat"], torch.float32).to(DEV))
+    recon, skl, gkl, align, z = m.forward(xb, yb, graph, 0, b, noise=noise)
+    # reference fp64 CPU vs fp32 device path: loss terms and latents rtol 1e-4 / atol 1e-5
+    assert float(recon) == pytest.approx(float(g["recon"]), rel=1e-4)
+    assert float(skl) == pytest.approx(float(g["SVGP_KL"]), rel=1e-4)
+    assert float(gkl) == pytest.approx(float(g["GAT_KL"]), rel=1e-4)
+    assert float(align) == pytest.approx(float(g["alignment"]), rel=1e-4)
+    np.testing.assert_allclose(z.detach().cpu().numpy(), g["final_latent"], rtol=1e-4, atol=1e-5)
+    # gradients of the step loss w.r.t. every parameter
+    loss = 0.1 * recon - 0.5 * skl + 1e-4 * gkl + 0.1 * align
+    m.zero_grad()
+    loss.backward()
+    for name, p in m.named_parameters():
+        ref = g["grad/" + name]
+        assert p.grad is not None, name
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=5e-3, atol=5e-5 * max(1e-3, np.abs(ref).max()),
+                                   err_msg=name)
+    # BatchNorm running statistics after one train-mode forward
+    sd = m.state_dict()
+    for k in g.files:
+        if k.startswith("sd_after/") and "running" in k:
+            np.testing.assert_allclose(sd[k[9:]].cpu().numpy(), g[k], rtol=1e-4, atol=1e-6, err_msg=k)
+
+
+def test_all_latent_samples_matches_reference(ops):
+    g = load_golden("model_composite.npz")
+    m = _model(g)
+    m.eval()
+    with torch.no_grad():
+        lat = m.all_latent_samples(g["X"], g["Y"].astype(np.float32), g["edge_index"], 1)
+    assert isinstance(lat, np.ndarray) and lat.shape == (g["X"].shape[0], 20)
+    np.testing.assert_allclose(lat, g["all_latent_tp1"], rtol=1e-4, atol=1e-5)
+
+
+def test_composite_forward_bf16_compute(ops):
+    g = load_golden("model_composite.npz")
+    m = _model(g, torch.bfloat16)
+    m.train()
+    b = int(g["batch_size"])
+    n_id = torch.as_tensor(g["n_id"])
+    xb = T(g["X"])[n_id].to(DEV)
+    yb = T(g["Y"], torch.float32)[n_id].to(DEV)
+    graph = _graph(g["sub_edge_index"], n_id.numel())
+    noise = (T(g["noise_svgp"]).to(DEV), T(g["noise_gat"], torch.float32).to(DEV))
+    recon, skl, gkl, align, z = m.forward(xb, yb, graph, 0, b, noise=noise)
+    # bf16 storage in the GAT branch: latents rtol 2e-2; the SVGP half is untouched
+    np.testing.assert_allclose(z.detach().cpu().numpy()[:, :10], g["final_latent"][:, :10], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(z.detach().cpu().numpy()[:, 10:], g["final_latent"][:, 10:], rtol=2e-2, atol=2e-2)
+    assert float(recon) == pytest.approx(float(g["recon"]), rel=2e-2)
+
+
+# ------------------------------------------------------------------ glue: k-means labels, optimiser
+
+def test_kmeans_assignment_is_bit_exact(ops):
+    g = load_golden("model_glue.npz")
+    for dt in (torch.float64, torch.float32):
+        lab = ops.kmeans_assign(T(g["km_points"], dt).to(DEV), T(g["km_centers"], dt).to(DEV))
+        assert lab.dtype == torch.int32
+        np.testing.assert_array_equal(lab.cpu().numpy(), g["km_predict"])
+    # ties go to the first centre, empty / single inputs work
+    x = torch.zeros((3, 4), dtype=torch.float64, device=DEV)
+    c = torch.zeros((5, 4), dtype=torch.float64, device=DEV)
+    assert ops.kmeans_assign(x, c).cpu().tolist() == [0, 0, 0]
+
+
+def test_flat_adamw_matches_torch_clip_and_adamw(ops):
+    torch.manual_seed(0)
+    shapes = [(7, 13), (13,), (5, 3, 2), (1,)]
+    ref_p = [torch.randn(s, device=DEV).requires_grad_(True) for s in shapes]
+    my_p = [p.detach().clone().requires_grad_(True) for p in ref_p]
+    opt_ref = torch.optim.AdamW(ref_p, lr=3e-4)
+    opt_my = ops.FlatAdamW(my_p, lr=3e-4, max_norm=0.3)
+    for step in range(4):
+        grads = [torch.randn(s, device=DEV) * (3.0 if step % 2 else 0.01) for s in shapes]   # clipped / not clipped
+        opt_ref.zero_grad(); opt_my.zero_grad()
+        for p, q, gr in zip(ref_p, my_p, grads):
+            p.grad = gr.clone()
+            q.grad.copy_(gr)
+        total = torch.nn.utils.clip_grad_norm_(ref_p, 0.3)
+        assert float(opt_my.grad_norm_sq().sqrt()) == pytest.approx(float(total), rel=1e-5)
+        opt_ref.step(); opt_my.step()
+        for p, q in zip(ref_p, my_p):
+            np.testing.assert_allclose(q.detach().cpu().numpy(), p.detach().cpu().numpy(), rtol=2e-6, atol=1e-7)
