@@ -1,0 +1,260 @@
+"""Training driver: mirror of /root/reference/SpaDOT/utils/_train_utils.py (same function names and
+meaning) with the whole step resident on the MI355X.
+
+What differs from the reference, on purpose (SURVEY 7 "hard parts", App. D):
+  * no dense N_t x N_t adjacency and no torch_geometric: the kNN graph is CSR from the start and the
+    (unshuffled, hence epoch-invariant) NeighborLoader batches are built once (spadot_amd.graph);
+  * expression, coordinates, graphs, K-means labels/centres and OT plans live on the device; the
+    step has no .item() / per-spot Python dict look-ups (losses are read back once per epoch);
+  * clip_grad_norm_(0.3) + AdamW.step are two HIP kernels over one flat parameter buffer, which is
+    also what the data-parallel path all-reduces (spadot_amd.parallel);
+  * backward(retain_graph=True) is not replicated (App. D.11);
+  * only the first growth solve of compute_transport_map is run (it is the one returned, App. D.1).
+"""
+import random
+from collections import OrderedDict
+from time import time
+
+import numpy as np
+import torch
+
+from ..graph import build_batch_graph, knn_graph, precompute_batches
+from ..model import SpaDOT
+from ..ops import FlatAdamW
+from .OT_loss.ot_solvers import compute_transport_map
+
+LOSS_NAMES = ["elbo", "Recon", "SVGP_KL", "GAT_KL", "alignment", "KMeans", "OT"]
+
+
+def _obtain_tp_loc_info(adata):
+    """_train_utils.py:118-140: per-time-point standardised coordinates ++ one-hot time point."""
+    tps = np.asarray(adata.obs["timepoint"])
+    uniq = sorted(set(tps.tolist()))
+    code = np.array([uniq.index(t) for t in tps.tolist()], dtype=int)
+    tp_mat = np.zeros((code.size, len(uniq)))
+    tp_mat[np.arange(code.size), code] = 1
+    loc = np.asarray(adata.obsm["spatial"], dtype=np.float64)
+    loc_scaled = np.zeros(loc.shape, dtype=np.float64)
+    for i in range(len(uniq)):
+        sel = code == i
+        tp_loc = loc[sel]
+        sd = tp_loc.std(axis=0)
+        sd[sd == 0] = 1.0                                   # StandardScaler's zero-variance rule
+        loc_scaled[sel] = (tp_loc - tp_loc.mean(axis=0)) / sd
+    return np.concatenate((loc_scaled, tp_mat), axis=1)
+
+
+def prepare_dataloader(adata, model_config):
+    """_train_utils.py:37-94.  Returns the same dict keys the reference's callers use
+    ('inducing_points', 'N_train', 'dataloaders', 'datasets') plus 'graphs' (full time-point CSR for
+    inference); 'adjacency_matrices' (dense N_t^2) is deliberately not built."""
+    device = torch.device(model_config["device"])
+    store = model_config.get("compute_dtype", torch.float32)
+    loc = _obtain_tp_loc_info(adata)
+    inducing_idx = random.sample(range(loc.shape[0]), model_config["inducing_point_nums"])
+    inducing_points = loc[inducing_idx, :]
+    timepoints = model_config["timepoints"]
+    tp_to_idx = {v: k for k, v in enumerate(timepoints)}
+    idx = np.argmax(loc[:, 2:], axis=1)
+    tp_index = {tp: np.nonzero(idx == tp_to_idx[tp])[0] for tp in timepoints}
+    inducing_tp = np.argmax(inducing_points[:, 2:], axis=1)
+    inducing_points_dict, N_train_dict = OrderedDict(), OrderedDict()
+    for tp in timepoints:
+        inducing_points_dict[tp] = inducing_points[np.where(inducing_tp == tp_to_idx[tp])[0], :2]
+        N_train_dict[tp] = int(np.sum(np.asarray(adata.obs["timepoint"]) == tp))
+    dataloaders, datasets, graphs = OrderedDict(), OrderedDict(), OrderedDict()
+    owned = model_config.get("owned_timepoints", timepoints)
+    X = adata.X
+    spatial = np.asarray(adata.obsm["spatial"], dtype=np.float64)
+    for tp in timepoints:
+        if tp not in owned:
+            continue
+        ix = tp_index[tp]
+        n = ix.size
+        k_cut = min(model_config["max_neighbors"], model_config["knn_cutoff"] * round(1 / 1000 * n))
+        print("Calculating spatial graph...")
+        ei = knn_graph(spatial[ix], k_cut, max_neigh=model_config["max_neighbors"])
+        print("The graph contains %d edges, %d cells." % (ei.shape[1] - n, n))
+        Y = torch.as_tensor(np.ascontiguousarray(np.asarray(X[ix]))).to(device=device, dtype=store)
+        datasets[tp] = (torch.as_tensor(loc[ix, :2]).to(device), Y, ix)
+        dataloaders[tp] = precompute_batches(ei, n, model_config["batch_size"], device)
+        graphs[tp] = build_batch_graph(ei, n, device)
+    return {"inducing_points": inducing_points_dict, "N_train": N_train_dict, "dataloaders": dataloaders,
+            "datasets": datasets, "graphs": graphs}
+
+
+def get_latent(model, model_config, adata, dataloader_dict):
+    """_train_utils.py:98-116 without AnnData: returns (latent [N, z_dim] in the order of adata rows of the
+    owned time points, row indices)."""
+    model.eval()
+    lat, rows = [], []
+    with torch.no_grad():
+        for tp in dataloader_dict["datasets"]:
+            loc, Y, ix = dataloader_dict["datasets"][tp]
+            lat.append(model.all_latent_samples(loc, Y, dataloader_dict["graphs"][tp], tp))
+            rows.append(ix)
+    return np.concatenate(lat), np.concatenate(rows)
+
+
+def _beta_cycle_linear(n_iter, start=0.0, stop=1, n_cycle=10, ratio=1):
+    """_train_utils.py:143-153."""
+    L = np.ones(n_iter) * stop
+    period = n_iter / n_cycle
+    step = (stop - start) / (period * ratio)
+    for c in range(n_cycle):
+        v, i = start, 0
+        while v <= stop and (int(i + c * period) < n_iter):
+            L[int(i + c * period)] = v
+            v += step
+            i += 1
+    return L
+
+
+# ------------------------------------------------------------------------------ regularisers
+
+def _device_state(model, tp):
+    """Per-time-point K-means state mirrored on the device: labels by local spot id, centres, and the
+    sorted list of cluster ids that occur in the time point."""
+    return model._kmeans_dev[tp]
+
+
+def _compute_kmeans_loss(model, model_config, tp, seed_ids, latent):
+    """_train_utils.py:240-253: ||z - c[label]||_F^2 / z_dim / (#distinct labels in the batch).
+    `seed_ids` are local spot ids of the time point (device int64)."""
+    st = _device_state(model, tp)
+    lab = st["labels"][seed_ids]
+    centers = st["centers"]
+    n_distinct = (torch.bincount(lab, minlength=centers.shape[0]) > 0).sum()
+    return torch.sum((latent - centers[lab]) ** 2) / latent.shape[1] / n_distinct
+
+
+def _compute_OT_loss(model, model_config, cur_tp, seed_ids, tp_p_m, prev_tp):
+    """_train_utils.py:272-307 on the device: batch means per cluster (stored centre when the cluster is
+    absent from the batch), row-normalised plan with NaN/inf -> 0, mean(gamma * cdist)."""
+    st = _device_state(model, cur_tp)
+    lab = st["labels"][seed_ids]
+    K = st["centers"].shape[0]
+    sums = torch.zeros((K, tp_p_m.shape[1]), dtype=tp_p_m.dtype, device=tp_p_m.device).index_add_(0, lab, tp_p_m)
+    cnt = torch.bincount(lab, minlength=K).to(tp_p_m.dtype).unsqueeze(1)
+    means = torch.where(cnt > 0, sums / cnt.clamp(min=1), st["centers"])
+    cur = means[st["cluster_list"]]
+    gamma = model._gamma_dev[f"{prev_tp}_{cur_tp}"]
+    cost = torch.cdist(_device_state(model, prev_tp)["centers"], cur, p=2)
+    return torch.mean(gamma * cost)
+
+
+def _set_kmeans_state(model, tp, centers, labels, global_idx, device):
+    """Stores the reference's three dicts (SpaDOT.py:47-50) and their device mirror."""
+    model.kmeans_center_dict[tp] = centers
+    model.kmeans_cluster_dict[tp] = labels.tolist()
+    model.kmeans_index_dict[tp] = dict(zip(np.asarray(global_idx).tolist(), labels.tolist()))
+    if not hasattr(model, "_kmeans_dev"):
+        model._kmeans_dev, model._gamma_dev = {}, {}
+    cl = sorted(set(labels.tolist()))
+    model._kmeans_dev[tp] = {"labels": torch.as_tensor(labels, dtype=torch.int64).to(device),
+                             "centers": torch.as_tensor(centers, dtype=torch.float32).to(device),
+                             "cluster_list": torch.as_tensor(cl, dtype=torch.int64).to(device)}
+
+
+def _update_Kmeans(model, model_config, dataloader_dict):
+    """_train_utils.py:255-269: full-time-point inference + sklearn KMeans(n_init=10) per time point."""
+    from sklearn.cluster import KMeans
+    model.eval()
+    device = torch.device(model_config["device"])
+    with torch.no_grad():
+        for tp in dataloader_dict["datasets"]:
+            loc, Y, ix = dataloader_dict["datasets"][tp]
+            latent = model.all_latent_samples(loc, Y, dataloader_dict["graphs"][tp], tp)
+            km = KMeans(n_clusters=model_config["n_clusters"], random_state=model_config["seed"], n_init=10).fit(latent)
+            _set_kmeans_state(model, tp, km.cluster_centers_, km.labels_, ix, device)
+
+
+def _set_gamma(model, key, gamma, device):
+    model.gammas[key] = gamma
+    with np.errstate(divide="ignore", invalid="ignore"):
+        g = gamma / gamma.sum(axis=1, keepdims=True)
+    g = np.nan_to_num(g, nan=0.0, posinf=0.0, neginf=0.0)
+    model._gamma_dev[key] = torch.as_tensor(g, dtype=torch.float32).to(device)
+
+
+def _update_OT_matrix(model, model_config):
+    """_train_utils.py:309-321: transport plan between the K-means centres of consecutive time points."""
+    model.eval()
+    device = torch.device(model_config["device"])
+    timepoints = model_config["timepoints"]
+    for tp_i, tp in enumerate(timepoints[:-1]):
+        nxt = timepoints[tp_i + 1]
+        if tp not in model.kmeans_center_dict or nxt not in model.kmeans_center_dict:
+            continue
+        gamma = compute_transport_map(model.kmeans_center_dict[tp], model.kmeans_center_dict[nxt],
+                                      model_config["ot_config"], G=None)
+        _set_gamma(model, f"{tp}_{nxt}", gamma, device)
+
+
+# ------------------------------------------------------------------------------ the step
+
+def training_step(model, optimizer, model_config, dataloader_dict, tp_i, tp, bi, epoch, beta1, grad_sync=None):
+    """One optimizer step on batch `bi` of time point `tp` (_train_utils.py:187-217).  Returns the seven
+    loss terms as a device tensor (no host sync)."""
+    batch = dataloader_dict["dataloaders"][tp][bi]
+    loc, Y, _ = dataloader_dict["datasets"][tp]
+    x_b, y_b = loc[batch.n_id], Y[batch.n_id]
+    seeds = batch.n_id[:batch.batch_size]
+    recon, svgp_kl, gat_kl, align, z = model.forward(x=x_b, y=y_b, edge_index=batch.graph, tp=tp,
+                                                     batch_size=batch.batch_size, batch_key=(tp, bi))
+    zero = torch.zeros((), dtype=torch.float32, device=z.device)
+    km = _compute_kmeans_loss(model, model_config, tp, seeds, z) if epoch >= 1 else zero
+    ot = zero
+    if epoch >= model_config["ot_epoch"] and tp_i != 0:
+        ot = _compute_OT_loss(model, model_config, tp, seeds, z, model_config["timepoints"][tp_i - 1])
+    elbo = (model_config["lambda1"] * recon - beta1 * svgp_kl + model_config["beta2"] * gat_kl
+            + model_config["omiga1"] * align + model_config["omiga2"] * km + model_config["omiga3"] * ot)
+    optimizer.zero_grad()
+    elbo.backward()
+    if grad_sync is not None:
+        grad_sync(optimizer.flat_grad)
+    optimizer.step()
+    return torch.stack([elbo.detach(), recon.detach(), svgp_kl.detach(), gat_kl.detach(), align.detach(),
+                        km.detach(), ot.detach()])
+
+
+def train_SpaDOT(dataloader_dict, model_config, verbose=True):
+    """_train_utils.py:155-236.  Returns (model, loss_df) with loss_df indexed like the reference's
+    (columns = epochs, rows = loss names; train.py:38 writes its transpose)."""
+    import pandas as pd
+    device = torch.device(model_config["device"])
+    model = SpaDOT.SpaDOT(model_config, dataloader_dict).to(device)
+    optimizer = FlatAdamW(model.parameters(), lr=model_config["lr"])
+    beta1s = _beta_cycle_linear(model_config["maxiter"], stop=model_config["beta1"])
+    tp_indexed_list = list(enumerate(model_config["timepoints"]))
+    loss_dict = OrderedDict((e, OrderedDict((n, 0.0) for n in LOSS_NAMES)) for e in range(model_config["maxiter"]))
+    if verbose:
+        print("Training SpaDOT model...")
+    t_start = time()
+    for epoch in range(model_config["maxiter"]):
+        beta1 = float(beta1s[epoch])
+        model.train()
+        ep_start = time()
+        random.shuffle(tp_indexed_list)
+        acc = {}
+        for tp_i, tp in tp_indexed_list:
+            if tp not in dataloader_dict["dataloaders"]:
+                continue
+            nb = len(dataloader_dict["dataloaders"][tp])
+            tot = torch.zeros(len(LOSS_NAMES), dtype=torch.float32, device=device)
+            for bi in range(nb):
+                tot += training_step(model, optimizer, model_config, dataloader_dict, tp_i, tp, bi, epoch, beta1).float()
+            acc[tp] = tot / nb
+        for tp, v in acc.items():                      # one device->host read per time point per epoch
+            for name, val in zip(LOSS_NAMES, v.cpu().tolist()):
+                loss_dict[epoch][name] += val
+        if verbose and epoch % 10 == 0:
+            print(f"Epoch {epoch + 1}: Training time: {int(time() - ep_start)} seconds, "
+                  + ", ".join(f"{n}: {loss_dict[epoch][n]:.8f}" for n in LOSS_NAMES))
+        _update_Kmeans(model, model_config, dataloader_dict)
+        if (epoch + 1) % model_config["ot_config"]["ot_epochs"] == 0:
+            _update_OT_matrix(model, model_config)
+    if verbose:
+        print("Training finished...")
+        print("Training time: %d seconds." % int(time() - t_start))
+    return model, pd.DataFrame.from_dict(loss_dict)
