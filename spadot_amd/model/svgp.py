@@ -84,7 +84,8 @@ class SVGP(nn.Module):
     # ---- batched path --------------------------------------------------------------------
     def _sigma_inv(self, bc, W):
         K_mm, _, _, eye = self._run_constants()
-        sigma = K_mm.unsqueeze(0) + bc.c * torch.einsum("bm,bl,bn->lmn", bc.K_nm, W, bc.K_nm)
+        A = bc.K_nm.unsqueeze(0) * W.T.unsqueeze(2)                        # [L, b, m] = diag(w_l) K_nm
+        sigma = K_mm.unsqueeze(0) + bc.c * torch.matmul(A.transpose(1, 2), bc.K_nm)   # batched m x b x m GEMM
         return torch.linalg.inv(sigma + self.jitter * eye)                 # [L, m, m]
 
     def posterior(self, bc_train, mu, var, bc_test=None):
@@ -114,8 +115,8 @@ class SVGP(nn.Module):
         tr = rowdot(torch.einsum("bm,lmn->lbn", bc.P, S_inv), bc.P).T      # [b, L]
         L_s = torch.linalg.cholesky(A_hat + self.jitter * eye)
         logdet_S = 2.0 * torch.sum(torch.log(torch.diagonal(L_s, dim1=-2, dim2=-1)), dim=-1)
-        kl = 0.5 * (logdet_K - logdet_S - m + torch.einsum("mn,lnm->l", K_inv, A_hat)
-                    + torch.einsum("lm,mn,ln->l", mu_hat, K_inv, mu_hat))
+        kl = 0.5 * (logdet_K - logdet_S - m + (A_hat * K_inv.T.unsqueeze(0)).sum(dim=(1, 2))
+                    + ((mu_hat @ K_inv) * mu_hat).sum(dim=1))
         l3_sum, ce_sum = elbo_reduce(mu, var, mv, tr, p_m, p_v, bc.ktilde)
         return p_m, p_v, l3_sum, kl.sum(), ce_sum
 

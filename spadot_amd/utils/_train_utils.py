@@ -193,9 +193,10 @@ def _update_OT_matrix(model, model_config):
 
 # ------------------------------------------------------------------------------ the step
 
-def training_step(model, optimizer, model_config, dataloader_dict, tp_i, tp, bi, epoch, beta1, grad_sync=None):
-    """One optimizer step on batch `bi` of time point `tp` (_train_utils.py:187-217).  Returns the seven
-    loss terms as a device tensor (no host sync)."""
+def forward_backward(model, model_config, dataloader_dict, tp_i, tp, bi, epoch, beta1):
+    """Forward of batch `bi` of time point `tp`, composite loss (_train_utils.py:193-212) and backward
+    into the parameters' .grad (the flat gradient buffer).  Returns the seven loss terms as a device
+    tensor (no host sync)."""
     batch = dataloader_dict["dataloaders"][tp][bi]
     loc, Y, _ = dataloader_dict["datasets"][tp]
     x_b, y_b = loc[batch.n_id], Y[batch.n_id]
@@ -209,13 +210,20 @@ def training_step(model, optimizer, model_config, dataloader_dict, tp_i, tp, bi,
         ot = _compute_OT_loss(model, model_config, tp, seeds, z, model_config["timepoints"][tp_i - 1])
     elbo = (model_config["lambda1"] * recon - beta1 * svgp_kl + model_config["beta2"] * gat_kl
             + model_config["omiga1"] * align + model_config["omiga2"] * km + model_config["omiga3"] * ot)
-    optimizer.zero_grad()
     elbo.backward()
+    return torch.stack([elbo.detach(), recon.detach(), svgp_kl.detach(), gat_kl.detach(), align.detach(),
+                        km.detach(), ot.detach()])
+
+
+def training_step(model, optimizer, model_config, dataloader_dict, tp_i, tp, bi, epoch, beta1, grad_sync=None):
+    """One optimizer step (_train_utils.py:187-217): zero_grad, forward_backward, optional gradient
+    all-reduce (data-parallel path), clip + AdamW."""
+    optimizer.zero_grad()
+    losses = forward_backward(model, model_config, dataloader_dict, tp_i, tp, bi, epoch, beta1)
     if grad_sync is not None:
         grad_sync(optimizer.flat_grad)
     optimizer.step()
-    return torch.stack([elbo.detach(), recon.detach(), svgp_kl.detach(), gat_kl.detach(), align.detach(),
-                        km.detach(), ot.detach()])
+    return losses
 
 
 def train_SpaDOT(dataloader_dict, model_config, verbose=True):

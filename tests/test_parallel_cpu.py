@@ -1,0 +1,133 @@
+"""CPU, world_size 2 over gloo: the multi-GPU path's sharding and collectives (spadot_amd.parallel).
+The HIP model cannot run here, so a small torch model stands in for `compute_grad` and the oracle
+stands in for the pair solver; what is under test is the schedule, the flat-gradient all-reduce, the
+buffer averaging, and the centre / plan gathers."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from spadot_amd import parallel as par
+
+
+def test_shard_plan_round_robin():
+    plan = par.ShardPlan([0, 1, 2, 3, 4], 2, 0)
+    assert plan.owned_timepoints(0) == [0, 2, 4] and plan.owned_timepoints(1) == [1, 3]
+    assert plan.owned_pairs(0) == [(0, 1), (2, 3)] and plan.owned_pairs(1) == [(1, 2), (3, 4)]
+    # more ranks than time points: the surplus ranks own nothing and only take part in collectives
+    plan8 = par.ShardPlan([0, 1, 2, 3, 4], 8, 6)
+    assert plan8.owned_timepoints() == [] and plan8.owned_pairs() == []
+    assert sorted(sum((plan8.owned_timepoints(r) for r in range(8)), [])) == [0, 1, 2, 3, 4]
+    per_rank, n = par.epoch_schedule(plan, {0: 3, 1: 2, 2: 1, 3: 4, 4: 2}, [(2, 2), (0, 0), (1, 1), (4, 4), (3, 3)])
+    assert per_rank[0] == [(2, 2, 0), (0, 0, 0), (0, 0, 1), (0, 0, 2), (4, 4, 0), (4, 4, 1)]
+    assert per_rank[1] == [(1, 1, 0), (1, 1, 1), (3, 3, 0), (3, 3, 1), (3, 3, 2), (3, 3, 3)]
+    assert n == 6
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _make_model(seed):
+    torch.manual_seed(seed)
+    m = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.BatchNorm1d(5), torch.nn.Linear(5, 1)).double()
+    flat = torch.zeros(sum(p.numel() for p in m.parameters()), dtype=torch.float64)
+    grad = torch.zeros_like(flat)
+    off = 0
+    for p in m.parameters():
+        n = p.numel()
+        flat[off:off + n].copy_(p.data.reshape(-1)); p.data = flat[off:off + n].view_as(p.data)
+        p.grad = grad[off:off + n].view_as(p.data)
+        off += n
+    return m, flat, grad
+
+
+def _data(tp, bi):
+    g = torch.Generator().manual_seed(100 * tp + bi)
+    return torch.randn((8, 6), generator=g, dtype=torch.float64), torch.randn((8, 1), generator=g, dtype=torch.float64)
+
+
+BATCHES = {0: 3, 1: 1, 2: 2}
+ORDER = [(1, 1), (0, 0), (2, 2)]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        plan = par.ShardPlan([0, 1, 2], world, rank)
+        m, flat, grad = _make_model(0 if rank == 0 else 5)     # different init: broadcast must fix it
+        for t in list(m.parameters()) + list(m.buffers()):
+            dist.broadcast(t.data, src=0)
+        opt = torch.optim.SGD(m.parameters(), lr=0.1)
+
+        def compute_grad(tp_i, tp, bi):
+            x, y = _data(tp, bi)
+            ((m(x) - y) ** 2).mean().backward()
+
+        steps = par.run_epoch(plan, BATCHES, ORDER, compute_grad, grad.zero_, grad, opt.step)
+        par.average_buffers(m)
+        centres = par.gather_centres({tp: np.full((4, 3), float(tp + 1)) for tp in plan.owned_timepoints()}, plan, 4, 3, "cpu")
+        # pair-sharded Sinkhorn: each rank solves its own pairs with no collective, plans gathered after
+        from oracle import ot_oracle
+        cfg = dict(lambda1=0.1, lambda2=5.0, epsilon=0.05, epsilon0=1.0, tolerance=1e-8, tau=1000.0,
+                   batch_size=5, max_iter=10 ** 7, growth_iters=3)
+        rng = np.random.default_rng(0)
+        cen = {tp: rng.normal(size=(4, 3)) for tp in (0, 1, 2)}
+        local = {p: ot_oracle.compute_transport_map(cen[p[0]], cen[p[1]], cfg, all_growth_iters=False)
+                 for p in plan.owned_pairs()}
+        plans = par.gather_small_plans(local, plan, (4, 4), "cpu")
+        q.put((rank, steps, flat.clone().numpy(), [b.clone().numpy() for b in m.buffers() if b.is_floating_point()],
+               {k: v.copy() for k, v in centres.items()}, {k: v.copy() for k, v in plans.items()},
+               sorted(local)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_epoch_over_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, s0, f0, b0, c0, p0, l0), (r1, s1, f1, b1, c1, p1, l1) = res
+    # rank 0 owns time points 0 and 2 (3 + 2 batches), rank 1 owns 1 (1 batch): 5 global steps on both
+    assert s0 == s1 == 5
+    np.testing.assert_array_equal(f0, f1)                       # replicas stay identical
+    for x, y in zip(b0, b1):
+        np.testing.assert_array_equal(x, y)                      # averaged BatchNorm statistics
+    # single-process emulation of the same schedule: per step the SUM of both ranks' gradients
+    m, flat, grad = _make_model(0)
+    opt = torch.optim.SGD(m.parameters(), lr=0.1)
+    plan0, plan1 = par.ShardPlan([0, 1, 2], 2, 0), par.ShardPlan([0, 1, 2], 2, 1)
+    per_rank, n = par.epoch_schedule(plan0, BATCHES, ORDER)
+    import copy
+    bn_states = []
+    for s in range(n):
+        grad.zero_()
+        for r in range(2):
+            if s < len(per_rank[r]):
+                tp_i, tp, bi = per_rank[r][s]
+                x, y = _data(tp, bi)
+                ((m(x) - y) ** 2).mean().backward()
+        opt.step()
+    # (BatchNorm running stats differ between the emulation and the replicas by construction; the
+    # parameters only depend on batch statistics in train mode, so they must match exactly)
+    np.testing.assert_allclose(f0, flat.numpy(), rtol=1e-12, atol=1e-14)
+    for tp in (0, 1, 2):
+        np.testing.assert_array_equal(c0[tp], np.full((4, 3), float(tp + 1)))
+        np.testing.assert_array_equal(c1[tp], c0[tp])
+    assert l0 == [(0, 1)] and l1 == [(1, 2)]                    # pairs sharded, disjoint
+    for k in p0:
+        np.testing.assert_array_equal(p0[k], p1[k])
+        assert p0[k].shape == (4, 4) and p0[k].sum() > 0

@@ -104,3 +104,49 @@ def test_train_end_to_end_writes_reference_outputs(tmp_path):
     # integer cluster assignments: the device assignment kernel reproduces sklearn's labels bit for bit
     from spadot_amd import ops
     lat0 = torch.as_tensor(z["X"][:1200], dtype=torch.float64, device=DEV)
+
+
+def _dp_worker(rank, world, port, q):
+    """One data-parallel rank on cuda:0 (both ranks share the one GPU of the test box; gloo carries the
+    collectives, on a real node the backend is nccl = RCCL)."""
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from spadot_amd import parallel as par
+        from spadot_amd.synthetic import make_dataset
+        from spadot_amd.utils import _train_utils as tu, _utils
+        cfg = _small_config()
+        cfg.update(maxiter=2, input_dim=40, timepoints=[0, 1, 2], device=torch.device(DEV))
+        plan = par.ShardPlan(cfg["timepoints"], world, rank)
+        cfg["owned_timepoints"] = plan.data_timepoints()
+        data = make_dataset(3, 1200, 40, seed=11)
+        _utils.set_seed(cfg["seed"])
+        dd = tu.prepare_dataloader(data, cfg)
+        model, losses = par.train_SpaDOT_parallel(dd, cfg)
+        flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu().numpy()
+        q.put((rank, flat, sorted(model.gammas), sorted(model.kmeans_center_dict), losses[1]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_training_two_ranks_one_gpu():
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (_, f0, g0, c0, l0), (_, f1, g1, c1, l1) = res
+    np.testing.assert_array_equal(f0, f1)              # replicas identical after 2 epochs
+    assert g0 == g1 == ["0_1", "1_2"]                  # every rank holds every (sharded) pair plan
+    assert c0 == c1 == [0, 1, 2]                       # centres of all time points everywhere
+    assert np.isfinite(l0).all() and np.isfinite(l1).all()
+    assert l0[6] > 0 and l1[6] > 0                     # OT term live on both ranks (ot_epoch = 1; tp 2 on rank 0, tp 1 on rank 1)
