@@ -332,7 +332,8 @@ __device__ __forceinline__ void fused_load(FusedRows<T, VPT, R> &buf, const T *_
 #pragma unroll
         for (int k = 0; k < VPT; k++) {
             const int j = min((tid + k * FUSED_THREADS) * V, ld - V);
-            buf.v[r][k] = *reinterpret_cast<const VT *>(base + j);
+            // K is streamed exactly once per launch and is larger than every cache: non-temporal
+            buf.v[r][k] = __builtin_nontemporal_load(reinterpret_cast<const VT *>(base + j));
         }
     }
 }
@@ -342,9 +343,7 @@ __device__ __forceinline__ void fused_group(FusedRows<T, VPT, R> &buf, int row0,
                                             const double *wl, double *red, double *arow,
                                             double *colacc, double *__restrict__ a,
                                             double *__restrict__ old_a, double *__restrict__ adx,
-                                            const double *__restrict__ p,
-                                            const double *__restrict__ dx,
-                                            const double *__restrict__ u, double alpha1,
+                                            const double *rowc, int band0, int band_rows, double alpha1,
                                             double inv_l1e, double tau, int ld, int *flag) {
     constexpr int V = Vec<T>::N;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -384,10 +383,13 @@ __device__ __forceinline__ void fused_group(FusedRows<T, VPT, R> &buf, int row0,
             double t = 0.0;
 #pragma unroll
             for (int wv = 0; wv < FUSED_THREADS / 64; wv++) t += red[wv * R + tid];
-            const double an = scale_update(p[row], t, alpha1, u[row] * inv_l1e);
-            old_a[row] = a[row];
+            // p, dx, u and the previous a of the band were staged in LDS at kernel entry: a global load
+            // here would sit behind the whole prefetch in the vmcnt queue and serialise the pipeline
+            const int lr = row - band0;
+            const double an = scale_update(rowc[lr], t, alpha1, rowc[2 * band_rows + lr] * inv_l1e);
+            old_a[row] = rowc[3 * band_rows + lr];
             a[row] = an;
-            x = an * dx[row];
+            x = an * rowc[band_rows + lr];
             adx[row] = x;
             if (an > tau) *flag = 1;
         }
@@ -419,24 +421,31 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_fused_pass(
     double *wl = smem;                       // WPAD doubles
     double *red = smem + WPAD;               // (FUSED_THREADS/64) * R
     double *arow = red + (FUSED_THREADS / 64) * R;   // R
+    double *rowc = arow + R;                         // 4 x rows_per_block: p, dx, u, previous a
     const int tid = threadIdx.x;
     const int r0 = blockIdx.x * rows_per_block;
     const int r1 = min(I, r0 + rows_per_block);
     FusedRows<T, VPT, R> bufA, bufB;
     fused_load<T, VPT, R>(bufA, K, r0, r1, ld, tid);
     for (int j = tid; j < WPAD; j += FUSED_THREADS) wl[j] = (j < ld) ? w[j] : 0.0;
+    for (int t = tid; t < r1 - r0; t += FUSED_THREADS) {
+        rowc[t] = p[r0 + t];
+        rowc[rows_per_block + t] = dx[r0 + t];
+        rowc[2 * rows_per_block + t] = u[r0 + t];
+        rowc[3 * rows_per_block + t] = a[r0 + t];
+    }
     double colacc[VPT * V];
 #pragma unroll
     for (int k = 0; k < VPT * V; k++) colacc[k] = 0.0;
     __syncthreads();
     for (int g = r0; g < r1; g += 2 * R) {
         fused_load<T, VPT, R>(bufB, K, g + R, r1, ld, tid);          // rows >= r1: clamped, weight 0
-        fused_group<T, VPT, R>(bufA, g, r1, wl, red, arow, colacc, a, old_a, adx, p, dx, u, alpha1,
-                               inv_l1e, tau, ld, flag);
+        fused_group<T, VPT, R>(bufA, g, r1, wl, red, arow, colacc, a, old_a, adx, rowc, r0, rows_per_block,
+                               alpha1, inv_l1e, tau, ld, flag);
         if (g + R < r1) {
             fused_load<T, VPT, R>(bufA, K, g + 2 * R, r1, ld, tid);
-            fused_group<T, VPT, R>(bufB, g + R, r1, wl, red, arow, colacc, a, old_a, adx, p, dx, u,
-                                   alpha1, inv_l1e, tau, ld, flag);
+            fused_group<T, VPT, R>(bufB, g + R, r1, wl, red, arow, colacc, a, old_a, adx, rowc, r0,
+                                   rows_per_block, alpha1, inv_l1e, tau, ld, flag);
         }
     }
     double *o = part + (size_t)blockIdx.x * ld;
@@ -991,8 +1000,8 @@ void choose_fused(spadot_ot_solver *s) {
     const int max_vpt = s->storage == SPADOT_F32 ? 8 : 12;
     if (vpt > max_vpt) return;
     const int R = vpt <= (s->storage == SPADOT_F32 ? 5 : 6) ? 2 : 1;     // must match the FUSED_CASE table
-    const size_t lds = sizeof(double) * ((size_t)vpt * FUSED_THREADS * V + (FUSED_THREADS / 64) * R + R);
-    if (lds > 160 * 1024) return;
+    size_t lds = sizeof(double) * ((size_t)vpt * FUSED_THREADS * V + (FUSED_THREADS / 64) * R + R);
+    if (lds + 4096 > 160 * 1024) return;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) {
         hipDeviceProp_t prop;
@@ -1003,6 +1012,8 @@ void choose_fused(spadot_ot_solver *s) {
     int rpb = (s->I + blocks - 1) / blocks;
     rpb = round_up(rpb, R);
     blocks = (s->I + rpb - 1) / rpb;
+    lds += sizeof(double) * 4 * (size_t)rpb;          // staged p, dx, u, previous a of the band
+    if (lds > 160 * 1024) return;
     s->fused_vpt = vpt; s->fused_r = R; s->fused_blocks = blocks; s->fused_rows_per_block = rpb;
     s->fused_lds = lds;
 }
