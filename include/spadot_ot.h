@@ -144,9 +144,16 @@ int spadot_ot_plan_rowsums_host(spadot_ot_solver *s, double *rowsums_host);
 
 /* Benchmark hook: run `iters` scaling iterations (one iteration = one update_a_b, ot_func.cpp:586-687)
  * at the solver's current state with the given stage epsilon, no convergence checks, no host syncs.
- * ms_out (may be NULL) receives the HIP-event time of the timed region in milliseconds. */
+ * ms_out (may be NULL) receives the HIP-event time of the timed region in milliseconds.  Returns 2 if a
+ * scaling exceeded tau during the run (the fast schedule is then not what a solve would execute). */
 int spadot_ot_run_iterations(spadot_ot_solver *s, const spadot_ot_config *cfg, double eps_stage,
                              int iters, float *ms_out);
+
+/* The solver's real inner loop `nbatches` times (snapshot, batch_size or 5 iterations, convergence measure,
+ * read-back + stream sync), ignoring the threshold: what "iterations per second" costs inside a solve.
+ * last_stage != 0 uses the duality-gap measure, else the dual-drift measure. */
+int spadot_ot_run_checked(spadot_ot_solver *s, const spadot_ot_config *cfg, double eps_stage, int last_stage,
+                          int nbatches, int *iters_out, float *ms_out);
 
 /* Per-kernel live timing for the roofline: each kernel of one scaling iteration launched `reps` times
  * between two HIP events on the solver's stream.  ms_out[6] = average ms per launch of

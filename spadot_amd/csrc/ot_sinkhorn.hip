@@ -289,7 +289,8 @@ __global__ __launch_bounds__(256) void k_col_fin(const double *__restrict__ part
     if (j >= J) { if (mode == 0) w[j] = 0.0; else t_out[j] = 0.0; return; }
     double t = 0.0;
     for (int c = 0; c < nchunk; c++) t += part[(size_t)c * ld + j];
-    if (mode == 1) { t_out[j] = t; return; }
+    if (t_out) t_out[j] = t;
+    if (mode == 1) return;
     const double bn = scale_update(q[j], t, alpha2, v[j] * inv_l2e);
     old_b[j] = b[j];
     b[j] = bn;
@@ -487,7 +488,8 @@ __global__ __launch_bounds__(1024) void k_col_fin2(const double *__restrict__ pa
 #pragma unroll
     for (int g = 0; g < 16; g++) t += sh[g][cx];
     if (j >= J) { if (mode == 0) w[j] = 0.0; else t_out[j] = 0.0; return; }
-    if (mode == 1) { t_out[j] = t; return; }
+    if (t_out) t_out[j] = t;
+    if (mode == 1) return;
     const double bn = scale_update(q[j], t, alpha2, v[j] * inv_l2e);
     old_b[j] = b[j];
     b[j] = bn;
@@ -502,11 +504,13 @@ __global__ __launch_bounds__(256) void k_absorb_vec(double *__restrict__ a, doub
                                                     double *__restrict__ w,
                                                     const double *__restrict__ dx,
                                                     const double *__restrict__ dy, double eps, int I,
-                                                    int J, const int *flag, int *absorb_count) {
+                                                    int J, const int *flag, int *absorb_count,
+                                                    double *__restrict__ tcol) {
     if (*flag == 0) return;
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t < I) { u[t] = u[t] + eps * log(a[t]); a[t] = 1.0; adx[t] = dx[t]; }
-    if (t < J) { v[t] = v[t] + eps * log(b[t]); b[t] = 1.0; w[t] = dy[t]; }
+    // t_j = sum_i K_ij a_i dx_i is kept for the gap check: with K_new = a K b and a_new = 1 it becomes b_j t_j
+    if (t < J) { v[t] = v[t] + eps * log(b[t]); tcol[t] = b[t] * tcol[t]; b[t] = 1.0; w[t] = dy[t]; }
     if (t == 0) *absorb_count += 1;
 }
 
@@ -660,6 +664,144 @@ __global__ __launch_bounds__(1024) void k_gap_fin(const double *__restrict__ rt,
     }
 }
 
+
+// Measure-only sweep (last-stage convergence check): sdot_i = sum_j K_ij w_j with the CURRENT w = b.dy.
+// One wave per row, non-temporal 16-byte loads.  Together with t_j = sum_i K_ij a_i dx_i (left behind by
+// the last column finalise) this is all the duality gap needs: see k_gap2_part.
+template <typename T>
+__global__ __launch_bounds__(256) void k_row_dot(const T *__restrict__ K, const double *__restrict__ w,
+                                                 double *__restrict__ sdot, int I, int ld) {
+    constexpr int V = Vec<T>::N;
+    using VT = typename Vec<T>::type;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * ROW_WAVES + (threadIdx.x >> 6);
+    if (row >= I) return;
+    const T *r = K + (size_t)row * ld;
+    double acc0 = 0.0, acc1 = 0.0;
+    int j = lane * V;
+    for (; j + WAVE * V < ld; j += 2 * WAVE * V) {
+        double k0[V], k1[V];
+        unpack<T>(__builtin_nontemporal_load(reinterpret_cast<const VT *>(r + j)), k0);
+        unpack<T>(__builtin_nontemporal_load(reinterpret_cast<const VT *>(r + j + WAVE * V)), k1);
+#pragma unroll
+        for (int k = 0; k < V; k++) {
+            acc0 = fma(k0[k], w[j + k], acc0);
+            acc1 = fma(k1[k], w[j + WAVE * V + k], acc1);
+        }
+    }
+    if (j < ld) {
+        double k0[V];
+        unpack<T>(__builtin_nontemporal_load(reinterpret_cast<const VT *>(r + j)), k0);
+#pragma unroll
+        for (int k = 0; k < V; k++) acc0 = fma(k0[k], w[j + k], acc0);
+    }
+    const double sm = wave_sum(acc0 + acc1);
+    if (lane == 0) sdot[row] = sm;
+}
+
+// Duality gap from vectors only (uniform dx = 1/I, dy = 1/J as the solver always has, ot_solvers.py:221).
+// With R_ij = a_i K_ij b_j and K_ij = exp((u_i + v_j - C_ij)/eps) the matrix part of the primal collapses:
+//   eps sum R ln R + sum R C = sum_ij R_ij (eps ln a_i + u_i + eps ln b_j + v_j)
+//                            = sum_i (eps ln a_i + u_i) rowsum_i + sum_j (eps ln b_j + v_j) colsum_j
+// (the per-element ln K_ij cancels against C_ij; entries with R_ij = 0 contribute 0 on both sides,
+// which is also what the reference's log(0) clamp gives, ot_func.cpp:29-40,:414).  So the check needs
+// rs_i = a_i sdot_i (= sum_j R_ij dy_j) and cs_j = b_j t_j (= sum_i R_ij dx_i) only.
+// Block partials -> red[blk*8 + {0..6}] = F1, F2, matrix, sumR, conj1, conj2.
+__global__ __launch_bounds__(256) void k_gap2_part(const double *__restrict__ sdot,
+                                                   const double *__restrict__ t,
+                                                   const double *__restrict__ a,
+                                                   const double *__restrict__ b,
+                                                   const double *__restrict__ u,
+                                                   const double *__restrict__ v,
+                                                   const double *__restrict__ p,
+                                                   const double *__restrict__ q, double eps, double l1,
+                                                   double l2, int I, int J, double *__restrict__ red) {
+    __shared__ double sh[16];
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    const double dx = 1.0 / I, dy = 1.0 / J;
+    double f1 = 0, f2 = 0, mat = 0, sr = 0, c1 = 0, c2 = 0;
+    if (e < I) {
+        const double rs = a[e] * sdot[e];                  // sum_j R_ij dy_j
+        f1 = dx * (rs * log(rs / p[e]) - rs + p[e]);
+        const double rsum = rs * (double)J;                // sum_j R_ij
+        if (rsum != 0.0) mat += (eps * log(a[e]) + u[e]) * rsum;
+        sr = rsum;
+        const double ab = a[e] * exp(u[e] / eps);
+        c1 = (p[e] * dx) * (exp((-eps * log(ab)) / l1) - 1.0);
+    }
+    if (e < J) {
+        const double cs = b[e] * t[e];                     // sum_i R_ij dx_i
+        f2 = dy * (cs * log(cs / q[e]) - cs + q[e]);
+        const double csum = cs * (double)I;
+        if (csum != 0.0) mat += (eps * log(b[e]) + v[e]) * csum;
+        const double bb = b[e] * exp(v[e] / eps);
+        c2 = (q[e] * dy) * (exp((-eps * log(bb)) / l2) - 1.0);
+    }
+    f1 = block_sum(f1, sh); f2 = block_sum(f2, sh); mat = block_sum(mat, sh); sr = block_sum(sr, sh);
+    c1 = block_sum(c1, sh); c2 = block_sum(c2, sh);
+    if (threadIdx.x == 0) {
+        double *o = red + (size_t)blockIdx.x * 8;
+        o[0] = f1; o[1] = f2; o[2] = mat; o[3] = sr; o[4] = c1; o[5] = c2;
+    }
+}
+__global__ __launch_bounds__(256) void k_gap2_final(const double *__restrict__ red, int nblk, double eps,
+                                                    double l1, double l2, int I, int J, double *scal) {
+    __shared__ double sh[16];
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int k = threadIdx.x; k < nblk; k += 256)
+#pragma unroll
+        for (int c = 0; c < 6; c++) acc[c] += red[(size_t)k * 8 + c];
+#pragma unroll
+    for (int c = 0; c < 6; c++) acc[c] = block_sum(acc[c], sh);
+    if (threadIdx.x == 0) {
+        const double skb = scal[3], mn = (double)I * (double)J;
+        const double pri = l1 * acc[0] + l2 * acc[1] + (acc[2] - eps * acc[3] + eps * skb) / mn;
+        const double dua = -(l1 * acc[4]) - (l2 * acc[5]) - eps * (acc[3] - skb) / mn;
+        scal[1] = pri; scal[2] = dua;
+        scal[0] = (pri - dua) / fabs(pri);
+    }
+}
+
+// Dual-variable drift (ot_func.cpp:876-923) as block partials + a one-block finish.
+__global__ __launch_bounds__(256) void k_drift_part(const double *__restrict__ a,
+                                                    const double *__restrict__ old_a,
+                                                    const double *__restrict__ u,
+                                                    const double *__restrict__ b,
+                                                    const double *__restrict__ old_b,
+                                                    const double *__restrict__ v, double eps, int I, int J,
+                                                    double *__restrict__ red) {
+    __shared__ double sh[16];
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    double d1 = 0, n1 = 0, d2 = 0, n2 = 0;
+    if (e < I) {
+        const double ex = exp(u[e] / eps), ta = a[e] * ex, df = ta - old_a[e] * ex;
+        d1 = df * df; n1 = ta * ta;
+    }
+    if (e < J) {
+        const double ex = exp(v[e] / eps), tb = b[e] * ex, df = tb - old_b[e] * ex;
+        d2 = df * df; n2 = tb * tb;
+    }
+    d1 = block_sum(d1, sh); n1 = block_sum(n1, sh); d2 = block_sum(d2, sh); n2 = block_sum(n2, sh);
+    if (threadIdx.x == 0) {
+        double *o = red + (size_t)blockIdx.x * 8;
+        o[0] = d1; o[1] = n1; o[2] = d2; o[3] = n2;
+    }
+}
+__global__ __launch_bounds__(256) void k_drift_final(const double *__restrict__ red, int nblk, double *scal) {
+    __shared__ double sh[16];
+    double acc[4] = {0, 0, 0, 0};
+    for (int k = threadIdx.x; k < nblk; k += 256)
+#pragma unroll
+        for (int c = 0; c < 4; c++) acc[c] += red[(size_t)k * 8 + c];
+#pragma unroll
+    for (int c = 0; c < 4; c++) acc[c] = block_sum(acc[c], sh);
+    if (threadIdx.x == 0) {
+        const double g1 = sqrt(acc[0]) / (1.0 + sqrt(acc[1]));
+        const double g2 = sqrt(acc[2]) / (1.0 + sqrt(acc[3]));
+        scal[0] = (g1 < g2) ? g2 : g1;   // std::max(g1, g2): a NaN g1 wins (ot_func.cpp:922)
+    }
+}
+
 // plan = a_i K_ij b_j * scale  (ot_solvers.py:449 with scale = 1/J)
 template <typename T, typename TO>
 __global__ __launch_bounds__(256) void k_plan(const T *__restrict__ K, const double *__restrict__ a,
@@ -768,6 +910,10 @@ struct spadot_ot_solver {
     // length-ld vectors
     double *b = nullptr, *old_b = nullptr, *v = nullptr, *q = nullptr, *dy = nullptr, *w = nullptr,
            *tcol = nullptr;
+    double *backup = nullptr;  // snapshot of the six mutable vectors (a, old_a, adx, b, old_b, w)
+    size_t mut_count = 0;
+    double *red = nullptr;     // block partials of the vector reductions
+    int redo_batches = 0;
     double *part = nullptr;    // nchunk x ld
     double *rt = nullptr;      // 4 x I
     double *scal = nullptr;    // 8 device scalars: gap, primal, dual, sumKbar, ...
@@ -873,55 +1019,84 @@ template <> void fused_pass_T<double>(spadot_ot_solver *s, const IterParams &P, 
 void absorb_if_flagged(spadot_ot_solver *s, const IterParams &P, int *flag) {
     const int mx = std::max(s->I, s->J);
     hipLaunchKernelGGL(k_absorb_vec, dim3((mx + 255) / 256), dim3(256), 0, s->stream, s->a, s->b, s->u,
-                       s->v, s->adx, s->w, s->dx, s->dy, P.eps, s->I, s->J, flag, s->flags + MAX_BATCH);
+                       s->v, s->adx, s->w, s->dx, s->dy, P.eps, s->I, s->J, flag, s->flags + MAX_BATCH, s->tcol);
     build_K(s, P.eps, flag);
 }
 
-template <typename T> void one_iteration_T(spadot_ot_solver *s, const IterParams &P, int *flag) {
+template <typename T> void one_iteration_T(spadot_ot_solver *s, const IterParams &P, int *flag, bool absorb) {
     constexpr int V = Vec<T>::N;
     const int I = s->I, J = s->J, ld = s->ld;
     if (s->fused_vpt > 0) {
         fused_pass_T<T>(s, P, flag);
         hipLaunchKernelGGL(k_col_fin2, dim3((ld + 63) / 64), dim3(1024), 0, s->stream, s->part,
                            s->fused_blocks, s->b, s->old_b, s->w, s->q, s->dy, s->v, P.al2,
-                           1.0 / (P.l2 + P.eps), P.tau, J, ld, flag, (double *)nullptr, 0);
-        absorb_if_flagged(s, P, flag);
-        return;
+                           1.0 / (P.l2 + P.eps), P.tau, J, ld, flag, s->tcol, 0);
+    } else {
+        hipLaunchKernelGGL(k_row_pass<T>, dim3((I + ROW_WAVES - 1) / ROW_WAVES), dim3(256), 0, s->stream,
+                           (const T *)s->K, s->w, s->a, s->old_a, s->adx, s->p, s->dx, s->u, P.al1,
+                           1.0 / (P.l1 + P.eps), P.tau, I, ld, flag);
+        hipLaunchKernelGGL(k_col_pass<T>, dim3((ld + 256 * V - 1) / (256 * V), s->nchunk), dim3(256), 0,
+                           s->stream, (const T *)s->K, s->adx, s->part, I, ld, s->rows_per_chunk);
+        hipLaunchKernelGGL(k_col_fin, dim3((ld + 255) / 256), dim3(256), 0, s->stream, s->part, s->nchunk,
+                           s->b, s->old_b, s->w, s->q, s->dy, s->v, P.al2, 1.0 / (P.l2 + P.eps), P.tau,
+                           J, ld, flag, s->tcol, 0);
     }
-    hipLaunchKernelGGL(k_row_pass<T>, dim3((I + ROW_WAVES - 1) / ROW_WAVES), dim3(256), 0, s->stream,
-                       (const T *)s->K, s->w, s->a, s->old_a, s->adx, s->p, s->dx, s->u, P.al1,
-                       1.0 / (P.l1 + P.eps), P.tau, I, ld, flag);
-    hipLaunchKernelGGL(k_col_pass<T>, dim3((ld + 256 * V - 1) / (256 * V), s->nchunk), dim3(256), 0,
-                       s->stream, (const T *)s->K, s->adx, s->part, I, ld, s->rows_per_chunk);
-    hipLaunchKernelGGL(k_col_fin, dim3((ld + 255) / 256), dim3(256), 0, s->stream, s->part, s->nchunk,
-                       s->b, s->old_b, s->w, s->q, s->dy, s->v, P.al2, 1.0 / (P.l2 + P.eps), P.tau,
-                       J, ld, flag, (double *)nullptr, 0);
-    absorb_if_flagged(s, P, flag);
+    if (absorb) absorb_if_flagged(s, P, flag);
 }
 
-// `iters` scaling iterations with device-side tau decisions (ot_func.cpp:726-819), no host sync.
-void run_iterations(spadot_ot_solver *s, const IterParams &P, int iters) {
+// `iters` scaling iterations, no host sync.
+//   safe mode (absorb = true): after every iteration the tau-absorb pair runs and acts if that
+//     iteration's flag is set (ot_func.cpp:778-819) -- exact reference semantics at any tau.
+//   fast mode (absorb = false): the two absorb launches are skipped; every iteration raises flags[0] if a
+//     scaling exceeds tau, and the CALLER must check it and redo the batch in safe mode from a snapshot
+//     (K, u, v are untouched in fast mode, so the snapshot is the six mutable vectors only).
+void run_iterations(spadot_ot_solver *s, const IterParams &P, int iters, bool absorb = true) {
     while (iters > 0) {
         const int nb = std::min(iters, MAX_BATCH);
         HIP_CHECK(hipMemsetAsync(s->flags, 0, sizeof(int) * MAX_BATCH, s->stream));
         for (int t = 0; t < nb; t++) {
-            if (s->storage == SPADOT_F32) one_iteration_T<float>(s, P, s->flags + t);
-            else one_iteration_T<double>(s, P, s->flags + t);
+            int *flag = absorb ? s->flags + t : s->flags;
+            if (s->storage == SPADOT_F32) one_iteration_T<float>(s, P, flag, absorb);
+            else one_iteration_T<double>(s, P, flag, absorb);
         }
         iters -= nb;
     }
 }
 
+void snapshot(spadot_ot_solver *s) {
+    HIP_CHECK(hipMemcpyAsync(s->backup, s->a, sizeof(double) * s->mut_count, hipMemcpyDeviceToDevice, s->stream));
+}
+void restore(spadot_ot_solver *s) {
+    HIP_CHECK(hipMemcpyAsync(s->a, s->backup, sizeof(double) * s->mut_count, hipMemcpyDeviceToDevice, s->stream));
+}
+
 double read_gap(spadot_ot_solver *s) {
     HIP_CHECK(hipMemcpyAsync(s->h_scal, s->scal, sizeof(double) * 4, hipMemcpyDeviceToHost, s->stream));
+    HIP_CHECK(hipMemcpyAsync(s->h_flags, s->flags, sizeof(int), hipMemcpyDeviceToHost, s->stream));
     HIP_CHECK(hipStreamSynchronize(s->stream));
     HIP_CHECK(hipGetLastError());
     return s->h_scal[0];
 }
 
 void drift_measure(spadot_ot_solver *s, double eps) {
-    hipLaunchKernelGGL(k_drift, dim3(1), dim3(1024), 0, s->stream, s->a, s->old_a, s->u, s->b, s->old_b,
-                       s->v, eps, s->I, s->J, s->scal);
+    const int nblk = (std::max(s->I, s->J) + 255) / 256;
+    hipLaunchKernelGGL(k_drift_part, dim3(nblk), dim3(256), 0, s->stream, s->a, s->old_a, s->u, s->b, s->old_b,
+                       s->v, eps, s->I, s->J, s->red);
+    hipLaunchKernelGGL(k_drift_final, dim3(1), dim3(256), 0, s->stream, s->red, nblk, s->scal);
+}
+
+// Solver-only gap (uniform dx, dy): ONE sweep of K for sdot, everything else from vectors (k_gap2_part).
+void gap_measure_fast(spadot_ot_solver *s, const IterParams &P) {
+    const int I = s->I, J = s->J, ld = s->ld;
+    dim3 g((I + ROW_WAVES - 1) / ROW_WAVES);
+    if (s->storage == SPADOT_F32)
+        hipLaunchKernelGGL(k_row_dot<float>, g, dim3(256), 0, s->stream, (const float *)s->K, s->w, s->rt, I, ld);
+    else
+        hipLaunchKernelGGL(k_row_dot<double>, g, dim3(256), 0, s->stream, (const double *)s->K, s->w, s->rt, I, ld);
+    const int nblk = (std::max(I, J) + 255) / 256;
+    hipLaunchKernelGGL(k_gap2_part, dim3(nblk), dim3(256), 0, s->stream, s->rt, s->tcol, s->a, s->b, s->u, s->v,
+                       s->p, s->q, P.eps, P.l1, P.l2, I, J, s->red);
+    hipLaunchKernelGGL(k_gap2_final, dim3(1), dim3(256), 0, s->stream, s->red, nblk, P.eps, P.l1, P.l2, I, J, s->scal);
 }
 
 // True primal-dual gap of the current (a, b, K) with R = a K b formed on the fly; scal[3] must
@@ -950,9 +1125,14 @@ void gap_measure(spadot_ot_solver *s, const IterParams &P, void *Rout) {
 // The reference's cur_iter bookkeeping (including its -1 quirk, :821-824 + :869) is kept on the host.
 double process_stage(spadot_ot_solver *s, const IterParams &P, bool last_stage, int batch_size,
                      double threshold, int cur_iter, int max_iter, void *Rout, int *iters_done,
-                     int *checks) {
+                     int *checks, bool fast = false) {
     double gap = 1e100;
     int done = 0, nchecks = 0;
+    auto measure = [&]() {
+        if (!last_stage) drift_measure(s, P.eps);
+        else if (fast) gap_measure_fast(s, P);
+        else gap_measure(s, P, Rout);
+    };
     while (gap > threshold) {
         const int iters = last_stage ? batch_size : 5;
         // step1_process: stops early (returning -1) once the counter reaches max_iter
@@ -962,7 +1142,23 @@ double process_stage(spadot_ot_solver *s, const IterParams &P, bool last_stage, 
             run = std::max(1, std::min(iters, max_iter - cur_iter));
             hit = true;
         }
-        run_iterations(s, P, run);
+        if (fast) {
+            snapshot(s);
+            run_iterations(s, P, run, /*absorb=*/false);
+            measure();
+            gap = read_gap(s);
+            if (s->h_flags[0] != 0) {          // a scaling exceeded tau somewhere in the batch: redo it exactly
+                restore(s);
+                run_iterations(s, P, run, /*absorb=*/true);
+                measure();
+                gap = read_gap(s);
+                s->redo_batches++;
+            }
+        } else {
+            run_iterations(s, P, run, /*absorb=*/true);
+            measure();
+            gap = read_gap(s);
+        }
         done += run;
         if (hit) {
             printf("Reached max_iter with duality gap still above threshold. Returning");
@@ -970,9 +1166,6 @@ double process_stage(spadot_ot_solver *s, const IterParams &P, bool last_stage, 
         } else {
             cur_iter += iters;
         }
-        if (last_stage) gap_measure(s, P, Rout);
-        else drift_measure(s, P.eps);
-        gap = read_gap(s);
         nchecks++;
     }
     if (iters_done) *iters_done = done;
@@ -1056,15 +1249,19 @@ int spadot_ot_create(spadot_ot_solver **out, int I, int J, int storage, void *st
     s->K = dmalloc(mat);
     HIP_CHECK(hipMemsetAsync(s->C, 0, mat, s->stream));
     HIP_CHECK(hipMemsetAsync(s->K, 0, mat, s->stream));
-    double *vi = (double *)dmalloc(sizeof(double) * 6 * (size_t)I);
-    s->a = vi; s->old_a = vi + I; s->u = vi + 2 * (size_t)I; s->p = vi + 3 * (size_t)I;
-    s->dx = vi + 4 * (size_t)I; s->adx = vi + 5 * (size_t)I;
     const size_t L = s->ld;
-    double *vj = (double *)dmalloc(sizeof(double) * 7 * L);
-    s->b = vj; s->old_b = vj + L; s->v = vj + 2 * L; s->q = vj + 3 * L; s->dy = vj + 4 * L;
-    s->w = vj + 5 * L; s->tcol = vj + 6 * L;
-    HIP_CHECK(hipMemsetAsync(vi, 0, sizeof(double) * 6 * (size_t)I, s->stream));
-    HIP_CHECK(hipMemsetAsync(vj, 0, sizeof(double) * 7 * L, s->stream));
+    // one block: [a old_a adx | b old_b w] (mutable, snapshot unit) then [u p dx | v q dy tcol]
+    s->mut_count = 3 * (size_t)I + 3 * L;
+    const size_t vec_count = 6 * (size_t)I + 7 * L;
+    double *vb = (double *)dmalloc(sizeof(double) * vec_count);
+    HIP_CHECK(hipMemsetAsync(vb, 0, sizeof(double) * vec_count, s->stream));
+    s->a = vb; s->old_a = vb + I; s->adx = vb + 2 * (size_t)I;
+    s->b = vb + 3 * (size_t)I; s->old_b = s->b + L; s->w = s->b + 2 * L;
+    double *cb = vb + s->mut_count;
+    s->u = cb; s->p = cb + I; s->dx = cb + 2 * (size_t)I;
+    s->v = cb + 3 * (size_t)I; s->q = s->v + L; s->dy = s->v + 2 * L; s->tcol = s->v + 3 * L;
+    s->backup = (double *)dmalloc(sizeof(double) * s->mut_count);
+    s->red = (double *)dmalloc(sizeof(double) * 8 * ((size_t)std::max<size_t>(I, L) / 256 + 2));
     s->part = (double *)dmalloc(sizeof(double) * (size_t)std::max(s->nchunk, s->fused_blocks) * L);
     s->rt = (double *)dmalloc(sizeof(double) * 4 * (size_t)I);
     s->scal = (double *)dmalloc(sizeof(double) * 8);
@@ -1082,7 +1279,7 @@ int spadot_ot_create(spadot_ot_solver **out, int I, int J, int storage, void *st
 void spadot_ot_destroy(spadot_ot_solver *s) {
     if (!s) return;
     (void)hipStreamSynchronize(s->stream);
-    void *dev[] = {s->C, s->K, s->a, s->b, s->part, s->rt, s->scal, s->flags};
+    void *dev[] = {s->C, s->K, s->a, s->backup, s->red, s->part, s->rt, s->scal, s->flags};
     for (void *p : dev) (void)hipFree(p);
     (void)hipHostFree(s->h_scal); (void)hipHostFree(s->h_flags);
     (void)hipEventDestroy(s->ev0); (void)hipEventDestroy(s->ev1);
@@ -1232,19 +1429,22 @@ int spadot_ot_solve(spadot_ot_solver *s, const double *G_host, const spadot_ot_c
     if (G_host) memcpy(g.data(), G_host, sizeof(double) * I);
     double gs = 0.0;
     for (int i = 0; i < I; i++) gs += g[i];
+    HIP_CHECK(hipMemsetAsync(s->a, 0, sizeof(double) * (6 * (size_t)I + 7 * (size_t)ld), s->stream));   // whole vector block
     upload_vec(s, s->p, g.data(), I);
     HIP_CHECK(hipStreamSynchronize(s->stream));   // g is a host temporary
     const int mx = std::max(I, ld);
     dim3 gv((mx + 255) / 256);
     hipLaunchKernelGGL(k_fill, dim3((I + 255) / 256), dim3(256), 0, s->stream, s->dx, 1.0 / I, I);
-    hipLaunchKernelGGL(k_fill, dim3((I + 255) / 256), dim3(256), 0, s->stream, s->u, 0.0, I);
     hipLaunchKernelGGL(k_fill, dim3((I + 255) / 256), dim3(256), 0, s->stream, s->a, 1.0, I);
-    HIP_CHECK(hipMemsetAsync(s->b, 0, sizeof(double) * 7 * (size_t)ld, s->stream));
     hipLaunchKernelGGL(k_fill, dim3((J + 255) / 256), dim3(256), 0, s->stream, s->dy, 1.0 / J, J);
     hipLaunchKernelGGL(k_fill, dim3((J + 255) / 256), dim3(256), 0, s->stream, s->q, gs / I, J);
     hipLaunchKernelGGL(k_fill, dim3((J + 255) / 256), dim3(256), 0, s->stream, s->b, 1.0, J);
     HIP_CHECK(hipMemsetAsync(s->flags, 0, sizeof(int) * (MAX_BATCH + 1), s->stream));
 
+    // speculative batches (skip the idle tau-absorb launches, vector-only gap); SPADOT_OT_NO_SPEC=1 keeps
+    // the always-safe schedule for A/B runs
+    const char *nospec = getenv("SPADOT_OT_NO_SPEC");
+    const bool spec = !(nospec && nospec[0] == '1');
     const double f = exp(-log(cfg->epsilon) / S);
     double eps_i = cfg->epsilon0 * f;
     double gap = INFINITY;
@@ -1260,7 +1460,7 @@ int spadot_ot_solve(spadot_ot_solver *s, const double *G_host, const spadot_ot_c
         build_K(s, eps_i, nullptr);
         if (e == S) sum_kbar(s, s->C, eps_i, true);   // only the last stage's gap needs sum(Kbar)
         gap = process_stage(s, P, e == S, cfg->batch_size, thr, 0, cfg->max_iter, nullptr,
-                            &rep.stage_iters[e], &rep.gap_checks);
+                            &rep.stage_iters[e], &rep.gap_checks, /*fast=*/spec);
     }
     HIP_CHECK(hipMemcpyAsync(s->h_flags, s->flags + MAX_BATCH, sizeof(int), hipMemcpyDeviceToHost, s->stream));
     HIP_CHECK(hipStreamSynchronize(s->stream));
@@ -1318,13 +1518,58 @@ int spadot_ot_run_iterations(spadot_ot_solver *s, const spadot_ot_config *cfg, d
     if (!s || !cfg || iters < 0) return -22;
     IterParams P{eps_stage, cfg->tau, cfg->lambda1, cfg->lambda2, cfg->lambda1 / (cfg->lambda1 + eps_stage),
                  cfg->lambda2 / (cfg->lambda2 + eps_stage)};
+    // same schedule as the solver's batches minus the convergence measure and its sync: snapshot +
+    // `batch_size` fast iterations per batch; a raised tau flag makes the run unusable (return 2)
+    const int bs = std::max(1, std::min(cfg->batch_size, MAX_BATCH));
+    HIP_CHECK(hipMemsetAsync(s->flags + MAX_BATCH - 1, 0, sizeof(int), s->stream));
     HIP_CHECK(hipEventRecord(s->ev0, s->stream));
-    run_iterations(s, P, iters);
+    for (int left = iters; left > 0; left -= bs) {
+        const int nb = std::min(left, bs);
+        snapshot(s);
+        for (int t = 0; t < nb; t++) {
+            if (s->storage == SPADOT_F32) one_iteration_T<float>(s, P, s->flags + MAX_BATCH - 1, false);
+            else one_iteration_T<double>(s, P, s->flags + MAX_BATCH - 1, false);
+        }
+    }
     HIP_CHECK(hipEventRecord(s->ev1, s->stream));
     if (ms_out) {
+        HIP_CHECK(hipMemcpyAsync(s->h_flags, s->flags + MAX_BATCH - 1, sizeof(int), hipMemcpyDeviceToHost, s->stream));
         HIP_CHECK(hipEventSynchronize(s->ev1));
+        HIP_CHECK(hipStreamSynchronize(s->stream));
         HIP_CHECK(hipEventElapsedTime(ms_out, s->ev0, s->ev1));
+        if (s->h_flags[0] != 0) return 2;
     }
+    return 0;
+}
+
+// The solver's real inner loop, `nbatches` times, ignoring the threshold: snapshot, batch_size (last stage)
+// or 5 iterations, convergence measure, 36-byte read-back + stream sync, redo in safe mode if tau fired.
+// iters_out = scaling iterations run; ms_out = host wall time of the whole call in milliseconds.
+int spadot_ot_run_checked(spadot_ot_solver *s, const spadot_ot_config *cfg, double eps_stage, int last_stage,
+                          int nbatches, int *iters_out, float *ms_out) {
+    if (!s || !cfg || nbatches < 1) return -22;
+    IterParams P{eps_stage, cfg->tau, cfg->lambda1, cfg->lambda2, cfg->lambda1 / (cfg->lambda1 + eps_stage),
+                 cfg->lambda2 / (cfg->lambda2 + eps_stage)};
+    if (last_stage) sum_kbar(s, s->C, eps_stage, true);
+    HIP_CHECK(hipStreamSynchronize(s->stream));
+    const int iters = last_stage ? cfg->batch_size : 5;
+    HIP_CHECK(hipEventRecord(s->ev0, s->stream));
+    for (int k = 0; k < nbatches; k++) {
+        snapshot(s);
+        run_iterations(s, P, iters, false);
+        if (last_stage) gap_measure_fast(s, P); else drift_measure(s, P.eps);
+        read_gap(s);
+        if (s->h_flags[0] != 0) {
+            restore(s);
+            run_iterations(s, P, iters, true);
+            if (last_stage) gap_measure_fast(s, P); else drift_measure(s, P.eps);
+            read_gap(s);
+        }
+    }
+    HIP_CHECK(hipEventRecord(s->ev1, s->stream));
+    HIP_CHECK(hipEventSynchronize(s->ev1));
+    if (ms_out) HIP_CHECK(hipEventElapsedTime(ms_out, s->ev0, s->ev1));
+    if (iters_out) *iters_out = nbatches * iters;
     return 0;
 }
 

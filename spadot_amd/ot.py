@@ -159,9 +159,22 @@ class OTSolver:
         ms = ctypes.c_float(0.0)
         rc = self.lib.spadot_ot_run_iterations(self.h, ctypes.byref(c), float(eps_stage), int(iters),
                                                ctypes.byref(ms) if timed else None)
+        if rc == 2:
+            raise RuntimeError("a scaling exceeded tau during run_iterations: not a steady-state timing run")
         if rc != 0:
             raise RuntimeError(f"run_iterations failed with {rc}")
         return ms.value if timed else None
+
+    def run_checked(self, cfg, eps_stage, nbatches, last_stage=True):
+        """The solver's real inner loop (with convergence measure + sync) `nbatches` times.
+        Returns (iterations run, milliseconds)."""
+        c = make_config(cfg)
+        it, ms = ctypes.c_int(0), ctypes.c_float(0.0)
+        rc = self.lib.spadot_ot_run_checked(self.h, ctypes.byref(c), float(eps_stage), int(last_stage), int(nbatches),
+                                            ctypes.byref(it), ctypes.byref(ms))
+        if rc != 0:
+            raise RuntimeError(f"run_checked failed with {rc}")
+        return it.value, ms.value
 
     def time_kernels(self, cfg, eps_stage, reps=20):
         """Average HIP-event milliseconds per launch of each kernel of one scaling iteration."""
