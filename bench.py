@@ -105,6 +105,16 @@ def cpu_train_step(model, dd, cfg, tp, bi, tp_prev):
 # ------------------------------------------------------------------------------ main
 
 def main():
+    # stdout carries exactly ONE line (the JSON); everything the library prints goes to stderr
+    real_stdout = sys.stdout
+    sys.stdout = sys.stderr
+    try:
+        _main(real_stdout)
+    finally:
+        sys.stdout = real_stdout
+
+
+def _main(real_stdout):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -272,7 +282,7 @@ def main():
             out["cpu_baseline"] = cb
             if train_res and sk_res and "cpu_baseline" in sk_res and "cpu_baseline" in train_res:
                 out["cpu_baseline_sinkhorn"] = sk_res["cpu_baseline"]
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=real_stdout, flush=True)
     if world > 1:
         dist.destroy_process_group()
 

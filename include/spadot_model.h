@@ -71,6 +71,12 @@ int spadot_gat_backward_source(const void *g_pre, int dtype, const float *alpha,
 int spadot_kernel_matrix(const void *x, const void *z, int n, int m, int d, double scale, int kind,
                          int dtype, void *K, void *stream);
 
+/* Batched SPD inverse and log-determinant (fp64): A [L, m, m] symmetric positive definite ->
+ * Ainv [L, m, m], logdet [L].  One workgroup per matrix, symmetric sweep operator, matrix resident in
+ * registers + LDS (m <= 279; returns -34 beyond: the caller uses the library's batched Cholesky).  Replaces the
+ * torch.linalg.inv / cholesky calls of svgp.py:50,75,87-88 on the L latent dimensions at once. */
+int spadot_spd_inverse_logdet(const double *A, int L, int m, double *Ainv, double *logdet, void *stream);
+
 /* Batched row-wise dot products: out[l, i] = sum_k A[l, i, k] * B[i, k]   (A [L,n,m], B [n,m]).
  * dtype F32 or F64. */
 int spadot_rowdot_forward(const void *A, const void *B, int L, int n, int m, int dtype, void *out,

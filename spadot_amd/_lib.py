@@ -103,6 +103,7 @@ def model_lib():
         "spadot_gat_backward_target": [vp, vp, vp, ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp],
         "spadot_gat_backward_source": [vp, ci, vp, vp, vp, vp, vp, ci, ci, ci, vp, vp, vp],
         "spadot_kernel_matrix": [vp, vp, ci, ci, ci, cd, ci, ci, vp, vp],
+        "spadot_spd_inverse_logdet": [vp, ci, ci, vp, vp, vp],
         "spadot_rowdot_forward": [vp, vp, ci, ci, ci, ci, vp, vp],
         "spadot_rowdot_backward": [vp, vp, ci, ci, ci, ci, vp, vp],
         "spadot_elbo_forward": [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp, vp],

@@ -18,7 +18,7 @@ library's batched routines.
 import torch
 import torch.nn as nn
 
-from ..ops import elbo_reduce, kernel_matrix, rowdot
+from ..ops import elbo_reduce, kernel_matrix, rowdot, spd_inverse_logdet
 
 F64 = torch.float64
 
@@ -86,7 +86,7 @@ class SVGP(nn.Module):
         K_mm, _, _, eye = self._run_constants()
         A = bc.K_nm.unsqueeze(0) * W.T.unsqueeze(2)                        # [L, b, m] = diag(w_l) K_nm
         sigma = K_mm.unsqueeze(0) + bc.c * torch.matmul(A.transpose(1, 2), bc.K_nm)   # batched m x b x m GEMM
-        return torch.linalg.inv(sigma + self.jitter * eye)                 # [L, m, m]
+        return spd_inverse_logdet(sigma + self.jitter * eye, need_logdet=False)[0]     # [L, m, m]
 
     def posterior(self, bc_train, mu, var, bc_test=None):
         """Posterior mean and variance at the test points for all latent dims at once.
@@ -113,8 +113,7 @@ class SVGP(nn.Module):
         A_hat = K_mm.unsqueeze(0) @ S_inv @ K_mm.unsqueeze(0)              # [L, m, m]
         mv = bc.Q @ mu_hat.T                                               # K_nm K^-1 mu_hat  [b, L]
         tr = rowdot(torch.einsum("bm,lmn->lbn", bc.P, S_inv), bc.P).T      # [b, L]
-        L_s = torch.linalg.cholesky(A_hat + self.jitter * eye)
-        logdet_S = 2.0 * torch.sum(torch.log(torch.diagonal(L_s, dim1=-2, dim2=-1)), dim=-1)
+        logdet_S = spd_inverse_logdet(A_hat + self.jitter * eye)[1]       # log|A_hat + jI| (svgp.py:88,90)
         kl = 0.5 * (logdet_K - logdet_S - m + (A_hat * K_inv.T.unsqueeze(0)).sum(dim=(1, 2))
                     + ((mu_hat @ K_inv) * mu_hat).sum(dim=1))
         l3_sum, ce_sum = elbo_reduce(mu, var, mv, tr, p_m, p_v, bc.ktilde)
@@ -143,7 +142,7 @@ class SVGP(nn.Module):
         m = K_mm.shape[0]
         mv = (bc.Q @ mu_hat).reshape(-1, 1)
         tr = rowdot((bc.Q @ A_hat).unsqueeze(0), bc.Q).T
-        logdet_S = 2.0 * torch.sum(torch.log(torch.diagonal(torch.linalg.cholesky(A_hat + self.jitter * eye))))
+        logdet_S = spd_inverse_logdet((A_hat + self.jitter * eye).unsqueeze(0))[1][0]
         kl = 0.5 * (logdet_K - logdet_S - m + torch.trace(K_inv @ A_hat) + torch.sum(mu_hat * (K_inv @ mu_hat)))
         zero = torch.zeros_like(y)
         l3, _ = elbo_reduce(y, noise, mv, tr, zero, zero, bc.ktilde)

@@ -145,6 +145,57 @@ def rowdot(A, B):
     return _RowDot.apply(A, B)
 
 
+SWEEP_MAX_M = 279      # largest matrix the register/LDS-resident sweep kernel takes (include/spadot_model.h)
+
+
+def _spd_inverse_logdet_nograd(A, need_logdet=True):
+    """A [L, m, m] SPD fp64 -> (A^-1, log|A|).  m <= SWEEP_MAX_M: ONE launch of the sweep kernel gives both.
+    Larger m: the library's batched Cholesky (potrf + potri), which is just as stable but costs ~100 small
+    launches -- a block/Schur split through an explicit inverse was tried and loses cond(A) digits."""
+    L, m, _ = A.shape
+    if m <= SWEEP_MAX_M:
+        X = torch.empty_like(A)
+        logdet = torch.empty(L, dtype=torch.float64, device=A.device)
+        _check(model_lib().spadot_spd_inverse_logdet(_p(A), L, m, _p(X), _p(logdet), _stream()),
+               "spadot_spd_inverse_logdet")
+        return X, logdet
+    Lc = torch.linalg.cholesky_ex(A, check_errors=False)[0]
+    X = torch.cholesky_inverse(Lc)
+    logdet = 2.0 * torch.log(torch.diagonal(Lc, dim1=-2, dim2=-1)).sum(-1)
+    return X, logdet
+
+
+class _SPDInverse(torch.autograd.Function):
+    """(A^-1, log|A|) of a batch of SPD matrices [L, m, m] (fp64).  Forward: the register-resident symmetric
+    sweep kernel (one launch, m <= 279; library Cholesky above).  Backward (A symmetric):
+    dA = -X G_X X + g_logdet X with X = A^-1 -- two batched GEMMs."""
+
+    @staticmethod
+    def forward(ctx, A, need_logdet):
+        _need_cuda(A)
+        assert A.dtype == torch.float64 and A.dim() == 3 and A.shape[1] == A.shape[2]
+        X, logdet = _spd_inverse_logdet_nograd(A.contiguous(), need_logdet)
+        ctx.save_for_backward(X)
+        return X, logdet
+
+    @staticmethod
+    def backward(ctx, gX, gl):
+        (X,) = ctx.saved_tensors
+        gA = None
+        if gX is not None:
+            gA = -(X @ gX @ X)
+        if gl is not None:
+            t = gl.view(-1, 1, 1) * X
+            gA = t if gA is None else gA + t
+        return gA, None
+
+
+def spd_inverse_logdet(A, need_logdet=True):
+    """A [L, m, m] SPD fp64 -> (A^-1 [L, m, m], log|A| [L]).  need_logdet=False lets matrices beyond the
+    kernel's size skip the library Cholesky (the returned logdet is then zeros)."""
+    return _SPDInverse.apply(A, need_logdet)
+
+
 class _ELBO(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mu, var, mv, tr, pm, pv, ktilde):

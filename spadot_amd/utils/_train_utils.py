@@ -124,7 +124,10 @@ def _compute_kmeans_loss(model, model_config, tp, seed_ids, latent):
     st = _device_state(model, tp)
     lab = st["labels"][seed_ids]
     centers = st["centers"]
-    n_distinct = (torch.bincount(lab, minlength=centers.shape[0]) > 0).sum()
+    # (torch.bincount would synchronise with the host to size its output)
+    occ = torch.zeros(centers.shape[0], dtype=torch.float32, device=lab.device).index_add_(
+        0, lab, torch.ones(lab.shape[0], dtype=torch.float32, device=lab.device))
+    n_distinct = (occ > 0).sum()
     return torch.sum((latent - centers[lab]) ** 2) / latent.shape[1] / n_distinct
 
 
@@ -135,7 +138,8 @@ def _compute_OT_loss(model, model_config, cur_tp, seed_ids, tp_p_m, prev_tp):
     lab = st["labels"][seed_ids]
     K = st["centers"].shape[0]
     sums = torch.zeros((K, tp_p_m.shape[1]), dtype=tp_p_m.dtype, device=tp_p_m.device).index_add_(0, lab, tp_p_m)
-    cnt = torch.bincount(lab, minlength=K).to(tp_p_m.dtype).unsqueeze(1)
+    cnt = torch.zeros(K, dtype=tp_p_m.dtype, device=lab.device).index_add_(
+        0, lab, torch.ones(lab.shape[0], dtype=tp_p_m.dtype, device=lab.device)).unsqueeze(1)
     means = torch.where(cnt > 0, sums / cnt.clamp(min=1), st["centers"])
     cur = means[st["cluster_list"]]
     gamma = model._gamma_dev[f"{prev_tp}_{cur_tp}"]

@@ -153,6 +153,33 @@ def test_reduction_kernels_gradients_vs_torch(ops):
     np.testing.assert_allclose(yh.grad.cpu().numpy(), (3.0 * -2.0 / 33 * (y - yh.detach())).cpu().numpy(), rtol=1e-6)
 
 
+@pytest.mark.parametrize("L,m", [(1, 1), (3, 17), (10, 217), (10, 236), (4, 248), (3, 279), (2, 389)])
+def test_spd_inverse_logdet_vs_torch(ops, L, m):
+    """Batched SPD inverse + logdet (sweep kernel: register tiles up to 217, + LDS border up to 279; library beyond) against
+    torch.linalg on matrices conditioned like the SVGP's Sigma_l (jitter 1e-2, cond ~1e6)."""
+    rng = np.random.default_rng(m)
+    B = rng.normal(size=(L, m, max(2, m // 3)))
+    A = T(B @ B.transpose(0, 2, 1) * 50.0 + 1e-2 * np.eye(m)).to(DEV).requires_grad_(True)
+    X, ld = ops.spd_inverse_logdet(A)
+    Ar = A.detach().clone().requires_grad_(True)
+    Xr = torch.linalg.inv(Ar)
+    ldr = torch.linalg.slogdet(Ar)[1]
+    eye = torch.eye(m, dtype=F64, device=DEV)
+    # residual-based check (the inverse itself is only defined to cond * eps): no worse than 10x the library's
+    res = float((A.detach() @ X.detach() - eye).abs().max())
+    res_ref = float((Ar.detach() @ Xr.detach() - eye).abs().max())
+    assert res <= 10 * res_ref + 1e-12, (res, res_ref)
+    # 2/3 of the pivots are jitter-sized Schur complements (cancellation ~ cond * eps): 1e-7 absolute
+    np.testing.assert_allclose(ld.detach().cpu().numpy(), ldr.detach().cpu().numpy(), rtol=1e-9, atol=1e-7)
+    np.testing.assert_allclose(X.detach().cpu().numpy(), Xr.detach().cpu().numpy(), rtol=1e-6, atol=1e-7 * float(Xr.abs().max()))
+    W = T(rng.normal(size=(L, m, m))).to(DEV)
+    wl = T(rng.normal(size=L)).to(DEV)
+    ((X * W).sum() + (ld * wl).sum()).backward()
+    ((Xr * W).sum() + (ldr * wl).sum()).backward()
+    ga, gr = A.grad.cpu().numpy(), Ar.grad.cpu().numpy()
+    np.testing.assert_allclose(ga, gr, rtol=1e-5, atol=1e-6 * np.abs(gr).max())
+
+
 # ------------------------------------------------------------------ composite model
 
 def _model(g, compute_dtype=torch.float32):
