@@ -134,11 +134,19 @@ def _main(real_stdout):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # rehearsal switches (one-GPU box): SPADOT_BENCH_SINGLE_DEVICE=1 puts every rank on cuda:0 and
+    # SPADOT_BENCH_BACKEND=gloo carries the collectives; the driver's multi-GPU runs use neither
+    if os.environ.get("SPADOT_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("SPADOT_BENCH_BACKEND", "nccl")
     dev = f"cuda:{local_rank}"
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(dev))
+        else:
+            dist.init_process_group(backend)
 
     def barrier():
         if world > 1:
