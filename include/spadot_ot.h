@@ -139,6 +139,11 @@ int spadot_ot_solve(spadot_ot_solver *s, const double *G_host, const spadot_ot_c
 /* Transport plan R/J (ot_solvers.py:449) of the last solve. */
 int spadot_ot_plan_dev(spadot_ot_solver *s, void *plan_dev, int dtype, int ldp);
 int spadot_ot_plan_host(spadot_ot_solver *s, double *plan_host);
+/* Column-group sums of the plan R/J without materialising it: Q_dev[i*ngroups + g] = sum over columns j with
+ * col_labels_dev[j] == g of plan[i][j] (labels int32 in [0, ngroups), ngroups <= 64, Q fp64 I x ngroups).
+ * one-hot(row labels)^T Q is the cluster transition table of the analyze stage (_analyze_utils.py:131-137). */
+int spadot_ot_plan_group_sums_dev(spadot_ot_solver *s, const int *col_labels_dev, int ngroups, double *Q_dev);
+
 /* Row sums of the plan (what compute_transport_map feeds back as growth, ot_solvers.py:117). */
 int spadot_ot_plan_rowsums_host(spadot_ot_solver *s, double *rowsums_host);
 

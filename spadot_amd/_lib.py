@@ -77,6 +77,8 @@ def ot_lib():
     lib.spadot_ot_solve.restype = ci
     lib.spadot_ot_plan_dev.argtypes = [vp, vp, ci, ci]
     lib.spadot_ot_plan_dev.restype = ci
+    lib.spadot_ot_plan_group_sums_dev.argtypes = [vp, vp, ci, vp]
+    lib.spadot_ot_plan_group_sums_dev.restype = ci
     lib.spadot_ot_plan_host.argtypes = [vp, vp]
     lib.spadot_ot_plan_host.restype = ci
     lib.spadot_ot_plan_rowsums_host.argtypes = [vp, vp]

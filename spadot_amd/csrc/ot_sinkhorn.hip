@@ -802,6 +802,36 @@ __global__ __launch_bounds__(256) void k_drift_final(const double *__restrict__ 
     }
 }
 
+
+// Column-group sums of the transport plan without materialising it: Q[i][g] = sum_{j: label_j = g} a_i K_ij b_j * scale.
+// One wave per row; every lane keeps its own accumulator per group in LDS (acc[g][lane], conflict-free and
+// summed in a fixed order => deterministic).  With one-hot(row labels)^T Q this gives the cluster-by-cluster
+// transition table the analyze stage reads off the spot-level plan (_analyze_utils.py:131-137).
+template <typename T>
+__global__ __launch_bounds__(256) void k_plan_group_sums(const T *__restrict__ K, const double *__restrict__ a,
+                                                         const double *__restrict__ b,
+                                                         const int *__restrict__ labels, int ngroups,
+                                                         double scale, double *__restrict__ Q, int I, int J,
+                                                         int ld) {
+    extern __shared__ double gacc[];            // ROW_WAVES x ngroups x 64
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int row = blockIdx.x * ROW_WAVES + wid;
+    double *acc = gacc + (size_t)wid * ngroups * WAVE;
+    for (int g = 0; g < ngroups; g++) acc[g * WAVE + lane] = 0.0;
+    if (row < I) {
+        const T *r = K + (size_t)row * ld;
+        for (int j = lane; j < J; j += WAVE) {
+            const int g = labels[j];
+            acc[g * WAVE + lane] += (double)r[j] * b[j];
+        }
+        const double ai = a[row] * scale;
+        for (int g = 0; g < ngroups; g++) {
+            const double t = wave_sum(acc[g * WAVE + lane]);
+            if (lane == 0) Q[(size_t)row * ngroups + g] = t * ai;
+        }
+    }
+}
+
 // plan = a_i K_ij b_j * scale  (ot_solvers.py:449 with scale = 1/J)
 template <typename T, typename TO>
 __global__ __launch_bounds__(256) void k_plan(const T *__restrict__ K, const double *__restrict__ a,
@@ -1485,6 +1515,18 @@ int spadot_ot_plan_dev(spadot_ot_solver *s, void *plan_dev, int dtype, int ldp) 
     else
         return -22;
     return 0;
+}
+
+int spadot_ot_plan_group_sums_dev(spadot_ot_solver *s, const int *col_labels_dev, int ngroups, double *Q_dev) {
+    if (!s || !col_labels_dev || !Q_dev || ngroups < 1 || ngroups > 64) return -22;
+    const size_t lds = sizeof(double) * ROW_WAVES * (size_t)ngroups * WAVE;
+    dim3 g((s->I + ROW_WAVES - 1) / ROW_WAVES);
+    const double sc = 1.0 / s->J;
+    if (s->storage == SPADOT_F32)
+        hipLaunchKernelGGL(k_plan_group_sums<float>, g, dim3(256), lds, s->stream, (const float *)s->K, s->a, s->b, col_labels_dev, ngroups, sc, Q_dev, s->I, s->J, s->ld);
+    else
+        hipLaunchKernelGGL(k_plan_group_sums<double>, g, dim3(256), lds, s->stream, (const double *)s->K, s->a, s->b, col_labels_dev, ngroups, sc, Q_dev, s->I, s->J, s->ld);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
 int spadot_ot_plan_host(spadot_ot_solver *s, double *plan_host) {

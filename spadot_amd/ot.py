@@ -128,6 +128,25 @@ class OTSolver:
         torch.cuda.current_stream(self.device).wait_stream(self._stream)
         return P
 
+    def transition_table(self, row_labels, col_labels, n_row_groups=None, n_col_groups=None):
+        """Cluster-by-cluster block sums of the plan (what wot's transition_table reads off a spot-level
+        transport map, _analyze_utils.py:131-137) computed on the device without materialising the plan.
+        Returns a torch fp64 tensor [n_row_groups, n_col_groups]."""
+        rl = torch.as_tensor(row_labels, dtype=torch.int64, device=self.device)
+        cl = torch.as_tensor(col_labels, dtype=torch.int32, device=self.device).contiguous()
+        assert rl.numel() == self.I and cl.numel() == self.J
+        Ka = int(n_row_groups) if n_row_groups is not None else int(rl.max()) + 1
+        Kb = int(n_col_groups) if n_col_groups is not None else int(cl.max()) + 1
+        Q = torch.empty((self.I, Kb), dtype=torch.float64, device=self.device)
+        self._stream.wait_stream(torch.cuda.current_stream(self.device))
+        rc = self.lib.spadot_ot_plan_group_sums_dev(self.h, ctypes.c_void_p(cl.data_ptr()), Kb, ctypes.c_void_p(Q.data_ptr()))
+        if rc != 0:
+            raise RuntimeError(f"plan_group_sums failed with {rc}")
+        torch.cuda.current_stream(self.device).wait_stream(self._stream)
+        onehot = torch.zeros((Ka, self.I), dtype=torch.float64, device=self.device)
+        onehot[rl, torch.arange(self.I, device=self.device)] = 1.0
+        return onehot @ Q
+
     def plan_rowsums(self):
         r = np.empty(self.I, dtype=np.float64)
         rc = self.lib.spadot_ot_plan_rowsums_host(self.h, r.ctypes.data_as(ctypes.c_void_p))

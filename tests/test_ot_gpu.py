@@ -347,3 +347,48 @@ def test_row_permutation_equivariance_at_scale(OTSolver, I, J, storage, rtol):
     assert it0 == it1
     big = P > 1e-9 * P.max()
     np.testing.assert_allclose(Pp[np.argsort(perm)][big], P[big], rtol=rtol)
+
+
+# ------------------------------------------------------------------ analyze-stage spot-level OT
+
+def test_transition_table_is_block_sum_of_reference_plan(OTSolver, oracle_ot):
+    g = load_golden("ot_solve_spots300x400.npz")
+    cfg = solve_cfg(g)
+    rng = np.random.default_rng(0)
+    la, lb = rng.integers(0, 7, size=300), rng.integers(0, 10, size=400)
+    want = np.zeros((7, 10))
+    np.add.at(want, (la[:, None], lb[None, :]), g["gamma"])
+    for storage, rtol in (("f64", 1e-8), ("f32", 1e-4)):
+        s = OTSolver(300, 400, storage=storage)
+        s.set_cost_from_latents(g["a"], g["b"])
+        s.solve(cfg)
+        tab = s.transition_table(la, lb, 7, 10).cpu().numpy()
+        np.testing.assert_allclose(tab, want, rtol=rtol)
+        # bitwise reproducible (no atomics)
+        np.testing.assert_array_equal(tab, s.transition_table(la, lb, 7, 10).cpu().numpy())
+        s.close()
+
+
+def test_spot_transport_growth_iterations_vs_oracle(oracle_ot):
+    from spadot_amd import analyze_ot
+    rng = np.random.default_rng(5)
+    cen = rng.normal(size=(10, 20))
+    x, y = _mixture(rng, 500, cen), _mixture(rng, 650, cen + 0.1)
+    cfg = dict(analyze_ot.ANALYZE_OT_CONFIG)
+    # oracle: three solves with row sums fed back (ot_solvers.py:112-120), keeping the LAST plan
+    C = oracle_ot.sqeuclidean_cost(x, y); C = C / np.median(C)
+    kw = {k: cfg[k] for k in ("lambda1", "lambda2", "epsilon", "batch_size", "tolerance", "tau", "epsilon0", "max_iter")}
+    gam, grow = None, np.ones(500)
+    for i in range(3):
+        if i > 0:
+            grow = gam.sum(axis=1)
+        gam = oracle_ot.optimal_transport_duality_gap(C, grow, **kw)
+    solver, infos = analyze_ot.spot_transport(x, y, cfg, which="last", storage="f64")
+    assert len(infos) == 3
+    np.testing.assert_allclose(solver.plan("numpy"), gam, rtol=1e-7, atol=1e-300)
+    la, lb = rng.integers(0, 10, size=500), rng.integers(0, 10, size=650)
+    want = np.zeros((10, 10)); np.add.at(want, (la[:, None], lb[None, :]), gam)
+    np.testing.assert_allclose(solver.transition_table(la, lb, 10, 10).cpu().numpy(), want, rtol=1e-7)
+    solver.close()
+    tabs = analyze_ot.transition_tables([x, y], [la, lb], cfg, storage="f32")
+    np.testing.assert_allclose(tabs[0][0], want, rtol=1e-3)
