@@ -128,6 +128,13 @@ int spadot_adamw_step(float *param, const float *grad, float *exp_avg, float *ex
                       const float *sumsq, long long count, double lr, double beta1, double beta2,
                       double eps, double weight_decay, double max_norm, int step, void *stream);
 
+/* Same update with the step count kept ON THE DEVICE (step_dev[0] is incremented, then used for the bias
+ * corrections): nothing in the launch depends on a host-side counter, so a captured hipGraph of a whole
+ * training step can be replayed. */
+int spadot_adamw_step_dev(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
+                          const float *sumsq, long long count, double lr, double beta1, double beta2,
+                          double eps, double weight_decay, double max_norm, int *step_dev, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -115,6 +115,7 @@ def model_lib():
         "spadot_kmeans_assign": [vp, vp, ci, ci, ci, ci, vp, vp],
         "spadot_grad_sumsq": [vp, ll, vp, vp, vp],
         "spadot_adamw_step": [vp, vp, vp, vp, vp, ll, cd, cd, cd, cd, cd, cd, ci, vp],
+        "spadot_adamw_step_dev": [vp, vp, vp, vp, vp, ll, cd, cd, cd, cd, cd, cd, vp, vp],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)

@@ -636,11 +636,18 @@ __global__ __launch_bounds__(256) void k_sumsq_part(const float *__restrict__ g,
     if (threadIdx.x == 0) part[blockIdx.x] = acc;
 }
 
+__global__ void k_step_inc(int *step) { step[0] += 1; }
+
 __global__ __launch_bounds__(256) void k_adamw(float *__restrict__ p, const float *__restrict__ g,
                                                float *__restrict__ m, float *__restrict__ v,
                                                const float *__restrict__ sumsq, long long count, float lr,
                                                float b1, float b2, float eps, float wd, float max_norm,
-                                               float bc1, float bc2_sqrt) {
+                                               float bc1, float bc2_sqrt, const int *__restrict__ step_dev) {
+    if (step_dev) {   // step count lives on the device (hipGraph replays): bias corrections computed here
+        const double t = (double)step_dev[0];
+        bc1 = (float)(1.0 - pow((double)b1, t));
+        bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, t));
+    }
     const float total = sqrtf(sumsq[0]);
     const float coef = fminf(1.f, max_norm / (total + 1e-6f));
     for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < count; k += (long long)gridDim.x * 256) {
@@ -866,6 +873,20 @@ int spadot_grad_sumsq(const float *grad, long long count, double *scratch, float
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
+int spadot_adamw_step_dev(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, const float *sumsq,
+                          long long count, double lr, double beta1, double beta2, double eps, double weight_decay,
+                          double max_norm, int *step_dev, void *stream) {
+    if (count <= 0 || !step_dev) return -22;
+    hipStream_t st_ = (hipStream_t)stream;
+    const long long want = (count + 255) / 256;
+    const int nb = (int)(want < 4096 ? want : 4096);
+    hipLaunchKernelGGL(k_step_inc, dim3(1), dim3(1), 0, st_, step_dev);
+    hipLaunchKernelGGL(k_adamw, dim3(nb), dim3(256), 0, st_, param, grad, exp_avg, exp_avg_sq, sumsq, count,
+                       (float)lr, (float)beta1, (float)beta2, (float)eps, (float)weight_decay, (float)max_norm,
+                       1.f, 1.f, (const int *)step_dev);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
 int spadot_adamw_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, const float *sumsq,
                       long long count, double lr, double beta1, double beta2, double eps, double weight_decay,
                       double max_norm, int step, void *stream) {
@@ -877,7 +898,7 @@ int spadot_adamw_step(float *param, const float *grad, float *exp_avg, float *ex
     const double bc2 = 1.0 - pow(beta2, (double)step);
     hipLaunchKernelGGL(k_adamw, dim3(nb), dim3(256), 0, st_, param, grad, exp_avg, exp_avg_sq, sumsq, count,
                        (float)lr, (float)beta1, (float)beta2, (float)eps, (float)weight_decay, (float)max_norm,
-                       (float)bc1, (float)sqrt(bc2));
+                       (float)bc1, (float)sqrt(bc2), (const int *)nullptr);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 

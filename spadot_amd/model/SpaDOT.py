@@ -53,26 +53,43 @@ class SpaDOT(nn.Module):
         b = batch_size
         svgp = self.svgp_dict[str(tp)]
         yb = y[:b]
-        q_mu, q_var = self.SVGPEncoder(yb.float())
-        bc = svgp.batch_constants(x[:b], key=batch_key)
-        p_m, p_v, l3_sum, kl_sum, ce = svgp.elbo_terms(bc, q_mu, q_var)
-        inside_elbo = l3_sum - (b / float(svgp.N_train)) * kl_sum
-        diff = ce - inside_elbo
-        # sign trick of SpaDOT.py:76-77 without the host round trip: -(|diff|) either way
-        SVGP_KL = -torch.abs(diff) / self.SVGP_z_dim
-        eps_s = torch.randn_like(p_m) if noise is None else noise[0].to(p_m.dtype)
-        SVGP_latent = (p_m + eps_s * torch.sqrt(p_v)).float()
+        # The SVGP branch is latency-bound (L small matrices: a handful of CUs) and the GAT branch is
+        # bandwidth-bound; they are independent until the decoder, so the SVGP branch runs on a side HIP
+        # stream and overlaps the GAT branch (autograd replays each op's backward on its forward stream).
+        main = torch.cuda.current_stream()
+        side = self._side_stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            q_mu, q_var = self.SVGPEncoder(yb.float())
+            bc = svgp.batch_constants(x[:b], key=batch_key)
+            p_m, p_v, l3_sum, kl_sum, ce = svgp.elbo_terms(bc, q_mu, q_var)
+            inside_elbo = l3_sum - (b / float(svgp.N_train)) * kl_sum
+            diff = ce - inside_elbo
+            # sign trick of SpaDOT.py:76-77 without the host round trip: -(|diff|) either way
+            SVGP_KL = (-torch.abs(diff) / self.SVGP_z_dim).float()
+            eps_s = torch.randn_like(p_m) if noise is None else noise[0].to(p_m.dtype)
+            SVGP_latent = (p_m + eps_s * torch.sqrt(p_v)).float()
 
         g_mu, g_var = self.GATEncoder(y, edge_index, rows=b)
         eps_g = torch.randn_like(g_mu) if noise is None else noise[1].to(g_mu.dtype)
         GAT_latent = g_mu + eps_g * torch.sqrt(g_var)
         GAT_KL = -0.5 * torch.sum(1 + torch.log(g_var) - g_mu.pow(2) - g_var) / self.GAT_z_dim
+        main.wait_stream(side)
+        SVGP_latent.record_stream(main)
+        SVGP_KL.record_stream(main)
 
         final_latent = torch.cat([SVGP_latent, GAT_latent], dim=1)
         recon_loss = sqerr_sum(yb.float(), self.decoder(final_latent), 1.0 / self.input_dim)
         alignment_loss = F.mse_loss(SVGP_latent.norm(dim=1) / self.SVGP_z_dim,
                                     GAT_latent.norm(dim=1) / self.GAT_z_dim, reduction="sum")
-        return recon_loss, SVGP_KL.float(), GAT_KL, alignment_loss, final_latent
+        return recon_loss, SVGP_KL, GAT_KL, alignment_loss, final_latent
+
+    def _side_stream(self):
+        st = getattr(self, "_svgp_stream", None)
+        if st is None:
+            st = torch.cuda.Stream(device=self.device)
+            self._svgp_stream = st
+        return st
 
     def all_latent_samples(self, X, Y, edge_index, tp, as_numpy=True):
         """Posterior means of the whole time point (SpaDOT.py:96-123); no N_t x N_t intermediates."""

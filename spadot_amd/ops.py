@@ -305,6 +305,7 @@ class FlatAdamW:
         self.params, self.count = params, tot
         self.lr, self.betas, self.eps, self.weight_decay, self.max_norm = lr, betas, eps, weight_decay, max_norm
         self.t = 0
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)   # device-side step count (graph replays)
 
     def zero_grad(self):
         self.flat_grad.zero_()
@@ -316,9 +317,11 @@ class FlatAdamW:
         return self.sumsq
 
     def step(self):
+        """clip + AdamW; the step count lives on the device, so the same launches can be captured in a
+        hipGraph and replayed."""
         self.t += 1
         self.grad_norm_sq()
-        _check(model_lib().spadot_adamw_step(_p(self.flat_param), _p(self.flat_grad), _p(self.exp_avg),
-                                             _p(self.exp_avg_sq), _p(self.sumsq), self.count, self.lr, self.betas[0],
-                                             self.betas[1], self.eps, self.weight_decay, self.max_norm, self.t,
-                                             _stream()), "spadot_adamw_step")
+        _check(model_lib().spadot_adamw_step_dev(_p(self.flat_param), _p(self.flat_grad), _p(self.exp_avg),
+                                                 _p(self.exp_avg_sq), _p(self.sumsq), self.count, self.lr,
+                                                 self.betas[0], self.betas[1], self.eps, self.weight_decay,
+                                                 self.max_norm, _p(self.step_dev), _stream()), "spadot_adamw_step_dev")

@@ -147,6 +147,17 @@ def _compute_OT_loss(model, model_config, cur_tp, seed_ids, tp_p_m, prev_tp):
     return torch.mean(gamma * cost)
 
 
+def _assign_or_copy(store, key, value):
+    """Keep device tensors at stable addresses (captured hipGraphs read them): copy in place when the shape
+    is unchanged, else replace and report it so that stale graphs can be dropped."""
+    cur = store.get(key)
+    if cur is not None and cur.shape == value.shape and cur.dtype == value.dtype:
+        cur.copy_(value)
+        return False
+    store[key] = value
+    return cur is not None
+
+
 def _set_kmeans_state(model, tp, centers, labels, global_idx, device):
     """Stores the reference's three dicts (SpaDOT.py:47-50) and their device mirror."""
     model.kmeans_center_dict[tp] = centers
@@ -155,9 +166,12 @@ def _set_kmeans_state(model, tp, centers, labels, global_idx, device):
     if not hasattr(model, "_kmeans_dev"):
         model._kmeans_dev, model._gamma_dev = {}, {}
     cl = sorted(set(labels.tolist()))
-    model._kmeans_dev[tp] = {"labels": torch.as_tensor(labels, dtype=torch.int64).to(device),
-                             "centers": torch.as_tensor(centers, dtype=torch.float32).to(device),
-                             "cluster_list": torch.as_tensor(cl, dtype=torch.int64).to(device)}
+    st = model._kmeans_dev.setdefault(tp, {})
+    changed = _assign_or_copy(st, "labels", torch.as_tensor(labels, dtype=torch.int64).to(device))
+    changed |= _assign_or_copy(st, "centers", torch.as_tensor(centers, dtype=torch.float32).to(device))
+    changed |= _assign_or_copy(st, "cluster_list", torch.as_tensor(cl, dtype=torch.int64).to(device))
+    if changed:
+        model._state_version = getattr(model, "_state_version", 0) + 1
 
 
 def _update_Kmeans(model, model_config, dataloader_dict):
@@ -178,7 +192,8 @@ def _set_gamma(model, key, gamma, device):
     with np.errstate(divide="ignore", invalid="ignore"):
         g = gamma / gamma.sum(axis=1, keepdims=True)
     g = np.nan_to_num(g, nan=0.0, posinf=0.0, neginf=0.0)
-    model._gamma_dev[key] = torch.as_tensor(g, dtype=torch.float32).to(device)
+    if _assign_or_copy(model._gamma_dev, key, torch.as_tensor(g, dtype=torch.float32).to(device)):
+        model._state_version = getattr(model, "_state_version", 0) + 1
 
 
 def _update_OT_matrix(model, model_config):
@@ -219,6 +234,56 @@ def forward_backward(model, model_config, dataloader_dict, tp_i, tp, bi, epoch, 
                         km.detach(), ot.detach()])
 
 
+class GraphedStepper:
+    """Training steps as replayed hipGraphs (torch.cuda.CUDAGraph on ROCm = hipGraph).
+
+    The unshuffled loader makes every (time point, batch) recur each epoch with identical shapes and
+    index tensors, and the step has no host synchronisation, so the ~500 launches of one step (forward,
+    backward, clip, AdamW, on two streams) are captured once per (time point, batch, active loss terms)
+    and replayed: the CPU issues one hipGraphLaunch instead of ~500 kernel launches.  First visit of a key
+    runs eagerly (warm-up: library handles, SVGP batch constants), the second visit captures, later
+    visits replay.  Anything that changes between replays lives in device memory at a fixed address: beta1
+    (a 0-dim tensor), K-means labels/centres and OT plans (copied in place), the optimizer's step count.
+    """
+
+    def __init__(self, model, optimizer, model_config, dataloader_dict):
+        self.model, self.opt, self.cfg, self.dd = model, optimizer, model_config, dataloader_dict
+        dev = optimizer.flat_param.device
+        self.beta1_t = torch.zeros((), dtype=torch.float32, device=dev)
+        self.graphs, self.seen = {}, set()
+        self.pool = None
+        self.version = getattr(model, "_state_version", 0)
+
+    def _body(self, tp_i, tp, bi, epoch):
+        self.opt.zero_grad()
+        losses = forward_backward(self.model, self.cfg, self.dd, tp_i, tp, bi, epoch, self.beta1_t)
+        self.opt.step()
+        return losses
+
+    def step(self, tp_i, tp, bi, epoch, beta1):
+        if getattr(self.model, "_state_version", 0) != self.version:      # a state tensor was re-allocated
+            self.graphs.clear()
+            self.version = getattr(self.model, "_state_version", 0)
+        self.beta1_t.fill_(float(beta1))
+        key = (tp, bi, epoch >= 1, epoch >= self.cfg["ot_epoch"] and tp_i != 0)
+        if key in self.graphs:
+            g, out = self.graphs[key]
+            g.replay()
+            return out.clone()
+        if key not in self.seen:                                            # warm-up visit: plain eager step
+            self.seen.add(key)
+            return self._body(tp_i, tp, bi, epoch)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        if self.pool is None:
+            self.pool = torch.cuda.graph_pool_handle()
+        with torch.cuda.graph(g, pool=self.pool):
+            out = self._body(tp_i, tp, bi, epoch)
+        self.graphs[key] = (g, out)
+        g.replay()
+        return out.clone()
+
+
 def training_step(model, optimizer, model_config, dataloader_dict, tp_i, tp, bi, epoch, beta1, grad_sync=None):
     """One optimizer step (_train_utils.py:187-217): zero_grad, forward_backward, optional gradient
     all-reduce (data-parallel path), clip + AdamW."""
@@ -237,6 +302,7 @@ def train_SpaDOT(dataloader_dict, model_config, verbose=True):
     device = torch.device(model_config["device"])
     model = SpaDOT.SpaDOT(model_config, dataloader_dict).to(device)
     optimizer = FlatAdamW(model.parameters(), lr=model_config["lr"])
+    stepper = GraphedStepper(model, optimizer, model_config, dataloader_dict) if model_config.get("use_hip_graphs", True) else None
     beta1s = _beta_cycle_linear(model_config["maxiter"], stop=model_config["beta1"])
     tp_indexed_list = list(enumerate(model_config["timepoints"]))
     loss_dict = OrderedDict((e, OrderedDict((n, 0.0) for n in LOSS_NAMES)) for e in range(model_config["maxiter"]))
@@ -255,7 +321,10 @@ def train_SpaDOT(dataloader_dict, model_config, verbose=True):
             nb = len(dataloader_dict["dataloaders"][tp])
             tot = torch.zeros(len(LOSS_NAMES), dtype=torch.float32, device=device)
             for bi in range(nb):
-                tot += training_step(model, optimizer, model_config, dataloader_dict, tp_i, tp, bi, epoch, beta1).float()
+                if stepper is not None:
+                    tot += stepper.step(tp_i, tp, bi, epoch, beta1).float()
+                else:
+                    tot += training_step(model, optimizer, model_config, dataloader_dict, tp_i, tp, bi, epoch, beta1).float()
             acc[tp] = tot / nb
         for tp, v in acc.items():                      # one device->host read per time point per epoch
             for name, val in zip(LOSS_NAMES, v.cpu().tolist()):

@@ -106,6 +106,44 @@ def test_train_end_to_end_writes_reference_outputs(tmp_path):
     lat0 = torch.as_tensor(z["X"][:1200], dtype=torch.float64, device=DEV)
 
 
+def test_graphed_steps_match_eager_steps(monkeypatch):
+    """hipGraph replay of the training step == the eager step (reparameterisation noise silenced so that the
+    two runs see the same numbers; what differs is only how the launches are issued)."""
+    from spadot_amd.model import SpaDOT
+    from spadot_amd.ops import FlatAdamW
+    from spadot_amd.synthetic import make_dataset
+    from spadot_amd.utils import _train_utils as tu, _utils
+    monkeypatch.setattr(torch, "randn_like", lambda x, **k: torch.zeros_like(x))
+    data = make_dataset(2, 1200, 40, seed=3)
+    cfg = _small_config()
+    cfg.update(input_dim=40, timepoints=[0, 1], device=torch.device(DEV))
+    results = []
+    for graphed in (False, True):
+        _utils.set_seed(7)
+        dd = tu.prepare_dataloader(data, cfg)
+        model = SpaDOT.SpaDOT(cfg, dd).to(DEV)
+        opt = FlatAdamW(model.parameters(), lr=cfg["lr"])
+        tu._update_Kmeans(model, cfg, dd)
+        tu._update_OT_matrix(model, cfg)
+        model.train()
+        stepper = tu.GraphedStepper(model, opt, cfg, dd) if graphed else None
+        losses = []
+        for rep in range(4):                       # visit 1 eager, visit 2 capture + replay, visits 3-4 replay
+            for bi in range(2):
+                if graphed:
+                    losses.append(stepper.step(1, 1, bi, 5, 0.3))
+                else:
+                    losses.append(tu.training_step(model, opt, cfg, dd, 1, 1, bi, 5, 0.3))
+        torch.cuda.synchronize()
+        results.append((torch.stack(losses).cpu().numpy(), opt.flat_param.detach().cpu().numpy().copy(), int(opt.step_dev.item())))
+        if graphed:
+            assert len(stepper.graphs) == 2
+    (l0, p0, s0), (l1, p1, s1) = results
+    assert s0 == s1 == 8
+    np.testing.assert_allclose(l1, l0, rtol=2e-3, atol=1e-4)       # atomics in index_add_/GEMM split-K order only
+    np.testing.assert_allclose(p1, p0, rtol=0, atol=5e-4)          # 8 AdamW steps of lr 3e-4 each
+
+
 def _dp_worker(rank, world, port, q):
     """One data-parallel rank on cuda:0 (both ranks share the one GPU of the test box; gloo carries the
     collectives, on a real node the backend is nccl = RCCL)."""
