@@ -392,3 +392,51 @@ def test_spot_transport_growth_iterations_vs_oracle(oracle_ot):
     solver.close()
     tabs = analyze_ot.transition_tables([x, y], [la, lb], cfg, storage="f32")
     np.testing.assert_allclose(tabs[0][0], want, rtol=1e-3)
+
+
+# ------------------------------------------------------------------ BASELINE.json full size (cfg3 pair problem)
+
+def test_full_size_10k_pair_problem_properties(OTSolver):
+    """10k x 10k (cfg3: 50k spots / 5 time points), fp32 storage: the oracle would need minutes, so the
+    solve is checked through size-independent properties: it converges in the reference's iteration
+    pattern, the plan's marginals reproduce the first-order conditions of the unbalanced problem from the
+    solver's own state, the transition table is a checksum of the plan, and fused == two-sweep kernels."""
+    import os
+    import torch
+    rng = np.random.default_rng(1993)
+    cen = rng.normal(size=(10, 20))
+    n = 10000
+    x, y = _mixture(rng, n, cen), _mixture(rng, n, cen + 0.05)
+    cfg = dict(lambda1=0.1, lambda2=5.0, epsilon=0.05, epsilon0=1.0, tolerance=1e-8, tau=1000.0,
+               batch_size=5, max_iter=10 ** 7)
+    s = OTSolver(n, n, storage="f32")
+    assert s.fused_geometry()["vpt"] == 5
+    s.set_cost_from_latents(x, y)
+    info = s.solve(cfg)
+    assert info.gap <= 1e-8 and list(info.stage_iters)[:3] == [10, 10, 10] and sum(info.stage_iters) <= 120
+    rows = s.plan_rowsums()
+    a, b, u = s.vector("a"), s.vector("b"), s.vector("u")
+    # first-order condition of the a-update (ot_func.cpp:633-636) with the plan's own row sums:
+    #   a_i = (p_i / (K (b.dy))_i)^alpha1 e^{-u_i/(lambda1+eps)}  and  rowsum_i(R)/J... = a_i (K (b.dy))_i
+    eps, l1 = cfg["epsilon"], cfg["lambda1"]
+    kb = rows / a                                   # (K (b.dy))_i recovered from the plan
+    a_fp = (1.0 / kb) ** (l1 / (l1 + eps)) * np.exp(-u / (l1 + eps))
+    np.testing.assert_allclose(a, a_fp, rtol=1e-3)  # fixed point up to the 1e-8 duality gap
+    la, lb = rng.integers(0, 10, n), rng.integers(0, 10, n)
+    tab = s.transition_table(la, lb, 10, 10).cpu().numpy()
+    assert tab.sum() == pytest.approx(rows.sum(), rel=1e-10)           # checksum of checksums
+    want_rows = np.zeros(10); np.add.at(want_rows, la, rows)
+    np.testing.assert_allclose(tab.sum(axis=1), want_rows, rtol=1e-10)
+    s.close()
+    # the two-sweep fallback kernels give the same solve
+    os.environ["SPADOT_OT_NO_FUSED"] = "1"
+    try:
+        s2 = OTSolver(n, n, storage="f32")
+        assert s2.fused_geometry()["vpt"] == 0
+        s2.set_cost_from_latents(x, y)
+        info2 = s2.solve(cfg)
+        assert list(info2.stage_iters) == list(info.stage_iters)
+        np.testing.assert_allclose(s2.plan_rowsums(), rows, rtol=1e-9)
+        s2.close()
+    finally:
+        del os.environ["SPADOT_OT_NO_FUSED"]
