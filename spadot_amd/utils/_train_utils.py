@@ -175,15 +175,23 @@ def _set_kmeans_state(model, tp, centers, labels, global_idx, device):
 
 
 def _update_Kmeans(model, model_config, dataloader_dict):
-    """_train_utils.py:255-269: full-time-point inference + sklearn KMeans(n_init=10) per time point."""
-    from sklearn.cluster import KMeans
+    """_train_utils.py:255-269: full-time-point inference + KMeans(n_clusters, random_state=seed, n_init=10)
+    per time point.  model_config['kmeans_backend']: 'sklearn' (default; the reference's host fit) or
+    'device' (spadot_amd.kmeans.KMeansDevice: same algorithm in HBM, no latent round trip)."""
     model.eval()
     device = torch.device(model_config["device"])
+    backend = model_config.get("kmeans_backend", "sklearn")
     with torch.no_grad():
         for tp in dataloader_dict["datasets"]:
             loc, Y, ix = dataloader_dict["datasets"][tp]
-            latent = model.all_latent_samples(loc, Y, dataloader_dict["graphs"][tp], tp)
-            km = KMeans(n_clusters=model_config["n_clusters"], random_state=model_config["seed"], n_init=10).fit(latent)
+            if backend == "device":
+                from ..kmeans import KMeansDevice
+                latent = model.all_latent_samples(loc, Y, dataloader_dict["graphs"][tp], tp, as_numpy=False)
+                km = KMeansDevice(model_config["n_clusters"], random_state=model_config["seed"], n_init=10).fit(latent)
+            else:
+                from sklearn.cluster import KMeans
+                latent = model.all_latent_samples(loc, Y, dataloader_dict["graphs"][tp], tp)
+                km = KMeans(n_clusters=model_config["n_clusters"], random_state=model_config["seed"], n_init=10).fit(latent)
             _set_kmeans_state(model, tp, km.cluster_centers_, km.labels_, ix, device)
 
 

@@ -188,3 +188,44 @@ def test_data_parallel_training_two_ranks_one_gpu():
     assert c0 == c1 == [0, 1, 2]                       # centres of all time points everywhere
     assert np.isfinite(l0).all() and np.isfinite(l1).all()
     assert l0[6] > 0 and l1[6] > 0                     # OT term live on both ranks (ot_epoch = 1; tp 2 on rank 0, tp 1 on rank 1)
+
+
+def test_device_kmeans_vs_sklearn():
+    """Device K-means: sklearn's fit is not pinned bit for bit, so the check is on what both
+    must agree on: labels are the nearest centres (exact), the inertia matches sklearn's optimum, the
+    partition is the same on well-separated data, and the fit is deterministic."""
+    from sklearn.cluster import KMeans
+    from sklearn.metrics import adjusted_rand_score
+    from spadot_amd.kmeans import KMeansDevice
+    from spadot_amd import ops
+    rng = np.random.default_rng(0)
+    cen = 3.0 * rng.normal(size=(10, 20))
+    X = cen[rng.integers(0, 10, 4000)] + 0.5 * rng.normal(size=(4000, 20))
+    sk = KMeans(n_clusters=10, random_state=1993, n_init=10).fit(X)
+    Xd = torch.as_tensor(X, device=DEV)
+    km = KMeansDevice(10, random_state=1993, n_init=10).fit(Xd)
+    assert km.labels_.dtype == np.int32 and km.cluster_centers_.shape == (10, 20)
+    assert km.inertia_ == pytest.approx(sk.inertia_, rel=1e-6)
+    assert adjusted_rand_score(sk.labels_, km.labels_) > 0.999
+    d = ((X[:, None, :] - km.cluster_centers_[None]) ** 2).sum(-1)
+    np.testing.assert_array_equal(km.labels_, d.argmin(1).astype(np.int32))       # integer labels: exact rule
+    km2 = KMeansDevice(10, random_state=1993, n_init=10).fit(Xd)
+    np.testing.assert_array_equal(km.labels_, km2.labels_)
+    np.testing.assert_array_equal(km.cluster_centers_, km2.cluster_centers_)
+    # harder, overlapping data: inertia within 1 % of sklearn's best of 10
+    Xh = rng.normal(size=(3000, 20)) + 0.8 * cen[rng.integers(0, 10, 3000)] / 3.0
+    skh = KMeans(n_clusters=10, random_state=1993, n_init=10).fit(Xh)
+    kmh = KMeansDevice(10, random_state=1993, n_init=10).fit(torch.as_tensor(Xh, device=DEV))
+    assert kmh.inertia_ <= 1.01 * skh.inertia_
+
+
+def test_training_with_device_kmeans_backend(tmp_path):
+    import spadot_amd, yaml
+    from spadot_amd.synthetic import make_dataset
+    cfg = _small_config(); cfg["kmeans_backend"] = "device"; cfg["maxiter"] = 2
+    p = tmp_path / "cfg.yaml"; yaml.safe_dump(cfg, open(p, "w"))
+    args = types.SimpleNamespace(data=make_dataset(2, 1200, 40, seed=11), output_dir=str(tmp_path / "o"), prefix="",
+                                 config=str(p), save_model=False, device=DEV)
+    model, loss = spadot_amd.train(args)
+    assert np.isfinite(loss.values).all() and set(model.kmeans_center_dict) == {0, 1}
+    assert len(model.kmeans_cluster_dict[0]) == 1200
