@@ -282,6 +282,16 @@ def _main(real_stdout):
         roof = {"bound": "hbm", "kernel": "k_" + dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS, "traffic": None, "alg_bytes_per_launch": alg,
                 "kernel_ms": kt, "fused_geometry": geo}
+        # HBM traffic per launch comes from separate rocprofv3 --pmc passes (FETCH_SIZE x2 for 16-byte/lane
+        # streams on gfx950, + WRITE_SIZE; MI355X_MICROARCH.md "HBM"): taken from the committed summary of the
+        # same workload, when there is one
+        pmc = os.path.join(ROOT, "profiles", "r01", "sinkhorn_cfg3_f32_pmc_summary.csv")
+        if dom == "fused_pass" and I == 10000 and args.ot_storage == "f32" and os.path.exists(pmc):
+            import csv
+            for row in csv.reader(open(pmc)):
+                if row and "k_fused_pass<float, 5, 2>" in row[0]:
+                    roof["traffic"] = (2.0 * float(row[1]) + float(row[3])) * 1024.0
+                    roof["traffic_source"] = "profiles/r01/sinkhorn_cfg3_f32_pmc_summary.csv (2*FETCH_SIZE + WRITE_SIZE, bytes per launch)"
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             sk_res["cpu_baseline"] = cpu_sinkhorn(I, J)
         solver.close()
