@@ -415,7 +415,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_fused_pass(
     const T *__restrict__ K, const double *__restrict__ w, double *__restrict__ a,
     double *__restrict__ old_a, double *__restrict__ adx, const double *__restrict__ p,
     const double *__restrict__ dx, const double *__restrict__ u, double alpha1, double inv_l1e,
-    double tau, double *__restrict__ part, int I, int ld, int rows_per_block, int *flag) {
+    double tau, T *__restrict__ part, int I, int ld, int rows_per_block, int *flag) {
     constexpr int V = Vec<T>::N;
     extern __shared__ double smem[];
     constexpr int WPAD = VPT * FUSED_THREADS * V;    // w image padded with zeros to the register tile
@@ -449,13 +449,13 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_fused_pass(
                                    rows_per_block, alpha1, inv_l1e, tau, ld, flag);
         }
     }
-    double *o = part + (size_t)blockIdx.x * ld;
+    T *o = part + (size_t)blockIdx.x * ld;        // partials in the storage type: fp32 K => fp32 partials
 #pragma unroll
     for (int k = 0; k < VPT; k++) {
         const int j = (tid + k * FUSED_THREADS) * V;
         if (j < ld) {
 #pragma unroll
-            for (int e = 0; e < V; e++) o[j + e] = colacc[k * V + e];
+            for (int e = 0; e < V; e++) o[j + e] = (T)colacc[k * V + e];
         }
     }
 }
@@ -463,7 +463,8 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_fused_pass(
 // Column finalise for many partial rows: 64 columns x 16 partial-groups per block; partials are
 // summed in ascending block order within a group and groups in ascending order (deterministic).
 // mode 0: b update (ot_func.cpp:657-668) ; mode 1: t_out[j] = sum only.
-__global__ __launch_bounds__(1024) void k_col_fin2(const double *__restrict__ part, int npart,
+template <typename PT>
+__global__ __launch_bounds__(1024) void k_col_fin2(const PT *__restrict__ part, int npart,
                                                    double *__restrict__ b,
                                                    double *__restrict__ old_b,
                                                    double *__restrict__ w,
@@ -479,7 +480,7 @@ __global__ __launch_bounds__(1024) void k_col_fin2(const double *__restrict__ pa
     if (j < ld) {
         const int per = (npart + 15) / 16;
         const int c0 = gy * per, c1 = min(npart, c0 + per);
-        for (int c = c0; c < c1; c++) t += part[(size_t)c * ld + j];
+        for (int c = c0; c < c1; c++) t += (double)part[(size_t)c * ld + j];
     }
     sh[gy][cx] = t;
     __syncthreads();
@@ -1024,7 +1025,7 @@ void launch_fused(spadot_ot_solver *s, const IterParams &P, int *flag) {
     }
     hipLaunchKernelGGL(kern, dim3(s->fused_blocks), dim3(FUSED_THREADS), s->fused_lds, s->stream,
                        (const T *)s->K, s->w, s->a, s->old_a, s->adx, s->p, s->dx, s->u, P.al1,
-                       1.0 / (P.l1 + P.eps), P.tau, s->part, s->I, s->ld, s->fused_rows_per_block, flag);
+                       1.0 / (P.l1 + P.eps), P.tau, (T *)s->part, s->I, s->ld, s->fused_rows_per_block, flag);
 }
 
 template <typename T> void fused_pass_T(spadot_ot_solver *s, const IterParams &P, int *flag);
@@ -1058,7 +1059,7 @@ template <typename T> void one_iteration_T(spadot_ot_solver *s, const IterParams
     const int I = s->I, J = s->J, ld = s->ld;
     if (s->fused_vpt > 0) {
         fused_pass_T<T>(s, P, flag);
-        hipLaunchKernelGGL(k_col_fin2, dim3((ld + 63) / 64), dim3(1024), 0, s->stream, s->part,
+        hipLaunchKernelGGL(k_col_fin2<T>, dim3((ld + 63) / 64), dim3(1024), 0, s->stream, (const T *)s->part,
                            s->fused_blocks, s->b, s->old_b, s->w, s->q, s->dy, s->v, P.al2,
                            1.0 / (P.l2 + P.eps), P.tau, J, ld, flag, s->tcol, 0);
     } else {
@@ -1671,7 +1672,10 @@ int spadot_ot_time_kernels(spadot_ot_solver *s, const spadot_ot_config *cfg, dou
             if (s->storage == SPADOT_F32) fused_pass_T<float>(s, P, flag);
             else fused_pass_T<double>(s, P, flag);
             HIP_CHECK(hipEventRecord(ev[3 * r + 1], s->stream));
-            hipLaunchKernelGGL(k_col_fin2, dim3((ld + 63) / 64), dim3(1024), 0, s->stream, s->part, s->fused_blocks, s->b, s->old_b, s->w, s->q, s->dy, s->v, P.al2, 1.0 / (P.l2 + P.eps), P.tau, J, ld, flag, s->tcol, 0);
+            if (s->storage == SPADOT_F32)
+                hipLaunchKernelGGL(k_col_fin2<float>, dim3((ld + 63) / 64), dim3(1024), 0, s->stream, (const float *)s->part, s->fused_blocks, s->b, s->old_b, s->w, s->q, s->dy, s->v, P.al2, 1.0 / (P.l2 + P.eps), P.tau, J, ld, flag, s->tcol, 0);
+            else
+                hipLaunchKernelGGL(k_col_fin2<double>, dim3((ld + 63) / 64), dim3(1024), 0, s->stream, (const double *)s->part, s->fused_blocks, s->b, s->old_b, s->w, s->q, s->dy, s->v, P.al2, 1.0 / (P.l2 + P.eps), P.tau, J, ld, flag, s->tcol, 0);
             HIP_CHECK(hipEventRecord(ev[3 * r + 2], s->stream));
         }
         HIP_CHECK(hipStreamSynchronize(s->stream));
