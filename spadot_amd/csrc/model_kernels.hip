@@ -76,6 +76,14 @@ __device__ __forceinline__ double block_sum_d(double x, double *sh) {
 
 __device__ __forceinline__ float leaky(float z, float slope) { return z > 0.f ? z : slope * z; }
 
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share one, each XCD has its own L2):
+// give every XCD a CONTIGUOUS range of nodes, so that with spatially ordered nodes the rows one XCD gathers
+// overlap and stay in its L2.  Speed only -- any placement gives the same result.  Grid = 8 * ceil(n/8).
+__device__ __forceinline__ int xcd_node(int n) {
+    const int chunk = (n + 7) >> 3;
+    return (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+}
+
 // ------------------------------------------------------------------------------------------
 // GAT forward.  NITER*64*VEC >= C; lane owns channels {(it*64 + lane)*VEC + k}.
 // ------------------------------------------------------------------------------------------
@@ -88,7 +96,8 @@ __global__ __launch_bounds__(256) void k_gat_fwd(const T *__restrict__ h, const 
                                                  int concat, int act, T *__restrict__ out,
                                                  float *__restrict__ alpha_out) {
     extern __shared__ float smem[];   // mean mode: 4 * C floats
-    const int i = blockIdx.x;
+    const int i = xcd_node(n);
+    if (i >= n) return;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int p0 = rowptr[i], deg = rowptr[i + 1] - p0;
     const size_t HC = (size_t)H * C;
@@ -200,7 +209,8 @@ __global__ __launch_bounds__(256) void k_gat_bwd_target(
     const float *__restrict__ s_src, const float *__restrict__ s_dst, const float *__restrict__ alpha,
     const int *__restrict__ rowptr, const int *__restrict__ col, int n, int H, int C, int concat, int act,
     T *__restrict__ g_pre, float *__restrict__ dz, float *__restrict__ ds_dst) {
-    const int i = blockIdx.x;
+    const int i = xcd_node(n);
+    if (i >= n) return;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int p0 = rowptr[i], deg = rowptr[i + 1] - p0;
     const size_t HC = (size_t)H * C;
@@ -278,7 +288,8 @@ __global__ __launch_bounds__(256) void k_gat_bwd_source(
     const T *__restrict__ g_pre, const float *__restrict__ alpha, const float *__restrict__ dz,
     const int *__restrict__ rowptr_t, const int *__restrict__ col_t, const int *__restrict__ eid_t, int n,
     int H, int C, T *__restrict__ dh, float *__restrict__ ds_src) {
-    const int j = blockIdx.x;
+    const int j = xcd_node(n);
+    if (j >= n) return;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int p0 = rowptr_t[j], deg = rowptr_t[j + 1] - p0;
     const size_t HC = (size_t)H * C;
@@ -694,10 +705,10 @@ int spadot_gat_forward(const void *h, int dtype, const float *s_src, const float
     hipStream_t st_ = (hipStream_t)stream;
     const size_t lds = concat ? 0 : sizeof(float) * 4 * (size_t)C;
     if (dtype == SPADOT_DT_F32)
-        GAT_DISPATCH(k_gat_fwd, float, dim3(n), dim3(256), lds, st_, (const float *)h, s_src, s_dst, rowptr, col,
+        GAT_DISPATCH(k_gat_fwd, float, dim3(8 * ((n + 7) / 8)), dim3(256), lds, st_, (const float *)h, s_src, s_dst, rowptr, col,
                      bias, n, H, C, concat, act, (float *)out, alpha_out);
     else if (dtype == SPADOT_DT_BF16)
-        GAT_DISPATCH(k_gat_fwd, __bf16, dim3(n), dim3(256), lds, st_, (const __bf16 *)h, s_src, s_dst, rowptr, col,
+        GAT_DISPATCH(k_gat_fwd, __bf16, dim3(8 * ((n + 7) / 8)), dim3(256), lds, st_, (const __bf16 *)h, s_src, s_dst, rowptr, col,
                      bias, n, H, C, concat, act, (__bf16 *)out, alpha_out);
     else
         return -22;
@@ -712,11 +723,11 @@ int spadot_gat_backward_target(const void *g_out, const void *out, const void *h
     if (n <= 0 || H <= 0 || pick_gat(C, vec, niter)) return -22;
     hipStream_t st_ = (hipStream_t)stream;
     if (dtype == SPADOT_DT_F32)
-        GAT_DISPATCH(k_gat_bwd_target, float, dim3(n), dim3(256), 0, st_, (const float *)g_out, (const float *)out,
+        GAT_DISPATCH(k_gat_bwd_target, float, dim3(8 * ((n + 7) / 8)), dim3(256), 0, st_, (const float *)g_out, (const float *)out,
                      (const float *)h, s_src, s_dst, alpha, rowptr, col, n, H, C, concat, act, (float *)g_pre, dz,
                      ds_dst);
     else if (dtype == SPADOT_DT_BF16)
-        GAT_DISPATCH(k_gat_bwd_target, __bf16, dim3(n), dim3(256), 0, st_, (const __bf16 *)g_out, (const __bf16 *)out,
+        GAT_DISPATCH(k_gat_bwd_target, __bf16, dim3(8 * ((n + 7) / 8)), dim3(256), 0, st_, (const __bf16 *)g_out, (const __bf16 *)out,
                      (const __bf16 *)h, s_src, s_dst, alpha, rowptr, col, n, H, C, concat, act, (__bf16 *)g_pre, dz,
                      ds_dst);
     else
@@ -731,10 +742,10 @@ int spadot_gat_backward_source(const void *g_pre, int dtype, const float *alpha,
     if (n <= 0 || H <= 0 || pick_gat(C, vec, niter)) return -22;
     hipStream_t st_ = (hipStream_t)stream;
     if (dtype == SPADOT_DT_F32)
-        GAT_DISPATCH(k_gat_bwd_source, float, dim3(n), dim3(256), 0, st_, (const float *)g_pre, alpha, dz, rowptr_t,
+        GAT_DISPATCH(k_gat_bwd_source, float, dim3(8 * ((n + 7) / 8)), dim3(256), 0, st_, (const float *)g_pre, alpha, dz, rowptr_t,
                      col_t, eid_t, n, H, C, (float *)dh, ds_src);
     else if (dtype == SPADOT_DT_BF16)
-        GAT_DISPATCH(k_gat_bwd_source, __bf16, dim3(n), dim3(256), 0, st_, (const __bf16 *)g_pre, alpha, dz, rowptr_t,
+        GAT_DISPATCH(k_gat_bwd_source, __bf16, dim3(8 * ((n + 7) / 8)), dim3(256), 0, st_, (const __bf16 *)g_pre, alpha, dz, rowptr_t,
                      col_t, eid_t, n, H, C, (__bf16 *)dh, ds_src);
     else
         return -22;

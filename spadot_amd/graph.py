@@ -60,10 +60,28 @@ def build_batch_graph(edge_index, n, device):
     return BatchGraph(n, *(torch.from_numpy(np.ascontiguousarray(p)).to(device) for p in parts))
 
 
-def induced_batch(edge_index, n_nodes, seeds, hops=2):
+def morton_key(coords):
+    """Z-order key of 2-D coordinates (16 bits per axis): nodes that are close in space get close keys."""
+    c = np.asarray(coords, dtype=np.float64)
+    lo, hi = c.min(axis=0), c.max(axis=0)
+    q = np.clip(((c - lo) / np.maximum(hi - lo, 1e-300) * 65535.0), 0, 65535).astype(np.uint64)
+
+    def spread(v):
+        v = (v | (v << 8)) & np.uint64(0x00FF00FF)
+        v = (v | (v << 4)) & np.uint64(0x0F0F0F0F)
+        v = (v | (v << 2)) & np.uint64(0x33333333)
+        v = (v | (v << 1)) & np.uint64(0x55555555)
+        return v
+
+    return spread(q[:, 0]) | (spread(q[:, 1]) << np.uint64(1))
+
+
+def induced_batch(edge_index, n_nodes, seeds, hops=2, order_key=None):
     """Seeds + their `hops`-hop in-neighbourhood (sources of edges pointing at the frontier), seeds
     first; edges = every original edge with both ends inside (NeighborLoader 'induced', fan-out >=
-    in-degree: SURVEY App. B).  Returns (n_id int64 [n_sub], sub_edge_index int64 [2, E_sub])."""
+    in-degree: SURVEY App. B).  Returns (n_id int64 [n_sub], sub_edge_index int64 [2, E_sub]).
+    order_key (optional, one value per node): the non-seed nodes are laid out by ascending key instead of
+    by hop and id -- the subgraph is the same up to relabelling, results on the seeds do not change."""
     ei = edge_index.cpu().numpy() if isinstance(edge_index, torch.Tensor) else np.asarray(edge_index)
     src, dst = ei[0], ei[1]
     seen = np.zeros(n_nodes, dtype=bool)
@@ -80,6 +98,9 @@ def induced_batch(edge_index, n_nodes, seeds, hops=2):
         frontier_mask = np.zeros(n_nodes, dtype=bool)
         frontier_mask[new] = True
     n_id = np.concatenate(n_id)
+    if order_key is not None:
+        rest = n_id[seeds.size:]
+        n_id = np.concatenate([seeds, rest[np.argsort(np.asarray(order_key)[rest], kind="stable")]])
     relabel = np.full(n_nodes, -1, dtype=np.int64)
     relabel[n_id] = np.arange(n_id.size)
     keep = seen[src] & seen[dst]
@@ -95,12 +116,15 @@ class Batch:
         self.batch_size = int(batch_size)
 
 
-def precompute_batches(edge_index, n_nodes, batch_size, device, hops=2):
-    """All batches of one time point in loader order (consecutive seed blocks, last one partial)."""
+def precompute_batches(edge_index, n_nodes, batch_size, device, hops=2, coords=None):
+    """All batches of one time point in loader order (consecutive seed blocks, last one partial).
+    With `coords`, the non-seed nodes of every batch are stored in Z-order of their coordinates: the
+    neighbours a GAT workgroup gathers are then close in memory and in launch order (L2 reuse per XCD)."""
+    key = morton_key(coords) if coords is not None else None
     out = []
     for s in range(0, n_nodes, batch_size):
         seeds = np.arange(s, min(n_nodes, s + batch_size))
-        n_id, sub = induced_batch(edge_index, n_nodes, seeds, hops)
+        n_id, sub = induced_batch(edge_index, n_nodes, seeds, hops, order_key=key)
         g = build_batch_graph(sub, n_id.size, device)
         out.append(Batch(torch.from_numpy(n_id).to(device), g, seeds.size))
     return out

@@ -77,7 +77,7 @@ def prepare_dataloader(adata, model_config):
         print("The graph contains %d edges, %d cells." % (ei.shape[1] - n, n))
         Y = torch.as_tensor(np.ascontiguousarray(np.asarray(X[ix]))).to(device=device, dtype=store)
         datasets[tp] = (torch.as_tensor(loc[ix, :2]).to(device), Y, ix)
-        dataloaders[tp] = precompute_batches(ei, n, model_config["batch_size"], device)
+        dataloaders[tp] = precompute_batches(ei, n, model_config["batch_size"], device, coords=spatial[ix])
         graphs[tp] = build_batch_graph(ei, n, device)
     return {"inducing_points": inducing_points_dict, "N_train": N_train_dict, "dataloaders": dataloaders,
             "datasets": datasets, "graphs": graphs}
