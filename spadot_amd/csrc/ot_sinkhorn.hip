@@ -339,9 +339,9 @@ __device__ __forceinline__ void fused_load(FusedRows<T, VPT, R> &buf, const T *_
     }
 }
 
-template <typename T, int VPT, int R>
+template <typename T, int VPT, int R, typename WT>
 __device__ __forceinline__ void fused_group(FusedRows<T, VPT, R> &buf, int row0, int row_end,
-                                            const double *wl, double *red, double *arow,
+                                            const WT *wl, double *red, double *arow,
                                             double *colacc, double *__restrict__ a,
                                             double *__restrict__ old_a, double *__restrict__ adx,
                                             const double *rowc, int band0, int band_rows, double alpha1,
@@ -356,7 +356,7 @@ __device__ __forceinline__ void fused_group(FusedRows<T, VPT, R> &buf, int row0,
         const int j = (tid + k * FUSED_THREADS) * V;
         double wv[V];
 #pragma unroll
-        for (int e = 0; e < V; e++) wv[e] = wl[j + e];     // 0 beyond ld (LDS image is padded)
+        for (int e = 0; e < V; e++) wv[e] = (double)wl[j + e];     // 0 beyond ld (LDS image is padded)
 #pragma unroll
         for (int r = 0; r < R; r++) {
             double kv[V];
@@ -410,7 +410,7 @@ __device__ __forceinline__ void fused_group(FusedRows<T, VPT, R> &buf, int row0,
     }
 }
 
-template <typename T, int VPT, int R>
+template <typename T, int VPT, int R, typename WT = double>
 __global__ __launch_bounds__(FUSED_THREADS) void k_fused_pass(
     const T *__restrict__ K, const double *__restrict__ w, double *__restrict__ a,
     double *__restrict__ old_a, double *__restrict__ adx, const double *__restrict__ p,
@@ -419,8 +419,8 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_fused_pass(
     constexpr int V = Vec<T>::N;
     extern __shared__ double smem[];
     constexpr int WPAD = VPT * FUSED_THREADS * V;    // w image padded with zeros to the register tile
-    double *wl = smem;                       // WPAD doubles
-    double *red = smem + WPAD;               // (FUSED_THREADS/64) * R
+    WT *wl = reinterpret_cast<WT *>(smem);   // WPAD entries of WT (double, or float for the widest fp32 rows)
+    double *red = smem + (WPAD * sizeof(WT) + 7) / 8;   // (FUSED_THREADS/64) * R
     double *arow = red + (FUSED_THREADS / 64) * R;   // R
     double *rowc = arow + R;                         // 4 x rows_per_block: p, dx, u, previous a
     const int tid = threadIdx.x;
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_fused_pass(
     const int r1 = min(I, r0 + rows_per_block);
     FusedRows<T, VPT, R> bufA, bufB;
     fused_load<T, VPT, R>(bufA, K, r0, r1, ld, tid);
-    for (int j = tid; j < WPAD; j += FUSED_THREADS) wl[j] = (j < ld) ? w[j] : 0.0;
+    for (int j = tid; j < WPAD; j += FUSED_THREADS) wl[j] = (j < ld) ? (WT)w[j] : (WT)0;
     for (int t = tid; t < r1 - r0; t += FUSED_THREADS) {
         rowc[t] = p[r0 + t];
         rowc[rows_per_block + t] = dx[r0 + t];
@@ -441,12 +441,12 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_fused_pass(
     __syncthreads();
     for (int g = r0; g < r1; g += 2 * R) {
         fused_load<T, VPT, R>(bufB, K, g + R, r1, ld, tid);          // rows >= r1: clamped, weight 0
-        fused_group<T, VPT, R>(bufA, g, r1, wl, red, arow, colacc, a, old_a, adx, rowc, r0, rows_per_block,
-                               alpha1, inv_l1e, tau, ld, flag);
+        fused_group<T, VPT, R, WT>(bufA, g, r1, wl, red, arow, colacc, a, old_a, adx, rowc, r0, rows_per_block,
+                                   alpha1, inv_l1e, tau, ld, flag);
         if (g + R < r1) {
             fused_load<T, VPT, R>(bufA, K, g + 2 * R, r1, ld, tid);
-            fused_group<T, VPT, R>(bufB, g + R, r1, wl, red, arow, colacc, a, old_a, adx, rowc, r0,
-                                   rows_per_block, alpha1, inv_l1e, tau, ld, flag);
+            fused_group<T, VPT, R, WT>(bufB, g + R, r1, wl, red, arow, colacc, a, old_a, adx, rowc, r0,
+                                       rows_per_block, alpha1, inv_l1e, tau, ld, flag);
         }
     }
     T *o = part + (size_t)blockIdx.x * ld;        // partials in the storage type: fp32 K => fp32 partials
@@ -1015,10 +1015,10 @@ void sum_kbar(spadot_ot_solver *s, const void *M, double eps, bool from_cost) {
 
 struct IterParams { double eps, tau, l1, l2, al1, al2; };
 
-template <typename T, int VPT, int R>
+template <typename T, int VPT, int R, typename WT = double>
 void launch_fused(spadot_ot_solver *s, const IterParams &P, int *flag) {
     static bool attr_set = false;
-    auto kern = k_fused_pass<T, VPT, R>;
+    auto kern = k_fused_pass<T, VPT, R, WT>;
     if (!attr_set) {
         HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
@@ -1034,6 +1034,9 @@ template <> void fused_pass_T<float>(spadot_ot_solver *s, const IterParams &P, i
     switch (s->fused_vpt) {
         FUSED_CASE(float, 1, 2) FUSED_CASE(float, 2, 2) FUSED_CASE(float, 3, 2) FUSED_CASE(float, 4, 2)
         FUSED_CASE(float, 5, 2) FUSED_CASE(float, 6, 1) FUSED_CASE(float, 7, 1) FUSED_CASE(float, 8, 1)
+        // wider rows (J up to 20 480, e.g. cfg5's 20k): w.dy is staged as fp32 so that it still fits LDS
+        case 9: launch_fused<float, 9, 1, float>(s, P, flag); break;
+        case 10: launch_fused<float, 10, 1, float>(s, P, flag); break;
         default: abort();
     }
 }
@@ -1221,10 +1224,11 @@ void choose_fused(spadot_ot_solver *s) {
     if (off && off[0] == '1') return;
     const int V = s->storage == SPADOT_F32 ? 4 : 2;
     const int vpt = (s->ld + V * FUSED_THREADS - 1) / (V * FUSED_THREADS);
-    const int max_vpt = s->storage == SPADOT_F32 ? 8 : 12;
+    const int max_vpt = s->storage == SPADOT_F32 ? 10 : 12;     // beyond: the register tile would spill
     if (vpt > max_vpt) return;
+    const size_t wbytes = (s->storage == SPADOT_F32 && vpt > 8) ? 4 : 8;   // fp32 w image for the widest rows
     const int R = vpt <= (s->storage == SPADOT_F32 ? 5 : 6) ? 2 : 1;     // must match the FUSED_CASE table
-    size_t lds = sizeof(double) * ((size_t)vpt * FUSED_THREADS * V + (FUSED_THREADS / 64) * R + R);
+    size_t lds = wbytes * (size_t)vpt * FUSED_THREADS * V + sizeof(double) * ((FUSED_THREADS / 64) * R + R) + 8;
     if (lds + 4096 > 160 * 1024) return;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) {

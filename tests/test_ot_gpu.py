@@ -440,3 +440,30 @@ def test_full_size_10k_pair_problem_properties(OTSolver):
         s2.close()
     finally:
         del os.environ["SPADOT_OT_NO_FUSED"]
+
+
+def test_wide_rows_cfg5_shape_fused_vs_two_sweep(OTSolver):
+    """J = 20 000 columns (cfg5: 200k spots / 10 time points): the fused pass with the fp32 w image
+    (vpt 10) against the two-sweep kernels on the same problem."""
+    import os
+    rng = np.random.default_rng(2)
+    cen = rng.normal(size=(10, 20))
+    x, y = _mixture(rng, 1500, cen), _mixture(rng, 20000, cen + 0.05)
+    cfg = dict(lambda1=0.1, lambda2=5.0, epsilon=0.05, epsilon0=1.0, tolerance=1e-8, tau=1000.0,
+               batch_size=5, max_iter=10 ** 7)
+    out = []
+    for nofused in ("0", "1"):
+        os.environ["SPADOT_OT_NO_FUSED"] = nofused
+        try:
+            s = OTSolver(1500, 20000, storage="f32")
+            assert (s.fused_geometry()["vpt"] == 10) == (nofused == "0")
+            s.set_cost_from_latents(x, y)
+            info = s.solve(cfg)
+            out.append((s.plan_rowsums(), s.vector("b"), list(info.stage_iters)))
+            s.close()
+        finally:
+            del os.environ["SPADOT_OT_NO_FUSED"]
+    (r0, b0, i0), (r1, b1, i1) = out
+    assert i0 == i1
+    np.testing.assert_allclose(r0, r1, rtol=1e-6)       # w carried as fp32 in LDS on the fused side
+    np.testing.assert_allclose(b0, b1, rtol=1e-6)
