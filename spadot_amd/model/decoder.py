@@ -1,20 +1,28 @@
-"""Decoder of the VAE: mirror of /root/reference/SpaDOT/model/decoder.py:3-20 (same module layout, hence
-the same state_dict keys decoder_net.{0,1,3,4,6}.*).  Dense linears run on MFMA through the library
-GEMM; LayerNorm/LeakyReLU are torch's device kernels."""
+"""Decoder half of the VAE: latent sample [b, z_dim] -> reconstructed expression [b, G].
+
+Same module tree as the reference's decoder (/root/reference/SpaDOT/model/decoder.py:3-20), because the
+state_dict keys are part of the drop-in surface: `decoder_net` is a Sequential whose entries 0/3/6 are the
+dense maps, 1/4 the LayerNorms, 2/5 the LeakyReLUs (hidden maps Xavier-uniform, output map default init).
+The dense maps run on MFMA through the library GEMM; LayerNorm / LeakyReLU are device element-wise kernels.
+"""
 import torch.nn as nn
+
+
+def _hidden_stage(fan_in, fan_out):
+    dense = nn.Linear(fan_in, fan_out)
+    nn.init.xavier_uniform_(dense.weight)
+    return dense, nn.LayerNorm(fan_out), nn.LeakyReLU()
 
 
 class Decoder(nn.Module):
     def __init__(self, input_dim, z_dim, decoder_layers):
         super().__init__()
-        layers = [z_dim] + list(decoder_layers) + [input_dim]
-        net = []
-        for i in range(1, len(layers) - 1):
-            lin = nn.Linear(layers[i - 1], layers[i])
-            nn.init.xavier_uniform_(lin.weight)
-            net += [lin, nn.LayerNorm(layers[i]), nn.LeakyReLU()]
-        net.append(nn.Linear(layers[-2], layers[-1]))
-        self.decoder_net = nn.Sequential(*net)
+        widths = [z_dim, *decoder_layers]
+        stages = []
+        for fan_in, fan_out in zip(widths[:-1], widths[1:]):
+            stages.extend(_hidden_stage(fan_in, fan_out))
+        stages.append(nn.Linear(widths[-1], input_dim))
+        self.decoder_net = nn.Sequential(*stages)
 
     def forward(self, latent_sample):
         return self.decoder_net(latent_sample)
