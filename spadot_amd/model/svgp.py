@@ -82,25 +82,47 @@ class SVGP(nn.Module):
         return bc
 
     # ---- batched path --------------------------------------------------------------------
-    def _sigma_inv(self, bc, W):
+    def _sigma_inv(self, bc, W, want_logdet_A=False):
+        """Sigma_l'^-1 = (K_mm + c K_mn diag(w_l) K_nm + jI)^-1 for all latent dims  [L, m, m].
+        With want_logdet_A it also returns log|A_hat_l + jI| (svgp.py:88,90) WITHOUT a second, dependent
+        factorisation: by Sylvester's identity
+            |K S K + jI| = j^m |S| |S^-1 + K K / j|,      S = Sigma_l'^-1,  K = K_mm,
+        so  log|A_hat + jI| = m log j - log|Sigma_l'| + log|Sigma_l' + K_mm^2 / j|,
+        and the two log-determinants are of INDEPENDENT matrices: one sweep launch over 2L matrices gives
+        both (the chain Sigma^-1 -> A_hat -> second factorisation was the critical path of the step)."""
         K_mm, _, _, eye = self._run_constants()
         A = bc.K_nm.unsqueeze(0) * W.T.unsqueeze(2)                        # [L, b, m] = diag(w_l) K_nm
-        sigma = K_mm.unsqueeze(0) + bc.c * torch.matmul(A.transpose(1, 2), bc.K_nm)   # batched m x b x m GEMM
-        return spd_inverse_logdet(sigma + self.jitter * eye, need_logdet=False)[0]     # [L, m, m]
+        sigma = K_mm.unsqueeze(0) + bc.c * torch.matmul(A.transpose(1, 2), bc.K_nm) + self.jitter * eye
+        if not want_logdet_A:
+            return spd_inverse_logdet(sigma, need_logdet=False)[0]
+        L, m = sigma.shape[0], sigma.shape[1]
+        X, ld = spd_inverse_logdet(torch.cat([sigma, sigma + self._k2_over_j()], dim=0))
+        logdet_A = m * float(torch.log(torch.tensor(self.jitter, dtype=F64))) - ld[:L] + ld[L:]
+        return X[:L], logdet_A
 
-    def posterior(self, bc_train, mu, var, bc_test=None):
+    def _k2_over_j(self):
+        if getattr(self, "_k2j", None) is None:
+            K_mm = self._run_constants()[0]
+            self._k2j = ((K_mm @ K_mm) / self.jitter).unsqueeze(0)
+        return self._k2j
+
+    def posterior(self, bc_train, mu, var, bc_test=None, want_logdet_A=False):
         """Posterior mean and variance at the test points for all latent dims at once.
         mu, var: [b, L] (encoder output at the training points).  Returns (p_m, p_v, extras)."""
         mu, var = mu.to(F64), var.to(F64)
         bt = bc_train if bc_test is None else bc_test
         W = 1.0 / var
-        S_inv = self._sigma_inv(bc_train, W)
+        logdet_A = None
+        if want_logdet_A:
+            S_inv, logdet_A = self._sigma_inv(bc_train, W, True)
+        else:
+            S_inv = self._sigma_inv(bc_train, W)
         t = torch.einsum("bm,bl->lm", bc_train.K_nm, mu * W)              # K_mn (y / noise)
         St = torch.einsum("lmn,ln->lm", S_inv, t)
         p_m = bc_train.c * (bt.K_nm @ St.T)                                # [b_test, L]
         KS = torch.einsum("bm,lmn->lbn", bt.K_nm, S_inv)                  # [L, b_test, m]
         p_v = bt.ktilde.unsqueeze(1) + rowdot(KS, bt.K_nm).T
-        return p_m, p_v, (S_inv, St)
+        return p_m, p_v, (S_inv, St, logdet_A)
 
     def elbo_terms(self, bc, mu, var):
         """(p_m, p_v, l3_sum, kl_sum, ce_sum) of one training batch: svgp.py:47-104 over all latent
@@ -108,12 +130,11 @@ class SVGP(nn.Module):
         mu, var = mu.to(F64), var.to(F64)
         K_mm, K_inv, logdet_K, eye = self._run_constants()
         m = K_mm.shape[0]
-        p_m, p_v, (S_inv, St) = self.posterior(bc, mu, var)
+        p_m, p_v, (S_inv, St, logdet_S) = self.posterior(bc, mu, var, want_logdet_A=True)
         mu_hat = bc.c * (St @ K_mm)                                        # [L, m]  (K_mm symmetric)
         A_hat = K_mm.unsqueeze(0) @ S_inv @ K_mm.unsqueeze(0)              # [L, m, m]
         mv = bc.Q @ mu_hat.T                                               # K_nm K^-1 mu_hat  [b, L]
         tr = rowdot(torch.einsum("bm,lmn->lbn", bc.P, S_inv), bc.P).T      # [b, L]
-        logdet_S = spd_inverse_logdet(A_hat + self.jitter * eye)[1]       # log|A_hat + jI| (svgp.py:88,90)
         kl = 0.5 * (logdet_K - logdet_S - m + (A_hat * K_inv.T.unsqueeze(0)).sum(dim=(1, 2))
                     + ((mu_hat @ K_inv) * mu_hat).sum(dim=1))
         l3_sum, ce_sum = elbo_reduce(mu, var, mv, tr, p_m, p_v, bc.ktilde)
@@ -130,7 +151,7 @@ class SVGP(nn.Module):
         same = index_points_test is index_points_train
         bc_te = bc_tr if same else self.batch_constants(index_points_test)
         K_mm = self._run_constants()[0]
-        p_m, p_v, (S_inv, St) = self.posterior(bc_tr, y.reshape(-1, 1), noise.reshape(-1, 1), None if same else bc_te)
+        p_m, p_v, (S_inv, St, _) = self.posterior(bc_tr, y.reshape(-1, 1), noise.reshape(-1, 1), None if same else bc_te)
         mu_hat = bc_tr.c * (St @ K_mm)[0]
         A_hat = K_mm @ S_inv[0] @ K_mm
         return p_m[:, 0], p_v[:, 0], mu_hat, A_hat
