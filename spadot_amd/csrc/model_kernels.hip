@@ -379,9 +379,9 @@ __global__ __launch_bounds__(256) void k_kernel_matrix(const T *__restrict__ x, 
 constexpr int SWEEP_NT = 512;
 constexpr int SWEEP_RS = 7;
 
-template <int TS>
+template <int TS, int RSMAX>
 struct SweepTile {
-    static constexpr int RS = TS < SWEEP_RS ? TS : SWEEP_RS;
+    static constexpr int RS = TS < RSMAX ? TS : RSMAX;
     double a[RS][RS];
     double *bord;     // LDS strip of this thread: element slot s lives at bord[s * SWEEP_NT]
     // border slot of (r, c): row-major rank among the entries with r >= RS or c >= RS
@@ -398,7 +398,7 @@ struct SweepTile {
     }
 };
 
-template <int TS>
+template <int TS, int RSMAX = SWEEP_RS>
 __global__ __launch_bounds__(SWEEP_NT) void k_spd_sweep(const double *__restrict__ A, int m, int T,
                                                         double *__restrict__ Ainv,
                                                         double *__restrict__ logdet) {
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(SWEEP_NT) void k_spd_sweep(const double *__restrict
     while (ti * (ti + 1) / 2 > t) ti--;
     const int tj = t - ti * (ti + 1) / 2;
     const bool live = t < ntiles;
-    SweepTile<TS> tile;
+    SweepTile<TS, RSMAX> tile;
     tile.bord = piv + m + 16 + t;
 #pragma unroll
     for (int r = 0; r < TS; r++) {
@@ -777,7 +777,7 @@ int spadot_spd_inverse_logdet(const double *A, int L, int m, double *Ainv, doubl
     const int TS = (m + 30) / 31;
     if (TS > 9) return -34;                       // m > 279: the caller uses the library's batched Cholesky
     const int T = (m + TS - 1) / TS;
-    const int RS = TS < SWEEP_RS ? TS : SWEEP_RS;
+    const int RS = TS == 9 ? 8 : (TS == 8 ? 7 : TS);   // register core per tile edge (must match the cases below)
     const size_t lds = sizeof(double) * (2 * (size_t)T * TS + (size_t)m + 16 + (size_t)(TS * TS - RS * RS) * SWEEP_NT);
 #define SWEEP_CASE(N)                                                                                         \
     case N: {                                                                                                 \
@@ -787,7 +787,16 @@ int spadot_spd_inverse_logdet(const double *A, int L, int m, double *Ainv, doubl
     } break;
     switch (TS) {
         SWEEP_CASE(1) SWEEP_CASE(2) SWEEP_CASE(3) SWEEP_CASE(4) SWEEP_CASE(5) SWEEP_CASE(6) SWEEP_CASE(7)
-        SWEEP_CASE(8) SWEEP_CASE(9)
+        case 8: {
+            static bool attr_set = false;
+            if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_spd_sweep<8, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+            hipLaunchKernelGGL((k_spd_sweep<8, 7>), dim3(L), dim3(SWEEP_NT), lds, st_, A, m, T, Ainv, logdet);
+        } break;
+        case 9: {
+            static bool attr_set = false;
+            if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_spd_sweep<9, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+            hipLaunchKernelGGL((k_spd_sweep<9, 8>), dim3(L), dim3(SWEEP_NT), lds, st_, A, m, T, Ainv, logdet);
+        } break;
         default: return -34;
     }
 #undef SWEEP_CASE

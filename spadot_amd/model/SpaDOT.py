@@ -27,13 +27,14 @@ class SpaDOT(nn.Module):
         self.device = torch.device(model_config["device"])
 
         self.SVGPEncoder = SVGPEncoder(input_dim=self.input_dim, SVGP_z_dim=self.SVGP_z_dim,
-                                       hidden_dims=model_config["svgp_encoder_layers"])
+                                       hidden_dims=model_config["svgp_encoder_layers"],
+                                       compute_dtype=self.compute_dtype)
         self.GATEncoder = GATEncoder(input_dim=self.input_dim, GAT_z_dim=self.GAT_z_dim,
                                      hidden_dim=model_config["gat_encoder_hidden"],
                                      num_heads=model_config["gat_attention_heads"],
                                      compute_dtype=self.compute_dtype)
         self.decoder = Decoder(input_dim=self.input_dim, z_dim=self.SVGP_z_dim + self.GAT_z_dim,
-                               decoder_layers=model_config["decoder_layers"])
+                               decoder_layers=model_config["decoder_layers"], compute_dtype=self.compute_dtype)
         self.svgp_dict = nn.ModuleDict({
             str(tp): SVGP(model_config=model_config, inducing_points=dataloader_dict["inducing_points"][tp],
                           N_train=dataloader_dict["N_train"][tp])
@@ -60,7 +61,7 @@ class SpaDOT(nn.Module):
         side = self._side_stream()
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            q_mu, q_var = self.SVGPEncoder(yb.float())
+            q_mu, q_var = self.SVGPEncoder(yb)
             bc = svgp.batch_constants(x[:b], key=batch_key)
             p_m, p_v, l3_sum, kl_sum, ce = svgp.elbo_terms(bc, q_mu, q_var)
             inside_elbo = l3_sum - (b / float(svgp.N_train)) * kl_sum
@@ -98,7 +99,7 @@ class SpaDOT(nn.Module):
         if not isinstance(edge_index, BatchGraph):
             edge_index = torch.as_tensor(edge_index)
         svgp = self.svgp_dict[str(tp)]
-        q_mu, q_var = self.SVGPEncoder(Y.float())
+        q_mu, q_var = self.SVGPEncoder(Y)
         bc = svgp.batch_constants(X, key=("all", str(tp)))
         p_m, _, _ = svgp.posterior(bc, q_mu, q_var)
         g_mu, _ = self.GATEncoder(Y, edge_index)

@@ -5,7 +5,9 @@ state_dict keys are part of the drop-in surface: `decoder_net` is a Sequential w
 dense maps, 1/4 the LayerNorms, 2/5 the LeakyReLUs (hidden maps Xavier-uniform, output map default init).
 The dense maps run on MFMA through the library GEMM; LayerNorm / LeakyReLU are device element-wise kernels.
 """
+import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 
 def _hidden_stage(fan_in, fan_out):
@@ -15,8 +17,9 @@ def _hidden_stage(fan_in, fan_out):
 
 
 class Decoder(nn.Module):
-    def __init__(self, input_dim, z_dim, decoder_layers):
+    def __init__(self, input_dim, z_dim, decoder_layers, compute_dtype=torch.float32):
         super().__init__()
+        self.compute_dtype = compute_dtype
         widths = [z_dim, *decoder_layers]
         stages = []
         for fan_in, fan_out in zip(widths[:-1], widths[1:]):
@@ -25,4 +28,12 @@ class Decoder(nn.Module):
         self.decoder_net = nn.Sequential(*stages)
 
     def forward(self, latent_sample):
-        return self.decoder_net(latent_sample)
+        if self.compute_dtype == torch.float32:
+            return self.decoder_net(latent_sample)
+        # hidden -> G is the only large GEMM here: compute dtype on MFMA (fp32 accumulate), fp32 result
+        stages = list(self.decoder_net)
+        h = latent_sample
+        for layer in stages[:-1]:
+            h = layer(h)
+        last, cd = stages[-1], self.compute_dtype
+        return F.linear(h.to(cd), last.weight.to(cd), last.bias.to(cd)).float()

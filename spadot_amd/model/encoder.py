@@ -17,8 +17,9 @@ from ..ops import BatchGraph, gat_edge
 class SVGPEncoder(nn.Module):
     """encoder.py:7-34: [Linear, BatchNorm1d, LeakyReLU] per hidden size, then Linear -> (mu, var)."""
 
-    def __init__(self, input_dim, SVGP_z_dim, hidden_dims):
+    def __init__(self, input_dim, SVGP_z_dim, hidden_dims, compute_dtype=torch.float32):
         super().__init__()
+        self.compute_dtype = compute_dtype
         layers = [input_dim] + list(hidden_dims)
         net = []
         for i in range(1, len(layers)):
@@ -30,7 +31,16 @@ class SVGPEncoder(nn.Module):
         nn.init.xavier_uniform_(self.SVGP_fc.weight)
 
     def forward(self, x):
-        h = self.SVGP_encoder_net(x)
+        if self.compute_dtype == torch.float32:
+            h = self.SVGP_encoder_net(x.float())
+        else:
+            # the G -> hidden map is the only large GEMM of this branch: run it in the compute dtype on MFMA
+            # (fp32 accumulate), everything after it (BatchNorm statistics onwards) stays fp32
+            first = self.SVGP_encoder_net[0]
+            cd = self.compute_dtype
+            h = F.linear(x.to(cd), first.weight.to(cd), first.bias.to(cd)).float()
+            for layer in list(self.SVGP_encoder_net)[1:]:
+                h = layer(h)
         mu, logvar = torch.chunk(self.SVGP_fc(h), 2, dim=1)
         return mu, torch.exp(logvar)
 

@@ -247,9 +247,8 @@ def test_composite_forward_bf16_compute(ops):
     graph = _graph(g["sub_edge_index"], n_id.numel())
     noise = (T(g["noise_svgp"]).to(DEV), T(g["noise_gat"], torch.float32).to(DEV))
     recon, skl, gkl, align, z = m.forward(xb, yb, graph, 0, b, noise=noise)
-    # bf16 storage in the GAT branch: latents rtol 2e-2; the SVGP half is untouched
-    np.testing.assert_allclose(z.detach().cpu().numpy()[:, :10], g["final_latent"][:, :10], rtol=1e-4, atol=1e-5)
-    np.testing.assert_allclose(z.detach().cpu().numpy()[:, 10:], g["final_latent"][:, 10:], rtol=2e-2, atol=2e-2)
+    # bf16 compute in the GAT branch and in the two G-sized dense maps: latents rtol 2e-2
+    np.testing.assert_allclose(z.detach().cpu().numpy(), g["final_latent"], rtol=2e-2, atol=2e-2)
     assert float(recon) == pytest.approx(float(g["recon"]), rel=2e-2)
 
 
