@@ -62,7 +62,21 @@ int spadot_gat_backward_target(const void *g_out, const void *out, const void *h
  */
 int spadot_gat_backward_source(const void *g_pre, int dtype, const float *alpha, const float *dz,
                                const int *rowptr_t, const int *col_t, const int *eid_t, int n, int H,
-                               int C, void *dh, float *ds_src, void *stream);
+                               int C, void *dh, float *ds_src, const float *ds_dst, const float *att_src,
+                               const float *att_dst, void *stream);
+/*   If att_src / att_dst ([H, C] fp32) are given (not NULL), the logits were produced by spadot_gat_logits
+ *   and their gradient is folded into dh in the same pass:
+ *       dh[j,h,c] += ds_src[j,h] att_src[h,c] + ds_dst[j,h] att_dst[h,c]        (ds_dst from the target half). */
+
+/* Attention logits from h: s_src[j,h] = sum_c h[j,h,c] att_src[h,c], s_dst[j,h] likewise (h read once). */
+int spadot_gat_logits(const void *h, int dtype, const float *att_src, const float *att_dst, int n, int H,
+                      int C, float *s_src, float *s_dst, void *stream);
+/* Gradient of the attention vectors: datt_src[h,c] = sum_j ds_src[j,h] h[j,h,c] (datt_dst with ds_dst).
+ * datt_src and datt_dst must be the two halves of ONE [2, H*C] fp32 buffer (datt_dst == datt_src + H*C);
+ * scratch: fp32 work space of scratch_floats >= 2*H*C entries (more = more parallel slabs). */
+int spadot_gat_att_grad(const void *h, int dtype, const float *ds_src, const float *ds_dst, int n, int H,
+                        int C, float *scratch, int scratch_floats, float *datt_src, float *datt_dst,
+                        void *stream);
 
 /* ---------------------------------------------------------------- SVGP pieces */
 

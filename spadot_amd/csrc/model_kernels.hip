@@ -200,6 +200,87 @@ __global__ __launch_bounds__(256) void k_gat_fwd(const T *__restrict__ h, const 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Attention logits straight from h: s_src[j,h] = sum_c h[j,h,c] att_src[h,c], s_dst likewise.
+// One wave per (node, head); h is read once (coalesced), the two attention vectors stay in L2.
+// ------------------------------------------------------------------------------------------
+template <typename T, int VEC, int NITER>
+__global__ __launch_bounds__(256) void k_gat_logits(const T *__restrict__ h, const float *__restrict__ att_src,
+                                                    const float *__restrict__ att_dst, int n, int H, int C,
+                                                    float *__restrict__ s_src, float *__restrict__ s_dst) {
+    const int j = xcd_node(n);
+    if (j >= n) return;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int hd = wid; hd < H; hd += 4) {
+        const T *row = h + (size_t)j * H * C + (size_t)hd * C;
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int it = 0; it < NITER; it++) {
+            const int c = (it * WAVE + lane) * VEC;
+            if (c < C) {
+                float v[VEC];
+                ldv<T, VEC>(row + c, v);
+#pragma unroll
+                for (int k = 0; k < VEC; k++) {
+                    a = fmaf(v[k], att_src[(size_t)hd * C + c + k], a);
+                    b = fmaf(v[k], att_dst[(size_t)hd * C + c + k], b);
+                }
+            }
+        }
+        a = wave_sum_f(a); b = wave_sum_f(b);
+        if (lane == 0) { s_src[(size_t)j * H + hd] = a; s_dst[(size_t)j * H + hd] = b; }
+    }
+}
+
+// d(att_src)[h,c] = sum_j ds_src[j,h] h[j,h,c] (and dst): block partials over a slab of nodes, then
+// k_colsum_parts adds the slabs in order (deterministic).  part: [nslab][2][H*C] fp32.
+template <typename T, int VEC, int NITER>
+__global__ __launch_bounds__(256) void k_gat_datt_part(const T *__restrict__ h, const float *__restrict__ ds_src,
+                                                       const float *__restrict__ ds_dst, int n, int H, int C,
+                                                       int nodes_per_slab, float *__restrict__ part) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int j0 = blockIdx.x * nodes_per_slab, j1 = min(n, j0 + nodes_per_slab);
+    const size_t HC = (size_t)H * C;
+    for (int hd = wid; hd < H; hd += 4) {
+        float as[NITER][VEC], ad[NITER][VEC];
+#pragma unroll
+        for (int it = 0; it < NITER; it++)
+#pragma unroll
+            for (int k = 0; k < VEC; k++) { as[it][k] = 0.f; ad[it][k] = 0.f; }
+        for (int j = j0; j < j1; j++) {
+            const float ws = ds_src[(size_t)j * H + hd], wd = ds_dst[(size_t)j * H + hd];
+            const T *row = h + (size_t)j * HC + (size_t)hd * C;
+#pragma unroll
+            for (int it = 0; it < NITER; it++) {
+                const int c = (it * WAVE + lane) * VEC;
+                if (c < C) {
+                    float v[VEC];
+                    ldv<T, VEC>(row + c, v);
+#pragma unroll
+                    for (int k = 0; k < VEC; k++) { as[it][k] = fmaf(ws, v[k], as[it][k]); ad[it][k] = fmaf(wd, v[k], ad[it][k]); }
+                }
+            }
+        }
+        float *ps = part + (size_t)blockIdx.x * 2 * HC + (size_t)hd * C;
+#pragma unroll
+        for (int it = 0; it < NITER; it++) {
+            const int c = (it * WAVE + lane) * VEC;
+            if (c < C)
+#pragma unroll
+                for (int k = 0; k < VEC; k++) { ps[c + k] = as[it][k]; ps[HC + c + k] = ad[it][k]; }
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_colsum_parts(const float *__restrict__ part, int nslab, int width,
+                                                      float *__restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= width) return;
+    float acc = 0.f;
+    for (int s = 0; s < nslab; s++) acc += part[(size_t)s * width + c];
+    out[c] = acc;
+}
+
 // ------------------------------------------------------------------------------------------
 // GAT backward, target side: g_pre, dz (per edge, per head), ds_dst.
 // ------------------------------------------------------------------------------------------
@@ -287,7 +368,8 @@ template <typename T, int VEC, int NITER>
 __global__ __launch_bounds__(256) void k_gat_bwd_source(
     const T *__restrict__ g_pre, const float *__restrict__ alpha, const float *__restrict__ dz,
     const int *__restrict__ rowptr_t, const int *__restrict__ col_t, const int *__restrict__ eid_t, int n,
-    int H, int C, T *__restrict__ dh, float *__restrict__ ds_src) {
+    int H, int C, T *__restrict__ dh, float *__restrict__ ds_src, const float *__restrict__ ds_dst,
+    const float *__restrict__ att_src, const float *__restrict__ att_dst) {
     const int j = xcd_node(n);
     if (j >= n) return;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -328,13 +410,22 @@ __global__ __launch_bounds__(256) void k_gat_bwd_source(
                 }
             }
         }
+        sds = wave_sum_f(sds);
+        if (lane == 0) ds_src[(size_t)j * H + hd] = sds;
+        // logits were s = h . att (k_gat_logits): their gradient reaches h here, no extra pass over dh
+        const float gsd = att_src ? ds_dst[(size_t)j * H + hd] : 0.f;
 #pragma unroll
         for (int it = 0; it < NITER; it++) {
             const int c = (it * WAVE + lane) * VEC;
-            if (c < C) stv<T, VEC>(dh + (size_t)j * HC + (size_t)hd * C + c, acc[it]);
+            if (c < C) {
+                if (att_src) {
+#pragma unroll
+                    for (int k = 0; k < VEC; k++)
+                        acc[it][k] += sds * att_src[(size_t)hd * C + c + k] + gsd * att_dst[(size_t)hd * C + c + k];
+                }
+                stv<T, VEC>(dh + (size_t)j * HC + (size_t)hd * C + c, acc[it]);
+            }
         }
-        sds = wave_sum_f(sds);
-        if (lane == 0) ds_src[(size_t)j * H + hd] = sds;
     }
 }
 
@@ -735,18 +826,56 @@ int spadot_gat_backward_target(const void *g_out, const void *out, const void *h
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
+int spadot_gat_logits(const void *h, int dtype, const float *att_src, const float *att_dst, int n, int H, int C,
+                      float *s_src, float *s_dst, void *stream) {
+    int vec, niter;
+    if (n <= 0 || H <= 0 || pick_gat(C, vec, niter)) return -22;
+    hipStream_t st_ = (hipStream_t)stream;
+    if (dtype == SPADOT_DT_F32)
+        GAT_DISPATCH(k_gat_logits, float, dim3(8 * ((n + 7) / 8)), dim3(256), 0, st_, (const float *)h, att_src, att_dst, n, H, C, s_src, s_dst);
+    else if (dtype == SPADOT_DT_BF16)
+        GAT_DISPATCH(k_gat_logits, __bf16, dim3(8 * ((n + 7) / 8)), dim3(256), 0, st_, (const __bf16 *)h, att_src, att_dst, n, H, C, s_src, s_dst);
+    else
+        return -22;
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+int spadot_gat_att_grad(const void *h, int dtype, const float *ds_src, const float *ds_dst, int n, int H, int C,
+                        float *scratch, int scratch_floats, float *datt_src, float *datt_dst, void *stream) {
+    int vec, niter;
+    if (n <= 0 || H <= 0 || pick_gat(C, vec, niter) || !scratch) return -22;
+    hipStream_t st_ = (hipStream_t)stream;
+    const int width = 2 * H * C;
+    int nslab = (n + 63) / 64;
+    if ((long long)nslab * width > scratch_floats) nslab = scratch_floats / width;
+    if (nslab < 1) return -22;
+    const int per = (n + nslab - 1) / nslab;
+    nslab = (n + per - 1) / per;
+    if (dtype == SPADOT_DT_F32)
+        GAT_DISPATCH(k_gat_datt_part, float, dim3(nslab), dim3(256), 0, st_, (const float *)h, ds_src, ds_dst, n, H, C, per, scratch);
+    else if (dtype == SPADOT_DT_BF16)
+        GAT_DISPATCH(k_gat_datt_part, __bf16, dim3(nslab), dim3(256), 0, st_, (const __bf16 *)h, ds_src, ds_dst, n, H, C, per, scratch);
+    else
+        return -22;
+    // scratch rows are [slab][src H*C | dst H*C]: one column sum writes both outputs (they are adjacent)
+    hipLaunchKernelGGL(k_colsum_parts, dim3((width + 255) / 256), dim3(256), 0, st_, scratch, nslab, width, datt_src);
+    (void)datt_dst;
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
 int spadot_gat_backward_source(const void *g_pre, int dtype, const float *alpha, const float *dz,
                                const int *rowptr_t, const int *col_t, const int *eid_t, int n, int H, int C,
-                               void *dh, float *ds_src, void *stream) {
+                               void *dh, float *ds_src, const float *ds_dst, const float *att_src,
+                               const float *att_dst, void *stream) {
     int vec, niter;
     if (n <= 0 || H <= 0 || pick_gat(C, vec, niter)) return -22;
     hipStream_t st_ = (hipStream_t)stream;
     if (dtype == SPADOT_DT_F32)
         GAT_DISPATCH(k_gat_bwd_source, float, dim3(8 * ((n + 7) / 8)), dim3(256), 0, st_, (const float *)g_pre, alpha, dz, rowptr_t,
-                     col_t, eid_t, n, H, C, (float *)dh, ds_src);
+                     col_t, eid_t, n, H, C, (float *)dh, ds_src, ds_dst, att_src, att_dst);
     else if (dtype == SPADOT_DT_BF16)
         GAT_DISPATCH(k_gat_bwd_source, __bf16, dim3(8 * ((n + 7) / 8)), dim3(256), 0, st_, (const __bf16 *)g_pre, alpha, dz, rowptr_t,
-                     col_t, eid_t, n, H, C, (__bf16 *)dh, ds_src);
+                     col_t, eid_t, n, H, C, (__bf16 *)dh, ds_src, ds_dst, att_src, att_dst);
     else
         return -22;
     return hipGetLastError() == hipSuccess ? 0 : -5;

@@ -2,9 +2,9 @@
 arguments and state_dict keys).
 
 GATConv here is this package's own layer (torch_geometric is not a dependency): the dense map
-x -> h = x W^T and the attention logits are library GEMMs on MFMA; the edge phase (scatter-softmax
-over incoming edges + weighted scatter-add, bias, activation, head concat/mean) is ONE hand-written
-HIP kernel forward and two backward (spadot_amd.ops.gat_edge).
+x -> h = x W^T is a library GEMM on MFMA; everything after it -- attention logits h . att, scatter-softmax
+over incoming edges, weighted scatter-add, bias, activation, head concat/mean -- is hand-written HIP
+(spadot_amd.ops.gat_edge: two launches forward, four backward, no atomics).
 """
 import torch
 import torch.nn as nn
@@ -72,15 +72,8 @@ class GATConv(nn.Module):
         if not isinstance(graph, BatchGraph):
             graph = build_batch_graph(graph, x.shape[0], x.device)
         cd = self.compute_dtype
-        W = self.lin.weight
-        xc = x.to(cd)
-        h = F.linear(xc, W.to(cd))                                   # [n, H*C]  (MFMA GEMM)
-        # logits without re-reading h: s = h.att = x (W_h^T att_h)    [n, H] each
-        Wh = W.view(H, C, self.in_channels)
-        w_att = torch.cat([torch.einsum("hci,hc->hi", Wh, self.att_src[0]),
-                           torch.einsum("hci,hc->hi", Wh, self.att_dst[0])], dim=0)      # [2H, in]
-        s = F.linear(xc, w_att.to(cd)).float()
-        return gat_edge(h, s[:, :H], s[:, H:], self.bias, graph, H, C, self.concat, act)
+        h = F.linear(x.to(cd), self.lin.weight.to(cd))              # [n, H*C]  (MFMA GEMM)
+        return gat_edge(h, self.att_src, self.att_dst, self.bias, graph, H, C, self.concat, act)
 
 
 class GATEncoder(nn.Module):

@@ -53,31 +53,51 @@ class BatchGraph:
 
 # ----------------------------------------------------------------------------- GAT edge phase
 
+_gat_scratch = {}
+
+
+def _gat_att_scratch(device, floats):
+    key = str(device)
+    cur = _gat_scratch.get(key)
+    if cur is None or cur.numel() < floats:
+        cur = torch.empty(floats, dtype=torch.float32, device=device)
+        _gat_scratch[key] = cur
+    return cur
+
+
 class _GATEdge(torch.autograd.Function):
+    """One GATConv layer after its dense map: logits s = h . att (k_gat_logits), scatter-softmax over incoming
+    edges + weighted scatter-add + bias + activation + head concat/mean (k_gat_fwd); backward in three
+    launches + a reduction for the attention vectors."""
+
     @staticmethod
-    def forward(ctx, h, s_src, s_dst, bias, graph, H, C, concat, act):
-        _need_cuda(h, s_src, s_dst, bias)
+    def forward(ctx, h, att_src, att_dst, bias, graph, H, C, concat, act):
+        _need_cuda(h, att_src, att_dst, bias)
         lib = model_lib()
         h = h.contiguous()
-        s_src = s_src.contiguous().float()
-        s_dst = s_dst.contiguous().float()
+        a_s = att_src.reshape(H, C).contiguous().float()
+        a_d = att_dst.reshape(H, C).contiguous().float()
         bias_f = bias.contiguous().float()
         n = graph.n
         assert h.shape == (n, H * C), (h.shape, n, H, C)
+        s_src = torch.empty((n, H), dtype=torch.float32, device=h.device)
+        s_dst = torch.empty((n, H), dtype=torch.float32, device=h.device)
+        _check(lib.spadot_gat_logits(_p(h), _DT[h.dtype], _p(a_s), _p(a_d), n, H, C, _p(s_src), _p(s_dst), _stream()),
+               "spadot_gat_logits")
         out = torch.empty((n, H * C if concat else C), dtype=h.dtype, device=h.device)
         alpha = torch.empty((graph.E, H), dtype=torch.float32, device=h.device)
         _check(lib.spadot_gat_forward(_p(h), _DT[h.dtype], _p(s_src), _p(s_dst), _p(graph.rowptr), _p(graph.col),
                                       _p(bias_f), n, H, C, int(concat), int(act), _p(out), _p(alpha), _stream()),
                "spadot_gat_forward")
-        ctx.save_for_backward(h, s_src, s_dst, out, alpha)
+        ctx.save_for_backward(h, s_src, s_dst, out, alpha, a_s, a_d)
         ctx.graph, ctx.H, ctx.C, ctx.concat, ctx.act = graph, H, C, concat, act
-        ctx.bias_dtype = bias.dtype
+        ctx.bias_dtype, ctx.att_shape, ctx.att_dtype = bias.dtype, att_src.shape, att_src.dtype
         return out
 
     @staticmethod
     def backward(ctx, g_out):
         lib = model_lib()
-        h, s_src, s_dst, out, alpha = ctx.saved_tensors
+        h, s_src, s_dst, out, alpha, a_s, a_d = ctx.saved_tensors
         graph, H, C = ctx.graph, ctx.H, ctx.C
         n = graph.n
         g_out = g_out.contiguous().to(h.dtype)
@@ -90,16 +110,24 @@ class _GATEdge(torch.autograd.Function):
         dh = torch.empty_like(h)
         ds_src = torch.empty((n, H), dtype=torch.float32, device=h.device)
         _check(lib.spadot_gat_backward_source(_p(g_pre), _DT[h.dtype], _p(alpha), _p(dz), _p(graph.rowptr_t),
-                                              _p(graph.col_t), _p(graph.eid_t), n, H, C, _p(dh), _p(ds_src), _stream()),
-               "spadot_gat_backward_source")
+                                              _p(graph.col_t), _p(graph.eid_t), n, H, C, _p(dh), _p(ds_src),
+                                              _p(ds_dst), _p(a_s), _p(a_d), _stream()), "spadot_gat_backward_source")
+        datt = torch.empty((2, H * C), dtype=torch.float32, device=h.device)
+        floats = 2 * H * C * max(1, min((n + 63) // 64, 512))
+        scratch = _gat_att_scratch(h.device, floats)
+        _check(lib.spadot_gat_att_grad(_p(h), _DT[h.dtype], _p(ds_src), _p(ds_dst), n, H, C, _p(scratch), floats,
+                                       _p(datt), ctypes.c_void_p(datt.data_ptr() + 4 * H * C), _stream()),
+               "spadot_gat_att_grad")
         gp = g_pre.float()
         dbias = gp.sum(dim=0) if ctx.concat else gp.view(n, H, C).sum(dim=(0, 1))
-        return dh, ds_src, ds_dst, dbias.to(ctx.bias_dtype), None, None, None, None, None
+        return (dh, datt[0].view(ctx.att_shape).to(ctx.att_dtype), datt[1].view(ctx.att_shape).to(ctx.att_dtype),
+                dbias.to(ctx.bias_dtype), None, None, None, None, None)
 
 
-def gat_edge(h, s_src, s_dst, bias, graph, heads, channels, concat=True, act=False):
-    """Edge phase of one GATConv layer (+ bias, optional leaky_relu(0.01), head concat/mean)."""
-    return _GATEdge.apply(h, s_src, s_dst, bias, graph, heads, channels, concat, act)
+def gat_edge(h, att_src, att_dst, bias, graph, heads, channels, concat=True, act=False):
+    """Everything of one GATConv layer after the dense map h = x W^T: attention logits, edge softmax,
+    aggregation, bias, optional leaky_relu(0.01), head concat/mean.  att_src / att_dst: [1, H, C] parameters."""
+    return _GATEdge.apply(h, att_src, att_dst, bias, graph, heads, channels, concat, act)
 
 
 # ----------------------------------------------------------------------------- SVGP pieces

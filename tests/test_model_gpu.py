@@ -61,10 +61,7 @@ def test_gat_edge_forward_backward_vs_oracle(ops, H, C, concat, act):
     g = _graph(ei, n)
     xd, Wd, asd, add_, bd = (t.to(DEV, torch.float32).requires_grad_(True) for t in (x, W, a_s, a_d, bias))
     h = xd @ Wd.T
-    Wh = Wd.view(H, C, fin)
-    s_src = xd @ torch.einsum("hci,hc->hi", Wh, asd[0]).T
-    s_dst = xd @ torch.einsum("hci,hc->hi", Wh, add_[0]).T
-    out_d = ops.gat_edge(h, s_src, s_dst, bd, g, H, C, concat, act)
+    out_d = ops.gat_edge(h, asd, add_, bd, g, H, C, concat, act)
     (out_d * gsel.to(DEV, torch.float32)).sum().backward()
     np.testing.assert_allclose(out_d.detach().cpu().numpy(), out_o.detach().numpy(), rtol=1e-4, atol=1e-5)
     for name, d, o in (("x", xd, xo), ("W", Wd, Wo), ("att_src", asd, aso), ("att_dst", add_, ado), ("bias", bd, bo)):
@@ -78,7 +75,7 @@ def test_gat_edge_bf16_storage(ops):
     ei = mo.knn_graph(rng.uniform(size=(n, 2)), 6)
     g = _graph(ei, n)
     h = T(rng.normal(size=(n, H * C)), torch.float32).to(DEV)
-    s1 = T(rng.normal(size=(n, H)), torch.float32).to(DEV); s2 = T(rng.normal(size=(n, H)), torch.float32).to(DEV)
+    s1 = T(rng.normal(size=(1, H, C)) * 0.05, torch.float32).to(DEV); s2 = T(rng.normal(size=(1, H, C)) * 0.05, torch.float32).to(DEV)
     bias = torch.zeros(H * C, device=DEV)
     o32 = ops.gat_edge(h, s1, s2, bias, g, H, C, True, True)
     o16 = ops.gat_edge(h.bfloat16(), s1, s2, bias, g, H, C, True, True)
@@ -298,8 +295,8 @@ def test_gat_edge_full_size_vs_torch_scatter(ops):
     g = _graph(ei, n)
     assert g.E == n * (k + 1)
     h = (torch.randn((n, H * C), device=DEV) * 0.5).requires_grad_(True)
-    s1 = torch.randn((n, H), device=DEV).requires_grad_(True)
-    s2 = torch.randn((n, H), device=DEV).requires_grad_(True)
+    s1 = (torch.randn((1, H, C), device=DEV) * 0.1).requires_grad_(True)      # att_src
+    s2 = (torch.randn((1, H, C), device=DEV) * 0.1).requires_grad_(True)      # att_dst
     bias = (0.1 * torch.randn(H * C, device=DEV)).requires_grad_(True)
     out = ops.gat_edge(h, s1, s2, bias, g, H, C, True, True)
     w = torch.randn_like(out)
@@ -310,7 +307,8 @@ def test_gat_edge_full_size_vs_torch_scatter(ops):
     # reference: explicit per-edge tensors + index_add (what a scatter-based GATConv does)
     tgt = torch.repeat_interleave(torch.arange(n, device=DEV), (g.rowptr[1:] - g.rowptr[:-1]).long())
     src = g.col.long()
-    e = torch.nn.functional.leaky_relu(s1[src] + s2[tgt], 0.2)
+    hv = h.view(n, H, C)
+    e = torch.nn.functional.leaky_relu((hv * s1).sum(-1)[src] + (hv * s2).sum(-1)[tgt], 0.2)
     emax = torch.full((n, H), -float("inf"), device=DEV).scatter_reduce(0, tgt[:, None].expand(-1, H), e, "amax")
     ex = torch.exp(e - emax[tgt])
     den = torch.zeros((n, H), device=DEV).index_add_(0, tgt, ex) + 1e-16
@@ -319,7 +317,7 @@ def test_gat_edge_full_size_vs_torch_scatter(ops):
     ref = torch.nn.functional.leaky_relu(ref.reshape(n, H * C) + bias, 0.01)
     (ref * w).sum().backward()
     np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().cpu().numpy(), rtol=2e-4, atol=2e-5)
-    for name, a, t in zip(("h", "s_src", "s_dst", "bias"), got, (h, s1, s2, bias)):
+    for name, a, t in zip(("h", "att_src", "att_dst", "bias"), got, (h, s1, s2, bias)):
         r = t.grad.cpu().numpy()
         bad = ~np.isclose(a.cpu().numpy(), r, rtol=2e-3, atol=2e-4 * np.abs(r).max())
         # a pre-activation within rounding of 0 can take the other LeakyReLU slope in one of the two
