@@ -272,12 +272,24 @@ __global__ __launch_bounds__(256) void k_gat_datt_part(const T *__restrict__ h, 
         }
     }
 }
-__global__ __launch_bounds__(256) void k_colsum_parts(const float *__restrict__ part, int nslab, int width,
-                                                      float *__restrict__ out) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= width) return;
+// out[c] = sum_s part[s][c]: 64 columns x 16 slab-groups per workgroup, groups combined in fixed order.
+__global__ __launch_bounds__(1024) void k_colsum_parts(const float *__restrict__ part, int nslab, int width,
+                                                       float *__restrict__ out) {
+    __shared__ float sh[16][65];
+    const int cx = threadIdx.x & 63, gy = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
     float acc = 0.f;
-    for (int s = 0; s < nslab; s++) acc += part[(size_t)s * width + c];
+    if (c < width) {
+        const int per = (nslab + 15) / 16;
+        const int s0 = gy * per, s1 = min(nslab, s0 + per);
+        for (int s = s0; s < s1; s++) acc += part[(size_t)s * width + c];
+    }
+    sh[gy][cx] = acc;
+    __syncthreads();
+    if (gy != 0 || c >= width) return;
+    acc = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; g++) acc += sh[g][cx];
     out[c] = acc;
 }
 
@@ -858,7 +870,7 @@ int spadot_gat_att_grad(const void *h, int dtype, const float *ds_src, const flo
     else
         return -22;
     // scratch rows are [slab][src H*C | dst H*C]: one column sum writes both outputs (they are adjacent)
-    hipLaunchKernelGGL(k_colsum_parts, dim3((width + 255) / 256), dim3(256), 0, st_, scratch, nslab, width, datt_src);
+    hipLaunchKernelGGL(k_colsum_parts, dim3((width + 63) / 64), dim3(1024), 0, st_, scratch, nslab, width, datt_src);
     (void)datt_dst;
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
