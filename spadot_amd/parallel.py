@@ -162,7 +162,8 @@ def train_SpaDOT_parallel(dataloader_dict, model_config, verbose=False):
         acc = []
 
         def compute_grad(tp_i, tp, bi):
-            acc.append(tu.forward_backward(model, model_config, dataloader_dict, tp_i, tp, bi, epoch, beta1))
+            acc.append(tu.forward_backward(model, model_config, dataloader_dict, tp_i, tp, bi, epoch, beta1,
+                                           optimizer=opt))
 
         run_epoch(plan, batches_per_tp, order, compute_grad, opt.zero_grad, opt.flat_grad, opt.step)
         losses[epoch] = torch.stack(acc).mean(0).cpu().tolist() if acc else None

@@ -220,10 +220,11 @@ def _update_OT_matrix(model, model_config):
 
 # ------------------------------------------------------------------------------ the step
 
-def forward_backward(model, model_config, dataloader_dict, tp_i, tp, bi, epoch, beta1):
+def forward_backward(model, model_config, dataloader_dict, tp_i, tp, bi, epoch, beta1, optimizer=None):
     """Forward of batch `bi` of time point `tp`, composite loss (_train_utils.py:193-212) and backward
-    into the parameters' .grad (the flat gradient buffer).  Returns the seven loss terms as a device
-    tensor (no host sync)."""
+    into the parameters' .grad (the flat gradient buffer; with `optimizer` a FlatAdamW, through its
+    backward(), which overwrites the buffer and so needs no zero_grad()).  Returns the seven loss terms
+    as a device tensor (no host sync)."""
     batch = dataloader_dict["dataloaders"][tp][bi]
     loc, Y, _ = dataloader_dict["datasets"][tp]
     x_b, y_b = loc[batch.n_id], Y[batch.n_id]
@@ -237,7 +238,10 @@ def forward_backward(model, model_config, dataloader_dict, tp_i, tp, bi, epoch, 
         ot = _compute_OT_loss(model, model_config, tp, seeds, z, model_config["timepoints"][tp_i - 1])
     elbo = (model_config["lambda1"] * recon - beta1 * svgp_kl + model_config["beta2"] * gat_kl
             + model_config["omiga1"] * align + model_config["omiga2"] * km + model_config["omiga3"] * ot)
-    elbo.backward()
+    if optimizer is not None and hasattr(optimizer, "backward"):
+        optimizer.backward(elbo)
+    else:
+        elbo.backward()
     return torch.stack([elbo.detach(), recon.detach(), svgp_kl.detach(), gat_kl.detach(), align.detach(),
                         km.detach(), ot.detach()])
 
@@ -263,8 +267,8 @@ class GraphedStepper:
         self.version = getattr(model, "_state_version", 0)
 
     def _body(self, tp_i, tp, bi, epoch):
-        self.opt.zero_grad()
-        losses = forward_backward(self.model, self.cfg, self.dd, tp_i, tp, bi, epoch, self.beta1_t)
+        losses = forward_backward(self.model, self.cfg, self.dd, tp_i, tp, bi, epoch, self.beta1_t,
+                                  optimizer=self.opt)
         self.opt.step()
         return losses
 
@@ -293,10 +297,10 @@ class GraphedStepper:
 
 
 def training_step(model, optimizer, model_config, dataloader_dict, tp_i, tp, bi, epoch, beta1, grad_sync=None):
-    """One optimizer step (_train_utils.py:187-217): zero_grad, forward_backward, optional gradient
-    all-reduce (data-parallel path), clip + AdamW."""
-    optimizer.zero_grad()
-    losses = forward_backward(model, model_config, dataloader_dict, tp_i, tp, bi, epoch, beta1)
+    """One optimizer step (_train_utils.py:187-217): forward_backward (which overwrites the flat
+    gradient, the reference's zero_grad + backward), optional gradient all-reduce (data-parallel path), clip + AdamW."""
+    losses = forward_backward(model, model_config, dataloader_dict, tp_i, tp, bi, epoch, beta1,
+                              optimizer=optimizer)
     if grad_sync is not None:
         grad_sync(optimizer.flat_grad)
     optimizer.step()

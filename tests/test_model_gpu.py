@@ -286,9 +286,13 @@ def test_flat_adamw_matches_torch_clip_and_adamw(ops):
 # ------------------------------------------------------------------ BASELINE.json full size (cfg3 batch graph)
 
 def test_gat_edge_full_size_vs_torch_scatter(ops):
-    """n = 10k nodes, k = 30 (+ self loops), H = 4, C = 512 (cfg3 layer shape): the HIP edge kernels against
-    an independent scatter-based formulation in plain torch on the same device (fp32), forward and backward."""
+    """n = 10k nodes, k = 30 (+ self loops), H = 4, C = 512 (cfg3 layer shape): the HIP edge kernels (fp32)
+    against an independent scatter-based formulation in plain torch, in fp64, forward and backward.
+    A LeakyReLU pre-activation within fp32 rounding of 0 may take the other slope than the fp64 one; the
+    rows such a tie feeds (found from the fp64 pre-activations) are left out of the gradient comparison,
+    everything else has to agree to fp32 accuracy."""
     rng = np.random.default_rng(0)
+    torch.manual_seed(1)
     n, H, C, k = 10000, 4, 512, 30
     from spadot_amd.graph import knn_graph
     ei = knn_graph(rng.uniform(size=(n, 2)), k)
@@ -302,27 +306,40 @@ def test_gat_edge_full_size_vs_torch_scatter(ops):
     w = torch.randn_like(out)
     (out * w).sum().backward()
     got = [t.grad.clone() for t in (h, s1, s2, bias)]
-    for t in (h, s1, s2, bias):
-        t.grad = None
-    # reference: explicit per-edge tensors + index_add (what a scatter-based GATConv does)
+    # reference: explicit per-edge tensors + index_add (what a scatter-based GATConv does), fp64
+    f64 = torch.float64
+    hd, s1d, s2d, bd = (t.detach().to(f64).requires_grad_(True) for t in (h, s1, s2, bias))
     tgt = torch.repeat_interleave(torch.arange(n, device=DEV), (g.rowptr[1:] - g.rowptr[:-1]).long())
     src = g.col.long()
-    hv = h.view(n, H, C)
-    e = torch.nn.functional.leaky_relu((hv * s1).sum(-1)[src] + (hv * s2).sum(-1)[tgt], 0.2)
-    emax = torch.full((n, H), -float("inf"), device=DEV).scatter_reduce(0, tgt[:, None].expand(-1, H), e, "amax")
+    hv = hd.view(n, H, C)
+    pre = (hv * s1d).sum(-1)[src] + (hv * s2d).sum(-1)[tgt]
+    e = torch.nn.functional.leaky_relu(pre, 0.2)
+    emax = torch.full((n, H), -float("inf"), device=DEV, dtype=f64).scatter_reduce(
+        0, tgt[:, None].expand(-1, H), e, "amax")
     ex = torch.exp(e - emax[tgt])
-    den = torch.zeros((n, H), device=DEV).index_add_(0, tgt, ex) + 1e-16
+    den = torch.zeros((n, H), device=DEV, dtype=f64).index_add_(0, tgt, ex) + 1e-16
     alpha = ex / den[tgt]
-    ref = torch.zeros((n, H, C), device=DEV).index_add_(0, tgt, alpha[:, :, None] * h.view(n, H, C)[src])
-    ref = torch.nn.functional.leaky_relu(ref.reshape(n, H * C) + bias, 0.01)
-    (ref * w).sum().backward()
-    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().cpu().numpy(), rtol=2e-4, atol=2e-5)
-    for name, a, t in zip(("h", "att_src", "att_dst", "bias"), got, (h, s1, s2, bias)):
-        r = t.grad.cpu().numpy()
-        bad = ~np.isclose(a.cpu().numpy(), r, rtol=2e-3, atol=2e-4 * np.abs(r).max())
-        # a pre-activation within rounding of 0 can take the other LeakyReLU slope in one of the two
-        # formulations; that moves a handful of the 2e7 entries and nothing else
-        assert bad.sum() <= max(64, 1e-5 * bad.size), (name, int(bad.sum()))
+    opre = torch.zeros((n, H, C), device=DEV, dtype=f64).index_add_(0, tgt, alpha[:, :, None] * hv[src])
+    opre = opre.reshape(n, H * C) + bd
+    ref = torch.nn.functional.leaky_relu(opre, 0.01)
+    (ref * w.to(f64)).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().cpu().numpy(), rtol=2e-5, atol=2e-6)
+    # rows a possible slope tie feeds: both ends of a tied edge; a tied output element's node and in-neighbours
+    tie_e = (pre.detach().abs() < 2e-5).any(1)
+    tie_o = (opre.detach().abs() < 5e-7).any(1)
+    skip = torch.zeros(n, dtype=torch.bool, device=DEV)
+    skip[src[tie_e]] = True
+    skip[tgt[tie_e]] = True
+    skip |= tie_o
+    skip[src[tie_o[tgt]]] = True
+    assert int(skip.sum()) < 0.25 * n
+    keep = (~skip).cpu().numpy()
+    for name, a, t in zip(("h", "att_src", "att_dst", "bias"), got, (hd, s1d, s2d, bd)):
+        r, a = t.grad.cpu().numpy(), a.cpu().numpy().astype(np.float64)
+        if name == "h":
+            np.testing.assert_allclose(a[keep], r[keep], rtol=2e-4, atol=1e-5 * np.abs(r).max(), err_msg=name)
+        else:       # sums over every edge / node: the ties stay in, each worth at most one term of the sum
+            np.testing.assert_allclose(a, r, rtol=2e-3, atol=2e-3 * np.abs(r).max(), err_msg=name)
     # bitwise reproducible (no atomics in the HIP path)
     out2 = ops.gat_edge(h, s1, s2, bias, g, H, C, True, True)
     assert torch.equal(out, out2)
