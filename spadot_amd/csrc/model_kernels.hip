@@ -480,7 +480,7 @@ __global__ __launch_bounds__(256) void k_kernel_matrix(const T *__restrict__ x, 
 // lanes of a wave touch 64 consecutive doubles: conflict-free): TS = 8, 9 reach m = 248, 279 without the
 // compiler spilling the tile (a spilled build measured ~10x slower; a 256-thread / 512-register build 4-40x).
 constexpr int SWEEP_NT = 512;
-constexpr int SWEEP_RS = 7;
+constexpr int SWEEP_RS = 9;
 
 template <int TS, int RSMAX>
 struct SweepTile {
@@ -505,9 +505,10 @@ template <int TS, int RSMAX = SWEEP_RS>
 __global__ __launch_bounds__(SWEEP_NT) void k_spd_sweep(const double *__restrict__ A, int m, int T,
                                                         double *__restrict__ Ainv,
                                                         double *__restrict__ logdet) {
-    extern __shared__ double colbuf[];          // 2 x (T*TS) column buffers, m pivots, 16 scratch, tile borders
-    const int mp = T * TS;
-    double *piv = colbuf + 2 * mp;
+    extern __shared__ double colbuf[];          // 2 x (T*TS + 1) column buffers (+ 1/pivot), m pivots, 16 scratch, tile borders
+    constexpr int CS = TS + ((TS & 1) ? 0 : 1);   // column-buffer stride per tile: odd, so lanes of consecutive tiles spread over the LDS banks
+    const int mp = T * CS;
+    double *piv = colbuf + 2 * (mp + 1);
     const double *Am = A + (size_t)blockIdx.x * m * m;
     double *Om = Ainv + (size_t)blockIdx.x * m * m;
     const int t = threadIdx.x;
@@ -531,61 +532,45 @@ __global__ __launch_bounds__(SWEEP_NT) void k_spd_sweep(const double *__restrict
             tile.set(r, c, v);
         }
     }
-    for (int k = 0; k < m; k++) {
-        double *col = colbuf + (k & 1) * mp;
-        const int kt = k / TS, kr = k - kt * TS;
-        if (live && tj == kt) {
+    // Pivot k = kt*TS + kr with kr unrolled: which register of a tile holds the pivot row / column is then
+    // known at compile time (no per-element selects; the selects were ~80% of the instructions issued).
+    for (int kt = 0; kt < T; kt++) {
 #pragma unroll
-            for (int r = 0; r < TS; r++) {
-                double v = 0.0;
+        for (int kr = 0; kr < TS; kr++) {
+            const int k = kt * TS + kr;
+            if (k >= m) break;
+            double *col = colbuf + (k & 1) * (mp + 1);
+            if (live && tj == kt) {
 #pragma unroll
-                for (int q = 0; q < TS; q++) v = (q == kr) ? tile.get(r, q) : v;
-                col[ti * TS + r] = v;
+                for (int r = 0; r < TS; r++) col[ti * CS + r] = tile.get(r, kr);
+                if (ti == kt) col[mp] = 1.0 / tile.get(kr, kr);
+            } else if (live && ti == kt) {
+#pragma unroll
+                for (int c = 0; c < TS; c++) col[tj * CS + c] = tile.get(kr, c);
             }
-        } else if (live && ti == kt) {
+            __syncthreads();
+            const double inv_d = col[mp];
+            if (t == 0) piv[k] = col[kt * CS + kr];          // log|A| = sum log d_k, taken after the sweep
+            if (live) {
+                // generic rank-1 update for every entry: a_rc -= (c_r / d) c_c
+                double sr[TS];
 #pragma unroll
-            for (int c = 0; c < TS; c++) {
-                double v = 0.0;
-#pragma unroll
-                for (int q = 0; q < TS; q++) v = (q == kr) ? tile.get(q, c) : v;
-                col[tj * TS + c] = v;
-            }
-        }
-        __syncthreads();
-        const double d = col[k];
-        const double inv_d = 1.0 / d;
-        if (t == 0) piv[k] = d;               // log|A| = sum log d_k, taken after the sweep
-        if (live) {
-            // generic rank-1 update for every entry: a_rc -= (c_r / d) c_c
-            double sr[TS];
-#pragma unroll
-            for (int r = 0; r < TS; r++) sr[r] = -col[ti * TS + r] * inv_d;
-#pragma unroll
-            for (int c = 0; c < TS; c++) {
-                const double ccv = col[tj * TS + c];
-#pragma unroll
-                for (int r = 0; r < TS; r++) tile.set(r, c, fma(sr[r], ccv, tile.get(r, c)));
-            }
-            // ... then the pivot column / row / pivot itself are overwritten with their closed forms
-            if (tj == kt) {
-#pragma unroll
-                for (int r = 0; r < TS; r++)
-#pragma unroll
-                    for (int q = 0; q < TS; q++)
-                        if (q == kr) tile.set(r, q, -sr[r]);            // c_r / d
-            }
-            if (ti == kt) {
+                for (int r = 0; r < TS; r++) sr[r] = -col[ti * CS + r] * inv_d;
 #pragma unroll
                 for (int c = 0; c < TS; c++) {
-                    const double v = col[tj * TS + c] * inv_d;
+                    const double ccv = col[tj * CS + c];
 #pragma unroll
-                    for (int q = 0; q < TS; q++)
-                        if (q == kr) tile.set(q, c, v);
+                    for (int r = 0; r < TS; r++) tile.set(r, c, fma(sr[r], ccv, tile.get(r, c)));
                 }
+                // ... then the pivot column / row / pivot itself are overwritten with their closed forms
                 if (tj == kt) {
 #pragma unroll
-                    for (int q = 0; q < TS; q++)
-                        if (q == kr) tile.set(q, q, -inv_d);
+                    for (int r = 0; r < TS; r++) tile.set(r, kr, -sr[r]);                 // c_r / d
+                }
+                if (ti == kt) {
+#pragma unroll
+                    for (int c = 0; c < TS; c++) tile.set(kr, c, col[tj * CS + c] * inv_d);
+                    if (tj == kt) tile.set(kr, kr, -inv_d);
                 }
             }
         }
@@ -916,10 +901,11 @@ int spadot_spd_inverse_logdet(const double *A, int L, int m, double *Ainv, doubl
     hipStream_t st_ = (hipStream_t)stream;
     // smallest tile edge whose lower-triangular tile grid fits the workgroup: T <= 31 (T(T+1)/2 <= 512)
     const int TS = (m + 30) / 31;
-    if (TS > 9) return -34;                       // m > 279: the caller uses the library's batched Cholesky
+    if (TS > 10) return -34;                      // m > 310: the caller uses the library's batched Cholesky
     const int T = (m + TS - 1) / TS;
-    const int RS = TS == 9 ? 8 : (TS == 8 ? 7 : TS);   // register core per tile edge (must match the cases below)
-    const size_t lds = sizeof(double) * (2 * (size_t)T * TS + (size_t)m + 16 + (size_t)(TS * TS - RS * RS) * SWEEP_NT);
+    const int RS = TS < SWEEP_RS ? TS : SWEEP_RS;   // register core per tile edge; the rest of a tile lives in LDS
+    const int CS = TS + ((TS & 1) ? 0 : 1);         // k_spd_sweep's column-buffer stride
+    const size_t lds = sizeof(double) * (2 * ((size_t)T * CS + 1) + (size_t)m + 16 + (size_t)(TS * TS - RS * RS) * SWEEP_NT);
 #define SWEEP_CASE(N)                                                                                         \
     case N: {                                                                                                 \
         static bool attr_set = false;                                                                         \
@@ -928,16 +914,7 @@ int spadot_spd_inverse_logdet(const double *A, int L, int m, double *Ainv, doubl
     } break;
     switch (TS) {
         SWEEP_CASE(1) SWEEP_CASE(2) SWEEP_CASE(3) SWEEP_CASE(4) SWEEP_CASE(5) SWEEP_CASE(6) SWEEP_CASE(7)
-        case 8: {
-            static bool attr_set = false;
-            if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_spd_sweep<8, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
-            hipLaunchKernelGGL((k_spd_sweep<8, 7>), dim3(L), dim3(SWEEP_NT), lds, st_, A, m, T, Ainv, logdet);
-        } break;
-        case 9: {
-            static bool attr_set = false;
-            if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_spd_sweep<9, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
-            hipLaunchKernelGGL((k_spd_sweep<9, 8>), dim3(L), dim3(SWEEP_NT), lds, st_, A, m, T, Ainv, logdet);
-        } break;
+        SWEEP_CASE(8) SWEEP_CASE(9) SWEEP_CASE(10)
         default: return -34;
     }
 #undef SWEEP_CASE

@@ -173,7 +173,7 @@ def rowdot(A, B):
     return _RowDot.apply(A, B)
 
 
-SWEEP_MAX_M = 279      # largest matrix the register/LDS-resident sweep kernel takes (include/spadot_model.h)
+SWEEP_MAX_M = 310      # largest matrix the register/LDS-resident sweep kernel takes (include/spadot_model.h)
 
 
 def _spd_inverse_logdet_nograd(A, need_logdet=True):
@@ -195,7 +195,7 @@ def _spd_inverse_logdet_nograd(A, need_logdet=True):
 
 class _SPDInverse(torch.autograd.Function):
     """(A^-1, log|A|) of a batch of SPD matrices [L, m, m] (fp64).  Forward: the register-resident symmetric
-    sweep kernel (one launch, m <= 279; library Cholesky above).  Backward (A symmetric):
+    sweep kernel (one launch, m <= 310; library Cholesky above).  Backward (A symmetric):
     dA = -X G_X X + g_logdet X with X = A^-1 -- two batched GEMMs."""
 
     @staticmethod
