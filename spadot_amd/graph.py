@@ -33,13 +33,15 @@ def knn_graph(coords, k_cutoff, max_neigh=30):
     return np.stack([key // n, key % n])
 
 
-def _csr_both(src, dst, n):
-    """CSR by target and its transpose for an edge list that already has exactly one self loop per node."""
+def _csr_both(src, dst, n, n_tgt=None):
+    """CSR by target (targets 0..n_tgt-1) and its transpose (sources 0..n-1) for an edge list that already
+    has exactly one self loop per target."""
+    n_tgt = n if n_tgt is None else n_tgt
     order = np.argsort(dst, kind="stable")
     col = src[order].astype(np.int32)
     tgt = dst[order]
-    rowptr = np.zeros(n + 1, dtype=np.int32)
-    np.cumsum(np.bincount(tgt, minlength=n), out=rowptr[1:])
+    rowptr = np.zeros(n_tgt + 1, dtype=np.int32)
+    np.cumsum(np.bincount(tgt, minlength=n_tgt), out=rowptr[1:])
     perm = np.argsort(col, kind="stable").astype(np.int32)
     col_t = tgt[perm].astype(np.int32)
     rowptr_t = np.zeros(n + 1, dtype=np.int32)
@@ -47,17 +49,26 @@ def _csr_both(src, dst, n):
     return rowptr, col, rowptr_t, col_t, perm
 
 
-def build_batch_graph(edge_index, n, device):
+def build_batch_graph(edge_index, n, device, seeds=None):
     """edge_index [2, E] (source, target) -> BatchGraph with GATConv's self-loop convention applied
-    (existing self loops dropped, one per node appended: SURVEY App. A)."""
+    (existing self loops dropped, one per node appended: SURVEY App. A).
+    seeds (optional int): also attach `.seed_graph`, the same graph with only the first `seeds` nodes as
+    targets -- what the last GAT layer needs when only the seeds' rows of its output are used."""
     ei = edge_index.cpu().numpy() if isinstance(edge_index, torch.Tensor) else np.asarray(edge_index)
     src, dst = ei[0].astype(np.int64), ei[1].astype(np.int64)
     keep = src != dst
     loops = np.arange(n, dtype=np.int64)
     src = np.concatenate([src[keep], loops])
     dst = np.concatenate([dst[keep], loops])
-    parts = _csr_both(src, dst, n)
-    return BatchGraph(n, *(torch.from_numpy(np.ascontiguousarray(p)).to(device) for p in parts))
+
+    def dev(parts):
+        return (torch.from_numpy(np.ascontiguousarray(p)).to(device) for p in parts)
+
+    g = BatchGraph(n, *dev(_csr_both(src, dst, n)))
+    if seeds is not None and 0 < seeds < n:
+        sel = dst < seeds
+        g.seed_graph = BatchGraph(n, *dev(_csr_both(src[sel], dst[sel], n, seeds)), n_tgt=seeds)
+    return g
 
 
 def morton_key(coords):
@@ -125,6 +136,6 @@ def precompute_batches(edge_index, n_nodes, batch_size, device, hops=2, coords=N
     for s in range(0, n_nodes, batch_size):
         seeds = np.arange(s, min(n_nodes, s + batch_size))
         n_id, sub = induced_batch(edge_index, n_nodes, seeds, hops, order_key=key)
-        g = build_batch_graph(sub, n_id.size, device)
+        g = build_batch_graph(sub, n_id.size, device, seeds=seeds.size)
         out.append(Batch(torch.from_numpy(n_id).to(device), g, seeds.size))
     return out

@@ -91,9 +91,13 @@ class GATEncoder(nn.Module):
         """`rows` (optional int): only the first `rows` nodes of the output are needed (the seeds)."""
         h = self.gat1(x, edge_index, act=True)
         h = self.gat2(h, edge_index, act=True)
-        h = self.gat3(h, edge_index, act=False)
-        if rows is not None:
-            h = h[:rows]
+        g3 = getattr(edge_index, "seed_graph", None) if rows is not None else None
+        if g3 is not None and g3.n_tgt == rows:
+            h = self.gat3(h, g3, act=False)          # edge phase for the seeds only: same rows, ~n/rows less work
+        else:
+            h = self.gat3(h, edge_index, act=False)
+            if rows is not None:
+                h = h[:rows]
         z = self.GAT_fc(h.float())
         mu, logvar = torch.chunk(z, 2, dim=1)
         return mu, torch.exp(logvar)

@@ -41,14 +41,20 @@ class BatchGraph:
     Built once per batch by spadot_amd.graph.build_batch_graph; self loops are already in the GATConv
     convention (exactly one per node)."""
 
-    def __init__(self, n, rowptr, col, rowptr_t, col_t, eid_t):
-        self.n = int(n)
+    def __init__(self, n, rowptr, col, rowptr_t, col_t, eid_t, n_tgt=None):
+        self.n = int(n)                                   # source nodes (rows of h)
+        self.n_tgt = self.n if n_tgt is None else int(n_tgt)   # target nodes = the first n_tgt (rows of the output)
         self.rowptr, self.col = rowptr, col
         self.rowptr_t, self.col_t, self.eid_t = rowptr_t, col_t, eid_t
         self.E = int(col.numel())
+        assert rowptr.numel() == self.n_tgt + 1 and rowptr_t.numel() == self.n + 1
+        self.seed_graph = None      # optional: the same graph restricted to the seeds as targets (last GAT layer)
 
     def to(self, device):
-        return BatchGraph(self.n, *(t.to(device) for t in (self.rowptr, self.col, self.rowptr_t, self.col_t, self.eid_t)))
+        g = BatchGraph(self.n, *(t.to(device) for t in (self.rowptr, self.col, self.rowptr_t, self.col_t, self.eid_t)),
+                       n_tgt=self.n_tgt)
+        g.seed_graph = self.seed_graph.to(device) if self.seed_graph is not None else None
+        return g
 
 
 # ----------------------------------------------------------------------------- GAT edge phase
@@ -78,16 +84,16 @@ class _GATEdge(torch.autograd.Function):
         a_s = att_src.reshape(H, C).contiguous().float()
         a_d = att_dst.reshape(H, C).contiguous().float()
         bias_f = bias.contiguous().float()
-        n = graph.n
+        n, nt = graph.n, graph.n_tgt        # targets are the first nt nodes (nt < n: seeds-only last layer)
         assert h.shape == (n, H * C), (h.shape, n, H, C)
         s_src = torch.empty((n, H), dtype=torch.float32, device=h.device)
         s_dst = torch.empty((n, H), dtype=torch.float32, device=h.device)
         _check(lib.spadot_gat_logits(_p(h), _DT[h.dtype], _p(a_s), _p(a_d), n, H, C, _p(s_src), _p(s_dst), _stream()),
                "spadot_gat_logits")
-        out = torch.empty((n, H * C if concat else C), dtype=h.dtype, device=h.device)
+        out = torch.empty((nt, H * C if concat else C), dtype=h.dtype, device=h.device)
         alpha = torch.empty((graph.E, H), dtype=torch.float32, device=h.device)
         _check(lib.spadot_gat_forward(_p(h), _DT[h.dtype], _p(s_src), _p(s_dst), _p(graph.rowptr), _p(graph.col),
-                                      _p(bias_f), n, H, C, int(concat), int(act), _p(out), _p(alpha), _stream()),
+                                      _p(bias_f), nt, H, C, int(concat), int(act), _p(out), _p(alpha), _stream()),
                "spadot_gat_forward")
         ctx.save_for_backward(h, s_src, s_dst, out, alpha, a_s, a_d)
         ctx.graph, ctx.H, ctx.C, ctx.concat, ctx.act = graph, H, C, concat, act
@@ -99,13 +105,14 @@ class _GATEdge(torch.autograd.Function):
         lib = model_lib()
         h, s_src, s_dst, out, alpha, a_s, a_d = ctx.saved_tensors
         graph, H, C = ctx.graph, ctx.H, ctx.C
-        n = graph.n
+        n, nt = graph.n, graph.n_tgt
         g_out = g_out.contiguous().to(h.dtype)
-        g_pre = torch.empty((n, H * C), dtype=h.dtype, device=h.device)
+        g_pre = torch.empty((nt, H * C), dtype=h.dtype, device=h.device)
         dz = torch.empty((graph.E, H), dtype=torch.float32, device=h.device)
-        ds_dst = torch.empty((n, H), dtype=torch.float32, device=h.device)
+        # rows >= nt are not targets: their destination-logit gradient is zero
+        ds_dst = (torch.empty if nt == n else torch.zeros)((n, H), dtype=torch.float32, device=h.device)
         _check(lib.spadot_gat_backward_target(_p(g_out), _p(out), _p(h), _DT[h.dtype], _p(s_src), _p(s_dst), _p(alpha),
-                                              _p(graph.rowptr), _p(graph.col), n, H, C, int(ctx.concat), int(ctx.act),
+                                              _p(graph.rowptr), _p(graph.col), nt, H, C, int(ctx.concat), int(ctx.act),
                                               _p(g_pre), _p(dz), _p(ds_dst), _stream()), "spadot_gat_backward_target")
         dh = torch.empty_like(h)
         ds_src = torch.empty((n, H), dtype=torch.float32, device=h.device)
@@ -119,7 +126,7 @@ class _GATEdge(torch.autograd.Function):
                                        _p(datt), ctypes.c_void_p(datt.data_ptr() + 4 * H * C), _stream()),
                "spadot_gat_att_grad")
         gp = g_pre.float()
-        dbias = gp.sum(dim=0) if ctx.concat else gp.view(n, H, C).sum(dim=(0, 1))
+        dbias = gp.sum(dim=0) if ctx.concat else gp.view(nt, H, C).sum(dim=(0, 1))
         return (dh, datt[0].view(ctx.att_shape).to(ctx.att_dtype), datt[1].view(ctx.att_shape).to(ctx.att_dtype),
                 dbias.to(ctx.bias_dtype), None, None, None, None, None)
 

@@ -69,6 +69,36 @@ def test_gat_edge_forward_backward_vs_oracle(ops, H, C, concat, act):
         np.testing.assert_allclose(d.grad.cpu().numpy(), ref, rtol=2e-3, atol=2e-4 * np.abs(ref).max(), err_msg=name)
 
 
+@pytest.mark.parametrize("H,C,concat,act,dt", [(4, 512, False, False, torch.float32), (4, 64, True, True, torch.float32),
+                                              (4, 512, False, False, torch.bfloat16)])
+def test_gat_edge_seed_targets_only(ops, H, C, concat, act, dt):
+    """Last GAT layer: the edge phase with only the first `rows` nodes as targets (BatchGraph.seed_graph) gives
+    the same seed rows and the same gradients as the full graph followed by [:rows]."""
+    from spadot_amd.graph import build_batch_graph
+    rng = np.random.default_rng(11)
+    n, k, rows = 300, 9, 41
+    ei = mo.knn_graph(rng.uniform(size=(n, 2)), k)
+    g = build_batch_graph(ei, n, DEV, seeds=rows)
+    gs = g.seed_graph
+    assert gs is not None and gs.n == n and gs.n_tgt == rows and gs.E == int(g.rowptr[rows])
+    h0 = T(rng.normal(size=(n, H * C)) * 0.5).to(DEV, dt)
+    a_s = T(rng.normal(size=(1, H, C)) * 0.2).to(DEV, torch.float32); a_d = T(rng.normal(size=(1, H, C)) * 0.2).to(DEV, torch.float32)
+    bias = T(rng.normal(size=(H * C if concat else C)) * 0.1).to(DEV, torch.float32)
+    w = T(rng.normal(size=(rows, H * C if concat else C))).to(DEV, dt)
+    res = []
+    for graph in (g, gs):
+        leaves = [t.clone().requires_grad_(True) for t in (h0, a_s, a_d, bias)]
+        out = ops.gat_edge(*leaves, graph, H, C, concat, act)
+        assert out.shape[0] == graph.n_tgt
+        out = out[:rows]
+        (out.float() * w.float()).sum().backward()
+        res.append([out.detach().float().cpu().numpy()] + [t.grad.float().cpu().numpy() for t in leaves])
+    assert np.array_equal(res[0][0], res[1][0])                       # forward: same launches per target row
+    tol = 2e-2 if dt == torch.bfloat16 else 1e-5
+    for name, a, b in zip(("h", "att_src", "att_dst", "bias"), res[0][1:], res[1][1:]):
+        np.testing.assert_allclose(b, a, rtol=tol, atol=tol * np.abs(a).max(), err_msg=name)
+
+
 def test_gat_edge_bf16_storage(ops):
     rng = np.random.default_rng(3)
     n, H, C = 64, 4, 512
