@@ -116,6 +116,38 @@ int spadot_elbo_backward(const void *g2, const void *mu, const void *var, const 
                          void *g_mu, void *g_var, void *g_mv, void *g_tr, void *g_pm, void *g_pv,
                          void *stream);
 
+/* ---------------------------------------------------------------- loss tail of a training step
+ * Single-workgroup kernels for the b x 20 / 10 x 10 arithmetic after the encoders (each replaces a few dozen
+ * library launches; reductions in a fixed order, fp64 accumulators).
+ *
+ * latent head (SpaDOT.py:78-93): zg [b, 2 Lg] fp32 = GAT_fc output (mu | logvar), p_m / p_v [b, Ls] fp64 = SVGP
+ * posterior, eps [b, Ls+Lg] fp32 standard normal.  latent [b, Ls+Lg] = (p_m + eps sqrt(p_v) | mu + eps
+ * sqrt(exp(logvar))); scal2 = (GAT_KL = -1/2 sum(1 + logvar - mu^2 - var) / Lg,
+ * alignment = sum_i (|s_i| / Ls - |g_i| / Lg)^2).  backward: g_latent [b, Ls+Lg] or NULL, g_kl / g_align device
+ * scalars or NULL -> d_zg [b, 2 Lg], d_pm, d_pv [b, Ls] fp64. */
+int spadot_latent_head_forward(const float *zg, const double *p_m, const double *p_v, const float *eps, int b, int Ls,
+                               int Lg, float *latent, float *scal2, void *stream);
+int spadot_latent_head_backward(const float *zg, const double *p_v, const float *eps, const float *latent,
+                                const float *g_latent, const float *g_kl, const float *g_align, int b, int Ls, int Lg,
+                                float *d_zg, double *d_pm, double *d_pv, void *stream);
+/* K-means loss (_train_utils.py:240-253) and OT loss (_train_utils.py:272-307) of one batch.  z [b, D] fp32;
+ * labels_all[seed_ids[i]] (int64) = cluster of seed i; centres [K, D]; prev_centres [Kp, D]; gamma [Kp, Kl]
+ * row-normalised plan; cluster_list [Kl] int64 = clusters of the time point, ascending.  K <= 64, D <= 64.
+ * out2 = (||z - c[label]||^2 / D / #distinct labels, mean(gamma * cdist(prev, batch means or stored centre))).
+ * work: K*D + K + 1 + b floats, written by forward, read by backward.  do_km / do_ot switch the terms. */
+int spadot_cluster_losses_forward(const float *z, const long long *labels_all, const long long *seed_ids,
+                                  const float *centres, const float *prev_centres, const float *gamma,
+                                  const long long *cluster_list, int b, int D, int K, int Kp, int Kl, int do_km,
+                                  int do_ot, float *out2, float *work, void *stream);
+int spadot_cluster_losses_backward(const float *z, const float *centres, const float *prev_centres, const float *gamma,
+                                   const long long *cluster_list, const float *work, const float *g_km,
+                                   const float *g_ot, int b, int D, int K, int Kp, int Kl, int do_km, int do_ot,
+                                   float *dz, void *stream);
+/* elbo = sum_k w6[k] * *terms6[k] (_train_utils.py:205-212); out7 [8 floats] = (elbo, the six terms, elbo again).
+ * terms6 is a HOST array of six device pointers.  backward: g6[k] = g_elbo[0] * w6[k]. */
+int spadot_mix_losses_forward(const float *const *terms6, const float *w6, float *out7, void *stream);
+int spadot_mix_losses_backward(const float *g_elbo, const float *w6, float *g6, void *stream);
+
 /* ---------------------------------------------------------------- VAE head losses (SpaDOT.py:78-93)
  * out1[0] = inv_scale * sum_k (y[k] - yhat[k])^2 over `count` elements (recon: inv_scale = 1/G),
  * deterministic two-stage reduction through `scratch` (>= 2048 doubles).

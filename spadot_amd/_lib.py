@@ -112,6 +112,12 @@ def model_lib():
         "spadot_rowdot_backward": [vp, vp, ci, ci, ci, ci, vp, vp],
         "spadot_elbo_forward": [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp, vp],
         "spadot_elbo_backward": [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp],
+        "spadot_latent_head_forward": [vp, vp, vp, vp, ci, ci, ci, vp, vp, vp],
+        "spadot_latent_head_backward": [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp],
+        "spadot_cluster_losses_forward": [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp],
+        "spadot_cluster_losses_backward": [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp],
+        "spadot_mix_losses_forward": [vp, vp, vp, vp],
+        "spadot_mix_losses_backward": [vp, vp, vp, vp],
         "spadot_sqerr_forward": [vp, vp, ll, cd, ci, vp, vp, vp],
         "spadot_sqerr_backward": [vp, vp, vp, ll, cd, ci, vp, vp],
         "spadot_kmeans_assign": [vp, vp, ci, ci, ci, ci, vp, vp],

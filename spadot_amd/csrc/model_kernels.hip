@@ -760,6 +760,185 @@ __global__ __launch_bounds__(256) void k_adamw(float *__restrict__ p, const floa
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Loss tail of a training step: three single-workgroup kernels (b <= a few thousand seed rows, 20 latent
+// columns, ~10 clusters) in place of ~130 tiny library launches.  Reductions are in a fixed order (fp64).
+
+// Reparameterised samples of both branches, GAT KL and the alignment term (SpaDOT.py:78-93).
+//   zg [b, 2*Lg] = GAT_fc output (mu | logvar), p_m / p_v [b, Ls] fp64 = SVGP posterior, eps [b, Ls+Lg].
+//   latent [b, Ls+Lg] = (p_m + eps sqrt(p_v) | mu + eps sqrt(var)),  scal = (GAT_KL, alignment).
+__global__ __launch_bounds__(512) void k_latent_head_fwd(const float *__restrict__ zg, const double *__restrict__ p_m,
+                                                         const double *__restrict__ p_v, const float *__restrict__ eps,
+                                                         int b, int Ls, int Lg, float *__restrict__ latent,
+                                                         float *__restrict__ scal) {
+    __shared__ double sh[16];
+    const int D = Ls + Lg;
+    double kl = 0.0, al = 0.0;
+    for (int i = threadIdx.x; i < b; i += blockDim.x) {
+        float ns = 0.f, ng = 0.f;
+        for (int l = 0; l < Ls; l++) {
+            const double s = p_m[(size_t)i * Ls + l] + (double)eps[(size_t)i * D + l] * sqrt(p_v[(size_t)i * Ls + l]);
+            const float sf = (float)s;
+            latent[(size_t)i * D + l] = sf;
+            ns += sf * sf;
+        }
+        for (int l = 0; l < Lg; l++) {
+            const float mu = zg[(size_t)i * 2 * Lg + l], lv = zg[(size_t)i * 2 * Lg + Lg + l];
+            const float var = expf(lv);
+            const float g = mu + eps[(size_t)i * D + Ls + l] * sqrtf(var);
+            latent[(size_t)i * D + Ls + l] = g;
+            ng += g * g;
+            kl += 1.0 + (double)logf(var) - (double)mu * mu - (double)var;
+        }
+        const float d = sqrtf(ns) / (float)Ls - sqrtf(ng) / (float)Lg;
+        al += (double)d * d;
+    }
+    kl = block_sum_d(kl, sh);
+    al = block_sum_d(al, sh);
+    if (threadIdx.x == 0) { scal[0] = (float)(-0.5 * kl / Lg); scal[1] = (float)al; }
+}
+
+// g_latent [b, Ls+Lg] (may be null), g_scal = device scalars (d loss / d GAT_KL, d loss / d alignment).
+__global__ __launch_bounds__(512) void k_latent_head_bwd(const float *__restrict__ zg, const double *__restrict__ p_v,
+                                                         const float *__restrict__ eps, const float *__restrict__ latent,
+                                                         const float *__restrict__ g_latent, const float *__restrict__ g_kl,
+                                                         const float *__restrict__ g_al, int b, int Ls, int Lg,
+                                                         float *__restrict__ d_zg, double *__restrict__ d_pm,
+                                                         double *__restrict__ d_pv) {
+    const int D = Ls + Lg;
+    const float gk = g_kl ? g_kl[0] : 0.f, ga = g_al ? g_al[0] : 0.f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < b; i += gridDim.x * blockDim.x) {
+        float ns = 0.f, ng = 0.f;
+        for (int l = 0; l < Ls; l++) { const float s = latent[(size_t)i * D + l]; ns += s * s; }
+        for (int l = 0; l < Lg; l++) { const float g = latent[(size_t)i * D + Ls + l]; ng += g * g; }
+        const float rs = sqrtf(ns), rg = sqrtf(ng);
+        const float d = rs / (float)Ls - rg / (float)Lg;
+        const float cs = rs > 0.f ? ga * 2.f * d / ((float)Ls * rs) : 0.f;      // d align / d s = cs * s
+        const float cg = rg > 0.f ? -ga * 2.f * d / ((float)Lg * rg) : 0.f;
+        for (int l = 0; l < Ls; l++) {
+            const float gl = g_latent ? g_latent[(size_t)i * D + l] : 0.f;
+            const double ds = (double)gl + (double)cs * latent[(size_t)i * D + l];
+            d_pm[(size_t)i * Ls + l] = ds;
+            d_pv[(size_t)i * Ls + l] = ds * (double)eps[(size_t)i * D + l] * 0.5 / sqrt(p_v[(size_t)i * Ls + l]);
+        }
+        for (int l = 0; l < Lg; l++) {
+            const float gl = g_latent ? g_latent[(size_t)i * D + Ls + l] : 0.f;
+            const float dg = gl + cg * latent[(size_t)i * D + Ls + l];
+            const float mu = zg[(size_t)i * 2 * Lg + l], var = expf(zg[(size_t)i * 2 * Lg + Lg + l]);
+            const float dvar = dg * eps[(size_t)i * D + Ls + l] * 0.5f / sqrtf(var) - gk * 0.5f / (float)Lg * (1.f / var - 1.f);
+            d_zg[(size_t)i * 2 * Lg + l] = dg + gk * mu / (float)Lg;
+            d_zg[(size_t)i * 2 * Lg + Lg + l] = dvar * var;
+        }
+    }
+}
+
+// K-means loss (_train_utils.py:240-253) and OT loss (:272-307) of one batch.
+//   z [b, D] latent of the seeds; labels_all[seed_ids[i]] = cluster of seed i; centres [K, D] of this time point;
+//   prev [Kp, D] centres of the previous time point; gamma [Kp, Kl] row-normalised plan; cluster_list [Kl].
+//   work (saved for the backward): means [K*D] | cnt [K] | n_distinct | lab [b] (as floats).
+constexpr int CL_MAXK = 64, CL_MAXD = 64;
+__global__ __launch_bounds__(512) void k_cluster_losses_fwd(const float *__restrict__ z, const long long *__restrict__ labels_all,
+                                                            const long long *__restrict__ seed_ids, const float *__restrict__ centres,
+                                                            const float *__restrict__ prev, const float *__restrict__ gamma,
+                                                            const long long *__restrict__ cluster_list, int b, int D, int K, int Kp,
+                                                            int Kl, int do_km, int do_ot, float *__restrict__ out2,
+                                                            float *__restrict__ work) {
+    __shared__ double sh[16];
+    __shared__ float s_means[CL_MAXK * CL_MAXD];
+    __shared__ int s_cnt[CL_MAXK];
+    float *w_means = work, *w_cnt = work + (size_t)K * D, *w_nd = w_cnt + K, *w_lab = w_nd + 1;
+    const int t = threadIdx.x;
+    for (int i = t; i < b; i += blockDim.x) w_lab[i] = (float)labels_all[seed_ids[i]];
+    __syncthreads();
+    // per-cluster sums over the batch rows, one (cluster, column) pair per thread, rows in order
+    for (int pq = t; pq < K * D; pq += blockDim.x) {
+        const int k = pq / D, d = pq - k * D;
+        float s = 0.f;
+        int c = 0;
+        for (int i = 0; i < b; i++)
+            if ((int)w_lab[i] == k) { s += z[(size_t)i * D + d]; c++; }
+        s_means[pq] = c > 0 ? s / (float)c : centres[pq];
+        if (d == 0) s_cnt[k] = c;
+    }
+    __syncthreads();
+    int nd = 0;
+    for (int k = 0; k < K; k++) nd += s_cnt[k] > 0;
+    for (int pq = t; pq < K * D; pq += blockDim.x) w_means[pq] = s_means[pq];
+    for (int k = t; k < K; k += blockDim.x) w_cnt[k] = (float)s_cnt[k];
+    if (t == 0) w_nd[0] = (float)nd;
+    double km = 0.0;
+    if (do_km)
+        for (int i = t; i < b; i += blockDim.x) {
+            const int k = (int)w_lab[i];
+            float a = 0.f;
+            for (int d = 0; d < D; d++) { const float e = z[(size_t)i * D + d] - centres[(size_t)k * D + d]; a += e * e; }
+            km += a;
+        }
+    km = block_sum_d(km, sh);
+    double ot = 0.0;
+    if (do_ot)
+        for (int pq = t; pq < Kp * Kl; pq += blockDim.x) {
+            const int p = pq / Kl, q = pq - p * Kl, k = (int)cluster_list[q];
+            float a = 0.f;
+            for (int d = 0; d < D; d++) { const float e = prev[(size_t)p * D + d] - s_means[k * D + d]; a += e * e; }
+            ot += (double)gamma[pq] * (double)sqrtf(a);
+        }
+    ot = block_sum_d(ot, sh);
+    if (t == 0) {
+        out2[0] = do_km ? (float)(km / D / (nd > 0 ? nd : 1)) : 0.f;
+        out2[1] = do_ot ? (float)(ot / ((double)Kp * Kl)) : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(512) void k_cluster_losses_bwd(const float *__restrict__ z, const float *__restrict__ centres,
+                                                            const float *__restrict__ prev, const float *__restrict__ gamma,
+                                                            const long long *__restrict__ cluster_list, const float *__restrict__ work,
+                                                            const float *__restrict__ g_km, const float *__restrict__ g_ot, int b,
+                                                            int D, int K, int Kp, int Kl, int do_km, int do_ot,
+                                                            float *__restrict__ dz) {
+    __shared__ float s_dm[CL_MAXK * CL_MAXD];     // d OT / d means[k, d], already divided by cnt[k]
+    const float *w_means = work, *w_cnt = work + (size_t)K * D, *w_nd = w_cnt + K, *w_lab = w_nd + 1;
+    const int t = threadIdx.x;
+    const float gk = (do_km && g_km) ? g_km[0] : 0.f, go = (do_ot && g_ot) ? g_ot[0] : 0.f;
+    for (int pq = t; pq < K * D; pq += blockDim.x) s_dm[pq] = 0.f;
+    __syncthreads();
+    if (do_ot)
+        for (int qd = t; qd < Kl * D; qd += blockDim.x) {
+            const int q = qd / D, d = qd - q * D, k = (int)cluster_list[q];
+            if (w_cnt[k] <= 0.f) continue;                      // the stored centre stands in: no gradient
+            float acc = 0.f;
+            for (int p = 0; p < Kp; p++) {
+                float a = 0.f;
+                for (int e = 0; e < D; e++) { const float df = w_means[k * D + e] - prev[(size_t)p * D + e]; a += df * df; }
+                const float dist = sqrtf(a);
+                if (dist > 0.f) acc += gamma[p * Kl + q] * (w_means[k * D + d] - prev[(size_t)p * D + d]) / dist;
+            }
+            s_dm[k * D + d] = go * acc / ((float)Kp * Kl) / w_cnt[k];
+        }
+    __syncthreads();
+    const float nd = w_nd[0] > 0.f ? w_nd[0] : 1.f;
+    for (int i = t; i < b; i += blockDim.x) {
+        const int k = (int)w_lab[i];
+        for (int d = 0; d < D; d++)
+            dz[(size_t)i * D + d] = gk * 2.f * (z[(size_t)i * D + d] - centres[(size_t)k * D + d]) / ((float)D * nd) + s_dm[k * D + d];
+    }
+}
+
+// elbo = sum_k w[k] * terms[k] over the six loss terms, and the 7-vector (elbo, terms...) for logging.
+__global__ void k_mix_losses_fwd(const float *t0, const float *t1, const float *t2, const float *t3, const float *t4,
+                                 const float *t5, const float *__restrict__ w, float *__restrict__ out7) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float v[6] = {t0[0], t1[0], t2[0], t3[0], t4[0], t5[0]};
+    float e = 0.f;
+    for (int k = 0; k < 6; k++) { e += w[k] * v[k]; out7[1 + k] = v[k]; }
+    out7[0] = e;
+    out7[7] = e;          // second copy: the differentiable output (out7[0..6] is the detached logging vector)
+}
+__global__ void k_mix_losses_bwd(const float *__restrict__ g, const float *__restrict__ w, float *__restrict__ g6) {
+    const int k = threadIdx.x;
+    if (k < 6) g6[k] = g[0] * w[k];
+}
+
 int pick_gat(int C, int &vec, int &niter) {
     if (C % 256 == 0 && C / 256 <= 4) { vec = 4; niter = C / 256; return 0; }
     if (C <= 512) { vec = 1; niter = (C + 63) / 64; return 0; }
@@ -962,6 +1141,55 @@ int spadot_elbo_backward(const void *g2, const void *mu, const void *var, const 
     FP_DISPATCH(dtype,
                 hipLaunchKernelGGL(k_elbo_bwd<float>, g, dim3(256), 0, st_, (const float *)g2, (const float *)mu, (const float *)var, (const float *)mv, (const float *)tr, (const float *)pm, (const float *)pv, (const float *)ktilde, b, L, (float *)g_mu, (float *)g_var, (float *)g_mv, (float *)g_tr, (float *)g_pm, (float *)g_pv),
                 hipLaunchKernelGGL(k_elbo_bwd<double>, g, dim3(256), 0, st_, (const double *)g2, (const double *)mu, (const double *)var, (const double *)mv, (const double *)tr, (const double *)pm, (const double *)pv, (const double *)ktilde, b, L, (double *)g_mu, (double *)g_var, (double *)g_mv, (double *)g_tr, (double *)g_pm, (double *)g_pv));
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+int spadot_latent_head_forward(const float *zg, const double *p_m, const double *p_v, const float *eps, int b, int Ls,
+                               int Lg, float *latent, float *scal2, void *stream) {
+    if (b <= 0 || Ls <= 0 || Lg <= 0) return -22;
+    hipLaunchKernelGGL(k_latent_head_fwd, dim3(1), dim3(512), 0, (hipStream_t)stream, zg, p_m, p_v, eps, b, Ls, Lg, latent, scal2);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+int spadot_latent_head_backward(const float *zg, const double *p_v, const float *eps, const float *latent,
+                                const float *g_latent, const float *g_kl, const float *g_align, int b, int Ls, int Lg,
+                                float *d_zg, double *d_pm, double *d_pv, void *stream) {
+    if (b <= 0 || Ls <= 0 || Lg <= 0) return -22;
+    hipLaunchKernelGGL(k_latent_head_bwd, dim3((b + 255) / 256), dim3(256), 0, (hipStream_t)stream, zg, p_v, eps, latent,
+                       g_latent, g_kl, g_align, b, Ls, Lg, d_zg, d_pm, d_pv);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+int spadot_cluster_losses_forward(const float *z, const long long *labels_all, const long long *seed_ids,
+                                  const float *centres, const float *prev_centres, const float *gamma,
+                                  const long long *cluster_list, int b, int D, int K, int Kp, int Kl, int do_km,
+                                  int do_ot, float *out2, float *work, void *stream) {
+    if (b <= 0 || D <= 0 || K <= 0 || K > CL_MAXK || D > CL_MAXD) return -22;
+    if (do_ot && (Kp <= 0 || Kl <= 0 || Kl > K || !prev_centres || !gamma || !cluster_list)) return -22;
+    hipLaunchKernelGGL(k_cluster_losses_fwd, dim3(1), dim3(512), 0, (hipStream_t)stream, z, labels_all, seed_ids, centres,
+                       prev_centres, gamma, cluster_list, b, D, K, Kp, Kl, do_km, do_ot, out2, work);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+int spadot_cluster_losses_backward(const float *z, const float *centres, const float *prev_centres, const float *gamma,
+                                   const long long *cluster_list, const float *work, const float *g_km,
+                                   const float *g_ot, int b, int D, int K, int Kp, int Kl, int do_km, int do_ot,
+                                   float *dz, void *stream) {
+    if (b <= 0 || D <= 0 || K <= 0 || K > CL_MAXK || D > CL_MAXD) return -22;
+    hipLaunchKernelGGL(k_cluster_losses_bwd, dim3(1), dim3(512), 0, (hipStream_t)stream, z, centres, prev_centres, gamma,
+                       cluster_list, work, g_km, g_ot, b, D, K, Kp, Kl, do_km, do_ot, dz);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+int spadot_mix_losses_forward(const float *const *terms6, const float *w6, float *out7, void *stream) {
+    if (!terms6 || !w6 || !out7) return -22;
+    hipLaunchKernelGGL(k_mix_losses_fwd, dim3(1), dim3(64), 0, (hipStream_t)stream, terms6[0], terms6[1], terms6[2],
+                       terms6[3], terms6[4], terms6[5], w6, out7);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+int spadot_mix_losses_backward(const float *g_elbo, const float *w6, float *g6, void *stream) {
+    hipLaunchKernelGGL(k_mix_losses_bwd, dim3(1), dim3(64), 0, (hipStream_t)stream, g_elbo, w6, g6);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 

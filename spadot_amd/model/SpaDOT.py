@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..ops import BatchGraph, sqerr_sum
+from ..ops import BatchGraph, latent_head, sqerr_sum
 from .decoder import Decoder
 from .encoder import GATEncoder, SVGPEncoder
 from .svgp import SVGP
@@ -68,21 +68,19 @@ class SpaDOT(nn.Module):
             diff = ce - inside_elbo
             # sign trick of SpaDOT.py:76-77 without the host round trip: -(|diff|) either way
             SVGP_KL = (-torch.abs(diff) / self.SVGP_z_dim).float()
-            eps_s = torch.randn_like(p_m) if noise is None else noise[0].to(p_m.dtype)
-            SVGP_latent = (p_m + eps_s * torch.sqrt(p_v)).float()
 
-        g_mu, g_var = self.GATEncoder(y, edge_index, rows=b)
-        eps_g = torch.randn_like(g_mu) if noise is None else noise[1].to(g_mu.dtype)
-        GAT_latent = g_mu + eps_g * torch.sqrt(g_var)
-        GAT_KL = -0.5 * torch.sum(1 + torch.log(g_var) - g_mu.pow(2) - g_var) / self.GAT_z_dim
+        zg = self.GATEncoder.pre_head(y, edge_index, rows=b)               # [b, 2 Lg]: mu | logvar
+        Ls, Lg = self.SVGP_z_dim, self.GAT_z_dim
+        if noise is None:
+            eps = torch.randn((b, Ls + Lg), dtype=torch.float32, device=zg.device)
+        else:
+            eps = torch.cat([noise[0].float(), noise[1].float()], dim=1)
         main.wait_stream(side)
-        SVGP_latent.record_stream(main)
-        SVGP_KL.record_stream(main)
-
-        final_latent = torch.cat([SVGP_latent, GAT_latent], dim=1)
+        for t in (p_m, p_v, SVGP_KL):
+            t.record_stream(main)
+        # both reparameterised samples, GAT KL and the alignment term: one launch (ops.latent_head)
+        final_latent, GAT_KL, alignment_loss = latent_head(zg, p_m, p_v, eps, Ls, Lg)
         recon_loss = sqerr_sum(yb.float(), self.decoder(final_latent), 1.0 / self.input_dim)
-        alignment_loss = F.mse_loss(SVGP_latent.norm(dim=1) / self.SVGP_z_dim,
-                                    GAT_latent.norm(dim=1) / self.GAT_z_dim, reduction="sum")
         return recon_loss, SVGP_KL, GAT_KL, alignment_loss, final_latent
 
     def _side_stream(self):

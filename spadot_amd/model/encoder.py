@@ -89,6 +89,11 @@ class GATEncoder(nn.Module):
 
     def forward(self, x, edge_index, rows=None):
         """`rows` (optional int): only the first `rows` nodes of the output are needed (the seeds)."""
+        mu, logvar = torch.chunk(self.pre_head(x, edge_index, rows), 2, dim=1)
+        return mu, torch.exp(logvar)
+
+    def pre_head(self, x, edge_index, rows=None):
+        """GAT_fc output (mu | logvar) [rows or n, 2 z]: what ops.latent_head consumes."""
         h = self.gat1(x, edge_index, act=True)
         h = self.gat2(h, edge_index, act=True)
         g3 = getattr(edge_index, "seed_graph", None) if rows is not None else None
@@ -98,6 +103,4 @@ class GATEncoder(nn.Module):
             h = self.gat3(h, edge_index, act=False)
             if rows is not None:
                 h = h[:rows]
-        z = self.GAT_fc(h.float())
-        mu, logvar = torch.chunk(z, 2, dim=1)
-        return mu, torch.exp(logvar)
+        return self.GAT_fc(h.float())

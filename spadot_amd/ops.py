@@ -137,6 +137,119 @@ def gat_edge(h, att_src, att_dst, bias, graph, heads, channels, concat=True, act
     return _GATEdge.apply(h, att_src, att_dst, bias, graph, heads, channels, concat, act)
 
 
+# ----------------------------------------------------------------------------- loss tail (single-workgroup kernels)
+
+class _LatentHead(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, zg, p_m, p_v, eps, Ls, Lg):
+        _need_cuda(zg, p_m, p_v, eps)
+        zg, eps = zg.contiguous().float(), eps.contiguous().float()
+        p_m, p_v = p_m.contiguous().double(), p_v.contiguous().double()
+        b = zg.shape[0]
+        assert zg.shape == (b, 2 * Lg) and p_m.shape == (b, Ls) and p_v.shape == (b, Ls) and eps.shape == (b, Ls + Lg)
+        latent = torch.empty((b, Ls + Lg), dtype=torch.float32, device=zg.device)
+        scal = torch.empty(2, dtype=torch.float32, device=zg.device)
+        _check(model_lib().spadot_latent_head_forward(_p(zg), _p(p_m), _p(p_v), _p(eps), b, Ls, Lg, _p(latent), _p(scal),
+                                                      _stream()), "spadot_latent_head_forward")
+        ctx.save_for_backward(zg, p_v, eps, latent)
+        ctx.dims = (b, Ls, Lg)
+        return latent, scal[0], scal[1]
+
+    @staticmethod
+    def backward(ctx, g_latent, g_kl, g_al):
+        zg, p_v, eps, latent = ctx.saved_tensors
+        b, Ls, Lg = ctx.dims
+        d_zg = torch.empty_like(zg)
+        d_pm = torch.empty((b, Ls), dtype=torch.float64, device=zg.device)
+        d_pv = torch.empty_like(d_pm)
+        keep = [None if t is None else t.contiguous().float() for t in (g_latent, g_kl, g_al)]
+        _check(model_lib().spadot_latent_head_backward(_p(zg), _p(p_v), _p(eps), _p(latent),
+                                                       *(None if t is None else _p(t) for t in keep), b, Ls, Lg,
+                                                       _p(d_zg), _p(d_pm), _p(d_pv), _stream()), "spadot_latent_head_backward")
+        return d_zg, d_pm, d_pv, None, None, None
+
+
+def latent_head(zg, p_m, p_v, eps, Ls, Lg):
+    """Reparameterised samples of both branches + GAT KL + alignment (SpaDOT.py:78-93) in one launch.
+    zg [b, 2 Lg] = GAT_fc output (mu | logvar); p_m, p_v [b, Ls] SVGP posterior; eps [b, Ls+Lg] ~ N(0, 1).
+    Returns (final_latent [b, Ls+Lg] fp32, GAT_KL, alignment)."""
+    return _LatentHead.apply(zg, p_m, p_v, eps, Ls, Lg)
+
+
+class _ClusterLosses(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, labels_all, seed_ids, centres, prev, gamma, cluster_list, do_km, do_ot):
+        _need_cuda(z, labels_all, seed_ids, centres)
+        z = z.contiguous().float()
+        b, D = z.shape
+        K = centres.shape[0]
+        Kp = Kl = 0
+        if do_ot:
+            Kp, Kl = prev.shape[0], cluster_list.shape[0]
+            assert gamma.shape == (Kp, Kl) and prev.shape[1] == D, (gamma.shape, prev.shape, Kl)
+            assert gamma.is_contiguous() and prev.is_contiguous() and gamma.dtype == prev.dtype == torch.float32
+        assert centres.shape == (K, D) and centres.dtype == torch.float32 and centres.is_contiguous()
+        assert labels_all.dtype == seed_ids.dtype == torch.int64 and seed_ids.numel() == b
+        out = torch.empty(2, dtype=torch.float32, device=z.device)
+        work = torch.empty(K * D + K + 1 + b, dtype=torch.float32, device=z.device)
+        ptr = lambda t: None if t is None else _p(t)
+        _check(model_lib().spadot_cluster_losses_forward(_p(z), _p(labels_all), _p(seed_ids.contiguous()), _p(centres), ptr(prev),
+                                                         ptr(gamma), ptr(cluster_list), b, D, K, Kp, Kl, int(do_km), int(do_ot),
+                                                         _p(out), _p(work), _stream()), "spadot_cluster_losses_forward")
+        ctx.save_for_backward(z, centres, work)
+        ctx.ot = (prev, gamma, cluster_list)
+        ctx.dims = (b, D, K, Kp, Kl, int(do_km), int(do_ot))
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, g_km, g_ot):
+        z, centres, work = ctx.saved_tensors
+        prev, gamma, cluster_list = ctx.ot
+        b, D, K, Kp, Kl, do_km, do_ot = ctx.dims
+        dz = torch.empty_like(z)
+        keep = [None if t is None else t.contiguous().float() for t in (g_km, g_ot)]
+        ptr = lambda t: None if t is None else _p(t)
+        _check(model_lib().spadot_cluster_losses_backward(_p(z), _p(centres), ptr(prev), ptr(gamma), ptr(cluster_list), _p(work),
+                                                          ptr(keep[0]), ptr(keep[1]), b, D, K, Kp, Kl, do_km, do_ot, _p(dz),
+                                                          _stream()), "spadot_cluster_losses_backward")
+        return dz, None, None, None, None, None, None, None, None
+
+
+def cluster_losses(z, labels_all, seed_ids, centres, prev_centres=None, gamma=None, cluster_list=None, do_km=True, do_ot=False):
+    """(K-means loss, OT loss) of one batch (_train_utils.py:240-253, 272-307) in one launch; see
+    include/spadot_model.h.  Gradients flow to z only (centres, plan and labels are epoch constants)."""
+    return _ClusterLosses.apply(z, labels_all, seed_ids, centres, prev_centres, gamma, cluster_list, do_km, do_ot)
+
+
+class _MixLosses(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, w6, *terms):
+        assert len(terms) == 6 and w6.numel() == 6 and w6.dtype == torch.float32
+        terms = [t.reshape(()).float() if t.dtype != torch.float32 else t for t in terms]
+        _need_cuda(w6, *terms)
+        out8 = torch.empty(8, dtype=torch.float32, device=w6.device)
+        arr = (ctypes.c_void_p * 6)(*(t.data_ptr() for t in terms))
+        _check(model_lib().spadot_mix_losses_forward(arr, _p(w6), _p(out8), _stream()), "spadot_mix_losses_forward")
+        ctx.save_for_backward(w6)
+        log7 = out8[:7]
+        ctx.mark_non_differentiable(log7)
+        return out8[7], log7
+
+    @staticmethod
+    def backward(ctx, g, _):
+        (w6,) = ctx.saved_tensors
+        g6 = torch.empty(6, dtype=torch.float32, device=w6.device)
+        _check(model_lib().spadot_mix_losses_backward(_p(g.contiguous().float()), _p(w6), _p(g6), _stream()),
+               "spadot_mix_losses_backward")
+        return (None, *(g6[k] if ctx.needs_input_grad[k + 1] else None for k in range(6)))
+
+
+def mix_losses(w6, terms):
+    """elbo = sum_k w6[k] * terms[k] (_train_utils.py:205-212) and the logging vector (elbo, terms...),
+    one launch each way.  w6: device fp32 [6]; terms: six 0-dim device tensors."""
+    return _MixLosses.apply(w6, *terms)
+
+
 # ----------------------------------------------------------------------------- SVGP pieces
 
 def kernel_matrix(x, z, kernel_type="Gaussian", scale=0.1):

@@ -20,7 +20,7 @@ import torch
 
 from ..graph import build_batch_graph, knn_graph, precompute_batches
 from ..model import SpaDOT
-from ..ops import FlatAdamW
+from ..ops import FlatAdamW, cluster_losses, mix_losses
 from .OT_loss.ot_solvers import compute_transport_map
 
 LOSS_NAMES = ["elbo", "Recon", "SVGP_KL", "GAT_KL", "alignment", "KMeans", "OT"]
@@ -122,29 +122,15 @@ def _compute_kmeans_loss(model, model_config, tp, seed_ids, latent):
     """_train_utils.py:240-253: ||z - c[label]||_F^2 / z_dim / (#distinct labels in the batch).
     `seed_ids` are local spot ids of the time point (device int64)."""
     st = _device_state(model, tp)
-    lab = st["labels"][seed_ids]
-    centers = st["centers"]
-    # (torch.bincount would synchronise with the host to size its output)
-    occ = torch.zeros(centers.shape[0], dtype=torch.float32, device=lab.device).index_add_(
-        0, lab, torch.ones(lab.shape[0], dtype=torch.float32, device=lab.device))
-    n_distinct = (occ > 0).sum()
-    return torch.sum((latent - centers[lab]) ** 2) / latent.shape[1] / n_distinct
+    return cluster_losses(latent, st["labels"], seed_ids, st["centers"], do_km=True, do_ot=False)[0]
 
 
 def _compute_OT_loss(model, model_config, cur_tp, seed_ids, tp_p_m, prev_tp):
     """_train_utils.py:272-307 on the device: batch means per cluster (stored centre when the cluster is
     absent from the batch), row-normalised plan with NaN/inf -> 0, mean(gamma * cdist)."""
     st = _device_state(model, cur_tp)
-    lab = st["labels"][seed_ids]
-    K = st["centers"].shape[0]
-    sums = torch.zeros((K, tp_p_m.shape[1]), dtype=tp_p_m.dtype, device=tp_p_m.device).index_add_(0, lab, tp_p_m)
-    cnt = torch.zeros(K, dtype=tp_p_m.dtype, device=lab.device).index_add_(
-        0, lab, torch.ones(lab.shape[0], dtype=tp_p_m.dtype, device=lab.device)).unsqueeze(1)
-    means = torch.where(cnt > 0, sums / cnt.clamp(min=1), st["centers"])
-    cur = means[st["cluster_list"]]
-    gamma = model._gamma_dev[f"{prev_tp}_{cur_tp}"]
-    cost = torch.cdist(_device_state(model, prev_tp)["centers"], cur, p=2)
-    return torch.mean(gamma * cost)
+    return cluster_losses(tp_p_m, st["labels"], seed_ids, st["centers"], _device_state(model, prev_tp)["centers"],
+                          model._gamma_dev[f"{prev_tp}_{cur_tp}"], st["cluster_list"], do_km=False, do_ot=True)[1]
 
 
 def _assign_or_copy(store, key, value):
@@ -220,6 +206,31 @@ def _update_OT_matrix(model, model_config):
 
 # ------------------------------------------------------------------------------ the step
 
+def _cluster_terms(model, model_config, tp, tp_i, seed_ids, z, do_km, do_ot):
+    """(K-means loss, OT loss) of one batch through ops.cluster_losses (one launch each way); zeros for the
+    terms that are not active yet (_train_utils.py:198-204)."""
+    if not (do_km or do_ot):
+        zero = torch.zeros((), dtype=torch.float32, device=z.device)
+        return zero, zero
+    st = _device_state(model, tp)
+    prev = gamma = None
+    if do_ot:
+        prev_tp = model_config["timepoints"][tp_i - 1]
+        prev = _device_state(model, prev_tp)["centers"]
+        gamma = model._gamma_dev[f"{prev_tp}_{tp}"]
+    return cluster_losses(z, st["labels"], seed_ids, st["centers"], prev, gamma, st["cluster_list"], do_km, do_ot)
+
+
+def _loss_weights(model, model_config, beta1):
+    """Device vector (lambda1, -beta1, beta2, omiga1, omiga2, omiga3) of _train_utils.py:205-212.  `beta1` may
+    already be such a vector (GraphedStepper keeps one at a fixed address and rewrites entry 1)."""
+    if isinstance(beta1, torch.Tensor) and beta1.numel() == 6:
+        return beta1
+    return torch.tensor([model_config["lambda1"], -float(beta1), model_config["beta2"], model_config["omiga1"],
+                         model_config["omiga2"], model_config["omiga3"]], dtype=torch.float32,
+                        device=next(model.parameters()).device)
+
+
 def forward_backward(model, model_config, dataloader_dict, tp_i, tp, bi, epoch, beta1, optimizer=None):
     """Forward of batch `bi` of time point `tp`, composite loss (_train_utils.py:193-212) and backward
     into the parameters' .grad (the flat gradient buffer; with `optimizer` a FlatAdamW, through its
@@ -231,19 +242,15 @@ def forward_backward(model, model_config, dataloader_dict, tp_i, tp, bi, epoch, 
     seeds = batch.n_id[:batch.batch_size]
     recon, svgp_kl, gat_kl, align, z = model.forward(x=x_b, y=y_b, edge_index=batch.graph, tp=tp,
                                                      batch_size=batch.batch_size, batch_key=(tp, bi))
-    zero = torch.zeros((), dtype=torch.float32, device=z.device)
-    km = _compute_kmeans_loss(model, model_config, tp, seeds, z) if epoch >= 1 else zero
-    ot = zero
-    if epoch >= model_config["ot_epoch"] and tp_i != 0:
-        ot = _compute_OT_loss(model, model_config, tp, seeds, z, model_config["timepoints"][tp_i - 1])
-    elbo = (model_config["lambda1"] * recon - beta1 * svgp_kl + model_config["beta2"] * gat_kl
-            + model_config["omiga1"] * align + model_config["omiga2"] * km + model_config["omiga3"] * ot)
+    do_km = epoch >= 1
+    do_ot = bool(epoch >= model_config["ot_epoch"] and tp_i != 0)
+    km, ot = _cluster_terms(model, model_config, tp, tp_i, seeds, z, do_km, do_ot)
+    elbo, losses = mix_losses(_loss_weights(model, model_config, beta1), (recon, svgp_kl, gat_kl, align, km, ot))
     if optimizer is not None and hasattr(optimizer, "backward"):
         optimizer.backward(elbo)
     else:
         elbo.backward()
-    return torch.stack([elbo.detach(), recon.detach(), svgp_kl.detach(), gat_kl.detach(), align.detach(),
-                        km.detach(), ot.detach()])
+    return losses
 
 
 class GraphedStepper:
@@ -261,7 +268,7 @@ class GraphedStepper:
     def __init__(self, model, optimizer, model_config, dataloader_dict):
         self.model, self.opt, self.cfg, self.dd = model, optimizer, model_config, dataloader_dict
         dev = optimizer.flat_param.device
-        self.beta1_t = torch.zeros((), dtype=torch.float32, device=dev)
+        self.beta1_t = _loss_weights(model, model_config, 0.0)     # (lambda1, -beta1, beta2, omiga1..3); entry 1 rewritten per step
         self.graphs, self.seen = {}, set()
         self.pool = None
         self.version = getattr(model, "_state_version", 0)
@@ -276,7 +283,7 @@ class GraphedStepper:
         if getattr(self.model, "_state_version", 0) != self.version:      # a state tensor was re-allocated
             self.graphs.clear()
             self.version = getattr(self.model, "_state_version", 0)
-        self.beta1_t.fill_(float(beta1))
+        self.beta1_t[1].fill_(-float(beta1))
         key = (tp, bi, epoch >= 1, epoch >= self.cfg["ot_epoch"] and tp_i != 0)
         if key in self.graphs:
             g, out = self.graphs[key]

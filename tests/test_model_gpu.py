@@ -313,6 +313,90 @@ def test_flat_adamw_matches_torch_clip_and_adamw(ops):
             np.testing.assert_allclose(q.detach().cpu().numpy(), p.detach().cpu().numpy(), rtol=2e-6, atol=1e-7)
 
 
+# ------------------------------------------------------------------ loss tail kernels
+
+@pytest.mark.parametrize("b,Ls,Lg", [(512, 10, 10), (37, 3, 5), (1300, 10, 10)])
+def test_latent_head_vs_torch_formulas(ops, b, Ls, Lg):
+    """ops.latent_head against the line-by-line torch formulation of SpaDOT.py:78-93 in fp64 (values and
+    gradients w.r.t. the GAT_fc output and the SVGP posterior)."""
+    rng = np.random.default_rng(b)
+    zg = T(rng.normal(size=(b, 2 * Lg)) * 0.7); p_m = T(rng.normal(size=(b, Ls))); p_v = T(rng.uniform(0.05, 2.0, size=(b, Ls)))
+    eps = T(rng.normal(size=(b, Ls + Lg))).float().double()            # the op takes fp32 noise
+    gl = T(rng.normal(size=(b, Ls + Lg))); wk, wa = 0.37, -1.3
+    # reference
+    zr, pmr, pvr = (t.clone().requires_grad_(True) for t in (zg, p_m, p_v))
+    mu, var = zr[:, :Lg], torch.exp(zr[:, Lg:])
+    s_lat = pmr + eps[:, :Ls] * torch.sqrt(pvr)
+    g_lat = mu + eps[:, Ls:] * torch.sqrt(var)
+    kl = -0.5 * torch.sum(1 + torch.log(var) - mu.pow(2) - var) / Lg
+    al = torch.nn.functional.mse_loss(s_lat.norm(dim=1) / Ls, g_lat.norm(dim=1) / Lg, reduction="sum")
+    lat_r = torch.cat([s_lat, g_lat], 1)
+    ((lat_r * gl).sum() + wk * kl + wa * al).backward()
+    # device
+    zd = zg.to(DEV, torch.float32).requires_grad_(True)
+    pmd, pvd = (t.to(DEV).requires_grad_(True) for t in (p_m, p_v))
+    lat, kl_d, al_d = ops.latent_head(zd, pmd, pvd, eps.to(DEV, torch.float32), Ls, Lg)
+    ((lat * gl.to(DEV, torch.float32)).sum() + wk * kl_d + wa * al_d).backward()
+    np.testing.assert_allclose(lat.detach().cpu().numpy(), lat_r.detach().numpy(), rtol=2e-6, atol=2e-6)
+    assert float(kl_d) == pytest.approx(float(kl), rel=1e-5) and float(al_d) == pytest.approx(float(al), rel=1e-5)
+    for name, d, r in (("zg", zd, zr), ("p_m", pmd, pmr), ("p_v", pvd, pvr)):
+        ref = r.grad.numpy()
+        np.testing.assert_allclose(d.grad.cpu().numpy(), ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max(), err_msg=name)
+
+
+@pytest.mark.parametrize("b,K,absent", [(512, 10, False), (64, 10, True), (700, 7, True)])
+def test_cluster_losses_vs_oracle_and_torch_gradient(ops, b, K, absent):
+    """ops.cluster_losses: values against the oracle's restatement of _train_utils.py:240-253/272-307, the
+    gradient against torch autograd of the same formulas in fp64."""
+    rng = np.random.default_rng(b + K)
+    D, N = 20, 3000
+    all_labels = rng.integers(0, K, size=N)
+    if absent:
+        all_labels[all_labels == 2] = 3                                   # cluster 2 does not exist in this time point
+    seeds = rng.choice(N, size=b, replace=False)
+    if absent:
+        seeds = np.array([s for s in seeds if all_labels[s] != 1][: max(8, b // 2)])   # cluster 1 absent from the batch
+    b = seeds.size
+    z = rng.normal(size=(b, D)); centres = rng.normal(size=(K, D)); prev = rng.normal(size=(K, D))
+    clusters = sorted(set(all_labels.tolist()))
+    gamma = rng.uniform(size=(K, len(clusters))); gamma[3] = 0.0          # a dead row: nan_to_num path of the reference
+    with np.errstate(invalid="ignore"):
+        g_norm = np.nan_to_num(gamma / gamma.sum(1, keepdims=True), nan=0.0, posinf=0.0, neginf=0.0)
+    lab = all_labels[seeds]
+    zr = T(z).requires_grad_(True)
+    km_r = mo.kmeans_loss(zr, centres, lab)
+    ot_r = mo.ot_loss(zr, lab, all_labels, centres, prev, gamma)
+    (0.7 * km_r - 1.9 * ot_r).backward()
+    f32 = lambda a: torch.as_tensor(a, dtype=torch.float32, device=DEV).contiguous()
+    zd = f32(z).requires_grad_(True)
+    km, ot = ops.cluster_losses(zd, torch.as_tensor(all_labels, dtype=torch.int64, device=DEV),
+                                torch.as_tensor(seeds, dtype=torch.int64, device=DEV), f32(centres), f32(prev), f32(g_norm),
+                                torch.as_tensor(clusters, dtype=torch.int64, device=DEV), True, True)
+    (0.7 * km - 1.9 * ot).backward()
+    assert float(km) == pytest.approx(float(km_r), rel=2e-5) and float(ot) == pytest.approx(float(ot_r), rel=2e-5)
+    ref = zr.grad.numpy()
+    np.testing.assert_allclose(zd.grad.cpu().numpy(), ref, rtol=2e-4, atol=2e-6 * np.abs(ref).max())
+    # each term alone (the switches of the first epochs)
+    km1, ot1 = ops.cluster_losses(zd.detach(), torch.as_tensor(all_labels, dtype=torch.int64, device=DEV),
+                                  torch.as_tensor(seeds, dtype=torch.int64, device=DEV), f32(centres), do_km=True, do_ot=False)
+    assert float(km1) == float(km) and float(ot1) == 0.0
+
+
+def test_mix_losses(ops):
+    w = torch.tensor([0.1, -0.4, 1e-4, 0.1, 0.1, 1.0], device=DEV)
+    terms = [torch.tensor(v, device=DEV, requires_grad=(i != 4)) for i, v in enumerate([3.0, -2.0, 50.0, 0.25, 7.0, 0.5])]
+    elbo, log7 = ops.mix_losses(w, terms)
+    want = sum(float(a) * float(t) for a, t in zip(w, terms))
+    assert float(elbo) == pytest.approx(want, rel=1e-6) and float(log7[0]) == float(elbo)
+    assert [float(v) for v in log7[1:]] == [float(t) for t in terms] and not log7.requires_grad
+    (2.0 * elbo).backward()
+    for i, t in enumerate(terms):
+        if i == 4:
+            assert t.grad is None
+        else:
+            assert float(t.grad) == pytest.approx(2.0 * float(w[i]), rel=1e-6)
+
+
 # ------------------------------------------------------------------ BASELINE.json full size (cfg3 batch graph)
 
 def test_gat_edge_full_size_vs_torch_scatter(ops):
