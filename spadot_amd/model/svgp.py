@@ -38,7 +38,78 @@ class Kernel(nn.Module):
 
 class BatchConstants:
     """Everything about (time point, batch coordinates) that does not depend on the encoder output."""
-    __slots__ = ("K_nm", "ktilde", "Q", "P", "c", "b")
+    __slots__ = ("K_nm", "ktilde", "Q", "P", "X2", "c", "b")
+
+
+class RunConstants:
+    """Per time point: everything built from the inducing points alone (not trainable: svgp.py:24-30)."""
+    __slots__ = ("K_mm", "K_inv", "logdet_K", "eye", "KjI", "K2j", "M", "m", "mlogj")
+
+
+class _SVGPCore(torch.autograd.Function):
+    """The encoder-dependent part of svgp.py:47-104 for all L latent dimensions, forward and HAND-WRITTEN
+    backward (autograd through the same algebra costs ~160 launches a step, this ~45).
+
+    With S_l = (K + jI + c K_mn diag(w_l) K_nm)^-1, w = 1/var, t_l = K_mn (mu_l w_l), r_l = S_l t_l,
+    M = K K_j^-1 K and P = K_nm K_j^-1 K (batch constant):
+        p_m = c K_nm r          mv = K_nm K_j^-1 mu_hat = c P r
+        p_v = k~ + diag(K_nm S K_mn)        tr = diag(P S P^T)
+        KL_l = 1/2 (log|K_j| - log|A_hat_l + jI| - m + <S_l, M> + c^2 r_l^T M r_l)
+    (tr(K_j^-1 A_hat) = <S, M> and mu_hat^T K_j^-1 mu_hat = c^2 r^T M r: A_hat and mu_hat are never formed),
+    log|A_hat + jI| by Sylvester's identity from log|Sigma| and log|Sigma + K^2/j| (one sweep, 2L matrices).
+    Backward, with D_l = K_mn diag(G_pv) K_nm + P^T diag(G_tr) P + g/2 M, dr = c K_mn G_pm + c P^T G_mv + g c^2 M r,
+    dt = S dr:   dSigma_l = -S D S - dt r^T + g/2 (S - S2),  S2 = (Sigma + K^2/j)^-1,
+        dw = c diag(K_nm dSigma K_mn) + mu (K_nm dt),   dmu = w (K_nm dt),   dvar = -dw w^2."""
+
+    @staticmethod
+    def forward(ctx, mu, var, bc, rc):
+        b, L = mu.shape
+        m, c = rc.m, bc.c
+        Kn, X2 = bc.K_nm, bc.X2
+        w = 1.0 / var
+        A = Kn.unsqueeze(0) * w.T.unsqueeze(2)                               # [L, b, m] = diag(w_l) K_nm
+        buf = torch.empty((2 * L, m, m), dtype=F64, device=mu.device)
+        torch.baddbmm(rc.KjI.expand(L, m, m), A.transpose(1, 2), Kn.unsqueeze(0).expand(L, b, m), alpha=c, out=buf[:L])
+        torch.add(buf[:L], rc.K2j, out=buf[L:])
+        X, ld = spd_inverse_logdet(buf)
+        S = X[:L]
+        t = (mu * w).T @ Kn                                                  # [L, m]
+        r = torch.bmm(S, t.unsqueeze(2)).squeeze(2)                          # [L, m]
+        pm_mv = c * (X2 @ r.T)                                               # [2b, L]
+        X2S = torch.matmul(X2, S)                                            # [L, 2b, m]
+        rd = rowdot(X2S, X2)                                                 # [L, 2b]
+        p_m, mv = pm_mv[:b], pm_mv[b:]
+        p_v = bc.ktilde.unsqueeze(1) + rd[:, :b].T
+        tr = rd[:, b:].T
+        Mr = r @ rc.M                                                        # [L, m]  (M symmetric)
+        sm = rowdot(S.reshape(L, 1, m * m), rc.M.reshape(1, m * m))[:, 0]    # <S_l, M>
+        kl = 0.5 * (rc.logdet_K - rc.mlogj + ld[:L] - ld[L:] - m + sm + (c * c) * (Mr * r).sum(dim=1))
+        ctx.save_for_backward(mu, w, X, r, Mr, X2S, p_m, p_v)
+        ctx.bc, ctx.rc = bc, rc
+        return p_m, p_v, mv, tr, kl.sum()
+
+    @staticmethod
+    def backward(ctx, G_pm, G_pv, G_mv, G_tr, g_kl):
+        mu, w, X, r, Mr, X2S, p_m, p_v = ctx.saved_tensors
+        bc, rc = ctx.bc, ctx.rc
+        b, L = mu.shape
+        m, c = rc.m, bc.c
+        Kn, X2 = bc.K_nm, bc.X2
+        S, S2 = X[:L], X[L:]
+        z = lambda g: torch.zeros((b, L), dtype=F64, device=mu.device) if g is None else g
+        g = torch.zeros((), dtype=F64, device=mu.device) if g_kl is None else g_kl
+        G1 = torch.cat([z(G_pm), z(G_mv)], dim=0)                            # [2b, L]
+        G2 = torch.cat([z(G_pv), z(G_tr)], dim=0)
+        dr = c * (G1.T @ X2) + (g * (c * c)) * Mr                            # [L, m]
+        dt = torch.bmm(S, dr.unsqueeze(2)).squeeze(2)                        # [L, m]
+        A2 = X2.unsqueeze(0) * G2.T.unsqueeze(2)                             # [L, 2b, m]
+        D = torch.baddbmm(((0.5 * g) * rc.M).expand(L, m, m), A2.transpose(1, 2), X2.unsqueeze(0).expand(L, 2 * b, m))
+        KS = X2S[:, :b].contiguous()                                         # [L, b, m] = K_nm S_l
+        q1 = rowdot(torch.bmm(KS, D).reshape(1, L * b, m), KS.reshape(L * b, m)).reshape(L, b)
+        q2 = rowdot(torch.matmul(Kn, S2), Kn)                                # diag(K_nm S2 K_mn)  [L, b]
+        Kdt = Kn @ dt.T                                                      # [b, L]
+        dw = c * ((0.5 * g) * (p_v - bc.ktilde.unsqueeze(1) - q2.T) - q1.T) + (mu - p_m) * Kdt
+        return w * Kdt, -dw * (w * w), None, None
 
 
 class SVGP(nn.Module):
@@ -77,6 +148,7 @@ class SVGP(nn.Module):
         bc.Q = bc.K_nm @ K_inv
         bc.P = bc.Q @ K_mm
         bc.ktilde = 1.0 - rowdot(bc.Q.unsqueeze(0), bc.K_nm)[0]          # K(x,x)_ii = k(0) = 1
+        bc.X2 = torch.cat([bc.K_nm, bc.P], dim=0).contiguous()            # [2b, m]: both row sets one GEMM serves
         if key is not None:
             self._batch_cache[key] = bc
         return bc
@@ -128,17 +200,23 @@ class SVGP(nn.Module):
         """(p_m, p_v, l3_sum, kl_sum, ce_sum) of one training batch: svgp.py:47-104 over all latent
         dimensions + the Gaussian cross entropy of SpaDOT.py:74-75."""
         mu, var = mu.to(F64), var.to(F64)
-        K_mm, K_inv, logdet_K, eye = self._run_constants()
-        m = K_mm.shape[0]
-        p_m, p_v, (S_inv, St, logdet_S) = self.posterior(bc, mu, var, want_logdet_A=True)
-        mu_hat = bc.c * (St @ K_mm)                                        # [L, m]  (K_mm symmetric)
-        A_hat = K_mm.unsqueeze(0) @ S_inv @ K_mm.unsqueeze(0)              # [L, m, m]
-        mv = bc.Q @ mu_hat.T                                               # K_nm K^-1 mu_hat  [b, L]
-        tr = rowdot(torch.einsum("bm,lmn->lbn", bc.P, S_inv), bc.P).T      # [b, L]
-        kl = 0.5 * (logdet_K - logdet_S - m + (A_hat * K_inv.T.unsqueeze(0)).sum(dim=(1, 2))
-                    + ((mu_hat @ K_inv) * mu_hat).sum(dim=1))
+        p_m, p_v, mv, tr, kl_sum = _SVGPCore.apply(mu, var, bc, self._rc())
         l3_sum, ce_sum = elbo_reduce(mu, var, mv, tr, p_m, p_v, bc.ktilde)
-        return p_m, p_v, l3_sum, kl.sum(), ce_sum
+        return p_m, p_v, l3_sum, kl_sum, ce_sum
+
+    def _rc(self):
+        if getattr(self, "_rc_obj", None) is None:
+            K_mm, K_inv, logdet_K, eye = self._run_constants()
+            rc = RunConstants()
+            rc.K_mm, rc.K_inv, rc.logdet_K, rc.eye = K_mm, K_inv, logdet_K, eye
+            rc.m = K_mm.shape[0]
+            rc.KjI = (K_mm + self.jitter * eye).contiguous()
+            rc.K2j = self._k2_over_j()[0].contiguous()
+            rc.M = (K_mm @ K_inv @ K_mm)
+            rc.M = (0.5 * (rc.M + rc.M.T)).contiguous()
+            rc.mlogj = rc.m * float(torch.log(torch.tensor(self.jitter, dtype=F64)))
+            self._rc_obj = rc
+        return self._rc_obj
 
     # ---- the reference's per-latent-dimension API (svgp.py:43-104) -------------------------
     def kernel_matrix(self, x, y, diag_only=False):
