@@ -55,11 +55,14 @@ class SpaDOT(nn.Module):
         svgp = self.svgp_dict[str(tp)]
         yb = y[:b]
         # The SVGP branch is latency-bound (L small matrices: a handful of CUs) and the GAT branch is
-        # bandwidth-bound; they are independent until the decoder, so the SVGP branch runs on a side HIP
+        # bandwidth-bound; they are independent until the latent head, so the SVGP branch runs on a side HIP
         # stream and overlaps the GAT branch (autograd replays each op's backward on its forward stream).
+        # The GAT branch is ISSUED first: its dozen long kernels are queued at once and the ~60 short SVGP
+        # launches follow while they run (in a captured graph the nodes replay in this order too).
         main = torch.cuda.current_stream()
         side = self._side_stream()
         side.wait_stream(main)
+        zg = self.GATEncoder.pre_head(y, edge_index, rows=b)               # [b, 2 Lg]: mu | logvar
         with torch.cuda.stream(side):
             q_mu, q_var = self.SVGPEncoder(yb)
             bc = svgp.batch_constants(x[:b], key=batch_key)
@@ -69,7 +72,6 @@ class SpaDOT(nn.Module):
             # sign trick of SpaDOT.py:76-77 without the host round trip: -(|diff|) either way
             SVGP_KL = (-torch.abs(diff) / self.SVGP_z_dim).float()
 
-        zg = self.GATEncoder.pre_head(y, edge_index, rows=b)               # [b, 2 Lg]: mu | logvar
         Ls, Lg = self.SVGP_z_dim, self.GAT_z_dim
         if noise is None:
             eps = torch.randn((b, Ls + Lg), dtype=torch.float32, device=zg.device)

@@ -82,7 +82,7 @@ class _SVGPCore(torch.autograd.Function):
         p_v = bc.ktilde.unsqueeze(1) + rd[:, :b].T
         tr = rd[:, b:].T
         Mr = r @ rc.M                                                        # [L, m]  (M symmetric)
-        sm = rowdot(S.reshape(L, 1, m * m), rc.M.reshape(1, m * m))[:, 0]    # <S_l, M>
+        sm = torch.mv(S.reshape(L, m * m), rc.M.reshape(m * m))               # <S_l, M>
         kl = 0.5 * (rc.logdet_K - rc.mlogj + ld[:L] - ld[L:] - m + sm + (c * c) * (Mr * r).sum(dim=1))
         ctx.save_for_backward(mu, w, X, r, Mr, X2S, p_m, p_v)
         ctx.bc, ctx.rc = bc, rc
