@@ -73,10 +73,12 @@ int spadot_gat_logits(const void *h, int dtype, const float *att_src, const floa
                       int C, float *s_src, float *s_dst, void *stream);
 /* Gradient of the attention vectors: datt_src[h,c] = sum_j ds_src[j,h] h[j,h,c] (datt_dst with ds_dst).
  * datt_src and datt_dst must be the two halves of ONE [2, H*C] fp32 buffer (datt_dst == datt_src + H*C);
- * scratch: fp32 work space of scratch_floats >= 2*H*C entries (more = more parallel slabs). */
+ * scratch: fp32 work space of scratch_floats >= 2*H*C entries (more = more parallel slabs).
+ * With g_pre ([n_pre, H*C], n_pre <= n; else NULL) the buffer is [3, H*C] (scratch >= 3*H*C) and its third
+ * block receives sum_i g_pre[i, :], the bias gradient before any head reduction, from the same pass. */
 int spadot_gat_att_grad(const void *h, int dtype, const float *ds_src, const float *ds_dst, int n, int H,
                         int C, float *scratch, int scratch_floats, float *datt_src, float *datt_dst,
-                        void *stream);
+                        const void *g_pre, int n_pre, void *stream);
 
 /* ---------------------------------------------------------------- SVGP pieces */
 

@@ -25,7 +25,11 @@ template <typename T> __device__ __forceinline__ void st(T *p, float v);
 template <> __device__ __forceinline__ void st<float>(float *p, float v) { *p = v; }
 template <> __device__ __forceinline__ void st<__bf16>(__bf16 *p, float v) { *p = (__bf16)v; }
 
-// VEC consecutive elements -> fp32 registers (16-byte / 8-byte vector access when VEC == 4)
+// VEC consecutive elements <-> fp32 registers; one 16-byte / 8-byte access for fp32 x 4, bf16 x 8, bf16 x 4
+__device__ __forceinline__ unsigned bf16_pack2(float lo, float hi) {
+    const unsigned short a = __builtin_bit_cast(unsigned short, (__bf16)lo), b = __builtin_bit_cast(unsigned short, (__bf16)hi);
+    return (unsigned)a | ((unsigned)b << 16);
+}
 template <typename T, int VEC> __device__ __forceinline__ void ldv(const T *p, float *o) {
     if constexpr (VEC == 4 && sizeof(T) == 4) {
         const float4 v = *reinterpret_cast<const float4 *>(p);
@@ -34,6 +38,12 @@ template <typename T, int VEC> __device__ __forceinline__ void ldv(const T *p, f
         const uint2 v = *reinterpret_cast<const uint2 *>(p);
         o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
         o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+    } else if constexpr (VEC == 8 && sizeof(T) == 2) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(p);
+        o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+        o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+        o[4] = __uint_as_float(v.z << 16); o[5] = __uint_as_float(v.z & 0xffff0000u);
+        o[6] = __uint_as_float(v.w << 16); o[7] = __uint_as_float(v.w & 0xffff0000u);
     } else {
 #pragma unroll
         for (int k = 0; k < VEC; k++) o[k] = ld<T>(p + k);
@@ -42,6 +52,11 @@ template <typename T, int VEC> __device__ __forceinline__ void ldv(const T *p, f
 template <typename T, int VEC> __device__ __forceinline__ void stv(T *p, const float *o) {
     if constexpr (VEC == 4 && sizeof(T) == 4) {
         *reinterpret_cast<float4 *>(p) = make_float4(o[0], o[1], o[2], o[3]);
+    } else if constexpr (VEC == 4 && sizeof(T) == 2) {
+        *reinterpret_cast<uint2 *>(p) = make_uint2(bf16_pack2(o[0], o[1]), bf16_pack2(o[2], o[3]));
+    } else if constexpr (VEC == 8 && sizeof(T) == 2) {
+        *reinterpret_cast<uint4 *>(p) = make_uint4(bf16_pack2(o[0], o[1]), bf16_pack2(o[2], o[3]), bf16_pack2(o[4], o[5]),
+                                                   bf16_pack2(o[6], o[7]));
     } else {
 #pragma unroll
         for (int k = 0; k < VEC; k++) st<T>(p + k, o[k]);
@@ -134,7 +149,7 @@ __global__ __launch_bounds__(256) void k_gat_fwd(const T *__restrict__ h, const 
                 alpha_out[(size_t)(p0 + t) * H + hd] = a;
             }
             const int cnt = min(WAVE, deg - base);
-#pragma unroll 4
+#pragma unroll 8
             for (int q = 0; q < cnt; q++) {
                 const int jj = __shfl(j, q, WAVE);
                 const float aa = __shfl(a, q, WAVE);
@@ -234,23 +249,27 @@ __global__ __launch_bounds__(256) void k_gat_logits(const T *__restrict__ h, con
 }
 
 // d(att_src)[h,c] = sum_j ds_src[j,h] h[j,h,c] (and dst): block partials over a slab of nodes, then
-// k_colsum_parts adds the slabs in order (deterministic).  part: [nslab][2][H*C] fp32.
+// k_colsum_parts adds the slabs in order (deterministic).  part: [nslab][2 or 3][H*C] fp32; with g_pre
+// (n_pre rows) the third block is its column sum, i.e. the bias gradient, taken in the same pass.
 template <typename T, int VEC, int NITER>
 __global__ __launch_bounds__(256) void k_gat_datt_part(const T *__restrict__ h, const float *__restrict__ ds_src,
                                                        const float *__restrict__ ds_dst, int n, int H, int C,
-                                                       int nodes_per_slab, float *__restrict__ part) {
+                                                       int nodes_per_slab, float *__restrict__ part,
+                                                       const T *__restrict__ g_pre, int n_pre) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int j0 = blockIdx.x * nodes_per_slab, j1 = min(n, j0 + nodes_per_slab);
     const size_t HC = (size_t)H * C;
     for (int hd = wid; hd < H; hd += 4) {
-        float as[NITER][VEC], ad[NITER][VEC];
+        float as[NITER][VEC], ad[NITER][VEC], ab[NITER][VEC];
 #pragma unroll
         for (int it = 0; it < NITER; it++)
 #pragma unroll
-            for (int k = 0; k < VEC; k++) { as[it][k] = 0.f; ad[it][k] = 0.f; }
+            for (int k = 0; k < VEC; k++) { as[it][k] = 0.f; ad[it][k] = 0.f; ab[it][k] = 0.f; }
         for (int j = j0; j < j1; j++) {
             const float ws = ds_src[(size_t)j * H + hd], wd = ds_dst[(size_t)j * H + hd];
             const T *row = h + (size_t)j * HC + (size_t)hd * C;
+            const bool with_g = g_pre != nullptr && j < n_pre;
+            const T *grow = g_pre + (size_t)(with_g ? j : 0) * HC + (size_t)hd * C;
 #pragma unroll
             for (int it = 0; it < NITER; it++) {
                 const int c = (it * WAVE + lane) * VEC;
@@ -259,16 +278,25 @@ __global__ __launch_bounds__(256) void k_gat_datt_part(const T *__restrict__ h, 
                     ldv<T, VEC>(row + c, v);
 #pragma unroll
                     for (int k = 0; k < VEC; k++) { as[it][k] = fmaf(ws, v[k], as[it][k]); ad[it][k] = fmaf(wd, v[k], ad[it][k]); }
+                    if (with_g) {
+                        ldv<T, VEC>(grow + c, v);
+#pragma unroll
+                        for (int k = 0; k < VEC; k++) ab[it][k] += v[k];
+                    }
                 }
             }
         }
-        float *ps = part + (size_t)blockIdx.x * 2 * HC + (size_t)hd * C;
+        const int nblk = g_pre ? 3 : 2;
+        float *ps = part + (size_t)blockIdx.x * nblk * HC + (size_t)hd * C;
 #pragma unroll
         for (int it = 0; it < NITER; it++) {
             const int c = (it * WAVE + lane) * VEC;
             if (c < C)
 #pragma unroll
-                for (int k = 0; k < VEC; k++) { ps[c + k] = as[it][k]; ps[HC + c + k] = ad[it][k]; }
+                for (int k = 0; k < VEC; k++) {
+                    ps[c + k] = as[it][k]; ps[HC + c + k] = ad[it][k];
+                    if (g_pre) ps[2 * HC + c + k] = ab[it][k];
+                }
         }
     }
 }
@@ -329,29 +357,57 @@ __global__ __launch_bounds__(256) void k_gat_bwd_target(
             }
         }
         const float sd = s_dst[(size_t)i * H + hd];
-        // phase 1: d(alpha) per edge (parked in dz), and sum_k alpha_k d(alpha_k)
+        // phase 1: d(alpha) per edge (parked in dz), and sum_k alpha_k d(alpha_k).  Edges go eight at a time:
+        // their row loads are issued together, and the eight wave-wide dot products are reduced by ONE
+        // butterfly (each exchange step halves the values a lane carries: 11 shuffles instead of 48).
         float dsum = 0.f;
         for (int base = 0; base < deg; base += WAVE) {
             const int t = base + lane;
             const int j = (t < deg) ? col[p0 + t] : 0;
             const int cnt = min(WAVE, deg - base);
             float da = 0.f;
-            for (int q = 0; q < cnt; q++) {
-                const int jj = __shfl(j, q, WAVE);
-                const T *row = h + (size_t)jj * HC + (size_t)hd * C;
-                float part = 0.f;
+            for (int q0 = 0; q0 < cnt; q0 += 8) {
+                float p[8];
 #pragma unroll
-                for (int it = 0; it < NITER; it++) {
-                    const int c = (it * WAVE + lane) * VEC;
-                    if (c < C) {
-                        float v[VEC];
-                        ldv<T, VEC>(row + c, v);
+                for (int u = 0; u < 8; u++) {
+                    const int jj = __shfl(j, min(q0 + u, cnt - 1), WAVE);
+                    const T *row = h + (size_t)jj * HC + (size_t)hd * C;
+                    float part = 0.f;
 #pragma unroll
-                        for (int k = 0; k < VEC; k++) part = fmaf(g[it][k], v[k], part);
+                    for (int it = 0; it < NITER; it++) {
+                        const int c = (it * WAVE + lane) * VEC;
+                        if (c < C) {
+                            float v[VEC];
+                            ldv<T, VEC>(row + c, v);
+#pragma unroll
+                            for (int k = 0; k < VEC; k++) part = fmaf(g[it][k], v[k], part);
+                        }
                     }
+                    p[u] = part;
                 }
-                part = wave_sum_f(part);
-                if (lane == q) da = part;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const bool hi = (lane & 32) != 0;
+                    const float keep = hi ? p[u + 4] : p[u], send = hi ? p[u] : p[u + 4];
+                    p[u] = keep + __shfl_xor(send, 32, WAVE);
+                }
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const bool hi = (lane & 16) != 0;
+                    const float keep = hi ? p[u + 2] : p[u], send = hi ? p[u] : p[u + 2];
+                    p[u] = keep + __shfl_xor(send, 16, WAVE);
+                }
+                {
+                    const bool hi = (lane & 8) != 0;
+                    const float keep = hi ? p[1] : p[0], send = hi ? p[0] : p[1];
+                    p[0] = keep + __shfl_xor(send, 8, WAVE);
+                }
+                p[0] += __shfl_xor(p[0], 4, WAVE);
+                p[0] += __shfl_xor(p[0], 2, WAVE);
+                p[0] += __shfl_xor(p[0], 1, WAVE);
+                // lane L now holds the dot product of edge q0 + ((L >> 3) & 7)
+                const float mine = __shfl(p[0], ((lane - q0) & 7) << 3, WAVE);
+                if (lane >= q0 && lane < q0 + 8) da = mine;
             }
             if (t < deg) {
                 const float a = alpha[(size_t)(p0 + t) * H + hd];
@@ -405,7 +461,7 @@ __global__ __launch_bounds__(256) void k_gat_bwd_source(
                 sds += dz[e];
             }
             const int cnt = min(WAVE, deg - base);
-#pragma unroll 4
+#pragma unroll 8
             for (int q = 0; q < cnt; q++) {
                 const int ii = __shfl(i, q, WAVE);
                 const float aa = __shfl(a, q, WAVE);
@@ -939,7 +995,9 @@ __global__ void k_mix_losses_bwd(const float *__restrict__ g, const float *__res
     if (k < 6) g6[k] = g[0] * w[k];
 }
 
-int pick_gat(int C, int &vec, int &niter) {
+int pick_gat(int C, int &vec, int &niter, int dtype = -1) {
+    // bf16 rows: 16-byte accesses (8 channels per lane) when a head's row is a multiple of 1 KiB
+    if (dtype == SPADOT_DT_BF16 && C % 512 == 0 && C / 512 <= 2) { vec = 8; niter = C / 512; return 0; }
     if (C % 256 == 0 && C / 256 <= 4) { vec = 4; niter = C / 256; return 0; }
     if (C <= 512) { vec = 1; niter = (C + 63) / 64; return 0; }
     return -22;
@@ -949,7 +1007,9 @@ int pick_gat(int C, int &vec, int &niter) {
 
 #define GAT_DISPATCH(KERNEL, T, ...)                                                            \
     do {                                                                                        \
-        if (vec == 4 && niter == 1) hipLaunchKernelGGL((KERNEL<T, 4, 1>), __VA_ARGS__);          \
+        if (vec == 8 && niter == 1) hipLaunchKernelGGL((KERNEL<T, 8, 1>), __VA_ARGS__);          \
+        else if (vec == 8) hipLaunchKernelGGL((KERNEL<T, 8, 2>), __VA_ARGS__);                   \
+        else if (vec == 4 && niter == 1) hipLaunchKernelGGL((KERNEL<T, 4, 1>), __VA_ARGS__);     \
         else if (vec == 4 && niter == 2) hipLaunchKernelGGL((KERNEL<T, 4, 2>), __VA_ARGS__);     \
         else if (vec == 4 && niter == 3) hipLaunchKernelGGL((KERNEL<T, 4, 3>), __VA_ARGS__);     \
         else if (vec == 4 && niter == 4) hipLaunchKernelGGL((KERNEL<T, 4, 4>), __VA_ARGS__);     \
@@ -967,7 +1027,7 @@ int spadot_gat_forward(const void *h, int dtype, const float *s_src, const float
                        const int *col, const float *bias, int n, int H, int C, int concat, int act, void *out,
                        float *alpha_out, void *stream) {
     int vec, niter;
-    if (n <= 0 || H <= 0 || pick_gat(C, vec, niter)) return -22;
+    if (n <= 0 || H <= 0 || pick_gat(C, vec, niter, dtype)) return -22;
     if (!concat && H > 4) return -22;   // head-mean reduces over the workgroup's 4 waves
     hipStream_t st_ = (hipStream_t)stream;
     const size_t lds = concat ? 0 : sizeof(float) * 4 * (size_t)C;
@@ -987,7 +1047,7 @@ int spadot_gat_backward_target(const void *g_out, const void *out, const void *h
                                int H, int C, int concat, int act, void *g_pre, float *dz, float *ds_dst,
                                void *stream) {
     int vec, niter;
-    if (n <= 0 || H <= 0 || pick_gat(C, vec, niter)) return -22;
+    if (n <= 0 || H <= 0 || pick_gat(C, vec, niter, dtype)) return -22;
     hipStream_t st_ = (hipStream_t)stream;
     if (dtype == SPADOT_DT_F32)
         GAT_DISPATCH(k_gat_bwd_target, float, dim3(8 * ((n + 7) / 8)), dim3(256), 0, st_, (const float *)g_out, (const float *)out,
@@ -1005,7 +1065,7 @@ int spadot_gat_backward_target(const void *g_out, const void *out, const void *h
 int spadot_gat_logits(const void *h, int dtype, const float *att_src, const float *att_dst, int n, int H, int C,
                       float *s_src, float *s_dst, void *stream) {
     int vec, niter;
-    if (n <= 0 || H <= 0 || pick_gat(C, vec, niter)) return -22;
+    if (n <= 0 || H <= 0 || pick_gat(C, vec, niter, dtype)) return -22;
     hipStream_t st_ = (hipStream_t)stream;
     if (dtype == SPADOT_DT_F32)
         GAT_DISPATCH(k_gat_logits, float, dim3(8 * ((n + 7) / 8)), dim3(256), 0, st_, (const float *)h, att_src, att_dst, n, H, C, s_src, s_dst);
@@ -1017,23 +1077,25 @@ int spadot_gat_logits(const void *h, int dtype, const float *att_src, const floa
 }
 
 int spadot_gat_att_grad(const void *h, int dtype, const float *ds_src, const float *ds_dst, int n, int H, int C,
-                        float *scratch, int scratch_floats, float *datt_src, float *datt_dst, void *stream) {
+                        float *scratch, int scratch_floats, float *datt_src, float *datt_dst, const void *g_pre,
+                        int n_pre, void *stream) {
     int vec, niter;
-    if (n <= 0 || H <= 0 || pick_gat(C, vec, niter) || !scratch) return -22;
+    if (n <= 0 || H <= 0 || pick_gat(C, vec, niter, dtype) || !scratch) return -22;
+    if (g_pre && (n_pre <= 0 || n_pre > n)) return -22;
     hipStream_t st_ = (hipStream_t)stream;
-    const int width = 2 * H * C;
+    const int width = (g_pre ? 3 : 2) * H * C;
     int nslab = (n + 63) / 64;
     if ((long long)nslab * width > scratch_floats) nslab = scratch_floats / width;
     if (nslab < 1) return -22;
     const int per = (n + nslab - 1) / nslab;
     nslab = (n + per - 1) / per;
     if (dtype == SPADOT_DT_F32)
-        GAT_DISPATCH(k_gat_datt_part, float, dim3(nslab), dim3(256), 0, st_, (const float *)h, ds_src, ds_dst, n, H, C, per, scratch);
+        GAT_DISPATCH(k_gat_datt_part, float, dim3(nslab), dim3(256), 0, st_, (const float *)h, ds_src, ds_dst, n, H, C, per, scratch, (const float *)g_pre, n_pre);
     else if (dtype == SPADOT_DT_BF16)
-        GAT_DISPATCH(k_gat_datt_part, __bf16, dim3(nslab), dim3(256), 0, st_, (const __bf16 *)h, ds_src, ds_dst, n, H, C, per, scratch);
+        GAT_DISPATCH(k_gat_datt_part, __bf16, dim3(nslab), dim3(256), 0, st_, (const __bf16 *)h, ds_src, ds_dst, n, H, C, per, scratch, (const __bf16 *)g_pre, n_pre);
     else
         return -22;
-    // scratch rows are [slab][src H*C | dst H*C]: one column sum writes both outputs (they are adjacent)
+    // scratch rows are [slab][src H*C | dst H*C (| g_pre column sums H*C)]: one column sum writes all outputs (adjacent)
     hipLaunchKernelGGL(k_colsum_parts, dim3((width + 63) / 64), dim3(1024), 0, st_, scratch, nslab, width, datt_src);
     (void)datt_dst;
     return hipGetLastError() == hipSuccess ? 0 : -5;
@@ -1044,7 +1106,7 @@ int spadot_gat_backward_source(const void *g_pre, int dtype, const float *alpha,
                                void *dh, float *ds_src, const float *ds_dst, const float *att_src,
                                const float *att_dst, void *stream) {
     int vec, niter;
-    if (n <= 0 || H <= 0 || pick_gat(C, vec, niter)) return -22;
+    if (n <= 0 || H <= 0 || pick_gat(C, vec, niter, dtype)) return -22;
     hipStream_t st_ = (hipStream_t)stream;
     if (dtype == SPADOT_DT_F32)
         GAT_DISPATCH(k_gat_bwd_source, float, dim3(8 * ((n + 7) / 8)), dim3(256), 0, st_, (const float *)g_pre, alpha, dz, rowptr_t,

@@ -119,14 +119,14 @@ class _GATEdge(torch.autograd.Function):
         _check(lib.spadot_gat_backward_source(_p(g_pre), _DT[h.dtype], _p(alpha), _p(dz), _p(graph.rowptr_t),
                                               _p(graph.col_t), _p(graph.eid_t), n, H, C, _p(dh), _p(ds_src),
                                               _p(ds_dst), _p(a_s), _p(a_d), _stream()), "spadot_gat_backward_source")
-        datt = torch.empty((2, H * C), dtype=torch.float32, device=h.device)
-        floats = 2 * H * C * max(1, min((n + 63) // 64, 512))
+        # attention-vector gradients and the bias gradient (column sums of g_pre) in one slab pass over the nodes
+        datt = torch.empty((3, H * C), dtype=torch.float32, device=h.device)
+        floats = 3 * H * C * max(1, min((n + 63) // 64, 512))
         scratch = _gat_att_scratch(h.device, floats)
         _check(lib.spadot_gat_att_grad(_p(h), _DT[h.dtype], _p(ds_src), _p(ds_dst), n, H, C, _p(scratch), floats,
-                                       _p(datt), ctypes.c_void_p(datt.data_ptr() + 4 * H * C), _stream()),
+                                       _p(datt), ctypes.c_void_p(datt.data_ptr() + 4 * H * C), _p(g_pre), nt, _stream()),
                "spadot_gat_att_grad")
-        gp = g_pre.float()
-        dbias = gp.sum(dim=0) if ctx.concat else gp.view(nt, H, C).sum(dim=(0, 1))
+        dbias = datt[2] if ctx.concat else datt[2].view(H, C).sum(dim=0)
         return (dh, datt[0].view(ctx.att_shape).to(ctx.att_dtype), datt[1].view(ctx.att_shape).to(ctx.att_dtype),
                 dbias.to(ctx.bias_dtype), None, None, None, None, None)
 
