@@ -892,7 +892,7 @@ __global__ __launch_bounds__(512) void k_latent_head_bwd(const float *__restrict
 //   z [b, D] latent of the seeds; labels_all[seed_ids[i]] = cluster of seed i; centres [K, D] of this time point;
 //   prev [Kp, D] centres of the previous time point; gamma [Kp, Kl] row-normalised plan; cluster_list [Kl].
 //   work (saved for the backward): means [K*D] | cnt [K] | n_distinct | lab [b] (as floats).
-constexpr int CL_MAXK = 64, CL_MAXD = 64;
+constexpr int CL_MAXK = 64, CL_MAXD = 64, CL_ROWS = 128;
 __global__ __launch_bounds__(512) void k_cluster_losses_fwd(const float *__restrict__ z, const long long *__restrict__ labels_all,
                                                             const long long *__restrict__ seed_ids, const float *__restrict__ centres,
                                                             const float *__restrict__ prev, const float *__restrict__ gamma,
@@ -902,19 +902,47 @@ __global__ __launch_bounds__(512) void k_cluster_losses_fwd(const float *__restr
     __shared__ double sh[16];
     __shared__ float s_means[CL_MAXK * CL_MAXD];
     __shared__ int s_cnt[CL_MAXK];
+    __shared__ float s_z[CL_ROWS * CL_MAXD];     // a chunk of latent rows, staged so every (cluster, column) owner scans LDS
+    __shared__ int s_lab[CL_ROWS];
     float *w_means = work, *w_cnt = work + (size_t)K * D, *w_nd = w_cnt + K, *w_lab = w_nd + 1;
     const int t = threadIdx.x;
-    for (int i = t; i < b; i += blockDim.x) w_lab[i] = (float)labels_all[seed_ids[i]];
-    __syncthreads();
-    // per-cluster sums over the batch rows, one (cluster, column) pair per thread, rows in order
-    for (int pq = t; pq < K * D; pq += blockDim.x) {
-        const int k = pq / D, d = pq - k * D;
-        float s = 0.f;
-        int c = 0;
-        for (int i = 0; i < b; i++)
-            if ((int)w_lab[i] == k) { s += z[(size_t)i * D + d]; c++; }
-        s_means[pq] = c > 0 ? s / (float)c : centres[pq];
-        if (d == 0) s_cnt[k] = c;
+    // per-cluster sums over the batch rows: one (cluster, column) pair per thread slot, rows in order
+    constexpr int PAIRS = (CL_MAXK * CL_MAXD + 511) / 512;
+    float ps[PAIRS];
+    int pc[PAIRS];
+#pragma unroll
+    for (int u = 0; u < PAIRS; u++) { ps[u] = 0.f; pc[u] = 0; }
+    for (int r0 = 0; r0 < b; r0 += CL_ROWS) {
+        const int rows = min(CL_ROWS, b - r0);
+        __syncthreads();
+        for (int e = t; e < rows * D; e += blockDim.x) s_z[e] = z[(size_t)r0 * D + e];
+        for (int i = t; i < rows; i += blockDim.x) {
+            const int lab = (int)labels_all[seed_ids[r0 + i]];
+            s_lab[i] = lab;
+            w_lab[r0 + i] = (float)lab;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < PAIRS; u++) {
+            const int pq = t + u * 512;
+            if (pq < K * D) {
+                const int k = pq / D, d = pq - k * D;
+                float s = ps[u];
+                int c = pc[u];
+                for (int i = 0; i < rows; i++)
+                    if (s_lab[i] == k) { s += s_z[i * D + d]; c++; }
+                ps[u] = s; pc[u] = c;
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < PAIRS; u++) {
+        const int pq = t + u * 512;
+        if (pq < K * D) {
+            const int k = pq / D, d = pq - k * D;
+            s_means[pq] = pc[u] > 0 ? ps[u] / (float)pc[u] : centres[pq];
+            if (d == 0) s_cnt[k] = pc[u];
+        }
     }
     __syncthreads();
     int nd = 0;

@@ -49,11 +49,15 @@ def _csr_both(src, dst, n, n_tgt=None):
     return rowptr, col, rowptr_t, col_t, perm
 
 
-def build_batch_graph(edge_index, n, device, seeds=None):
+def build_batch_graph(edge_index, n, device, seeds=None, tiers=None):
     """edge_index [2, E] (source, target) -> BatchGraph with GATConv's self-loop convention applied
     (existing self loops dropped, one per node appended: SURVEY App. A).
     seeds (optional int): also attach `.seed_graph`, the same graph with only the first `seeds` nodes as
-    targets -- what the last GAT layer needs when only the seeds' rows of its output are used."""
+    targets -- what the last GAT layer needs when only the seeds' rows of its output are used.
+    tiers (optional, cumulative hop sizes [b, n1, n] of a 2-hop batch whose nodes are ordered seeds, hop 1,
+    hop 2): also attach `.layer_graphs` = (g2, g3), the graphs the 2nd and 3rd GAT layer need when only the
+    seeds' rows of the 3rd layer are used: g2 has the first n1 nodes as targets (the sources of g3), g3 has
+    n1 sources and the b seeds as targets."""
     ei = edge_index.cpu().numpy() if isinstance(edge_index, torch.Tensor) else np.asarray(edge_index)
     src, dst = ei[0].astype(np.int64), ei[1].astype(np.int64)
     keep = src != dst
@@ -68,6 +72,14 @@ def build_batch_graph(edge_index, n, device, seeds=None):
     if seeds is not None and 0 < seeds < n:
         sel = dst < seeds
         g.seed_graph = BatchGraph(n, *dev(_csr_both(src[sel], dst[sel], n, seeds)), n_tgt=seeds)
+    if tiers is not None and len(tiers) == 3 and tiers[2] == n and 0 < tiers[0] <= tiers[1] <= n:
+        b, n1 = int(tiers[0]), int(tiers[1])
+        s2 = dst < n1
+        s3 = dst < b
+        if src[s3].max(initial=0) < n1:           # every in-neighbour of a seed is a seed or hop-1 node
+            g2 = BatchGraph(n, *dev(_csr_both(src[s2], dst[s2], n, n1)), n_tgt=n1)
+            g3 = BatchGraph(n1, *dev(_csr_both(src[s3], dst[s3], n1, b)), n_tgt=b)
+            g.layer_graphs = (g2, g3)
     return g
 
 
@@ -87,12 +99,13 @@ def morton_key(coords):
     return spread(q[:, 0]) | (spread(q[:, 1]) << np.uint64(1))
 
 
-def induced_batch(edge_index, n_nodes, seeds, hops=2, order_key=None):
+def induced_batch(edge_index, n_nodes, seeds, hops=2, order_key=None, return_tiers=False):
     """Seeds + their `hops`-hop in-neighbourhood (sources of edges pointing at the frontier), seeds
     first; edges = every original edge with both ends inside (NeighborLoader 'induced', fan-out >=
     in-degree: SURVEY App. B).  Returns (n_id int64 [n_sub], sub_edge_index int64 [2, E_sub]).
-    order_key (optional, one value per node): the non-seed nodes are laid out by ascending key instead of
-    by hop and id -- the subgraph is the same up to relabelling, results on the seeds do not change."""
+    order_key (optional, one value per node): inside each hop the nodes are laid out by ascending key
+    instead of by id -- the subgraph is the same up to relabelling, results on the seeds do not change.
+    return_tiers: also return the cumulative node counts per hop (seeds, seeds + hop 1, ...)."""
     ei = edge_index.cpu().numpy() if isinstance(edge_index, torch.Tensor) else np.asarray(edge_index)
     src, dst = ei[0], ei[1]
     seen = np.zeros(n_nodes, dtype=bool)
@@ -108,14 +121,16 @@ def induced_batch(edge_index, n_nodes, seeds, hops=2, order_key=None):
         n_id.append(new)
         frontier_mask = np.zeros(n_nodes, dtype=bool)
         frontier_mask[new] = True
-    n_id = np.concatenate(n_id)
     if order_key is not None:
-        rest = n_id[seeds.size:]
-        n_id = np.concatenate([seeds, rest[np.argsort(np.asarray(order_key)[rest], kind="stable")]])
+        key = np.asarray(order_key)
+        n_id = [n_id[0]] + [t[np.argsort(key[t], kind="stable")] for t in n_id[1:]]
+    tiers = np.cumsum([t.size for t in n_id]).tolist()
+    n_id = np.concatenate(n_id)
     relabel = np.full(n_nodes, -1, dtype=np.int64)
     relabel[n_id] = np.arange(n_id.size)
     keep = seen[src] & seen[dst]
-    return n_id, np.stack([relabel[src[keep]], relabel[dst[keep]]])
+    sub = np.stack([relabel[src[keep]], relabel[dst[keep]]])
+    return (n_id, sub, tiers) if return_tiers else (n_id, sub)
 
 
 class Batch:
@@ -129,13 +144,14 @@ class Batch:
 
 def precompute_batches(edge_index, n_nodes, batch_size, device, hops=2, coords=None):
     """All batches of one time point in loader order (consecutive seed blocks, last one partial).
-    With `coords`, the non-seed nodes of every batch are stored in Z-order of their coordinates: the
-    neighbours a GAT workgroup gathers are then close in memory and in launch order (L2 reuse per XCD)."""
+    With `coords`, the nodes of each hop of every batch are stored in Z-order of their coordinates: the
+    neighbours a GAT workgroup gathers are then close in memory and in launch order (L2 reuse per XCD).
+    Each batch graph carries the per-layer graphs of build_batch_graph(tiers=...)."""
     key = morton_key(coords) if coords is not None else None
     out = []
     for s in range(0, n_nodes, batch_size):
         seeds = np.arange(s, min(n_nodes, s + batch_size))
-        n_id, sub = induced_batch(edge_index, n_nodes, seeds, hops, order_key=key)
-        g = build_batch_graph(sub, n_id.size, device, seeds=seeds.size)
+        n_id, sub, tiers = induced_batch(edge_index, n_nodes, seeds, hops, order_key=key, return_tiers=True)
+        g = build_batch_graph(sub, n_id.size, device, seeds=seeds.size, tiers=tiers if hops == 2 else None)
         out.append(Batch(torch.from_numpy(n_id).to(device), g, seeds.size))
     return out

@@ -94,12 +94,18 @@ class GATEncoder(nn.Module):
 
     def pre_head(self, x, edge_index, rows=None):
         """GAT_fc output (mu | logvar) [rows or n, 2 z]: what ops.latent_head consumes."""
-        h = self.gat1(x, edge_index, act=True)
-        h = self.gat2(h, edge_index, act=True)
+        lg = getattr(edge_index, "layer_graphs", None) if rows is not None else None
         g3 = getattr(edge_index, "seed_graph", None) if rows is not None else None
-        if g3 is not None and g3.n_tgt == rows:
+        h = self.gat1(x, edge_index, act=True)
+        if lg is not None and lg[1].n_tgt == rows:
+            # only what the seeds' rows of layer 3 depend on: layer 2 for seeds + hop 1, layer 3 for the seeds
+            h = self.gat2(h, lg[0], act=True)
+            h = self.gat3(h, lg[1], act=False)
+        elif g3 is not None and g3.n_tgt == rows:
+            h = self.gat2(h, edge_index, act=True)
             h = self.gat3(h, g3, act=False)          # edge phase for the seeds only: same rows, ~n/rows less work
         else:
+            h = self.gat2(h, edge_index, act=True)
             h = self.gat3(h, edge_index, act=False)
             if rows is not None:
                 h = h[:rows]

@@ -49,11 +49,13 @@ class BatchGraph:
         self.E = int(col.numel())
         assert rowptr.numel() == self.n_tgt + 1 and rowptr_t.numel() == self.n + 1
         self.seed_graph = None      # optional: the same graph restricted to the seeds as targets (last GAT layer)
+        self.layer_graphs = None    # optional: (g2, g3) of graph.build_batch_graph(tiers=...)
 
     def to(self, device):
         g = BatchGraph(self.n, *(t.to(device) for t in (self.rowptr, self.col, self.rowptr_t, self.col_t, self.eid_t)),
                        n_tgt=self.n_tgt)
         g.seed_graph = self.seed_graph.to(device) if self.seed_graph is not None else None
+        g.layer_graphs = tuple(t.to(device) for t in self.layer_graphs) if self.layer_graphs is not None else None
         return g
 
 

@@ -99,6 +99,42 @@ def test_gat_edge_seed_targets_only(ops, H, C, concat, act, dt):
         np.testing.assert_allclose(b, a, rtol=tol, atol=tol * np.abs(a).max(), err_msg=name)
 
 
+def test_gat_encoder_layer_graphs_match_full_graph(ops):
+    """Batches carry per-layer graphs (layer 2 for seeds + hop 1 only, layer 3 for the seeds only): the seeds'
+    encoder output and every parameter gradient equal those of the three layers run on the whole batch graph."""
+    from spadot_amd.graph import knn_graph, precompute_batches, build_batch_graph, induced_batch
+    from spadot_amd.model.encoder import GATEncoder
+    rng = np.random.default_rng(21)
+    n, k, bs, G = 900, 6, 64, 30
+    side = 30
+    coords = np.stack(np.meshgrid(np.arange(side), np.arange(side)), -1).reshape(-1, 2) + rng.uniform(-0.3, 0.3, (n, 2))
+    ei = knn_graph(coords, k)                       # spatially ordered spots: the 2-hop closure is a small part of the graph
+    batch = precompute_batches(ei, n, bs, DEV, coords=coords)[5]
+    g = batch.graph
+    assert g.layer_graphs is not None
+    g2, g3 = g.layer_graphs
+    assert bs == g3.n_tgt < g3.n == g2.n_tgt < g2.n == g.n < n
+    # same node set and edges as the reference batch construction (oracle), up to the order inside a hop
+    n_id_o, _ = mo.induced_batch(torch.as_tensor(ei), n, np.arange(5 * bs, 6 * bs))
+    assert sorted(batch.n_id.cpu().tolist()) == sorted(np.asarray(n_id_o).tolist())
+    torch.manual_seed(3)
+    enc = GATEncoder(G, 5, hidden_dim=16, num_heads=4).to(DEV)
+    x = torch.randn((g.n, G), device=DEV)
+    w = torch.randn((bs, 10), device=DEV)
+    full = build_batch_graph(torch.stack([g.col.long(), torch.repeat_interleave(
+        torch.arange(g.n, device=DEV), (g.rowptr[1:] - g.rowptr[:-1]).long())]), g.n, DEV)      # no per-layer graphs
+    res = []
+    for graph in (full, g):
+        enc.zero_grad()
+        z = enc.pre_head(x, graph, rows=bs)
+        (z * w).sum().backward()
+        res.append((z.detach().cpu().numpy(), {k_: p.grad.cpu().numpy().copy() for k_, p in enc.named_parameters()}))
+    np.testing.assert_allclose(res[1][0], res[0][0], rtol=1e-5, atol=1e-6)
+    for name in res[0][1]:
+        a, b_ = res[0][1][name], res[1][1][name]
+        np.testing.assert_allclose(b_, a, rtol=1e-4, atol=1e-6 * max(1.0, np.abs(a).max()), err_msg=name)
+
+
 def test_gat_edge_bf16_storage(ops):
     rng = np.random.default_rng(3)
     n, H, C = 64, 4, 512
