@@ -140,6 +140,8 @@ class Batch:
         self.n_id = n_id            # int64 device tensor, seeds first
         self.graph = graph          # BatchGraph on the device
         self.batch_size = int(batch_size)
+        self.x = None               # optional cache: coordinates of the batch nodes [n_sub, 2]
+        self.y = None               # optional cache: expression rows in the compute dtype, K padded to 128
 
 
 def precompute_batches(edge_index, n_nodes, batch_size, device, hops=2, coords=None):

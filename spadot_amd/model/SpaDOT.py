@@ -46,14 +46,15 @@ class SpaDOT(nn.Module):
         self.kmeans_index_dict = {}
 
     def forward(self, x, y, edge_index, tp, batch_size, noise=None, batch_key=None):
-        """x: coordinates [n_sub, 2]; y: expression [n_sub, G]; edge_index: BatchGraph (or [2, E] tensor);
+        """x: coordinates [n_sub, 2]; y: expression [n_sub, G] (or [n_sub, G'] with G' - G zero pad columns,
+        see prepare_dataloader's batch cache); edge_index: BatchGraph (or [2, E] tensor);
         the first `batch_size` rows are the seeds.  Returns (recon, SVGP_KL, GAT_KL, alignment,
         final_latent) like SpaDOT.py:52-94.  `noise` = (eps_svgp, eps_gat), each [b, L], replaces the
         two torch.randn_like draws (SpaDOT.py:78,83) for parity tests; `batch_key` lets the SVGP cache
         the coordinate-only constants of a recurring batch."""
         b = batch_size
         svgp = self.svgp_dict[str(tp)]
-        yb = y[:b]
+        yb = y[:b, :self.input_dim]                 # y may carry zero pad columns (cached batch inputs)
         # The SVGP branch is latency-bound (L small matrices: a handful of CUs) and the GAT branch is
         # bandwidth-bound; they are independent until the latent head, so the SVGP branch runs on a side HIP
         # stream and overlaps the GAT branch (autograd replays each op's backward on its forward stream).

@@ -11,7 +11,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..graph import build_batch_graph
-from ..ops import BatchGraph, gat_edge
+from ..ops import BatchGraph, dense_cd, gat_edge
 
 
 class SVGPEncoder(nn.Module):
@@ -72,7 +72,10 @@ class GATConv(nn.Module):
         if not isinstance(graph, BatchGraph):
             graph = build_batch_graph(graph, x.shape[0], x.device)
         cd = self.compute_dtype
-        h = F.linear(x.to(cd), self.lin.weight.to(cd))              # [n, H*C]  (MFMA GEMM)
+        if cd == torch.float32:
+            h = F.linear(x[:, :self.in_channels].float(), self.lin.weight)
+        else:                                                       # [n, H*C]  (MFMA GEMM; x may be K-padded)
+            h = dense_cd(x.to(cd), self.lin.weight, self)
         return gat_edge(h, self.att_src, self.att_dst, self.bias, graph, H, C, self.concat, act)
 
 

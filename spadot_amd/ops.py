@@ -139,6 +139,45 @@ def gat_edge(h, att_src, att_dst, bias, graph, heads, channels, concat=True, act
     return _GATEdge.apply(h, att_src, att_dst, bias, graph, heads, channels, concat, act)
 
 
+# ----------------------------------------------------------------------------- dense maps in the compute dtype
+
+class _DenseCD(torch.autograd.Function):
+    """h = x W^T with x already in the compute dtype (bf16) and possibly zero-padded along K (so that the
+    G-sized GEMM gets a K that is a multiple of 128), W the fp32 parameter [N, K].  Backward writes the weight
+    gradient in fp32 straight out of the GEMM (no bf16 round trip)."""
+
+    @staticmethod
+    def forward(ctx, x, W, wbuf):
+        N, K = W.shape
+        Kp = x.shape[1]
+        assert Kp >= K and wbuf.shape == (N, Kp) and wbuf.dtype == x.dtype
+        wbuf[:, :K].copy_(W)                       # cast into the persistent padded image (pad columns stay zero)
+        ctx.save_for_backward(x, wbuf)
+        ctx.K = K
+        return torch.nn.functional.linear(x, wbuf)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, wbuf = ctx.saved_tensors
+        g = g.contiguous()
+        dx = g @ wbuf if ctx.needs_input_grad[0] else None
+        # (x[:, :K] is a strided view: the GEMM takes its row stride, the result is a dense [N, K])
+        dW = torch.mm(g.t(), x[:, :ctx.K], out_dtype=torch.float32) if ctx.needs_input_grad[1] else None
+        return dx, dW, None
+
+
+def dense_cd(x, W, holder, tag="_wpad"):
+    """x [n, Kp >= K] in the compute dtype, W fp32 [N, K]; `holder` (a module) keeps the padded compute-dtype
+    image of W between calls."""
+    N, K = W.shape
+    tag = f"{tag}_{x.shape[1]}_{str(x.dtype).split('.')[-1]}"   # one image per input width: training (padded) and
+    buf = getattr(holder, tag, None)                            # inference (unpadded) keep theirs, addresses stay valid
+    if buf is None or buf.device != x.device:
+        buf = torch.zeros((N, x.shape[1]), dtype=x.dtype, device=x.device)
+        object.__setattr__(holder, tag, buf)       # plain attribute: not a parameter, not a buffer (state_dict unchanged)
+    return _DenseCD.apply(x, W, buf)
+
+
 # ----------------------------------------------------------------------------- loss tail (single-workgroup kernels)
 
 class _LatentHead(torch.autograd.Function):
