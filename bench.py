@@ -289,7 +289,7 @@ def _main(real_stdout):
         if dom == "fused_pass" and I == 10000 and args.ot_storage == "f32" and os.path.exists(pmc):
             import csv
             for row in csv.reader(open(pmc)):
-                if row and "k_fused_pass<float, 5, 2>" in row[0]:
+                if row and "k_fused_pass<float, 5, 2" in row[0]:
                     roof["traffic"] = (2.0 * float(row[1]) + float(row[3])) * 1024.0
                     roof["traffic_source"] = "profiles/r01/sinkhorn_cfg3_f32_pmc_summary.csv (2*FETCH_SIZE + WRITE_SIZE, bytes per launch)"
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
