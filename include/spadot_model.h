@@ -118,6 +118,26 @@ int spadot_elbo_backward(const void *g2, const void *mu, const void *var, const 
                          void *g_mu, void *g_var, void *g_mv, void *g_tr, void *g_pm, void *g_pv,
                          void *stream);
 
+/* SVGP branch after the batched inverse, all latent dimensions, fp64 (svgp.py:62-104, SpaDOT.py:72-77).
+ * forward: raw = X2 r^T [2b, L] (X2 = [K_nm; K_nm K^-1 K_mm]), rd = rowdot(X2 S, X2) [L, 2b], r and Mr = r M [L, m],
+ * ld [2L] log-determinants, sm [L] = <S_l, M>, mu / var [b, L] encoder output, ktilde [b]  ->  p_m, mv, p_v, tr [b, L]
+ * and out4 = (l3, ce, KL sum, SVGP_KL = -|ce - (l3 - (b/N) KL)| / L); kl_const = log|K| - m log j - m.
+ * backward: g_skl fp32 device scalar, G_pm / G_pv upstream gradients or NULL -> direct g_mu, g_var [b, L], the operands
+ * G1 [2b, L] and G2T [L, 2b] of the algebra's backward, g_kl, gMr = g_kl c^2 Mr [L, m], gM = g_kl/2 M [m, m].
+ * grad_tail: the last element-wise step of that backward (see model/svgp.py:_SVGPCore). */
+int spadot_svgp_post_forward(const double *raw, const double *rd, const double *r, const double *Mr, const double *ld,
+                             const double *sm, const double *mu, const double *var, const double *ktilde, int b, int L,
+                             int m, double c, double kl_const, double b_over_N, double *p_m, double *mv, double *p_v,
+                             double *tr, double *out4, void *stream);
+int spadot_svgp_post_backward(const float *g_skl, const double *out4, const double *G_pm, const double *G_pv,
+                              const double *mu, const double *var, const double *mv, const double *tr, const double *p_m,
+                              const double *p_v, const double *ktilde, const double *Mr, const double *M, int b, int L,
+                              int m, double c, double b_over_N, double *g_mu, double *g_var, double *G1, double *G2T,
+                              double *g_kl, double *gMr, double *gM, void *stream);
+int spadot_svgp_grad_tail(const double *q1, const double *q2, const double *Kdt, const double *p_v, const double *ktilde,
+                          const double *p_m, const double *mu, const double *w, const double *g_kl, const double *g_mu,
+                          const double *g_var, int b, int L, double c, double *dmu, double *dvar, void *stream);
+
 /* ---------------------------------------------------------------- loss tail of a training step
  * Single-workgroup kernels for the b x 20 / 10 x 10 arithmetic after the encoders (each replaces a few dozen
  * library launches; reductions in a fixed order, fp64 accumulators).

@@ -706,6 +706,100 @@ __global__ __launch_bounds__(1024) void k_elbo_fwd(const T *mu, const T *var, co
     if (threadIdx.x == 0) { out2[0] = (T)(-0.5 * l3); out2[1] = (T)(-0.5 * ce); }
 }
 
+// ------------------------------------------------------------------------------------------
+// SVGP branch after the batched inverse (fp64, single workgroup: b*L ~ 5k elements, L*m ~ 2.4k, m*m ~ 58k).
+//   raw = X2 r^T [2b, L] with X2 = [K_nm; P];  rd = rowdot(X2 S, X2) [L, 2b];  r, Mr [L, m];  ld [2L];  sm [L]
+//   p_m = c raw[:b], mv = c raw[b:], p_v = k~ + rd[:, :b]^T, tr = rd[:, b:]^T                         (svgp.py:62-84)
+//   l3, ce as k_elbo_fwd; kl = sum_l 1/2 (kl_const + ld_l - ld_{L+l} + sm_l + c^2 Mr_l . r_l)        (svgp.py:86-104)
+//   SVGP_KL = -|ce - (l3 - (b/N) kl)| / L                                                             (SpaDOT.py:72-77)
+//   out4 = (l3, ce, kl, SVGP_KL)
+__global__ __launch_bounds__(1024) void k_svgp_post_fwd(const double *__restrict__ raw, const double *__restrict__ rd,
+                                                        const double *__restrict__ r, const double *__restrict__ Mr,
+                                                        const double *__restrict__ ld, const double *__restrict__ sm,
+                                                        const double *__restrict__ mu, const double *__restrict__ var,
+                                                        const double *__restrict__ kt, int b, int L, int m, double c,
+                                                        double kl_const, double b_over_N, double *__restrict__ p_m,
+                                                        double *__restrict__ mv, double *__restrict__ p_v,
+                                                        double *__restrict__ tr, double *__restrict__ out4) {
+    __shared__ double sh[16];
+    double l3 = 0.0, ce = 0.0, kl = 0.0;
+    const int tot = b * L;
+    for (int e = threadIdx.x; e < tot; e += blockDim.x) {
+        const int i = e / L, l = e - i * L;
+        const double pm = c * raw[e], mvv = c * raw[(size_t)(b + i) * L + l];
+        const double pv = kt[i] + rd[(size_t)l * 2 * b + i], trv = rd[(size_t)l * 2 * b + b + i];
+        p_m[e] = pm; mv[e] = mvv; p_v[e] = pv; tr[e] = trv;
+        const double v = var[e], m_ = mu[e], d = m_ - mvv;
+        l3 += (kt[i] + trv) / v + log(v) + LOG_2PI + d * d / v;
+        ce += LOG_2PI + log(v) + (pv + pm * pm - 2.0 * pm * m_ + m_ * m_) / v;
+    }
+    for (int e = threadIdx.x; e < L * m; e += blockDim.x) kl += c * c * Mr[e] * r[e];
+    for (int l = threadIdx.x; l < L; l += blockDim.x) kl += kl_const + ld[l] - ld[L + l] + sm[l];
+    l3 = -0.5 * block_sum_d(l3, sh);
+    ce = -0.5 * block_sum_d(ce, sh);
+    kl = 0.5 * block_sum_d(kl, sh);
+    if (threadIdx.x == 0) {
+        out4[0] = l3; out4[1] = ce; out4[2] = kl;
+        out4[3] = -fabs(ce - (l3 - b_over_N * kl)) / L;
+    }
+}
+
+// Backward of the above: g_skl = d loss / d SVGP_KL (fp32 device scalar), G_pm / G_pv = upstream gradients of the
+// posterior (from the latent head; may be null).  Writes the direct gradients g_mu, g_var [b, L], the two operands of
+// the algebra's backward G1 = [dL/dp_m; dL/dmv] [2b, L] and G2T = [dL/dp_v | dL/dtr]^T [L, 2b], the scalar g_kl,
+// gMr = g_kl c^2 Mr [L, m] and gM = g_kl/2 M [m, m].
+__global__ __launch_bounds__(256) void k_svgp_post_bwd(const float *__restrict__ g_skl, const double *__restrict__ out4,
+                                                       const double *__restrict__ G_pm, const double *__restrict__ G_pv,
+                                                       const double *__restrict__ mu, const double *__restrict__ var,
+                                                       const double *__restrict__ mv, const double *__restrict__ tr,
+                                                       const double *__restrict__ pm, const double *__restrict__ pv,
+                                                       const double *__restrict__ kt, const double *__restrict__ Mr,
+                                                       const double *__restrict__ M, int b, int L, int m, double c,
+                                                       double b_over_N, double *__restrict__ g_mu,
+                                                       double *__restrict__ g_var, double *__restrict__ G1,
+                                                       double *__restrict__ G2T, double *__restrict__ g_kl,
+                                                       double *__restrict__ gMr, double *__restrict__ gM) {
+    const double gs = g_skl ? (double)g_skl[0] : 0.0;
+    const double dd = out4[1] - (out4[0] - b_over_N * out4[2]);
+    const double sg = dd > 0.0 ? 1.0 : (dd < 0.0 ? -1.0 : 0.0);
+    const double gl = -0.5 * (gs * sg / L), gc = -0.5 * (-gs * sg / L);     // through l3 = -1/2 sum, ce = -1/2 sum
+    const double gk = -gs * sg * b_over_N / L;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx == 0) g_kl[0] = gk;
+    if (idx < (long long)b * L) {
+        const int e = (int)idx, i = e / L, l = e - i * L;
+        const double v = var[e], m_ = mu[e], d = m_ - mv[e], p = pm[e];
+        const double q = pv[e] + p * p - 2.0 * p * m_ + m_ * m_;
+        const double a3 = kt[i] + tr[e];
+        g_mu[e] = gl * (2.0 * d / v) + gc * ((2.0 * m_ - 2.0 * p) / v);
+        g_var[e] = gl * (-a3 / (v * v) + 1.0 / v - d * d / (v * v)) + gc * (1.0 / v - q / (v * v));
+        G1[e] = (G_pm ? G_pm[e] : 0.0) + gc * ((2.0 * p - 2.0 * m_) / v);
+        G1[(size_t)(b + i) * L + l] = gl * (-2.0 * d / v);
+        G2T[(size_t)l * 2 * b + i] = (G_pv ? G_pv[e] : 0.0) + gc / v;
+        G2T[(size_t)l * 2 * b + b + i] = gl / v;
+    }
+    if (idx < (long long)L * m) gMr[idx] = gk * c * c * Mr[idx];
+    if (idx < (long long)m * m) gM[idx] = 0.5 * gk * M[idx];
+}
+
+// Last step of the algebra's backward: q1 = diag(K_nm S D S K_mn) [L, b], q2 = diag(K_nm S2 K_mn) [L, b],
+// Kdt = K_nm dt [b, L]:  dw = c (g_kl/2 (p_v - k~ - q2) - q1) + (mu - p_m) Kdt,  dmu = w Kdt + g_mu,  dvar = -dw w^2 + g_var.
+__global__ __launch_bounds__(256) void k_svgp_grad_tail(const double *__restrict__ q1, const double *__restrict__ q2,
+                                                        const double *__restrict__ Kdt, const double *__restrict__ pv,
+                                                        const double *__restrict__ kt, const double *__restrict__ pm,
+                                                        const double *__restrict__ mu, const double *__restrict__ w,
+                                                        const double *__restrict__ g_kl, const double *__restrict__ g_mu,
+                                                        const double *__restrict__ g_var, int b, int L, double c,
+                                                        double *__restrict__ dmu, double *__restrict__ dvar) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= b * L) return;
+    const int i = e / L, l = e - i * L;
+    const double g = g_kl[0], ww = w[e], kd = Kdt[e];
+    const double dw = c * (0.5 * g * (pv[e] - kt[i] - q2[(size_t)l * b + i]) - q1[(size_t)l * b + i]) + (mu[e] - pm[e]) * kd;
+    dmu[e] = ww * kd + g_mu[e];
+    dvar[e] = -dw * ww * ww + g_var[e];
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_elbo_bwd(const T *g2, const T *mu, const T *var, const T *mv,
                                                   const T *tr, const T *pm, const T *pv, const T *kt, int b,
@@ -1231,6 +1325,40 @@ int spadot_elbo_backward(const void *g2, const void *mu, const void *var, const 
     FP_DISPATCH(dtype,
                 hipLaunchKernelGGL(k_elbo_bwd<float>, g, dim3(256), 0, st_, (const float *)g2, (const float *)mu, (const float *)var, (const float *)mv, (const float *)tr, (const float *)pm, (const float *)pv, (const float *)ktilde, b, L, (float *)g_mu, (float *)g_var, (float *)g_mv, (float *)g_tr, (float *)g_pm, (float *)g_pv),
                 hipLaunchKernelGGL(k_elbo_bwd<double>, g, dim3(256), 0, st_, (const double *)g2, (const double *)mu, (const double *)var, (const double *)mv, (const double *)tr, (const double *)pm, (const double *)pv, (const double *)ktilde, b, L, (double *)g_mu, (double *)g_var, (double *)g_mv, (double *)g_tr, (double *)g_pm, (double *)g_pv));
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+int spadot_svgp_post_forward(const double *raw, const double *rd, const double *r, const double *Mr, const double *ld,
+                             const double *sm, const double *mu, const double *var, const double *ktilde, int b, int L,
+                             int m, double c, double kl_const, double b_over_N, double *p_m, double *mv, double *p_v,
+                             double *tr, double *out4, void *stream) {
+    if (b <= 0 || L <= 0 || m <= 0) return -22;
+    hipLaunchKernelGGL(k_svgp_post_fwd, dim3(1), dim3(1024), 0, (hipStream_t)stream, raw, rd, r, Mr, ld, sm, mu, var, ktilde,
+                       b, L, m, c, kl_const, b_over_N, p_m, mv, p_v, tr, out4);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+int spadot_svgp_post_backward(const float *g_skl, const double *out4, const double *G_pm, const double *G_pv,
+                              const double *mu, const double *var, const double *mv, const double *tr, const double *p_m,
+                              const double *p_v, const double *ktilde, const double *Mr, const double *M, int b, int L,
+                              int m, double c, double b_over_N, double *g_mu, double *g_var, double *G1, double *G2T,
+                              double *g_kl, double *gMr, double *gM, void *stream) {
+    if (b <= 0 || L <= 0 || m <= 0) return -22;
+    long long tot = (long long)b * L;
+    if ((long long)L * m > tot) tot = (long long)L * m;
+    if ((long long)m * m > tot) tot = (long long)m * m;
+    hipLaunchKernelGGL(k_svgp_post_bwd, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g_skl, out4,
+                       G_pm, G_pv, mu, var, mv, tr, p_m, p_v, ktilde, Mr, M, b, L, m, c, b_over_N, g_mu, g_var, G1, G2T,
+                       g_kl, gMr, gM);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+int spadot_svgp_grad_tail(const double *q1, const double *q2, const double *Kdt, const double *p_v, const double *ktilde,
+                          const double *p_m, const double *mu, const double *w, const double *g_kl, const double *g_mu,
+                          const double *g_var, int b, int L, double c, double *dmu, double *dvar, void *stream) {
+    if (b <= 0 || L <= 0) return -22;
+    hipLaunchKernelGGL(k_svgp_grad_tail, dim3((b * L + 255) / 256), dim3(256), 0, (hipStream_t)stream, q1, q2, Kdt, p_v,
+                       ktilde, p_m, mu, w, g_kl, g_mu, g_var, b, L, c, dmu, dvar);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 

@@ -24,6 +24,7 @@ class SpaDOT(nn.Module):
         self.GAT_z_dim = model_config["z_dim"] // 2
         self.dtype = torch.float32
         self.compute_dtype = model_config.get("compute_dtype", torch.float32)
+        self.svgp_issue = model_config.get("svgp_issue", __import__("os").environ.get("SPADOT_SVGP_ISSUE", "first"))
         self.device = torch.device(model_config["device"])
 
         self.SVGPEncoder = SVGPEncoder(input_dim=self.input_dim, SVGP_z_dim=self.SVGP_z_dim,
@@ -55,23 +56,32 @@ class SpaDOT(nn.Module):
         b = batch_size
         svgp = self.svgp_dict[str(tp)]
         yb = y[:b, :self.input_dim]                 # y may carry zero pad columns (cached batch inputs)
-        # The SVGP branch is latency-bound (L small matrices: a handful of CUs) and the GAT branch is
-        # bandwidth-bound; they are independent until the latent head, so the SVGP branch runs on a side HIP
-        # stream and overlaps the GAT branch (autograd replays each op's backward on its forward stream).
-        # The GAT branch is ISSUED first: its dozen long kernels are queued at once and the ~60 short SVGP
-        # launches follow while they run (in a captured graph the nodes replay in this order too).
+        # The SVGP branch is latency-bound (L small matrices: a handful of CUs, ~110 short launches) and the GAT
+        # branch is bandwidth-bound; they are independent until the latent head, so the SVGP branch runs on a side
+        # HIP stream beside the GAT branch (autograd replays each op's backward on its forward stream).
+        # Kernels are dispatched in ISSUE order (also when a captured graph replays), and a launch that waits on
+        # its predecessor holds back whatever was issued after it, so the two branches are interleaved by hand:
+        # largest GAT GEMM | SVGP encoder + Sigma + the batched inverse (its long pole) | rest of the GAT branch |
+        # rest of the SVGP branch.
         main = torch.cuda.current_stream()
         side = self._side_stream()
         side.wait_stream(main)
-        zg = self.GATEncoder.pre_head(y, edge_index, rows=b)               # [b, 2 Lg]: mu | logvar
+        state = {}
+
+        def svgp_first_half():
+            with torch.cuda.stream(side):
+                q_mu, q_var = self.SVGPEncoder(yb)
+                state["bc"] = svgp.batch_constants(x[:b], key=batch_key)
+                state["started"] = svgp.elbo_start(state["bc"], q_mu, q_var)
+
+        if self.svgp_issue == "first":
+            svgp_first_half()
+            zg = self.GATEncoder.pre_head(y, edge_index, rows=b)                                   # [b, 2 Lg]: mu | logvar
+        else:
+            zg = self.GATEncoder.pre_head(y, edge_index, rows=b, after_first_dense=svgp_first_half)
         with torch.cuda.stream(side):
-            q_mu, q_var = self.SVGPEncoder(yb)
-            bc = svgp.batch_constants(x[:b], key=batch_key)
-            p_m, p_v, l3_sum, kl_sum, ce = svgp.elbo_terms(bc, q_mu, q_var)
-            inside_elbo = l3_sum - (b / float(svgp.N_train)) * kl_sum
-            diff = ce - inside_elbo
-            # sign trick of SpaDOT.py:76-77 without the host round trip: -(|diff|) either way
-            SVGP_KL = (-torch.abs(diff) / self.SVGP_z_dim).float()
+            # posterior + SVGP_KL = -|ce - (l3 - b/N KL)| / L (sign trick of SpaDOT.py:76-77, no host round trip)
+            p_m, p_v, SVGP_KL = svgp.elbo_finish(state["bc"], state["started"])
 
         Ls, Lg = self.SVGP_z_dim, self.GAT_z_dim
         if noise is None:

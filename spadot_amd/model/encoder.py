@@ -69,14 +69,20 @@ class GATConv(nn.Module):
 
     def forward(self, x, graph, act=False):
         H, C = self.heads, self.out_channels
-        if not isinstance(graph, BatchGraph):
-            graph = build_batch_graph(graph, x.shape[0], x.device)
+        return self.edge(self.dense(x), graph, act)
+
+    def dense(self, x):
+        """h = x W^T  [n, H*C] (MFMA GEMM in the compute dtype; x may be K-padded)."""
         cd = self.compute_dtype
         if cd == torch.float32:
-            h = F.linear(x[:, :self.in_channels].float(), self.lin.weight)
-        else:                                                       # [n, H*C]  (MFMA GEMM; x may be K-padded)
-            h = dense_cd(x.to(cd), self.lin.weight, self)
-        return gat_edge(h, self.att_src, self.att_dst, self.bias, graph, H, C, self.concat, act)
+            return F.linear(x[:, :self.in_channels].float(), self.lin.weight)
+        return dense_cd(x.to(cd), self.lin.weight, self)
+
+    def edge(self, h, graph, act=False):
+        """Everything after the dense map (ops.gat_edge)."""
+        if not isinstance(graph, BatchGraph):
+            graph = build_batch_graph(graph, h.shape[0], h.device)
+        return gat_edge(h, self.att_src, self.att_dst, self.bias, graph, self.heads, self.out_channels, self.concat, act)
 
 
 class GATEncoder(nn.Module):
@@ -95,11 +101,18 @@ class GATEncoder(nn.Module):
         mu, logvar = torch.chunk(self.pre_head(x, edge_index, rows), 2, dim=1)
         return mu, torch.exp(logvar)
 
-    def pre_head(self, x, edge_index, rows=None):
-        """GAT_fc output (mu | logvar) [rows or n, 2 z]: what ops.latent_head consumes."""
+    def pre_head(self, x, edge_index, rows=None, after_first_dense=None):
+        """GAT_fc output (mu | logvar) [rows or n, 2 z]: what ops.latent_head consumes.
+        after_first_dense: optional callable run right after the first (largest) GEMM has been issued -- the
+        composite model issues the start of its SVGP branch there, on another stream."""
         lg = getattr(edge_index, "layer_graphs", None) if rows is not None else None
         g3 = getattr(edge_index, "seed_graph", None) if rows is not None else None
-        h = self.gat1(x, edge_index, act=True)
+        if not isinstance(edge_index, BatchGraph):
+            edge_index = build_batch_graph(edge_index, x.shape[0], x.device)
+        h = self.gat1.dense(x)
+        if after_first_dense is not None:
+            after_first_dense()
+        h = self.gat1.edge(h, edge_index, act=True)
         if lg is not None and lg[1].n_tgt == rows:
             # only what the seeds' rows of layer 3 depend on: layer 2 for seeds + hop 1, layer 3 for the seeds
             h = self.gat2(h, lg[0], act=True)

@@ -18,7 +18,8 @@ library's batched routines.
 import torch
 import torch.nn as nn
 
-from ..ops import elbo_reduce, kernel_matrix, rowdot, spd_inverse_logdet
+from .._lib import model_lib
+from ..ops import _check, _p, _stream, elbo_reduce, kernel_matrix, rowdot, spd_inverse_logdet
 
 F64 = torch.float64
 
@@ -43,12 +44,13 @@ class BatchConstants:
 
 class RunConstants:
     """Per time point: everything built from the inducing points alone (not trainable: svgp.py:24-30)."""
-    __slots__ = ("K_mm", "K_inv", "logdet_K", "eye", "KjI", "K2j", "M", "m", "mlogj")
+    __slots__ = ("K_mm", "K_inv", "logdet_K", "logdet_K_f", "eye", "KjI", "K2j", "M", "m", "mlogj")
 
 
 class _SVGPCore(torch.autograd.Function):
-    """The encoder-dependent part of svgp.py:47-104 for all L latent dimensions, forward and HAND-WRITTEN
-    backward (autograd through the same algebra costs ~160 launches a step, this ~45).
+    """The encoder-dependent part of svgp.py:47-104 for all L latent dimensions plus SpaDOT.py:72-77, forward and
+    HAND-WRITTEN backward: (mu, var) -> (p_m, p_v, SVGP_KL).  Autograd through the same algebra costs ~200
+    launches a step, this ~30.
 
     With S_l = (K + jI + c K_mn diag(w_l) K_nm)^-1, w = 1/var, t_l = K_mn (mu_l w_l), r_l = S_l t_l,
     M = K K_j^-1 K and P = K_nm K_j^-1 K (batch constant):
@@ -56,60 +58,88 @@ class _SVGPCore(torch.autograd.Function):
         p_v = k~ + diag(K_nm S K_mn)        tr = diag(P S P^T)
         KL_l = 1/2 (log|K_j| - log|A_hat_l + jI| - m + <S_l, M> + c^2 r_l^T M r_l)
     (tr(K_j^-1 A_hat) = <S, M> and mu_hat^T K_j^-1 mu_hat = c^2 r^T M r: A_hat and mu_hat are never formed),
-    log|A_hat + jI| by Sylvester's identity from log|Sigma| and log|Sigma + K^2/j| (one sweep, 2L matrices).
+    log|A_hat + jI| by Sylvester's identity from log|Sigma| and log|Sigma + K^2/j| (one sweep, 2L matrices);
+    l3, the cross entropy and SVGP_KL = -|ce - (l3 - (b/N) KL)| / L in the same kernel (k_svgp_post_fwd).
     Backward, with D_l = K_mn diag(G_pv) K_nm + P^T diag(G_tr) P + g/2 M, dr = c K_mn G_pm + c P^T G_mv + g c^2 M r,
     dt = S dr:   dSigma_l = -S D S - dt r^T + g/2 (S - S2),  S2 = (Sigma + K^2/j)^-1,
-        dw = c diag(K_nm dSigma K_mn) + mu (K_nm dt),   dmu = w (K_nm dt),   dvar = -dw w^2."""
+        dw = c diag(K_nm dSigma K_mn) + mu (K_nm dt),   dmu = w (K_nm dt),   dvar = -dw w^2  (+ the direct terms)."""
 
     @staticmethod
-    def forward(ctx, mu, var, bc, rc):
+    def start(mu, var, bc, rc):
+        """First half of forward: Sigma_l for every latent dim, the sweep launch (the long pole of the branch,
+        ~0.2 ms on 2L compute units) and t.  Separate so that the caller can issue it early."""
+        with torch.no_grad():
+            b, L = mu.shape
+            m, c = rc.m, bc.c
+            Kn = bc.K_nm
+            w = 1.0 / var
+            A = Kn.unsqueeze(0) * w.T.unsqueeze(2)                           # [L, b, m] = diag(w_l) K_nm
+            buf = torch.empty((2 * L, m, m), dtype=F64, device=mu.device)
+            torch.baddbmm(rc.KjI.expand(L, m, m), A.transpose(1, 2), Kn.unsqueeze(0).expand(L, b, m), alpha=c, out=buf[:L])
+            torch.add(buf[:L], rc.K2j, out=buf[L:])
+            X, ld = spd_inverse_logdet(buf)
+            t = (mu * w).T @ Kn                                              # [L, m]
+        return w, X, ld, t
+
+    @staticmethod
+    def forward(ctx, mu, var, bc, rc, started, b_over_N):
         b, L = mu.shape
         m, c = rc.m, bc.c
-        Kn, X2 = bc.K_nm, bc.X2
-        w = 1.0 / var
-        A = Kn.unsqueeze(0) * w.T.unsqueeze(2)                               # [L, b, m] = diag(w_l) K_nm
-        buf = torch.empty((2 * L, m, m), dtype=F64, device=mu.device)
-        torch.baddbmm(rc.KjI.expand(L, m, m), A.transpose(1, 2), Kn.unsqueeze(0).expand(L, b, m), alpha=c, out=buf[:L])
-        torch.add(buf[:L], rc.K2j, out=buf[L:])
-        X, ld = spd_inverse_logdet(buf)
+        X2 = bc.X2
+        lib = model_lib()
+        w, X, ld, t = started if started is not None else _SVGPCore.start(mu, var, bc, rc)
         S = X[:L]
-        t = (mu * w).T @ Kn                                                  # [L, m]
         r = torch.bmm(S, t.unsqueeze(2)).squeeze(2)                          # [L, m]
-        pm_mv = c * (X2 @ r.T)                                               # [2b, L]
+        raw = X2 @ r.T                                                       # [2b, L]
         X2S = torch.matmul(X2, S)                                            # [L, 2b, m]
         rd = rowdot(X2S, X2)                                                 # [L, 2b]
-        p_m, mv = pm_mv[:b], pm_mv[b:]
-        p_v = bc.ktilde.unsqueeze(1) + rd[:, :b].T
-        tr = rd[:, b:].T
         Mr = r @ rc.M                                                        # [L, m]  (M symmetric)
-        sm = torch.mv(S.reshape(L, m * m), rc.M.reshape(m * m))               # <S_l, M>
-        kl = 0.5 * (rc.logdet_K - rc.mlogj + ld[:L] - ld[L:] - m + sm + (c * c) * (Mr * r).sum(dim=1))
-        ctx.save_for_backward(mu, w, X, r, Mr, X2S, p_m, p_v)
-        ctx.bc, ctx.rc = bc, rc
-        return p_m, p_v, mv, tr, kl.sum()
+        sm = torch.mv(S.reshape(L, m * m), rc.M.reshape(m * m))              # <S_l, M>
+        p_m, mv, p_v, tr = (torch.empty((b, L), dtype=F64, device=mu.device) for _ in range(4))
+        out4 = torch.empty(4, dtype=F64, device=mu.device)
+        mu, var = mu.contiguous(), var.contiguous()
+        _check(lib.spadot_svgp_post_forward(_p(raw), _p(rd), _p(r), _p(Mr), _p(ld), _p(sm), _p(mu), _p(var), _p(bc.ktilde),
+                                            b, L, m, c, rc.logdet_K_f - rc.mlogj - m, b_over_N, _p(p_m), _p(mv), _p(p_v), _p(tr),
+                                            _p(out4), _stream()), "spadot_svgp_post_forward")
+        ctx.save_for_backward(mu, var, w, X, r, Mr, X2S, p_m, p_v, mv, tr, out4)
+        ctx.bc, ctx.rc, ctx.bN = bc, rc, b_over_N
+        ctx.mark_non_differentiable(out4)
+        return p_m, p_v, out4[3].float(), out4
 
     @staticmethod
-    def backward(ctx, G_pm, G_pv, G_mv, G_tr, g_kl):
-        mu, w, X, r, Mr, X2S, p_m, p_v = ctx.saved_tensors
+    def backward(ctx, G_pm, G_pv, g_skl, _unused):
+        mu, var, w, X, r, Mr, X2S, p_m, p_v, mv, tr, out4 = ctx.saved_tensors
         bc, rc = ctx.bc, ctx.rc
         b, L = mu.shape
         m, c = rc.m, bc.c
         Kn, X2 = bc.K_nm, bc.X2
         S, S2 = X[:L], X[L:]
-        z = lambda g: torch.zeros((b, L), dtype=F64, device=mu.device) if g is None else g
-        g = torch.zeros((), dtype=F64, device=mu.device) if g_kl is None else g_kl
-        G1 = torch.cat([z(G_pm), z(G_mv)], dim=0)                            # [2b, L]
-        G2 = torch.cat([z(G_pv), z(G_tr)], dim=0)
-        dr = c * (G1.T @ X2) + (g * (c * c)) * Mr                            # [L, m]
+        lib = model_lib()
+        dev = mu.device
+        g_mu, g_var, dmu, dvar = (torch.empty((b, L), dtype=F64, device=dev) for _ in range(4))
+        G1 = torch.empty((2 * b, L), dtype=F64, device=dev)
+        G2T = torch.empty((L, 2 * b), dtype=F64, device=dev)
+        g_kl = torch.empty(1, dtype=F64, device=dev)
+        gMr = torch.empty((L, m), dtype=F64, device=dev)
+        gM = torch.empty((m, m), dtype=F64, device=dev)
+        keep = [None if g is None else g.contiguous() for g in (G_pm, G_pv)]
+        gs = None if g_skl is None else g_skl.contiguous().float()
+        opt = lambda t_: None if t_ is None else _p(t_)
+        _check(lib.spadot_svgp_post_backward(opt(gs), _p(out4), opt(keep[0]), opt(keep[1]), _p(mu), _p(var), _p(mv), _p(tr),
+                                             _p(p_m), _p(p_v), _p(bc.ktilde), _p(Mr), _p(rc.M), b, L, m, c, ctx.bN, _p(g_mu),
+                                             _p(g_var), _p(G1), _p(G2T), _p(g_kl), _p(gMr), _p(gM), _stream()),
+               "spadot_svgp_post_backward")
+        dr = torch.addmm(gMr, G1.T, X2, alpha=c)                             # [L, m]
         dt = torch.bmm(S, dr.unsqueeze(2)).squeeze(2)                        # [L, m]
-        A2 = X2.unsqueeze(0) * G2.T.unsqueeze(2)                             # [L, 2b, m]
-        D = torch.baddbmm(((0.5 * g) * rc.M).expand(L, m, m), A2.transpose(1, 2), X2.unsqueeze(0).expand(L, 2 * b, m))
+        A2 = X2.unsqueeze(0) * G2T.unsqueeze(2)                              # [L, 2b, m]
+        D = torch.baddbmm(gM.expand(L, m, m), A2.transpose(1, 2), X2.unsqueeze(0).expand(L, 2 * b, m))
         KS = X2S[:, :b].contiguous()                                         # [L, b, m] = K_nm S_l
         q1 = rowdot(torch.bmm(KS, D).reshape(1, L * b, m), KS.reshape(L * b, m)).reshape(L, b)
         q2 = rowdot(torch.matmul(Kn, S2), Kn)                                # diag(K_nm S2 K_mn)  [L, b]
         Kdt = Kn @ dt.T                                                      # [b, L]
-        dw = c * ((0.5 * g) * (p_v - bc.ktilde.unsqueeze(1) - q2.T) - q1.T) + (mu - p_m) * Kdt
-        return w * Kdt, -dw * (w * w), None, None
+        _check(lib.spadot_svgp_grad_tail(_p(q1), _p(q2), _p(Kdt), _p(p_v), _p(bc.ktilde), _p(p_m), _p(mu), _p(w), _p(g_kl),
+                                         _p(g_mu), _p(g_var), b, L, c, _p(dmu), _p(dvar), _stream()), "spadot_svgp_grad_tail")
+        return dmu, dvar, None, None, None, None
 
 
 class SVGP(nn.Module):
@@ -198,11 +228,26 @@ class SVGP(nn.Module):
 
     def elbo_terms(self, bc, mu, var):
         """(p_m, p_v, l3_sum, kl_sum, ce_sum) of one training batch: svgp.py:47-104 over all latent
-        dimensions + the Gaussian cross entropy of SpaDOT.py:74-75."""
+        dimensions + the Gaussian cross entropy of SpaDOT.py:74-75 (values; gradients flow through
+        elbo_start/elbo_finish's SVGP_KL, which is what the training step uses)."""
+        p_m, p_v, _, out4 = self._finish(bc, self.elbo_start(bc, mu, var))
+        return p_m, p_v, out4[0], out4[2], out4[1]
+
+    def elbo_start(self, bc, mu, var):
+        """Builds Sigma_l and launches the batched inverse; elbo_finish() does the rest.  Two calls so that the
+        composite model can issue the GAT kernels in between (the sweep then runs beside them)."""
         mu, var = mu.to(F64), var.to(F64)
-        p_m, p_v, mv, tr, kl_sum = _SVGPCore.apply(mu, var, bc, self._rc())
-        l3_sum, ce_sum = elbo_reduce(mu, var, mv, tr, p_m, p_v, bc.ktilde)
-        return p_m, p_v, l3_sum, kl_sum, ce_sum
+        return mu, var, _SVGPCore.start(mu.detach(), var.detach(), bc, self._rc())
+
+    def _finish(self, bc, started):
+        mu, var, pre = started
+        return _SVGPCore.apply(mu, var, bc, self._rc(), pre, bc.b / float(self.N_train))
+
+    def elbo_finish(self, bc, started):
+        """(p_m, p_v, SVGP_KL): posterior at the batch points and -|ce - (l3 - b/N KL)| / L (SpaDOT.py:72-77: the
+        sign trick without its host round trip)."""
+        p_m, p_v, skl, _ = self._finish(bc, started)
+        return p_m, p_v, skl
 
     def _rc(self):
         if getattr(self, "_rc_obj", None) is None:
@@ -215,6 +260,7 @@ class SVGP(nn.Module):
             rc.M = (K_mm @ K_inv @ K_mm)
             rc.M = (0.5 * (rc.M + rc.M.T)).contiguous()
             rc.mlogj = rc.m * float(torch.log(torch.tensor(self.jitter, dtype=F64)))
+            rc.logdet_K_f = float(logdet_K)
             self._rc_obj = rc
         return self._rc_obj
 
