@@ -118,6 +118,26 @@ int spadot_elbo_backward(const void *g2, const void *mu, const void *var, const 
                          void *g_mu, void *g_var, void *g_mv, void *g_tr, void *g_pm, void *g_pv,
                          void *stream);
 
+/* ---------------------------------------------------------------- small-MLP stages (encoder.py:7-34, decoder.py:3-20)
+ * BatchNorm1d in training mode + LeakyReLU(slope) in one launch: y = leaky((x + lin_bias - mean) invstd gamma + beta);
+ * x [b, F] fp32 or bf16 (the preceding Linear's output WITHOUT its bias; lin_bias [F] or NULL is added here), batch
+ * statistics over the b rows, running_mean / running_var / num_batches_tracked updated as nn.BatchNorm1d does
+ * (momentum; unbiased running variance).  save_mean / save_invstd [F] feed the backward, which returns dx (dtype of x),
+ * dgamma, dbeta (the gradient of lin_bias is identically zero: the batch mean removes it).
+ * LayerNorm over the F features + LeakyReLU likewise (fp32; save_mean / save_invstd [b]). */
+int spadot_bn_act_forward(const void *x, int x_dtype, const float *lin_bias, const float *gamma, const float *beta,
+                          float *running_mean, float *running_var, long long *num_batches_tracked, int b, int F,
+                          double momentum, double eps, double slope, float *y, float *save_mean, float *save_invstd,
+                          void *stream);
+int spadot_bn_act_backward(const float *dy, const float *y, const void *x, int x_dtype, const float *lin_bias,
+                           const float *gamma, const float *save_mean, const float *save_invstd, int b, int F,
+                           double slope, void *dx, float *dgamma, float *dbeta, void *stream);
+int spadot_ln_act_forward(const float *x, const float *gamma, const float *beta, int b, int F, double eps, double slope,
+                          float *y, float *save_mean, float *save_invstd, void *stream);
+int spadot_ln_act_backward(const float *dy, const float *y, const float *x, const float *gamma, const float *save_mean,
+                           const float *save_invstd, int b, int F, double slope, float *dx, float *dgamma, float *dbeta,
+                           void *stream);
+
 /* SVGP branch after the batched inverse, all latent dimensions, fp64 (svgp.py:62-104, SpaDOT.py:72-77).
  * forward: raw = X2 r^T [2b, L] (X2 = [K_nm; K_nm K^-1 K_mm]), rd = rowdot(X2 S, X2) [L, 2b], r and Mr = r M [L, m],
  * ld [2L] log-determinants, sm [L] = <S_l, M>, mu / var [b, L] encoder output, ktilde [b]  ->  p_m, mv, p_v, tr [b, L]

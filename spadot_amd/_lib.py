@@ -112,6 +112,10 @@ def model_lib():
         "spadot_rowdot_backward": [vp, vp, ci, ci, ci, ci, vp, vp],
         "spadot_elbo_forward": [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp, vp],
         "spadot_elbo_backward": [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp],
+        "spadot_bn_act_forward": [vp, ci, vp, vp, vp, vp, vp, vp, ci, ci, cd, cd, cd, vp, vp, vp, vp],
+        "spadot_bn_act_backward": [vp, vp, vp, ci, vp, vp, vp, vp, ci, ci, cd, vp, vp, vp, vp],
+        "spadot_ln_act_forward": [vp, vp, vp, ci, ci, cd, cd, vp, vp, vp, vp],
+        "spadot_ln_act_backward": [vp, vp, vp, vp, vp, vp, ci, ci, cd, vp, vp, vp, vp],
         "spadot_svgp_post_forward": [vp] * 9 + [ci, ci, ci, cd, cd, cd] + [vp] * 6,
         "spadot_svgp_post_backward": [vp] * 13 + [ci, ci, ci, cd, cd] + [vp] * 8,
         "spadot_svgp_grad_tail": [vp] * 11 + [ci, ci, cd] + [vp] * 3,

@@ -724,6 +724,7 @@ __global__ __launch_bounds__(1024) void k_svgp_post_fwd(const double *__restrict
     __shared__ double sh[16];
     double l3 = 0.0, ce = 0.0, kl = 0.0;
     const int tot = b * L;
+#pragma unroll 5
     for (int e = threadIdx.x; e < tot; e += blockDim.x) {
         const int i = e / L, l = e - i * L;
         const double pm = c * raw[e], mvv = c * raw[(size_t)(b + i) * L + l];
@@ -733,6 +734,7 @@ __global__ __launch_bounds__(1024) void k_svgp_post_fwd(const double *__restrict
         l3 += (kt[i] + trv) / v + log(v) + LOG_2PI + d * d / v;
         ce += LOG_2PI + log(v) + (pv + pm * pm - 2.0 * pm * m_ + m_ * m_) / v;
     }
+#pragma unroll 3
     for (int e = threadIdx.x; e < L * m; e += blockDim.x) kl += c * c * Mr[e] * r[e];
     for (int l = threadIdx.x; l < L; l += blockDim.x) kl += kl_const + ld[l] - ld[L + l] + sm[l];
     l3 = -0.5 * block_sum_d(l3, sh);
@@ -911,6 +913,167 @@ __global__ __launch_bounds__(256) void k_adamw(float *__restrict__ p, const floa
 }
 
 // ------------------------------------------------------------------------------------------
+// Small-MLP stages: BatchNorm1d (training) + LeakyReLU, LayerNorm + LeakyReLU, each ONE launch forward and one
+// (LayerNorm: two) backward instead of the library's 4-5 and 3-4.  b rows <= a few thousand, F features <= 1024.
+// ------------------------------------------------------------------------------------------
+constexpr int BN_COLS = 32, BN_RG = 8;      // 32 columns x 8 row lanes per workgroup
+
+__device__ __forceinline__ float bn_col_sum(float v, float (*sh)[BN_COLS + 1], int cl, int rg) {
+    __syncthreads();
+    sh[rg][cl] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < BN_RG; g++) t += sh[g][cl];
+    return t;
+}
+
+// y = leaky((x + lb - mean) invstd gamma + beta, slope); batch statistics over the b rows; running statistics
+// updated like nn.BatchNorm1d (momentum, unbiased running variance); lb = bias of the preceding Linear or null.
+template <typename TX>
+__global__ __launch_bounds__(256) void k_bn_act_fwd(const TX *__restrict__ x, const float *__restrict__ lb,
+                                                    const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                    float *__restrict__ run_mean, float *__restrict__ run_var,
+                                                    long long *__restrict__ nbt, int b, int F, float momentum, float eps,
+                                                    float slope, float *__restrict__ y, float *__restrict__ save_mean,
+                                                    float *__restrict__ save_invstd) {
+    __shared__ float sh[BN_RG][BN_COLS + 1];
+    const int cl = threadIdx.x & (BN_COLS - 1), rg = threadIdx.x >> 5;
+    const int c = blockIdx.x * BN_COLS + cl;
+    const bool on = c < F;
+    const float add = (on && lb) ? lb[c] : 0.f;
+    float s = 0.f;
+    if (on)
+#pragma unroll 4
+        for (int i = rg; i < b; i += BN_RG) s += ld<TX>(x + (size_t)i * F + c) + add;
+    const float mean = bn_col_sum(s, sh, cl, rg) / (float)b;
+    float ss = 0.f;
+    if (on)
+#pragma unroll 4
+        for (int i = rg; i < b; i += BN_RG) { const float d = ld<TX>(x + (size_t)i * F + c) + add - mean; ss += d * d; }
+    const float var = bn_col_sum(ss, sh, cl, rg) / (float)b;
+    const float invstd = rsqrtf(var + eps);
+    if (on) {
+        const float g = gamma[c] * invstd, o = beta[c];
+#pragma unroll 4
+        for (int i = rg; i < b; i += BN_RG) {
+            const float v = (ld<TX>(x + (size_t)i * F + c) + add - mean) * g + o;
+            y[(size_t)i * F + c] = v > 0.f ? v : slope * v;
+        }
+        if (rg == 0) {
+            save_mean[c] = mean; save_invstd[c] = invstd;
+            run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean;
+            run_var[c] = (1.f - momentum) * run_var[c] + momentum * var * ((float)b / (float)(b > 1 ? b - 1 : 1));
+        }
+    }
+    if (nbt && blockIdx.x == 0 && threadIdx.x == 0) nbt[0] += 1;
+}
+
+template <typename TX>
+__global__ __launch_bounds__(256) void k_bn_act_bwd(const float *__restrict__ dy, const float *__restrict__ y,
+                                                    const TX *__restrict__ x, const float *__restrict__ lb,
+                                                    const float *__restrict__ gamma, const float *__restrict__ save_mean,
+                                                    const float *__restrict__ save_invstd, int b, int F, float slope,
+                                                    TX *__restrict__ dx, float *__restrict__ dgamma,
+                                                    float *__restrict__ dbeta) {
+    __shared__ float sh[BN_RG][BN_COLS + 1];
+    const int cl = threadIdx.x & (BN_COLS - 1), rg = threadIdx.x >> 5;
+    const int c = blockIdx.x * BN_COLS + cl;
+    const bool on = c < F;
+    const float add = (on && lb) ? lb[c] : 0.f;
+    const float mean = on ? save_mean[c] : 0.f, invstd = on ? save_invstd[c] : 0.f;
+    float sb = 0.f, sg = 0.f;
+    if (on)
+#pragma unroll 4
+        for (int i = rg; i < b; i += BN_RG) {
+            const size_t e = (size_t)i * F + c;
+            const float dz = dy[e] * (y[e] > 0.f ? 1.f : slope);
+            sb += dz;
+            sg += dz * (ld<TX>(x + e) + add - mean) * invstd;
+        }
+    sb = bn_col_sum(sb, sh, cl, rg);
+    sg = bn_col_sum(sg, sh, cl, rg);
+    if (on) {
+        const float g = gamma[c] * invstd, mb = sb / (float)b, mg = sg / (float)b;
+#pragma unroll 4
+        for (int i = rg; i < b; i += BN_RG) {
+            const size_t e = (size_t)i * F + c;
+            const float dz = dy[e] * (y[e] > 0.f ? 1.f : slope);
+            const float xh = (ld<TX>(x + e) + add - mean) * invstd;
+            st<TX>(dx + e, g * (dz - mb - xh * mg));
+        }
+        if (rg == 0) { dgamma[c] = sg; dbeta[c] = sb; }
+    }
+}
+
+// LayerNorm over the F features of a row + LeakyReLU: one wave per row.
+__global__ __launch_bounds__(256) void k_ln_act_fwd(const float *__restrict__ x, const float *__restrict__ gamma,
+                                                    const float *__restrict__ beta, int b, int F, float eps, float slope,
+                                                    float *__restrict__ y, float *__restrict__ save_mean,
+                                                    float *__restrict__ save_invstd) {
+    const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= b) return;
+    const float *xr = x + (size_t)i * F;
+    float s = 0.f;
+    for (int c = lane; c < F; c += WAVE) s += xr[c];
+    const float mean = wave_sum_f(s) / (float)F;
+    float ss = 0.f;
+    for (int c = lane; c < F; c += WAVE) { const float d = xr[c] - mean; ss += d * d; }
+    const float invstd = rsqrtf(wave_sum_f(ss) / (float)F + eps);
+    for (int c = lane; c < F; c += WAVE) {
+        const float v = (xr[c] - mean) * invstd * gamma[c] + beta[c];
+        y[(size_t)i * F + c] = v > 0.f ? v : slope * v;
+    }
+    if (lane == 0) { save_mean[i] = mean; save_invstd[i] = invstd; }
+}
+
+__global__ __launch_bounds__(256) void k_ln_act_bwd_rows(const float *__restrict__ dy, const float *__restrict__ y,
+                                                         const float *__restrict__ x, const float *__restrict__ gamma,
+                                                         const float *__restrict__ save_mean,
+                                                         const float *__restrict__ save_invstd, int b, int F, float slope,
+                                                         float *__restrict__ dx) {
+    const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= b) return;
+    const size_t r = (size_t)i * F;
+    const float mean = save_mean[i], invstd = save_invstd[i];
+    float a = 0.f, bs = 0.f;
+    for (int c = lane; c < F; c += WAVE) {
+        const float dz = dy[r + c] * (y[r + c] > 0.f ? 1.f : slope) * gamma[c];
+        a += dz;
+        bs += dz * (x[r + c] - mean) * invstd;
+    }
+    a = wave_sum_f(a) / (float)F;
+    bs = wave_sum_f(bs) / (float)F;
+    for (int c = lane; c < F; c += WAVE) {
+        const float dz = dy[r + c] * (y[r + c] > 0.f ? 1.f : slope) * gamma[c];
+        dx[r + c] = invstd * (dz - a - (x[r + c] - mean) * invstd * bs);
+    }
+}
+
+// dgamma[c] = sum_i dz x_hat, dbeta[c] = sum_i dz  (column reduction, same geometry as the BatchNorm kernels)
+__global__ __launch_bounds__(256) void k_ln_act_bwd_cols(const float *__restrict__ dy, const float *__restrict__ y,
+                                                         const float *__restrict__ x, const float *__restrict__ save_mean,
+                                                         const float *__restrict__ save_invstd, int b, int F, float slope,
+                                                         float *__restrict__ dgamma, float *__restrict__ dbeta) {
+    __shared__ float sh[BN_RG][BN_COLS + 1];
+    const int cl = threadIdx.x & (BN_COLS - 1), rg = threadIdx.x >> 5;
+    const int c = blockIdx.x * BN_COLS + cl;
+    const bool on = c < F;
+    float sb = 0.f, sg = 0.f;
+    if (on)
+#pragma unroll 4
+        for (int i = rg; i < b; i += BN_RG) {
+            const size_t e = (size_t)i * F + c;
+            const float dz = dy[e] * (y[e] > 0.f ? 1.f : slope);
+            sb += dz;
+            sg += dz * (x[e] - save_mean[i]) * save_invstd[i];
+        }
+    sb = bn_col_sum(sb, sh, cl, rg);
+    sg = bn_col_sum(sg, sh, cl, rg);
+    if (on && rg == 0) { dgamma[c] = sg; dbeta[c] = sb; }
+}
+
+// ------------------------------------------------------------------------------------------
 // Loss tail of a training step: three single-workgroup kernels (b <= a few thousand seed rows, 20 latent
 // columns, ~10 clusters) in place of ~130 tiny library launches.  Reductions are in a fixed order (fp64).
 
@@ -926,12 +1089,14 @@ __global__ __launch_bounds__(512) void k_latent_head_fwd(const float *__restrict
     double kl = 0.0, al = 0.0;
     for (int i = threadIdx.x; i < b; i += blockDim.x) {
         float ns = 0.f, ng = 0.f;
+#pragma unroll 5
         for (int l = 0; l < Ls; l++) {
             const double s = p_m[(size_t)i * Ls + l] + (double)eps[(size_t)i * D + l] * sqrt(p_v[(size_t)i * Ls + l]);
             const float sf = (float)s;
             latent[(size_t)i * D + l] = sf;
             ns += sf * sf;
         }
+#pragma unroll 5
         for (int l = 0; l < Lg; l++) {
             const float mu = zg[(size_t)i * 2 * Lg + l], lv = zg[(size_t)i * 2 * Lg + Lg + l];
             const float var = expf(lv);
@@ -959,18 +1124,22 @@ __global__ __launch_bounds__(512) void k_latent_head_bwd(const float *__restrict
     const float gk = g_kl ? g_kl[0] : 0.f, ga = g_al ? g_al[0] : 0.f;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < b; i += gridDim.x * blockDim.x) {
         float ns = 0.f, ng = 0.f;
+#pragma unroll 5
         for (int l = 0; l < Ls; l++) { const float s = latent[(size_t)i * D + l]; ns += s * s; }
+#pragma unroll 5
         for (int l = 0; l < Lg; l++) { const float g = latent[(size_t)i * D + Ls + l]; ng += g * g; }
         const float rs = sqrtf(ns), rg = sqrtf(ng);
         const float d = rs / (float)Ls - rg / (float)Lg;
         const float cs = rs > 0.f ? ga * 2.f * d / ((float)Ls * rs) : 0.f;      // d align / d s = cs * s
         const float cg = rg > 0.f ? -ga * 2.f * d / ((float)Lg * rg) : 0.f;
+#pragma unroll 5
         for (int l = 0; l < Ls; l++) {
             const float gl = g_latent ? g_latent[(size_t)i * D + l] : 0.f;
             const double ds = (double)gl + (double)cs * latent[(size_t)i * D + l];
             d_pm[(size_t)i * Ls + l] = ds;
             d_pv[(size_t)i * Ls + l] = ds * (double)eps[(size_t)i * D + l] * 0.5 / sqrt(p_v[(size_t)i * Ls + l]);
         }
+#pragma unroll 5
         for (int l = 0; l < Lg; l++) {
             const float gl = g_latent ? g_latent[(size_t)i * D + Ls + l] : 0.f;
             const float dg = gl + cg * latent[(size_t)i * D + Ls + l];
@@ -986,36 +1155,41 @@ __global__ __launch_bounds__(512) void k_latent_head_bwd(const float *__restrict
 //   z [b, D] latent of the seeds; labels_all[seed_ids[i]] = cluster of seed i; centres [K, D] of this time point;
 //   prev [Kp, D] centres of the previous time point; gamma [Kp, Kl] row-normalised plan; cluster_list [Kl].
 //   work (saved for the backward): means [K*D] | cnt [K] | n_distinct | lab [b] (as floats).
-constexpr int CL_MAXK = 64, CL_MAXD = 64, CL_ROWS = 128;
+constexpr int CL_MAXK = 64, CL_MAXD = 64;
 __global__ __launch_bounds__(512) void k_cluster_losses_fwd(const float *__restrict__ z, const long long *__restrict__ labels_all,
                                                             const long long *__restrict__ seed_ids, const float *__restrict__ centres,
                                                             const float *__restrict__ prev, const float *__restrict__ gamma,
                                                             const long long *__restrict__ cluster_list, int b, int D, int K, int Kp,
                                                             int Kl, int do_km, int do_ot, float *__restrict__ out2,
-                                                            float *__restrict__ work) {
+                                                            float *__restrict__ work, int chunk_rows) {
+    // Latency-bound single workgroup: everything that is scanned repeatedly sits in LDS and the scans are
+    // branch-free and unrolled, so the LDS reads of successive rows are in flight together.
     __shared__ double sh[16];
-    __shared__ float s_means[CL_MAXK * CL_MAXD];
+    __shared__ float s_means[CL_MAXK * CL_MAXD];  // centres first, batch means once the sums are complete
     __shared__ int s_cnt[CL_MAXK];
-    __shared__ float s_z[CL_ROWS * CL_MAXD];     // a chunk of latent rows, staged so every (cluster, column) owner scans LDS
-    __shared__ int s_lab[CL_ROWS];
+    extern __shared__ float s_dyn[];              // chunk_rows * D latent values (>= CL_MAXK * D: reused for the
+    float *s_z = s_dyn;                           // previous centres), then chunk_rows labels
+    int *s_lab = (int *)(s_dyn + (size_t)chunk_rows * D);
     float *w_means = work, *w_cnt = work + (size_t)K * D, *w_nd = w_cnt + K, *w_lab = w_nd + 1;
     const int t = threadIdx.x;
-    // per-cluster sums over the batch rows: one (cluster, column) pair per thread slot, rows in order
+    for (int e = t; e < K * D; e += blockDim.x) s_means[e] = centres[e];
     constexpr int PAIRS = (CL_MAXK * CL_MAXD + 511) / 512;
     float ps[PAIRS];
     int pc[PAIRS];
 #pragma unroll
     for (int u = 0; u < PAIRS; u++) { ps[u] = 0.f; pc[u] = 0; }
-    for (int r0 = 0; r0 < b; r0 += CL_ROWS) {
-        const int rows = min(CL_ROWS, b - r0);
+    double km = 0.0;
+    for (int r0 = 0; r0 < b; r0 += chunk_rows) {           // one chunk when the batch fits (b = 512, D = 20: 40 KB)
+        const int rows = min(chunk_rows, b - r0);
         __syncthreads();
         for (int e = t; e < rows * D; e += blockDim.x) s_z[e] = z[(size_t)r0 * D + e];
-        for (int i = t; i < rows; i += blockDim.x) {
-            const int lab = (int)labels_all[seed_ids[r0 + i]];
+        for (int i = t; i < chunk_rows; i += blockDim.x) {
+            const int lab = i < rows ? (int)labels_all[seed_ids[r0 + i]] : -1;      // -1: matches no cluster
             s_lab[i] = lab;
-            w_lab[r0 + i] = (float)lab;
+            if (i < rows) w_lab[r0 + i] = (float)lab;
         }
         __syncthreads();
+        // per-cluster sums: one (cluster, column) pair per thread slot, rows in order
 #pragma unroll
         for (int u = 0; u < PAIRS; u++) {
             const int pq = t + u * 512;
@@ -1023,42 +1197,51 @@ __global__ __launch_bounds__(512) void k_cluster_losses_fwd(const float *__restr
                 const int k = pq / D, d = pq - k * D;
                 float s = ps[u];
                 int c = pc[u];
-                for (int i = 0; i < rows; i++)
-                    if (s_lab[i] == k) { s += s_z[i * D + d]; c++; }
+#pragma unroll 8
+                for (int i = 0; i < chunk_rows; i++) {              // chunk_rows is a multiple of 8; pad rows carry label -1
+                    const bool hit = s_lab[i] == k;
+                    s += hit ? s_z[(i < rows ? i : 0) * D + d] : 0.f;
+                    c += hit ? 1 : 0;
+                }
                 ps[u] = s; pc[u] = c;
             }
         }
+        // K-means term of this chunk's rows (centres still in s_means)
+        if (do_km)
+            for (int i = t; i < rows; i += blockDim.x) {
+                const int k = s_lab[i];
+                float a = 0.f;
+#pragma unroll 4
+                for (int d = 0; d < D; d++) { const float e = s_z[i * D + d] - s_means[k * D + d]; a += e * e; }
+                km += a;
+            }
     }
+    __syncthreads();
 #pragma unroll
     for (int u = 0; u < PAIRS; u++) {
         const int pq = t + u * 512;
         if (pq < K * D) {
             const int k = pq / D, d = pq - k * D;
-            s_means[pq] = pc[u] > 0 ? ps[u] / (float)pc[u] : centres[pq];
+            if (pc[u] > 0) s_means[pq] = ps[u] / (float)pc[u];      // else: the stored centre stays
             if (d == 0) s_cnt[k] = pc[u];
         }
     }
+    if (do_ot)                                                        // previous centres into the idle row buffer
+        for (int e = t; e < Kp * D; e += blockDim.x) s_z[e] = prev[e];
     __syncthreads();
     int nd = 0;
     for (int k = 0; k < K; k++) nd += s_cnt[k] > 0;
     for (int pq = t; pq < K * D; pq += blockDim.x) w_means[pq] = s_means[pq];
     for (int k = t; k < K; k += blockDim.x) w_cnt[k] = (float)s_cnt[k];
     if (t == 0) w_nd[0] = (float)nd;
-    double km = 0.0;
-    if (do_km)
-        for (int i = t; i < b; i += blockDim.x) {
-            const int k = (int)w_lab[i];
-            float a = 0.f;
-            for (int d = 0; d < D; d++) { const float e = z[(size_t)i * D + d] - centres[(size_t)k * D + d]; a += e * e; }
-            km += a;
-        }
     km = block_sum_d(km, sh);
     double ot = 0.0;
     if (do_ot)
         for (int pq = t; pq < Kp * Kl; pq += blockDim.x) {
             const int p = pq / Kl, q = pq - p * Kl, k = (int)cluster_list[q];
             float a = 0.f;
-            for (int d = 0; d < D; d++) { const float e = prev[(size_t)p * D + d] - s_means[k * D + d]; a += e * e; }
+#pragma unroll 4
+            for (int d = 0; d < D; d++) { const float e = s_z[p * D + d] - s_means[k * D + d]; a += e * e; }
             ot += (double)gamma[pq] * (double)sqrtf(a);
         }
     ot = block_sum_d(ot, sh);
@@ -1328,6 +1511,61 @@ int spadot_elbo_backward(const void *g2, const void *mu, const void *var, const 
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
+int spadot_bn_act_forward(const void *x, int x_dtype, const float *lin_bias, const float *gamma, const float *beta,
+                          float *running_mean, float *running_var, long long *num_batches_tracked, int b, int F,
+                          double momentum, double eps, double slope, float *y, float *save_mean, float *save_invstd,
+                          void *stream) {
+    if (b <= 0 || F <= 0) return -22;
+    hipStream_t st_ = (hipStream_t)stream;
+    dim3 g((F + BN_COLS - 1) / BN_COLS);
+    if (x_dtype == SPADOT_DT_F32)
+        hipLaunchKernelGGL(k_bn_act_fwd<float>, g, dim3(256), 0, st_, (const float *)x, lin_bias, gamma, beta, running_mean,
+                           running_var, num_batches_tracked, b, F, (float)momentum, (float)eps, (float)slope, y, save_mean, save_invstd);
+    else if (x_dtype == SPADOT_DT_BF16)
+        hipLaunchKernelGGL(k_bn_act_fwd<__bf16>, g, dim3(256), 0, st_, (const __bf16 *)x, lin_bias, gamma, beta, running_mean,
+                           running_var, num_batches_tracked, b, F, (float)momentum, (float)eps, (float)slope, y, save_mean, save_invstd);
+    else
+        return -22;
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+int spadot_bn_act_backward(const float *dy, const float *y, const void *x, int x_dtype, const float *lin_bias,
+                           const float *gamma, const float *save_mean, const float *save_invstd, int b, int F,
+                           double slope, void *dx, float *dgamma, float *dbeta, void *stream) {
+    if (b <= 0 || F <= 0) return -22;
+    hipStream_t st_ = (hipStream_t)stream;
+    dim3 g((F + BN_COLS - 1) / BN_COLS);
+    if (x_dtype == SPADOT_DT_F32)
+        hipLaunchKernelGGL(k_bn_act_bwd<float>, g, dim3(256), 0, st_, dy, y, (const float *)x, lin_bias, gamma, save_mean,
+                           save_invstd, b, F, (float)slope, (float *)dx, dgamma, dbeta);
+    else if (x_dtype == SPADOT_DT_BF16)
+        hipLaunchKernelGGL(k_bn_act_bwd<__bf16>, g, dim3(256), 0, st_, dy, y, (const __bf16 *)x, lin_bias, gamma, save_mean,
+                           save_invstd, b, F, (float)slope, (__bf16 *)dx, dgamma, dbeta);
+    else
+        return -22;
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+int spadot_ln_act_forward(const float *x, const float *gamma, const float *beta, int b, int F, double eps, double slope,
+                          float *y, float *save_mean, float *save_invstd, void *stream) {
+    if (b <= 0 || F <= 0) return -22;
+    hipLaunchKernelGGL(k_ln_act_fwd, dim3((b + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, b, F, (float)eps,
+                       (float)slope, y, save_mean, save_invstd);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+int spadot_ln_act_backward(const float *dy, const float *y, const float *x, const float *gamma, const float *save_mean,
+                           const float *save_invstd, int b, int F, double slope, float *dx, float *dgamma, float *dbeta,
+                           void *stream) {
+    if (b <= 0 || F <= 0) return -22;
+    hipStream_t st_ = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_ln_act_bwd_rows, dim3((b + 3) / 4), dim3(256), 0, st_, dy, y, x, gamma, save_mean, save_invstd, b, F,
+                       (float)slope, dx);
+    hipLaunchKernelGGL(k_ln_act_bwd_cols, dim3((F + BN_COLS - 1) / BN_COLS), dim3(256), 0, st_, dy, y, x, save_mean,
+                       save_invstd, b, F, (float)slope, dgamma, dbeta);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
 int spadot_svgp_post_forward(const double *raw, const double *rd, const double *r, const double *Mr, const double *ld,
                              const double *sm, const double *mu, const double *var, const double *ktilde, int b, int L,
                              int m, double c, double kl_const, double b_over_N, double *p_m, double *mv, double *p_v,
@@ -1383,9 +1621,15 @@ int spadot_cluster_losses_forward(const float *z, const long long *labels_all, c
                                   const long long *cluster_list, int b, int D, int K, int Kp, int Kl, int do_km,
                                   int do_ot, float *out2, float *work, void *stream) {
     if (b <= 0 || D <= 0 || K <= 0 || K > CL_MAXK || D > CL_MAXD) return -22;
-    if (do_ot && (Kp <= 0 || Kl <= 0 || Kl > K || !prev_centres || !gamma || !cluster_list)) return -22;
-    hipLaunchKernelGGL(k_cluster_losses_fwd, dim3(1), dim3(512), 0, (hipStream_t)stream, z, labels_all, seed_ids, centres,
-                       prev_centres, gamma, cluster_list, b, D, K, Kp, Kl, do_km, do_ot, out2, work);
+    if (do_ot && (Kp <= 0 || Kp > CL_MAXK || Kl <= 0 || Kl > K || !prev_centres || !gamma || !cluster_list)) return -22;
+    // rows staged per pass: the whole batch when it fits 40 KB, never fewer than the previous centres need
+    int chunk = 10240 / D;
+    if (chunk > b) chunk = b;
+    if (chunk < CL_MAXK) chunk = CL_MAXK;
+    chunk = (chunk + 7) / 8 * 8;
+    const size_t lds = sizeof(float) * (size_t)chunk * D + sizeof(int) * (size_t)chunk;
+    hipLaunchKernelGGL(k_cluster_losses_fwd, dim3(1), dim3(512), lds, (hipStream_t)stream, z, labels_all, seed_ids, centres,
+                       prev_centres, gamma, cluster_list, b, D, K, Kp, Kl, do_km, do_ot, out2, work, chunk);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 

@@ -64,13 +64,13 @@ class SpaDOT(nn.Module):
         # largest GAT GEMM | SVGP encoder + Sigma + the batched inverse (its long pole) | rest of the GAT branch |
         # rest of the SVGP branch.
         main = torch.cuda.current_stream()
-        side = self._side_stream()
+        side = self._side_stream() if __import__("os").environ.get("SPADOT_NO_SIDE") != "1" else main
         side.wait_stream(main)
         state = {}
 
         def svgp_first_half():
             with torch.cuda.stream(side):
-                q_mu, q_var = self.SVGPEncoder(yb)
+                q_mu, q_var = self.SVGPEncoder(y[:b])              # (pad columns, if any, meet zero weights)
                 state["bc"] = svgp.batch_constants(x[:b], key=batch_key)
                 state["started"] = svgp.elbo_start(state["bc"], q_mu, q_var)
 

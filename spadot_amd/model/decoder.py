@@ -9,6 +9,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ..ops import ln_act
+
 
 def _hidden_stage(fan_in, fan_out):
     dense = nn.Linear(fan_in, fan_out)
@@ -28,12 +30,15 @@ class Decoder(nn.Module):
         self.decoder_net = nn.Sequential(*stages)
 
     def forward(self, latent_sample):
-        if self.compute_dtype == torch.float32:
-            return self.decoder_net(latent_sample)
-        # hidden -> G is the only large GEMM here: compute dtype on MFMA (fp32 accumulate), fp32 result
         stages = list(self.decoder_net)
         h = latent_sample
-        for layer in stages[:-1]:
-            h = layer(h)
+        fused = h.is_cuda
+        for i in range(0, len(stages) - 1, 3):
+            dense, norm, act = stages[i], stages[i + 1], stages[i + 2]
+            h = dense(h)
+            h = ln_act(h, norm, act.negative_slope) if fused else act(norm(h))     # LayerNorm + LeakyReLU: one launch
         last, cd = stages[-1], self.compute_dtype
+        if cd == torch.float32:
+            return last(h)
+        # hidden -> G is the only large GEMM here: compute dtype on MFMA (fp32 accumulate), fp32 result
         return F.linear(h.to(cd), last.weight.to(cd), last.bias.to(cd)).float()

@@ -11,7 +11,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..graph import build_batch_graph
-from ..ops import BatchGraph, dense_cd, gat_edge
+from ..ops import BatchGraph, bn_act, dense_cd, gat_edge
 
 
 class SVGPEncoder(nn.Module):
@@ -31,18 +31,34 @@ class SVGPEncoder(nn.Module):
         nn.init.xavier_uniform_(self.SVGP_fc.weight)
 
     def forward(self, x):
-        if self.compute_dtype == torch.float32:
-            h = self.SVGP_encoder_net(x.float())
-        else:
-            # the G -> hidden map is the only large GEMM of this branch: run it in the compute dtype on MFMA
-            # (fp32 accumulate), everything after it (BatchNorm statistics onwards) stays fp32
-            first = self.SVGP_encoder_net[0]
-            cd = self.compute_dtype
-            h = F.linear(x.to(cd), first.weight.to(cd), first.bias.to(cd)).float()
-            for layer in list(self.SVGP_encoder_net)[1:]:
-                h = layer(h)
-        mu, logvar = torch.chunk(self.SVGP_fc(h), 2, dim=1)
+        mu, logvar = torch.chunk(self.pre_head(x), 2, dim=1)
         return mu, torch.exp(logvar)
+
+    def pre_head(self, x):
+        """SVGP_fc output (mu | logvar) [b, 2 z]."""
+        net = list(self.SVGP_encoder_net)
+        fused = self.training and x.is_cuda            # eval mode (running statistics) takes the library path
+        if not fused:
+            x = x[:, :net[0].in_features]
+            if self.compute_dtype == torch.float32:
+                h = self.SVGP_encoder_net(x.float())
+            else:
+                first, cd = net[0], self.compute_dtype
+                h = F.linear(x.to(cd), first.weight.to(cd), first.bias.to(cd)).float()
+                for layer in net[1:]:
+                    h = layer(h)
+            return self.SVGP_fc(h)
+        # training: per hidden size  Linear (bias folded into the next kernel) -> BatchNorm + LeakyReLU in ONE launch;
+        # the G -> hidden map is the only large GEMM of this branch: compute dtype on MFMA (fp32 accumulate)
+        h = x
+        for i in range(0, len(net), 3):
+            lin, bn, act = net[i], net[i + 1], net[i + 2]
+            if i == 0 and self.compute_dtype != torch.float32:
+                h = dense_cd(h.to(self.compute_dtype), lin.weight, lin)
+            else:
+                h = F.linear(h[:, :lin.in_features].float(), lin.weight)
+            h = bn_act(h, lin.bias, bn, act.negative_slope)
+        return self.SVGP_fc(h)
 
 
 class GATConv(nn.Module):

@@ -178,6 +178,81 @@ def dense_cd(x, W, holder, tag="_wpad"):
     return _DenseCD.apply(x, W, buf)
 
 
+# ----------------------------------------------------------------------------- small-MLP stages
+
+class _BNAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, lin_bias, gamma, beta, bn, slope):
+        _need_cuda(x, gamma, beta)
+        x = x.contiguous()
+        b, F_ = x.shape
+        y = torch.empty((b, F_), dtype=torch.float32, device=x.device)
+        sm = torch.empty(F_, dtype=torch.float32, device=x.device)
+        si = torch.empty(F_, dtype=torch.float32, device=x.device)
+        mom = 0.1 if bn.momentum is None else float(bn.momentum)
+        _check(model_lib().spadot_bn_act_forward(_p(x), _DT[x.dtype], None if lin_bias is None else _p(lin_bias), _p(gamma),
+                                                 _p(beta), _p(bn.running_mean), _p(bn.running_var),
+                                                 _p(bn.num_batches_tracked), b, F_, mom, float(bn.eps), float(slope), _p(y),
+                                                 _p(sm), _p(si), _stream()), "spadot_bn_act_forward")
+        ctx.save_for_backward(x, lin_bias, gamma, y, sm, si)
+        ctx.slope = float(slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, lin_bias, gamma, y, sm, si = ctx.saved_tensors
+        b, F_ = x.shape
+        dx = torch.empty_like(x)
+        dg = torch.empty(F_, dtype=torch.float32, device=x.device)
+        db = torch.empty(F_, dtype=torch.float32, device=x.device)
+        _check(model_lib().spadot_bn_act_backward(_p(dy.contiguous().float()), _p(y), _p(x), _DT[x.dtype],
+                                                  None if lin_bias is None else _p(lin_bias), _p(gamma), _p(sm), _p(si), b, F_,
+                                                  ctx.slope, _p(dx), _p(dg), _p(db), _stream()), "spadot_bn_act_backward")
+        # the batch mean removes a per-feature shift: the preceding Linear's bias has a zero gradient
+        dlb = None if lin_bias is None else torch.zeros_like(lin_bias)
+        return dx, dlb, dg, db, None, None
+
+
+def bn_act(x, lin_bias, bn, slope=0.01):
+    """leaky_relu(BatchNorm1d(x + lin_bias)) in training mode as one launch each way (bn: the nn.BatchNorm1d
+    module whose parameters and running statistics are used and updated; x fp32 or bf16, result fp32)."""
+    assert bn.training and bn.track_running_stats and bn.affine
+    return _BNAct.apply(x, lin_bias, bn.weight, bn.bias, bn, slope)
+
+
+class _LNAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, slope):
+        _need_cuda(x, gamma, beta)
+        x = x.contiguous().float()
+        b, F_ = x.shape
+        y = torch.empty_like(x)
+        sm = torch.empty(b, dtype=torch.float32, device=x.device)
+        si = torch.empty(b, dtype=torch.float32, device=x.device)
+        _check(model_lib().spadot_ln_act_forward(_p(x), _p(gamma), _p(beta), b, F_, float(eps), float(slope), _p(y), _p(sm),
+                                                 _p(si), _stream()), "spadot_ln_act_forward")
+        ctx.save_for_backward(x, gamma, y, sm, si)
+        ctx.slope = float(slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, y, sm, si = ctx.saved_tensors
+        b, F_ = x.shape
+        dx = torch.empty_like(x)
+        dg = torch.empty(F_, dtype=torch.float32, device=x.device)
+        db = torch.empty(F_, dtype=torch.float32, device=x.device)
+        _check(model_lib().spadot_ln_act_backward(_p(dy.contiguous().float()), _p(y), _p(x), _p(gamma), _p(sm), _p(si), b, F_,
+                                                  ctx.slope, _p(dx), _p(dg), _p(db), _stream()), "spadot_ln_act_backward")
+        return dx, dg, db, None, None
+
+
+def ln_act(x, ln, slope=0.01):
+    """leaky_relu(LayerNorm(x)) over the last dimension of a 2-D fp32 tensor, one launch forward, two backward."""
+    assert ln.elementwise_affine and len(ln.normalized_shape) == 1
+    return _LNAct.apply(x, ln.weight, ln.bias, ln.eps, slope)
+
+
 # ----------------------------------------------------------------------------- loss tail (single-workgroup kernels)
 
 class _LatentHead(torch.autograd.Function):

@@ -349,6 +349,56 @@ def test_flat_adamw_matches_torch_clip_and_adamw(ops):
             np.testing.assert_allclose(q.detach().cpu().numpy(), p.detach().cpu().numpy(), rtol=2e-6, atol=1e-7)
 
 
+# ------------------------------------------------------------------ fused small-MLP stages
+
+@pytest.mark.parametrize("b,F_,dt", [(512, 256, torch.float32), (37, 70, torch.float32), (512, 256, torch.bfloat16), (300, 64, torch.float32)])
+def test_bn_act_matches_batchnorm_leakyrelu(ops, b, F_, dt):
+    """ops.bn_act = leaky_relu(BatchNorm1d(x + bias)) in training mode: output, running statistics, counter and
+    all gradients against torch's modules (fp64 reference)."""
+    rng = np.random.default_rng(b + F_)
+    x = T(rng.normal(size=(b, F_)) * 2 + 0.5).to(dt).double(); lb = T(rng.normal(size=F_))
+    w = T(rng.normal(size=(b, F_)))
+    ref_bn = torch.nn.BatchNorm1d(F_).double(); my_bn = torch.nn.BatchNorm1d(F_).to(DEV)
+    with torch.no_grad():
+        for bn in (ref_bn, my_bn):
+            bn.weight.copy_(T(rng.normal(size=F_) * 0.5 + 1).to(bn.weight)) if bn is ref_bn else bn.weight.copy_(ref_bn.weight.float())
+            bn.bias.copy_(T(rng.normal(size=F_) * 0.3).to(bn.bias)) if bn is ref_bn else bn.bias.copy_(ref_bn.bias.float())
+    xr = x.clone().requires_grad_(True); lbr = lb.clone().requires_grad_(True)
+    yr = torch.nn.functional.leaky_relu(ref_bn(xr + lbr), 0.01)
+    (yr * w).sum().backward()
+    xd = x.to(DEV, dt).requires_grad_(True); lbd = lb.to(DEV, torch.float32).requires_grad_(True)
+    yd = ops.bn_act(xd, lbd, my_bn, 0.01)
+    (yd * w.to(DEV, torch.float32)).sum().backward()
+    tol = 2e-2 if dt == torch.bfloat16 else 2e-4
+    np.testing.assert_allclose(yd.detach().cpu().numpy(), yr.detach().numpy(), rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(my_bn.running_mean.cpu().numpy(), ref_bn.running_mean.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(my_bn.running_var.cpu().numpy(), ref_bn.running_var.numpy(), rtol=1e-5, atol=1e-6)
+    assert int(my_bn.num_batches_tracked) == 1
+    for name, a, r in (("x", xd.grad, xr.grad), ("gamma", my_bn.weight.grad, ref_bn.weight.grad), ("beta", my_bn.bias.grad, ref_bn.bias.grad)):
+        r = r.numpy()
+        np.testing.assert_allclose(a.float().cpu().numpy(), r, rtol=tol, atol=tol * np.abs(r).max(), err_msg=name)
+    assert float(lbd.grad.abs().max()) == 0.0 and float(lbr.grad.abs().max()) < 1e-9      # the batch mean removes the shift
+
+
+@pytest.mark.parametrize("b,F_", [(512, 64), (512, 256), (19, 100)])
+def test_ln_act_matches_layernorm_leakyrelu(ops, b, F_):
+    rng = np.random.default_rng(b * 3 + F_)
+    x = T(rng.normal(size=(b, F_)) * 1.5 - 0.2); w = T(rng.normal(size=(b, F_)))
+    ref = torch.nn.LayerNorm(F_).double(); mine = torch.nn.LayerNorm(F_).to(DEV)
+    with torch.no_grad():
+        ref.weight.copy_(T(rng.normal(size=F_) * 0.5 + 1)); ref.bias.copy_(T(rng.normal(size=F_) * 0.3))
+        mine.weight.copy_(ref.weight.float()); mine.bias.copy_(ref.bias.float())
+    xr = x.clone().requires_grad_(True)
+    (torch.nn.functional.leaky_relu(ref(xr), 0.01) * w).sum().backward()
+    xd = x.to(DEV, torch.float32).requires_grad_(True)
+    yd = ops.ln_act(xd, mine, 0.01)
+    (yd * w.to(DEV, torch.float32)).sum().backward()
+    np.testing.assert_allclose(yd.detach().cpu().numpy(), torch.nn.functional.leaky_relu(ref(x), 0.01).detach().numpy(), rtol=2e-4, atol=2e-5)
+    for name, a, r in (("x", xd.grad, xr.grad), ("gamma", mine.weight.grad, ref.weight.grad), ("beta", mine.bias.grad, ref.bias.grad)):
+        r = r.numpy()
+        np.testing.assert_allclose(a.cpu().numpy(), r, rtol=2e-4, atol=2e-4 * np.abs(r).max(), err_msg=name)
+
+
 # ------------------------------------------------------------------ loss tail kernels
 
 @pytest.mark.parametrize("b,Ls,Lg", [(512, 10, 10), (37, 3, 5), (1300, 10, 10)])

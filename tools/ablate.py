@@ -64,3 +64,12 @@ for rep in range(3):
     for i in range(20): step(i)
 torch.cuda.synchronize()
 print(f"ABLATE={mode}: {(time.perf_counter()-t0)/60*1e3:.3f} ms/step")
+# host-side cost of one graph launch (no sync inside the timed call)
+torch.cuda.synchronize()
+hs = []
+for i in range(20):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter(); step(i); hs.append(time.perf_counter() - t0)
+torch.cuda.synchronize()
+import numpy as np
+print(f"host time per step() call (GPU idle at entry): median {np.median(hs)*1e3:.3f} ms, min {min(hs)*1e3:.3f} ms")
