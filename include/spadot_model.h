@@ -156,7 +156,12 @@ int spadot_svgp_post_backward(const float *g_skl, const double *out4, const doub
                               double *g_kl, double *gMr, double *gM, void *stream);
 int spadot_svgp_grad_tail(const double *q1, const double *q2, const double *Kdt, const double *p_v, const double *ktilde,
                           const double *p_m, const double *mu, const double *w, const double *g_kl, const double *g_mu,
-                          const double *g_var, int b, int L, double c, double *dmu, double *dvar, void *stream);
+                          const double *g_var, int b, int L, double c, double *dmu, double *dvar, float *dz,
+                          void *stream);
+/* z [b, 2L] fp32 = SVGP_fc output (mu | logvar) -> mu, var = exp(logvar), w = 1/var, mu w, each [b, L] fp64
+ * (encoder.py:31-34 + the first element-wise steps of svgp.py:62-70).  grad_tail's dz [b, 2L] fp32 is the matching
+ * gradient (d/dlogvar = d/dvar * var); dmu/dvar may then be NULL. */
+int spadot_svgp_pre(const float *z, int b, int L, double *mu, double *var, double *w, double *muw, void *stream);
 
 /* ---------------------------------------------------------------- loss tail of a training step
  * Single-workgroup kernels for the b x 20 / 10 x 10 arithmetic after the encoders (each replaces a few dozen

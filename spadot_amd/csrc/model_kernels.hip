@@ -784,6 +784,18 @@ __global__ __launch_bounds__(256) void k_svgp_post_bwd(const float *__restrict__
     if (idx < (long long)m * m) gM[idx] = 0.5 * gk * M[idx];
 }
 
+// z [b, 2L] fp32 = SVGP_fc output (mu | logvar)  ->  mu, var = exp(logvar), w = 1/var, mu*w  (all [b, L] fp64)
+__global__ __launch_bounds__(256) void k_svgp_pre(const float *__restrict__ z, int b, int L, double *__restrict__ mu,
+                                                  double *__restrict__ var, double *__restrict__ w,
+                                                  double *__restrict__ muw) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= b * L) return;
+    const int i = e / L, l = e - i * L;
+    const double m_ = (double)z[(size_t)i * 2 * L + l];
+    const double v = (double)expf(z[(size_t)i * 2 * L + L + l]);       // torch.exp in fp32, like the encoder's own
+    mu[e] = m_; var[e] = v; w[e] = 1.0 / v; muw[e] = m_ / v;
+}
+
 // Last step of the algebra's backward: q1 = diag(K_nm S D S K_mn) [L, b], q2 = diag(K_nm S2 K_mn) [L, b],
 // Kdt = K_nm dt [b, L]:  dw = c (g_kl/2 (p_v - k~ - q2) - q1) + (mu - p_m) Kdt,  dmu = w Kdt + g_mu,  dvar = -dw w^2 + g_var.
 __global__ __launch_bounds__(256) void k_svgp_grad_tail(const double *__restrict__ q1, const double *__restrict__ q2,
@@ -792,14 +804,19 @@ __global__ __launch_bounds__(256) void k_svgp_grad_tail(const double *__restrict
                                                         const double *__restrict__ mu, const double *__restrict__ w,
                                                         const double *__restrict__ g_kl, const double *__restrict__ g_mu,
                                                         const double *__restrict__ g_var, int b, int L, double c,
-                                                        double *__restrict__ dmu, double *__restrict__ dvar) {
+                                                        double *__restrict__ dmu, double *__restrict__ dvar,
+                                                        float *__restrict__ dz) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= b * L) return;
     const int i = e / L, l = e - i * L;
     const double g = g_kl[0], ww = w[e], kd = Kdt[e];
     const double dw = c * (0.5 * g * (pv[e] - kt[i] - q2[(size_t)l * b + i]) - q1[(size_t)l * b + i]) + (mu[e] - pm[e]) * kd;
-    dmu[e] = ww * kd + g_mu[e];
-    dvar[e] = -dw * ww * ww + g_var[e];
+    const double dm = ww * kd + g_mu[e], dv = -dw * ww * ww + g_var[e];
+    if (dmu) { dmu[e] = dm; dvar[e] = dv; }
+    if (dz) {                                     // gradient w.r.t. (mu | logvar): d/dlogvar = d/dvar * var
+        dz[(size_t)i * 2 * L + l] = (float)dm;
+        dz[(size_t)i * 2 * L + L + l] = (float)(dv / ww);
+    }
 }
 
 template <typename T>
@@ -1593,10 +1610,17 @@ int spadot_svgp_post_backward(const float *g_skl, const double *out4, const doub
 
 int spadot_svgp_grad_tail(const double *q1, const double *q2, const double *Kdt, const double *p_v, const double *ktilde,
                           const double *p_m, const double *mu, const double *w, const double *g_kl, const double *g_mu,
-                          const double *g_var, int b, int L, double c, double *dmu, double *dvar, void *stream) {
-    if (b <= 0 || L <= 0) return -22;
+                          const double *g_var, int b, int L, double c, double *dmu, double *dvar, float *dz,
+                          void *stream) {
+    if (b <= 0 || L <= 0 || (!dz && !(dmu && dvar))) return -22;
     hipLaunchKernelGGL(k_svgp_grad_tail, dim3((b * L + 255) / 256), dim3(256), 0, (hipStream_t)stream, q1, q2, Kdt, p_v,
-                       ktilde, p_m, mu, w, g_kl, g_mu, g_var, b, L, c, dmu, dvar);
+                       ktilde, p_m, mu, w, g_kl, g_mu, g_var, b, L, c, dmu, dvar, dz);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+int spadot_svgp_pre(const float *z, int b, int L, double *mu, double *var, double *w, double *muw, void *stream) {
+    if (b <= 0 || L <= 0) return -22;
+    hipLaunchKernelGGL(k_svgp_pre, dim3((b * L + 255) / 256), dim3(256), 0, (hipStream_t)stream, z, b, L, mu, var, w, muw);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 

@@ -70,9 +70,9 @@ class SpaDOT(nn.Module):
 
         def svgp_first_half():
             with torch.cuda.stream(side):
-                q_mu, q_var = self.SVGPEncoder(y[:b])              # (pad columns, if any, meet zero weights)
+                z_enc = self.SVGPEncoder.pre_head(y[:b])           # (mu | logvar); pad columns, if any, meet zero weights
                 state["bc"] = svgp.batch_constants(x[:b], key=batch_key)
-                state["started"] = svgp.elbo_start(state["bc"], q_mu, q_var)
+                state["started"] = svgp.elbo_start(state["bc"], z_enc)
 
         if self.svgp_issue == "first":
             svgp_first_half()

@@ -65,29 +65,32 @@ class _SVGPCore(torch.autograd.Function):
         dw = c diag(K_nm dSigma K_mn) + mu (K_nm dt),   dmu = w (K_nm dt),   dvar = -dw w^2  (+ the direct terms)."""
 
     @staticmethod
-    def start(mu, var, bc, rc):
-        """First half of forward: Sigma_l for every latent dim, the sweep launch (the long pole of the branch,
-        ~0.2 ms on 2L compute units) and t.  Separate so that the caller can issue it early."""
+    def start(z, bc, rc):
+        """First half of forward, from z = (mu | logvar) [b, 2L] fp32: Sigma_l for every latent dim, the sweep launch
+        (the long pole of the branch, ~0.2 ms on 2L compute units) and t.  Separate so that the caller can issue
+        it early."""
         with torch.no_grad():
-            b, L = mu.shape
+            z = z.contiguous().float()
+            b, L = z.shape[0], z.shape[1] // 2
             m, c = rc.m, bc.c
             Kn = bc.K_nm
-            w = 1.0 / var
+            mu, var, w, muw = (torch.empty((b, L), dtype=F64, device=z.device) for _ in range(4))
+            _check(model_lib().spadot_svgp_pre(_p(z), b, L, _p(mu), _p(var), _p(w), _p(muw), _stream()), "spadot_svgp_pre")
             A = Kn.unsqueeze(0) * w.T.unsqueeze(2)                           # [L, b, m] = diag(w_l) K_nm
             buf = torch.empty((2 * L, m, m), dtype=F64, device=mu.device)
             torch.baddbmm(rc.KjI.expand(L, m, m), A.transpose(1, 2), Kn.unsqueeze(0).expand(L, b, m), alpha=c, out=buf[:L])
             torch.add(buf[:L], rc.K2j, out=buf[L:])
             X, ld = spd_inverse_logdet(buf)
-            t = (mu * w).T @ Kn                                              # [L, m]
-        return w, X, ld, t
+            t = muw.T @ Kn                                                   # [L, m]
+        return mu, var, w, X, ld, t
 
     @staticmethod
-    def forward(ctx, mu, var, bc, rc, started, b_over_N):
+    def forward(ctx, z, bc, rc, started, b_over_N):
+        mu, var, w, X, ld, t = started if started is not None else _SVGPCore.start(z, bc, rc)
         b, L = mu.shape
         m, c = rc.m, bc.c
         X2 = bc.X2
         lib = model_lib()
-        w, X, ld, t = started if started is not None else _SVGPCore.start(mu, var, bc, rc)
         S = X[:L]
         r = torch.bmm(S, t.unsqueeze(2)).squeeze(2)                          # [L, m]
         raw = X2 @ r.T                                                       # [2b, L]
@@ -97,7 +100,6 @@ class _SVGPCore(torch.autograd.Function):
         sm = torch.mv(S.reshape(L, m * m), rc.M.reshape(m * m))              # <S_l, M>
         p_m, mv, p_v, tr = (torch.empty((b, L), dtype=F64, device=mu.device) for _ in range(4))
         out4 = torch.empty(4, dtype=F64, device=mu.device)
-        mu, var = mu.contiguous(), var.contiguous()
         _check(lib.spadot_svgp_post_forward(_p(raw), _p(rd), _p(r), _p(Mr), _p(ld), _p(sm), _p(mu), _p(var), _p(bc.ktilde),
                                             b, L, m, c, rc.logdet_K_f - rc.mlogj - m, b_over_N, _p(p_m), _p(mv), _p(p_v), _p(tr),
                                             _p(out4), _stream()), "spadot_svgp_post_forward")
@@ -116,7 +118,8 @@ class _SVGPCore(torch.autograd.Function):
         S, S2 = X[:L], X[L:]
         lib = model_lib()
         dev = mu.device
-        g_mu, g_var, dmu, dvar = (torch.empty((b, L), dtype=F64, device=dev) for _ in range(4))
+        g_mu, g_var = (torch.empty((b, L), dtype=F64, device=dev) for _ in range(2))
+        dz = torch.empty((b, 2 * L), dtype=torch.float32, device=dev)
         G1 = torch.empty((2 * b, L), dtype=F64, device=dev)
         G2T = torch.empty((L, 2 * b), dtype=F64, device=dev)
         g_kl = torch.empty(1, dtype=F64, device=dev)
@@ -138,8 +141,8 @@ class _SVGPCore(torch.autograd.Function):
         q2 = rowdot(torch.matmul(Kn, S2), Kn)                                # diag(K_nm S2 K_mn)  [L, b]
         Kdt = Kn @ dt.T                                                      # [b, L]
         _check(lib.spadot_svgp_grad_tail(_p(q1), _p(q2), _p(Kdt), _p(p_v), _p(bc.ktilde), _p(p_m), _p(mu), _p(w), _p(g_kl),
-                                         _p(g_mu), _p(g_var), b, L, c, _p(dmu), _p(dvar), _stream()), "spadot_svgp_grad_tail")
-        return dmu, dvar, None, None, None, None
+                                         _p(g_mu), _p(g_var), b, L, c, None, None, _p(dz), _stream()), "spadot_svgp_grad_tail")
+        return dz, None, None, None, None
 
 
 class SVGP(nn.Module):
@@ -228,20 +231,20 @@ class SVGP(nn.Module):
 
     def elbo_terms(self, bc, mu, var):
         """(p_m, p_v, l3_sum, kl_sum, ce_sum) of one training batch: svgp.py:47-104 over all latent
-        dimensions + the Gaussian cross entropy of SpaDOT.py:74-75 (values; gradients flow through
-        elbo_start/elbo_finish's SVGP_KL, which is what the training step uses)."""
-        p_m, p_v, _, out4 = self._finish(bc, self.elbo_start(bc, mu, var))
+        dimensions + the Gaussian cross entropy of SpaDOT.py:74-75 (values only; the training step uses
+        elbo_start/elbo_finish, whose SVGP_KL carries the gradient)."""
+        z = torch.cat([mu, torch.log(var)], dim=1)
+        p_m, p_v, _, out4 = self._finish(bc, self.elbo_start(bc, z))
         return p_m, p_v, out4[0], out4[2], out4[1]
 
-    def elbo_start(self, bc, mu, var):
-        """Builds Sigma_l and launches the batched inverse; elbo_finish() does the rest.  Two calls so that the
-        composite model can issue the GAT kernels in between (the sweep then runs beside them)."""
-        mu, var = mu.to(F64), var.to(F64)
-        return mu, var, _SVGPCore.start(mu.detach(), var.detach(), bc, self._rc())
+    def elbo_start(self, bc, z):
+        """z = SVGP_fc output (mu | logvar) [b, 2L].  Builds Sigma_l and launches the batched inverse; elbo_finish()
+        does the rest.  Two calls so that the composite model can issue the GAT kernels in between."""
+        return z, _SVGPCore.start(z.detach(), bc, self._rc())
 
     def _finish(self, bc, started):
-        mu, var, pre = started
-        return _SVGPCore.apply(mu, var, bc, self._rc(), pre, bc.b / float(self.N_train))
+        z, pre = started
+        return _SVGPCore.apply(z, bc, self._rc(), pre, bc.b / float(self.N_train))
 
     def elbo_finish(self, bc, started):
         """(p_m, p_v, SVGP_KL): posterior at the batch points and -|ce - (l3 - b/N KL)| / L (SpaDOT.py:72-77: the

@@ -33,9 +33,9 @@ if mode in ("svgp", "gat", "decoder"):
             zg = self.GATEncoder.pre_head(y, edge_index, rows=bb)
         else:
             svgp = self.svgp_dict[str(tp)]
-            q_mu, q_var = self.SVGPEncoder(yb)
+            z_enc = self.SVGPEncoder.pre_head(yb)
             bc = svgp.batch_constants(x[:bb], key=batch_key)
-            p_m, p_v, l3_sum, kl_sum, ce = svgp.elbo_terms(bc, q_mu, q_var)
+            p_m, p_v, l3_sum, kl_sum, ce = svgp.elbo_terms(bc, *((lambda zz: (zz[:, :Ls], torch.exp(zz[:, Ls:])))(z_enc)))
             SVGP_KL = (-torch.abs(ce - (l3_sum - (bb / float(svgp.N_train)) * kl_sum)) / Ls).float()
             if mode == "gat":
                 zg = (self.GATEncoder.GAT_fc.weight.sum() * 0 + torch.zeros((bb, 2 * Lg), device=y.device))
