@@ -141,6 +141,9 @@ def gat_edge(h, att_src, att_dst, bias, graph, heads, channels, concat=True, act
 
 # ----------------------------------------------------------------------------- dense maps in the compute dtype
 
+_DIRECT_GRAD = [False]     # True only inside FlatAdamW.backward (a plain .backward() would ADD the returned view to itself)
+
+
 class _DenseCD(torch.autograd.Function):
     """h = x W^T with x already in the compute dtype (bf16) and possibly zero-padded along K (so that the
     G-sized GEMM gets a K that is a multiple of 128), W the fp32 parameter [N, K].  Backward writes the weight
@@ -154,6 +157,10 @@ class _DenseCD(torch.autograd.Function):
         wbuf[:, :K].copy_(W)                       # cast into the persistent padded image (pad columns stay zero)
         ctx.save_for_backward(x, wbuf)
         ctx.K = K
+        # FlatAdamW keeps W.grad as a view of its flat gradient buffer: the weight-gradient GEMM writes there
+        # directly (FlatAdamW.backward then has nothing to copy for this parameter)
+        g = W.grad
+        ctx.wgrad = g if (g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.shape == W.shape) else None
         return torch.nn.functional.linear(x, wbuf)
 
     @staticmethod
@@ -162,7 +169,12 @@ class _DenseCD(torch.autograd.Function):
         g = g.contiguous()
         dx = g @ wbuf if ctx.needs_input_grad[0] else None
         # (x[:, :K] is a strided view: the GEMM takes its row stride, the result is a dense [N, K])
-        dW = torch.mm(g.t(), x[:, :ctx.K], out_dtype=torch.float32) if ctx.needs_input_grad[1] else None
+        dW = None
+        if ctx.needs_input_grad[1]:
+            if ctx.wgrad is not None and _DIRECT_GRAD[0]:
+                dW = torch.mm(g.t(), x[:, :ctx.K], out_dtype=torch.float32, out=ctx.wgrad)
+            else:
+                dW = torch.mm(g.t(), x[:, :ctx.K], out_dtype=torch.float32)
         return dx, dW, None
 
 
@@ -578,9 +590,15 @@ class FlatAdamW:
         """Gradients of `loss` written (not accumulated) into the flat gradient buffer: one multi-tensor
         copy instead of one AccumulateGrad add per parameter (~45 launches a step).  Parameters the loss
         does not reach get zeros, like a backward() after zero_grad()."""
-        grads = torch.autograd.grad(loss, self.params, allow_unused=True)
-        dst = [p.grad for p, g in zip(self.params, grads) if g is not None]
-        src = [g for g in grads if g is not None]
+        _DIRECT_GRAD[0] = True
+        try:
+            grads = torch.autograd.grad(loss, self.params, allow_unused=True)
+        finally:
+            _DIRECT_GRAD[0] = False
+        # (a gradient that already IS the flat view -- written in place by ops.dense_cd -- needs no copy)
+        pairs = [(p.grad, g) for p, g in zip(self.params, grads) if g is not None and g.data_ptr() != p.grad.data_ptr()]
+        dst = [d for d, _ in pairs]
+        src = [s for _, s in pairs]
         for p, g in zip(self.params, grads):
             if g is None:
                 p.grad.zero_()

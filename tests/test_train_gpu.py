@@ -144,6 +144,45 @@ def test_graphed_steps_match_eager_steps(monkeypatch):
     np.testing.assert_allclose(p1, p0, rtol=0, atol=5e-4)          # 8 AdamW steps of lr 3e-4 each
 
 
+def test_flat_backward_with_in_place_weight_gradients_matches_autograd():
+    """bf16 compute: the GAT dense maps write their fp32 weight gradient straight into the flat buffer inside
+    FlatAdamW.backward; the buffer must equal what plain autograd returns for every parameter, and a plain
+    .backward() must not be affected by the in-place path."""
+    from spadot_amd.model import SpaDOT
+    from spadot_amd.ops import FlatAdamW
+    from spadot_amd.synthetic import make_dataset
+    from spadot_amd.utils import _train_utils as tu, _utils
+    data = make_dataset(2, 1200, 40, seed=4)
+    cfg = _small_config()
+    cfg.update(input_dim=40, timepoints=[0, 1], device=torch.device(DEV), compute_dtype=torch.bfloat16)
+    _utils.set_seed(5)
+    dd = tu.prepare_dataloader(data, cfg)
+    model = SpaDOT.SpaDOT(cfg, dd).to(DEV)
+    opt = FlatAdamW(model.parameters(), lr=cfg["lr"])
+    model.train()
+    batch = dd["dataloaders"][1][0]
+    noise = (torch.zeros((batch.batch_size, 10), device=DEV), torch.zeros((batch.batch_size, 10), device=DEV))
+
+    def loss_fn():
+        for m in model.modules():                      # same BatchNorm state for every evaluation
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.reset_running_stats()
+        rec, skl, gkl, ali, _ = model.forward(batch.x, batch.y, batch.graph, 1, batch.batch_size, noise=noise)
+        return 0.1 * rec - 0.5 * skl + 1e-4 * gkl + 0.1 * ali
+
+    ref = torch.autograd.grad(loss_fn(), opt.params, allow_unused=True)
+    opt.flat_grad.fill_(123.0)                          # stale content must not survive
+    opt.backward(loss_fn())
+    for p, g in zip(opt.params, ref):
+        want = torch.zeros_like(p) if g is None else g
+        np.testing.assert_allclose(p.grad.cpu().numpy(), want.float().cpu().numpy(), rtol=1e-5, atol=1e-7)
+    opt.zero_grad()
+    loss_fn().backward()                                # accumulate path: once, not twice
+    for p, g in zip(opt.params, ref):
+        want = torch.zeros_like(p) if g is None else g
+        np.testing.assert_allclose(p.grad.cpu().numpy(), want.float().cpu().numpy(), rtol=1e-5, atol=1e-7)
+
+
 def _dp_worker(rank, world, port, q):
     """One data-parallel rank on cuda:0 (both ranks share the one GPU of the test box; gloo carries the
     collectives, on a real node the backend is nccl = RCCL)."""
