@@ -204,11 +204,12 @@ def _main(real_stdout):
         epoch = cfg["ot_epoch"]                     # every loss term active
         beta1 = 0.5
 
-        # 1 GPU: steady-state training replays one captured hipGraph per (time point, batch) (epochs >= 2 of
-        # a real run); the keys the timed region touches are visited twice beforehand (eager, then capture).
-        # Multi-rank: eager steps (the RCCL all-reduce sits between backward and the optimizer).
-        use_graphs = world == 1 and os.environ.get("SPADOT_BENCH_NO_GRAPHS") != "1"
-        stepper = tu.GraphedStepper(model, opt, cfg, dd) if use_graphs else None
+        # Steady-state training replays one captured hipGraph per (time point, batch) (epochs >= 2 of a real
+        # run); the keys the timed region touches are visited twice beforehand (eager, then capture).
+        # Multi-rank: forward + backward graph, the RCCL all-reduce of the flat gradient (not captured), then
+        # one clip + AdamW graph.
+        use_graphs = os.environ.get("SPADOT_BENCH_NO_GRAPHS") != "1"
+        stepper = tu.GraphedStepper(model, opt, cfg, dd, grad_sync=grad_sync) if use_graphs else None
 
         def step(i):
             t, bi = sched[i % len(sched)]

@@ -80,8 +80,8 @@ class _SVGPCore(torch.autograd.Function):
             buf = torch.empty((2 * L, m, m), dtype=F64, device=mu.device)
             torch.baddbmm(rc.KjI.expand(L, m, m), A.transpose(1, 2), Kn.unsqueeze(0).expand(L, b, m), alpha=c, out=buf[:L])
             torch.add(buf[:L], rc.K2j, out=buf[L:])
-            X, ld = spd_inverse_logdet(buf)
             t = muw.T @ Kn                                                   # [L, m]
+            X, ld = spd_inverse_logdet(buf)                                  # last launch of this half: see SpaDOT.forward
         return mu, var, w, X, ld, t
 
     @staticmethod

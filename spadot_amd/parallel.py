@@ -155,6 +155,9 @@ def train_SpaDOT_parallel(dataloader_dict, model_config, verbose=False):
         dist.all_reduce(cnt, op=dist.ReduceOp.MAX)
         batches_per_tp = dict(zip(model_config["timepoints"], cnt.cpu().tolist()))
     losses = {}
+    # replayed hipGraphs, as in the single-replica trainer: one forward+backward graph per (time point, batch),
+    # the all-reduce of the flat gradient between replays (not captured), one clip + AdamW graph
+    stepper = tu.GraphedStepper(model, opt, model_config, dataloader_dict) if model_config.get("use_hip_graphs", True) else None
     for epoch in range(model_config["maxiter"]):
         beta1 = float(beta1s[epoch])
         model.train()
@@ -162,10 +165,14 @@ def train_SpaDOT_parallel(dataloader_dict, model_config, verbose=False):
         acc = []
 
         def compute_grad(tp_i, tp, bi):
-            acc.append(tu.forward_backward(model, model_config, dataloader_dict, tp_i, tp, bi, epoch, beta1,
-                                           optimizer=opt))
+            if stepper is not None:
+                acc.append(stepper.fb(tp_i, tp, bi, epoch, beta1))
+            else:
+                acc.append(tu.forward_backward(model, model_config, dataloader_dict, tp_i, tp, bi, epoch, beta1,
+                                               optimizer=opt))
 
-        run_epoch(plan, batches_per_tp, order, compute_grad, opt.zero_grad, opt.flat_grad, opt.step)
+        run_epoch(plan, batches_per_tp, order, compute_grad, opt.zero_grad, opt.flat_grad,
+                  stepper.update if stepper is not None else opt.step)
         losses[epoch] = torch.stack(acc).mean(0).cpu().tolist() if acc else None
         average_buffers(model)
         tu._update_Kmeans(model, model_config, dataloader_dict)

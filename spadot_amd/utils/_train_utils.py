@@ -297,42 +297,77 @@ class GraphedStepper:
     (a 0-dim tensor), K-means labels/centres and OT plans (copied in place), the optimizer's step count.
     """
 
-    def __init__(self, model, optimizer, model_config, dataloader_dict):
+    def __init__(self, model, optimizer, model_config, dataloader_dict, grad_sync=None):
+        """grad_sync (data-parallel replicas): callable on the flat gradient buffer, e.g. an RCCL all-reduce.  The
+        step is then TWO graphs -- forward + backward per key, and one clip + AdamW graph shared by all keys -- with
+        the collective issued between their replays (nothing of the collective is captured)."""
         self.model, self.opt, self.cfg, self.dd = model, optimizer, model_config, dataloader_dict
-        dev = optimizer.flat_param.device
+        self.grad_sync = grad_sync
         self.beta1_t = _loss_weights(model, model_config, 0.0)     # (lambda1, -beta1, beta2, omiga1..3); entry 1 rewritten per step
         self.graphs, self.seen = {}, set()
+        self.opt_graph = None
         self.pool = None
         self.version = getattr(model, "_state_version", 0)
 
-    def _body(self, tp_i, tp, bi, epoch):
+    def _body(self, tp_i, tp, bi, epoch, with_update=True):
         losses = forward_backward(self.model, self.cfg, self.dd, tp_i, tp, bi, epoch, self.beta1_t,
                                   optimizer=self.opt)
-        self.opt.step()
+        if with_update:
+            self.opt.step()
         return losses
 
-    def step(self, tp_i, tp, bi, epoch, beta1):
+    def _capture(self, fn):
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        if self.pool is None:
+            self.pool = torch.cuda.graph_pool_handle()
+        # thread_local: a process group's watchdog thread may touch the runtime while this thread captures
+        with torch.cuda.graph(g, pool=self.pool, capture_error_mode="thread_local"):
+            out = fn()
+        return g, out
+
+    def update(self):
+        """clip + AdamW as its own graph (data-parallel path: after the gradient exchange): eager once, then one
+        replayed graph shared by all keys."""
+        if self.opt_graph is None:
+            self.opt.step()
+            self.opt_graph = False                  # warmed up; capture on the next call
+        elif self.opt_graph is False:
+            self.opt_graph, _ = self._capture(self.opt.step)
+            self.opt_graph.replay()
+        else:
+            self.opt_graph.replay()
+
+    def _run(self, tp_i, tp, bi, epoch, beta1, with_update):
         if getattr(self.model, "_state_version", 0) != self.version:      # a state tensor was re-allocated
             self.graphs.clear()
             self.version = getattr(self.model, "_state_version", 0)
         self.beta1_t[1].fill_(-float(beta1))
-        key = (tp, bi, epoch >= 1, epoch >= self.cfg["ot_epoch"] and tp_i != 0)
+        key = (tp, bi, epoch >= 1, epoch >= self.cfg["ot_epoch"] and tp_i != 0, with_update)
         if key in self.graphs:
             g, out = self.graphs[key]
             g.replay()
             return out.clone()
         if key not in self.seen:                                            # warm-up visit: plain eager step
             self.seen.add(key)
-            return self._body(tp_i, tp, bi, epoch)
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        if self.pool is None:
-            self.pool = torch.cuda.graph_pool_handle()
-        with torch.cuda.graph(g, pool=self.pool):
-            out = self._body(tp_i, tp, bi, epoch)
+            return self._body(tp_i, tp, bi, epoch, with_update=with_update)
+        g, out = self._capture(lambda: self._body(tp_i, tp, bi, epoch, with_update=with_update))
         self.graphs[key] = (g, out)
         g.replay()
         return out.clone()
+
+    def fb(self, tp_i, tp, bi, epoch, beta1):
+        """Forward + backward of one batch into the flat gradient buffer, no parameter update (data-parallel
+        replicas: exchange the gradient, then update())."""
+        return self._run(tp_i, tp, bi, epoch, beta1, False)
+
+    def step(self, tp_i, tp, bi, epoch, beta1):
+        if self.grad_sync is None:                  # single replica: the optimizer step is part of the step graph
+            return self._run(tp_i, tp, bi, epoch, beta1, True)
+        res = self.fb(tp_i, tp, bi, epoch, beta1)
+        self.grad_sync(self.opt.flat_grad)
+        self.update()
+        return res
 
 
 def training_step(model, optimizer, model_config, dataloader_dict, tp_i, tp, bi, epoch, beta1, grad_sync=None):

@@ -118,7 +118,8 @@ def test_graphed_steps_match_eager_steps(monkeypatch):
     cfg = _small_config()
     cfg.update(input_dim=40, timepoints=[0, 1], device=torch.device(DEV))
     results = []
-    for graphed in (False, True):
+    sync = lambda flat: flat.mul_(1.0)                 # stands in for the replicas' all-reduce (identity)
+    for graphed in (False, True, "split"):             # "split": forward+backward graph | gradient exchange | optimizer graph
         _utils.set_seed(7)
         dd = tu.prepare_dataloader(data, cfg)
         model = SpaDOT.SpaDOT(cfg, dd).to(DEV)
@@ -126,7 +127,7 @@ def test_graphed_steps_match_eager_steps(monkeypatch):
         tu._update_Kmeans(model, cfg, dd)
         tu._update_OT_matrix(model, cfg)
         model.train()
-        stepper = tu.GraphedStepper(model, opt, cfg, dd) if graphed else None
+        stepper = tu.GraphedStepper(model, opt, cfg, dd, grad_sync=sync if graphed == "split" else None) if graphed else None
         losses = []
         for rep in range(4):                       # visit 1 eager, visit 2 capture + replay, visits 3-4 replay
             for bi in range(2):
@@ -138,10 +139,12 @@ def test_graphed_steps_match_eager_steps(monkeypatch):
         results.append((torch.stack(losses).cpu().numpy(), opt.flat_param.detach().cpu().numpy().copy(), int(opt.step_dev.item())))
         if graphed:
             assert len(stepper.graphs) == 2
-    (l0, p0, s0), (l1, p1, s1) = results
-    assert s0 == s1 == 8
-    np.testing.assert_allclose(l1, l0, rtol=2e-3, atol=1e-4)       # atomics in index_add_/GEMM split-K order only
-    np.testing.assert_allclose(p1, p0, rtol=0, atol=5e-4)          # 8 AdamW steps of lr 3e-4 each
+            assert (stepper.opt_graph is not None and stepper.opt_graph is not False) == (graphed == "split")
+    (l0, p0, s0) = results[0]
+    for l1, p1, s1 in results[1:]:
+        assert s0 == s1 == 8
+        np.testing.assert_allclose(l1, l0, rtol=2e-3, atol=1e-4)   # GEMM split-K order / RNG stream differences only
+        np.testing.assert_allclose(p1, p0, rtol=0, atol=5e-4)      # 8 AdamW steps of lr 3e-4 each
 
 
 def test_flat_backward_with_in_place_weight_gradients_matches_autograd():
