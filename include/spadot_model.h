@@ -210,6 +210,11 @@ int spadot_sqerr_backward(const void *g1, const void *y, const void *yhat, long 
 int spadot_kmeans_assign(const void *x, const void *centers, int n, int k, int d, int dtype, int *labels,
                          void *stream);
 
+/* Exact kk nearest neighbours of every point among all n points (self included), brute force in fp64, ordered by
+ * (squared distance, index): out [n, kk] int32.  x [n, d] fp64, d <= 4, kk <= min(n, 128).  Replaces the host
+ * NearestNeighbors call of _Cal_Spatial_Net (_utils.py:66-75) when the coordinates already live in HBM. */
+int spadot_knn(const double *x, int n, int d, int kk, int *out, void *stream);
+
 /* ---------------------------------------------------------------- optimiser (one flat fp32 buffer)
  * sumsq[0] = sum g^2 over `count` gradients (deterministic two-stage reduction; scratch >= 2048 doubles). */
 int spadot_grad_sumsq(const float *grad, long long count, double *scratch, float *sumsq, void *stream);

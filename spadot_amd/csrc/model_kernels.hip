@@ -888,6 +888,55 @@ __global__ __launch_bounds__(256) void k_kmeans_assign(const T *__restrict__ x, 
     labels[i] = arg;
 }
 
+// ------------------------------------------------------------------------------------------
+// Exact k nearest neighbours by brute force (spatial graph construction, _utils.py:52-100): one thread per query
+// point, candidates streamed through LDS in tiles of 256, the running k-best list of every thread in LDS
+// ([slot][thread]: conflict-free), ordered by (squared distance in fp64, index).  out [n, kk] int32, self included.
+// ------------------------------------------------------------------------------------------
+constexpr int KNN_T = 256, KNN_MAXD = 4;
+__global__ __launch_bounds__(KNN_T) void k_knn(const double *__restrict__ x, int n, int d, int kk,
+                                               int *__restrict__ out) {
+    extern __shared__ double knn_sh[];
+    double *tile = knn_sh;                                   // [KNN_T][d] candidate coordinates
+    double *bd = knn_sh + KNN_T * KNN_MAXD;                  // [kk][KNN_T] best distances
+    int *bi = (int *)(bd + (size_t)kk * KNN_T);              // [kk][KNN_T] best indices
+    const int t = threadIdx.x, i = blockIdx.x * KNN_T + t;
+    double q[KNN_MAXD];
+    for (int c = 0; c < KNN_MAXD; c++) q[c] = (i < n && c < d) ? x[(size_t)i * d + c] : 0.0;
+    for (int s = 0; s < kk; s++) { bd[s * KNN_T + t] = INFINITY; bi[s * KNN_T + t] = 0x7fffffff; }
+    double worst = INFINITY;
+    int worst_i = 0x7fffffff;
+    for (int j0 = 0; j0 < n; j0 += KNN_T) {
+        __syncthreads();
+        for (int e = t; e < KNN_T * d; e += KNN_T) {
+            const int jj = j0 + e / d;
+            tile[e] = jj < n ? x[(size_t)j0 * d + e] : 0.0;
+        }
+        __syncthreads();
+        const int cnt = min(KNN_T, n - j0);
+        if (i < n)
+            for (int u = 0; u < cnt; u++) {
+                double dist = 0.0;
+                for (int c = 0; c < d; c++) { const double df = q[c] - tile[u * d + c]; dist += df * df; }
+                const int j = j0 + u;
+                if (dist < worst || (dist == worst && j < worst_i)) {
+                    int pos = kk - 1;                                   // the worst entry drops out
+                    while (pos > 0) {
+                        const double pd = bd[(pos - 1) * KNN_T + t];
+                        const int pi = bi[(pos - 1) * KNN_T + t];
+                        if (pd < dist || (pd == dist && pi < j)) break;
+                        bd[pos * KNN_T + t] = pd; bi[pos * KNN_T + t] = pi;
+                        pos--;
+                    }
+                    bd[pos * KNN_T + t] = dist; bi[pos * KNN_T + t] = j;
+                    worst = bd[(kk - 1) * KNN_T + t]; worst_i = bi[(kk - 1) * KNN_T + t];
+                }
+            }
+    }
+    if (i < n)
+        for (int s = 0; s < kk; s++) out[(size_t)i * kk + s] = bi[s * KNN_T + t];
+}
+
 __global__ __launch_bounds__(256) void k_sumsq_part(const float *__restrict__ g, long long count,
                                                     double *__restrict__ part) {
     __shared__ double sh[16];
@@ -1711,6 +1760,15 @@ int spadot_kmeans_assign(const void *x, const void *centers, int n, int k, int d
     FP_DISPATCH(dtype,
                 hipLaunchKernelGGL(k_kmeans_assign<float>, g, dim3(256), 0, st_, (const float *)x, (const float *)centers, n, k, d, labels),
                 hipLaunchKernelGGL(k_kmeans_assign<double>, g, dim3(256), 0, st_, (const double *)x, (const double *)centers, n, k, d, labels));
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+int spadot_knn(const double *x, int n, int d, int kk, int *out, void *stream) {
+    if (n <= 0 || d <= 0 || d > KNN_MAXD || kk <= 0 || kk > n || kk > 128) return -22;
+    const size_t lds = sizeof(double) * KNN_T * KNN_MAXD + (sizeof(double) + sizeof(int)) * (size_t)kk * KNN_T;
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_knn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+    hipLaunchKernelGGL(k_knn, dim3((n + KNN_T - 1) / KNN_T), dim3(KNN_T), lds, (hipStream_t)stream, x, n, d, kk, out);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 

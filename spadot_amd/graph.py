@@ -13,16 +13,22 @@ import torch
 from .ops import BatchGraph
 
 
-def knn_graph(coords, k_cutoff, max_neigh=30):
+def knn_graph(coords, k_cutoff, max_neigh=30, backend="sklearn", device=None):
     """Directed edges i -> j for j among the k_cutoff nearest neighbours of i (self excluded), plus one
     self loop per node (_utils.py:66-100: kNN over max_neigh+1 candidates, columns 1..k_cutoff kept;
     `G + eye`).  Returns int64 edge_index [2, E], row 0 = source i, row 1 = target j, sorted row-major
-    like dense_to_sparse of the reference's adjacency."""
-    from sklearn.neighbors import NearestNeighbors
+    like dense_to_sparse of the reference's adjacency.
+    backend: 'sklearn' (the reference's host NearestNeighbors) or 'device' (ops.knn: brute force in HBM, same
+    neighbours whenever no two candidates are exactly equidistant)."""
     coords = np.asarray(coords, dtype=np.float64)
     n = coords.shape[0]
     kk = min(max_neigh + 1, n)
-    _, idx = NearestNeighbors(n_neighbors=kk, algorithm="auto").fit(coords).kneighbors(coords)
+    if backend == "device":
+        from .ops import knn
+        idx = knn(torch.as_tensor(coords).to(device or "cuda"), kk).cpu().numpy().astype(np.int64)
+    else:
+        from sklearn.neighbors import NearestNeighbors
+        _, idx = NearestNeighbors(n_neighbors=kk, algorithm="auto").fit(coords).kneighbors(coords)
     nb = idx[:, 1:k_cutoff + 1]
     src = np.repeat(np.arange(n, dtype=np.int64), nb.shape[1])
     dst = nb.reshape(-1).astype(np.int64)

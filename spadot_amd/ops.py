@@ -552,6 +552,17 @@ def kmeans_assign(x, centers):
 
 # ----------------------------------------------------------------------------- optimiser
 
+def knn(coords, kk):
+    """Indices [n, kk] (int32, device) of the kk nearest points of every point, itself included, ordered by
+    (distance, index); brute force in fp64 on the device (include/spadot_model.h: spadot_knn)."""
+    _need_cuda(coords)
+    x = coords.contiguous().double()
+    n, d = x.shape
+    out = torch.empty((n, kk), dtype=torch.int32, device=x.device)
+    _check(model_lib().spadot_knn(_p(x), n, d, int(kk), _p(out), _stream()), "spadot_knn")
+    return out
+
+
 class FlatAdamW:
     """clip_grad_norm_(max_norm) + AdamW.step (_train_utils.py:214-217) as two HIP kernels over ONE
     flat fp32 parameter buffer.  Parameters of `module` are re-pointed into the flat buffer (so the

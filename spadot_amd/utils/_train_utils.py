@@ -73,7 +73,8 @@ def prepare_dataloader(adata, model_config):
         n = ix.size
         k_cut = min(model_config["max_neighbors"], model_config["knn_cutoff"] * round(1 / 1000 * n))
         print("Calculating spatial graph...")
-        ei = knn_graph(spatial[ix], k_cut, max_neigh=model_config["max_neighbors"])
+        ei = knn_graph(spatial[ix], k_cut, max_neigh=model_config["max_neighbors"],
+                       backend=model_config.get("knn_backend", "sklearn"), device=device)
         print("The graph contains %d edges, %d cells." % (ei.shape[1] - n, n))
         Y = torch.as_tensor(np.ascontiguousarray(np.asarray(X[ix]))).to(device=device, dtype=store)
         datasets[tp] = (torch.as_tensor(loc[ix, :2]).to(device), Y, ix)

@@ -315,6 +315,29 @@ def test_composite_forward_bf16_compute(ops):
     assert float(recon) == pytest.approx(float(g["recon"]), rel=2e-2)
 
 
+# ------------------------------------------------------------------ spatial graph on the device
+
+@pytest.mark.parametrize("n,kk,d", [(1500, 31, 2), (300, 7, 2), (50, 50, 3), (10000, 31, 2)])
+def test_device_knn_matches_host_neighbours(ops, n, kk, d):
+    """ops.knn (brute force, fp64) returns sklearn's neighbours in sklearn's order on points without exact ties;
+    graph.knn_graph gives the same edge list with either backend."""
+    from sklearn.neighbors import NearestNeighbors
+    from spadot_amd.graph import knn_graph
+    rng = np.random.default_rng(n + kk)
+    pts = rng.uniform(size=(n, d)) * 30.0
+    _, ref = NearestNeighbors(n_neighbors=kk).fit(pts).kneighbors(pts)
+    got = ops.knn(torch.as_tensor(pts, device=DEV), kk).cpu().numpy()
+    np.testing.assert_array_equal(got, ref)
+    if d == 2 and kk > 8:
+        a = knn_graph(pts, 6, max_neigh=kk - 1)
+        b_ = knn_graph(pts, 6, max_neigh=kk - 1, backend="device", device=DEV)
+        np.testing.assert_array_equal(a, b_)
+    # exact duplicates: ordered by index among equal distances, every point finds itself at distance 0
+    dup = np.repeat(pts[:20], 2, axis=0)
+    g2 = ops.knn(torch.as_tensor(dup, device=DEV), 4).cpu().numpy()
+    assert (g2[:, :2] // 2 == np.arange(40)[:, None] // 2).all() and (g2[:, 0] < g2[:, 1]).all()
+
+
 # ------------------------------------------------------------------ glue: k-means labels, optimiser
 
 def test_kmeans_assignment_is_bit_exact(ops):
