@@ -32,11 +32,9 @@ class Decoder(nn.Module):
     def forward(self, latent_sample):
         stages = list(self.decoder_net)
         h = latent_sample
-        fused = h.is_cuda
         for i in range(0, len(stages) - 1, 3):
             dense, norm, act = stages[i], stages[i + 1], stages[i + 2]
-            h = dense(h)
-            h = ln_act(h, norm, act.negative_slope) if fused else act(norm(h))     # LayerNorm + LeakyReLU: one launch
+            h = ln_act(dense(h), norm, act.negative_slope)                  # LayerNorm + LeakyReLU: one launch
         last, cd = stages[-1], self.compute_dtype
         if cd == torch.float32:
             return last(h)

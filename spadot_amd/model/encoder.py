@@ -37,7 +37,7 @@ class SVGPEncoder(nn.Module):
     def pre_head(self, x):
         """SVGP_fc output (mu | logvar) [b, 2 z]."""
         net = list(self.SVGP_encoder_net)
-        fused = self.training and x.is_cuda            # eval mode (running statistics) takes the library path
+        fused = self.training                          # eval mode (running statistics) takes the library modules
         if not fused:
             x = x[:, :net[0].in_features]
             if self.compute_dtype == torch.float32:
