@@ -261,10 +261,11 @@ def test_device_kmeans_vs_sklearn():
     assert kmh.inertia_ <= 1.01 * skh.inertia_
 
 
-def test_training_with_device_kmeans_backend(tmp_path):
+def test_training_with_device_kmeans_and_knn_backends(tmp_path):
+    """Everything after the h5ad read on the device: spatial kNN graph, K-means fits, training (bf16 compute)."""
     import spadot_amd, yaml
     from spadot_amd.synthetic import make_dataset
-    cfg = _small_config(); cfg["kmeans_backend"] = "device"; cfg["maxiter"] = 2
+    cfg = _small_config(); cfg["kmeans_backend"] = "device"; cfg["knn_backend"] = "device"; cfg["maxiter"] = 2
     p = tmp_path / "cfg.yaml"; yaml.safe_dump(cfg, open(p, "w"))
     args = types.SimpleNamespace(data=make_dataset(2, 1200, 40, seed=11), output_dir=str(tmp_path / "o"), prefix="",
                                  config=str(p), save_model=False, device=DEV)
