@@ -210,6 +210,14 @@ int spadot_sqerr_backward(const void *g1, const void *y, const void *yhat, long 
 int spadot_kmeans_assign(const void *x, const void *centers, int n, int k, int d, int dtype, int *labels,
                          void *stream);
 
+/* One Lloyd iteration of K-means for R restarts at once (fp64, no atomics: two fits of the same data are bitwise
+ * identical).  X [n, D] (centred data), C [R, K, D] centres (updated in place unless done[r]), part: work space of
+ * R * ceil(n/256) * (K*(D+1) + 1) doubles, done [R] int flags (set when the squared centre shift <= tol), inertia [R]
+ * = inertia of the centres the iteration started from, labels [R, n] int32 or NULL.  update = 0: assignment, partial
+ * sums and labels only.  K <= 32, D <= 32.  (KMeans of _train_utils.py:255-269.) */
+int spadot_lloyd_step(const double *X, double *C, int n, int D, int K, int R, double tol, double *part, int *done,
+                      double *inertia, int *labels, int update, void *stream);
+
 /* Exact kk nearest neighbours of every point among all n points (self included), brute force in fp64, ordered by
  * (squared distance, index): out [n, kk] int32.  x [n, d] fp64, d <= 4, kk <= min(n, 128).  Replaces the host
  * NearestNeighbors call of _Cal_Spatial_Net (_utils.py:66-75) when the coordinates already live in HBM. */

@@ -937,6 +937,88 @@ __global__ __launch_bounds__(KNN_T) void k_knn(const double *__restrict__ x, int
         for (int s = 0; s < kk; s++) out[(size_t)i * kk + s] = bi[s * KNN_T + t];
 }
 
+// ------------------------------------------------------------------------------------------
+// Lloyd iterations of K-means for R restarts at once (fp64, deterministic: no atomics).
+//   k_lloyd_assign: block = (restart r, chunk of 256 points): nearest centre per point (first minimum wins),
+//                   per-block cluster sums / counts / inertia in a fixed order -> part[r][chunk][K*(D+1) + 1]
+//   k_lloyd_update: block = restart: partials summed in chunk order, centres moved (empty cluster: kept), squared
+//                   shift compared with tol, `done` restarts frozen.
+// ------------------------------------------------------------------------------------------
+constexpr int LL_PTS = 256, LL_MAXK = 32, LL_MAXD = 32;
+__global__ __launch_bounds__(LL_PTS) void k_lloyd_assign(const double *__restrict__ X, const double *__restrict__ C,
+                                                         int n, int D, int K, double *__restrict__ part,
+                                                         int *__restrict__ labels /* [R, n] or null */) {
+    extern __shared__ double ll_dyn[];           // K*D centres, then 256*D point coordinates
+    double *s_c = ll_dyn, *s_x = ll_dyn + (size_t)K * D;
+    __shared__ int s_lab[LL_PTS];
+    __shared__ double s_red[16];
+    const int r = blockIdx.y, chunk = blockIdx.x, t = threadIdx.x;
+    const int i = chunk * LL_PTS + t;
+    const int nchunk = gridDim.x;
+    for (int e = t; e < K * D; e += LL_PTS) s_c[e] = C[(size_t)r * K * D + e];
+    const int rows = min(LL_PTS, n - chunk * LL_PTS);
+#pragma unroll 4
+    for (int e = t; e < rows * D; e += LL_PTS) s_x[e] = X[(size_t)chunk * LL_PTS * D + e];
+    __syncthreads();
+    double best = INFINITY;
+    int arg = -1;
+    if (i < n) {
+        for (int k = 0; k < K; k++) {
+            double d2 = 0.0;
+#pragma unroll 4
+            for (int c = 0; c < D; c++) { const double df = s_x[t * D + c] - s_c[k * D + c]; d2 += df * df; }
+            if (d2 < best) { best = d2; arg = k; }
+        }
+        if (labels) labels[(size_t)r * n + i] = arg;
+    }
+    s_lab[t] = arg;
+    const double inertia = block_sum_d(i < n ? best : 0.0, s_red);       // (includes the barrier after s_lab)
+    double *out = part + ((size_t)r * nchunk + chunk) * ((size_t)K * (D + 1) + 1);
+    for (int pq = t; pq < K * (D + 1); pq += LL_PTS) {
+        const int k = pq / (D + 1), c = pq - k * (D + 1);
+        double acc = 0.0;
+#pragma unroll 8
+        for (int u = 0; u < LL_PTS; u++) {
+            const bool hit = s_lab[u] == k;
+            acc += hit ? (c < D ? s_x[(u < rows ? u : 0) * D + c] : 1.0) : 0.0;
+        }
+        out[pq] = acc;
+    }
+    if (t == 0) out[(size_t)K * (D + 1)] = inertia;
+}
+
+__global__ __launch_bounds__(256) void k_lloyd_update(const double *__restrict__ part, int nchunk, int D, int K,
+                                                      double tol, double *__restrict__ C, int *__restrict__ done,
+                                                      double *__restrict__ inertia) {
+    __shared__ double s_new[LL_MAXK * (LL_MAXD + 1)];
+    __shared__ double s_red[16];
+    const int r = blockIdx.x, t = threadIdx.x;
+    const size_t stride = (size_t)K * (D + 1) + 1;
+    for (int pq = t; pq < K * (D + 1); pq += 256) {
+        double acc = 0.0;
+        for (int ch = 0; ch < nchunk; ch++) acc += part[((size_t)r * nchunk + ch) * stride + pq];
+        s_new[pq] = acc;
+    }
+    double in = 0.0;
+    for (int ch = t; ch < nchunk; ch += 256) in += part[((size_t)r * nchunk + ch) * stride + K * (D + 1)];
+    in = block_sum_d(in, s_red);
+    __syncthreads();
+    double sh = 0.0;
+    const bool frozen = done[r] != 0;
+    for (int e = t; e < K * D; e += 256) {
+        const int k = e / D, c = e - k * D;
+        const double cnt = s_new[k * (D + 1) + D], old = C[(size_t)r * K * D + e];
+        const double nw = cnt > 0.0 ? s_new[k * (D + 1) + c] / cnt : old;
+        sh += (nw - old) * (nw - old);
+        if (!frozen) C[(size_t)r * K * D + e] = nw;
+    }
+    sh = block_sum_d(sh, s_red);
+    if (t == 0) {
+        inertia[r] = in;                     // inertia of the centres this iteration STARTED from
+        if (!frozen && sh <= tol) done[r] = 1;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_sumsq_part(const float *__restrict__ g, long long count,
                                                     double *__restrict__ part) {
     __shared__ double sh[16];
@@ -1769,6 +1851,19 @@ int spadot_knn(const double *x, int n, int d, int kk, int *out, void *stream) {
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_knn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
     hipLaunchKernelGGL(k_knn, dim3((n + KNN_T - 1) / KNN_T), dim3(KNN_T), lds, (hipStream_t)stream, x, n, d, kk, out);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+int spadot_lloyd_step(const double *X, double *C, int n, int D, int K, int R, double tol, double *part, int *done,
+                      double *inertia, int *labels, int update, void *stream) {
+    if (n <= 0 || D <= 0 || D > LL_MAXD || K <= 0 || K > LL_MAXK || R <= 0 || R > 65535 || !part) return -22;
+    if ((size_t)K * D + (size_t)LL_PTS * D > 7936) return -22;     // dynamic LDS stays under 62 KB
+    hipStream_t st_ = (hipStream_t)stream;
+    const int nchunk = (n + LL_PTS - 1) / LL_PTS;
+    const size_t lds = sizeof(double) * ((size_t)K * D + (size_t)LL_PTS * D);      // <= 8 KB + 64 KB
+    hipLaunchKernelGGL(k_lloyd_assign, dim3(nchunk, R), dim3(LL_PTS), lds, st_, X, (const double *)C, n, D, K, part, labels);
+    if (update)
+        hipLaunchKernelGGL(k_lloyd_update, dim3(R), dim3(256), 0, st_, (const double *)part, nchunk, D, K, tol, C, done, inertia);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 

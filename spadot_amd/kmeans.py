@@ -2,7 +2,7 @@
 sklearn.cluster.KMeans(n_clusters, random_state=seed, n_init=10) on the host for every time point
 (/root/reference/SpaDOT/utils/_train_utils.py:255-269) -- at cfg3 that costs more wall time per epoch than
 the 100 training steps.  This module runs the same algorithm (k-means++ seeding with sklearn's candidate
-rule, Lloyd iterations for all n_init restarts at once, tol = 1e-4 * mean feature variance, best inertia
+rule, Lloyd iterations for all n_init restarts at once (two HIP launches per iteration: spadot_lloyd_step), tol = 1e-4 * mean feature variance, best inertia
 wins) on the MI355X; random draws come from a host numpy RandomState seeded like sklearn's, everything
 that touches the data stays in HBM.
 
@@ -14,7 +14,7 @@ It is therefore opt-in: model_config['kmeans_backend'] = 'device' (default 'skle
 import numpy as np
 import torch
 
-from .ops import kmeans_assign
+from .ops import kmeans_assign, lloyd_steps
 
 
 class KMeansDevice:
@@ -22,27 +22,39 @@ class KMeansDevice:
         self.k, self.seed, self.n_init, self.max_iter, self.tol, self.check_every = \
             int(n_clusters), int(random_state), int(n_init), int(max_iter), float(tol), int(check_every)
 
-    # ---- k-means++ (sklearn _kmeans_plusplus: 2 + log(k) candidates per centre, best potential wins)
-    def _init_centers(self, X, xsq, rs):
+    # ---- k-means++ (sklearn _kmeans_plusplus: 2 + log(k) candidates per centre, best potential wins),
+    # all restarts at once: the random draws of every restart are made up front on the host (one RandomState per
+    # restart, same call order as a restart-by-restart loop), the k - 1 selection rounds run batched in HBM
+    def _init_centers(self, X, xsq, seeds):
         n, d = X.shape
-        k = self.k
+        k, R = self.k, len(seeds)
         trials = 2 + int(np.log(k))
-        centers = torch.empty((k, d), dtype=X.dtype, device=X.device)
-        first = int(rs.choice(n))
-        centers[0] = X[first]
-        closest = (xsq - 2.0 * (X @ centers[0]) + centers[0].dot(centers[0])).clamp_(min=0)
-        pot = closest.sum()
+        first = np.empty(R, dtype=np.int64)
+        U = np.empty((R, max(k - 1, 1), trials), dtype=np.float64)
+        for r, s in enumerate(seeds):
+            rs = np.random.RandomState(int(s))
+            first[r] = int(rs.choice(n))
+            for c in range(1, k):
+                U[r, c - 1] = rs.uniform(size=trials)
+        first = torch.as_tensor(first, device=X.device)
+        U = torch.as_tensor(U, dtype=X.dtype, device=X.device)
+        centers = torch.empty((R, k, d), dtype=X.dtype, device=X.device)
+        centers[:, 0] = X[first]
+        c0 = centers[:, 0]                                                        # [R, d]
+        closest = (xsq[None, :] - 2.0 * (c0 @ X.T) + (c0 * c0).sum(1)[:, None]).clamp_(min=0)     # [R, n]
+        pot = closest.sum(1)                                                      # [R]
+        ar = torch.arange(R, device=X.device)
         for c in range(1, k):
-            rv = torch.as_tensor(rs.uniform(size=trials), dtype=X.dtype, device=X.device) * pot
-            cand = torch.searchsorted(torch.cumsum(closest, 0), rv).clamp_(max=n - 1)
-            Xc = X[cand]                                                          # [trials, d]
-            dist = (xsq[None, :] - 2.0 * (Xc @ X.T) + (Xc * Xc).sum(1)[:, None]).clamp_(min=0)
-            dist = torch.minimum(dist, closest[None, :])
-            pots = dist.sum(1)
-            best = torch.argmin(pots)
-            centers[c] = Xc[best]
-            closest = dist[best]
-            pot = pots[best]
+            rv = U[:, c - 1] * pot[:, None]                                       # [R, trials]
+            cand = torch.searchsorted(torch.cumsum(closest, 1), rv).clamp_(max=n - 1)
+            Xc = X[cand]                                                          # [R, trials, d]
+            dist = (xsq[None, None, :] - 2.0 * torch.matmul(Xc, X.T) + (Xc * Xc).sum(2)[:, :, None]).clamp_(min=0)
+            dist = torch.minimum(dist, closest[:, None, :])                       # [R, trials, n]
+            pots = dist.sum(2)                                                    # [R, trials]
+            best = torch.argmin(pots, dim=1)                                      # [R]
+            centers[:, c] = Xc[ar, best]
+            closest = dist[ar, best]
+            pot = pots[ar, best]
         return centers
 
     def fit(self, X):
@@ -57,29 +69,23 @@ class KMeansDevice:
         tol = float(self.tol) * Xc.var(0, unbiased=False).mean()
         rs = np.random.RandomState(self.seed)
         seeds = rs.randint(np.iinfo(np.int32).max, size=self.n_init)
-        C = torch.stack([self._init_centers(Xc, xsq, np.random.RandomState(int(s))) for s in seeds])   # [R, k, d]
+        C = self._init_centers(Xc, xsq, seeds)                                    # [R, k, d]
         R, k = C.shape[0], self.k
-        done = torch.zeros(R, dtype=torch.bool, device=X.device)
+        C = C.contiguous()
+        Xc = Xc.contiguous()
+        done = torch.zeros(R, dtype=torch.int32, device=X.device)
+        inertia = torch.zeros(R, dtype=torch.float64, device=X.device)
+        part = torch.empty(R * ((n + 255) // 256) * (k * (d + 1) + 1), dtype=torch.float64, device=X.device)
         it = 0
         while it < self.max_iter:
-            for _ in range(self.check_every):
-                d2 = xsq[None, :, None] - 2.0 * torch.einsum("nd,rkd->rnk", Xc, C) + (C * C).sum(2)[:, None, :]
-                lab = d2.argmin(2)                                                  # [R, n]
-                # segment sums as a one-hot GEMM: no atomics, so two fits of the same data are bitwise identical
-                onehot = torch.nn.functional.one_hot(lab, k).to(torch.float64)    # [R, n, k]
-                sums = torch.einsum("rnk,nd->rkd", onehot, Xc)
-                cnt = onehot.sum(1)
-                newC = torch.where(cnt[:, :, None] > 0, sums / cnt.clamp(min=1)[:, :, None], C)   # empty cluster: keep
-                shift = ((newC - C) ** 2).sum((1, 2))
-                C = torch.where(done[:, None, None], C, newC)
-                done = done | (shift <= tol)
-                it += 1
-                if it >= self.max_iter:
-                    break
+            steps = min(self.check_every, self.max_iter - it)
+            lloyd_steps(Xc, C, tol, done, inertia, part, steps)          # two launches per iteration, all restarts
+            it += steps
             if bool(done.all()):                          # one host sync per `check_every` Lloyd iterations
                 break
-        d2 = xsq[None, :, None] - 2.0 * torch.einsum("nd,rkd->rnk", Xc, C) + (C * C).sum(2)[:, None, :]
-        inertia = d2.min(2).values.clamp_(min=0).sum(1)
+        # inertia of the final centres (a frozen restart's centres did not move: its last value is exact already)
+        final = C.clone()
+        lloyd_steps(Xc, final, -1.0, torch.ones_like(done), inertia, part, 1)
         best = int(torch.argmin(inertia))
         centers = C[best] + mean
         labels = kmeans_assign(X, centers)                # the exact nearest-centre rule (HIP kernel)

@@ -552,6 +552,17 @@ def kmeans_assign(x, centers):
 
 # ----------------------------------------------------------------------------- optimiser
 
+def lloyd_steps(X, C, tol, done, inertia, part, steps):
+    """`steps` Lloyd iterations for all restarts (include/spadot_model.h: spadot_lloyd_step); X [n, D], C [R, K, D]
+    fp64 device tensors, C / done / inertia updated in place."""
+    n, D = X.shape
+    R, K, _ = C.shape
+    lib = model_lib()
+    for _ in range(steps):
+        _check(lib.spadot_lloyd_step(_p(X), _p(C), n, D, K, R, float(tol), _p(part), _p(done), _p(inertia), None, 1,
+                                     _stream()), "spadot_lloyd_step")
+
+
 def knn(coords, kk):
     """Indices [n, kk] (int32, device) of the kk nearest points of every point, itself included, ordered by
     (distance, index); brute force in fp64 on the device (include/spadot_model.h: spadot_knn)."""
