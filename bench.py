@@ -211,10 +211,17 @@ def _main(real_stdout):
         use_graphs = os.environ.get("SPADOT_BENCH_NO_GRAPHS") != "1"
         stepper = tu.GraphedStepper(model, opt, cfg, dd, grad_sync=grad_sync) if use_graphs else None
 
+        state = {"stepper": stepper}
+
         def step(i):
             t, bi = sched[i % len(sched)]
-            if stepper is not None:
-                return stepper.step(t, t, bi, epoch, beta1)
+            if state["stepper"] is not None:
+                try:
+                    return state["stepper"].step(t, t, bi, epoch, beta1)
+                except RuntimeError as ex:          # a capture the runtime refuses: keep measuring, eagerly
+                    print(f"[bench] rank {rank}: hipGraph path disabled ({str(ex)[:200]})", file=sys.stderr)
+                    state["stepper"] = None
+                    torch.cuda.synchronize()
             return tu.training_step(model, opt, cfg, dd, t, t, bi, epoch, beta1, grad_sync=grad_sync)
 
         if stepper is not None:
@@ -237,7 +244,7 @@ def _main(real_stdout):
                      "setup_s": setup_s, "n_sub": b0.graph.n, "E_sub": b0.graph.E,
                      "m_inducing": int(dd["inducing_points"][train_tps[0]].shape[0]),
                      "params": int(opt.count), "last_losses": [float(v) for v in last.cpu().tolist()],
-                     "hip_graphs": bool(use_graphs)}
+                     "hip_graphs": state["stepper"] is not None}
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             t, bi = sched[0]
             train_res["cpu_baseline"] = cpu_train_step(model, dd, cfg, t, bi, t - 1)
