@@ -170,10 +170,11 @@ int spadot_svgp_pre(const float *z, int b, int L, double *mu, double *var, doubl
  * latent head (SpaDOT.py:78-93): zg [b, 2 Lg] fp32 = GAT_fc output (mu | logvar), p_m / p_v [b, Ls] fp64 = SVGP
  * posterior, eps [b, Ls+Lg] fp32 standard normal.  latent [b, Ls+Lg] = (p_m + eps sqrt(p_v) | mu + eps
  * sqrt(exp(logvar))); scal2 = (GAT_KL = -1/2 sum(1 + logvar - mu^2 - var) / Lg,
- * alignment = sum_i (|s_i| / Ls - |g_i| / Lg)^2).  backward: g_latent [b, Ls+Lg] or NULL, g_kl / g_align device
+ * alignment = sum_i (|s_i| / Ls - |g_i| / Lg)^2); Ls + Lg <= 32; partials: 2 * ceil(b/8) doubles of work space, counter: one
+ * unsigned that is 0 before the first launch (the kernel leaves it 0).  backward: g_latent [b, Ls+Lg] or NULL, g_kl / g_align device
  * scalars or NULL -> d_zg [b, 2 Lg], d_pm, d_pv [b, Ls] fp64. */
 int spadot_latent_head_forward(const float *zg, const double *p_m, const double *p_v, const float *eps, int b, int Ls,
-                               int Lg, float *latent, float *scal2, void *stream);
+                               int Lg, float *latent, float *scal2, double *partials, unsigned *counter, void *stream);
 int spadot_latent_head_backward(const float *zg, const double *p_v, const float *eps, const float *latent,
                                 const float *g_latent, const float *g_kl, const float *g_align, int b, int Ls, int Lg,
                                 float *d_zg, double *d_pm, double *d_pv, void *stream);

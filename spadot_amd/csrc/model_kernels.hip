@@ -1064,14 +1064,14 @@ __global__ __launch_bounds__(256) void k_adamw(float *__restrict__ p, const floa
 // Small-MLP stages: BatchNorm1d (training) + LeakyReLU, LayerNorm + LeakyReLU, each ONE launch forward and one
 // (LayerNorm: two) backward instead of the library's 4-5 and 3-4.  b rows <= a few thousand, F features <= 1024.
 // ------------------------------------------------------------------------------------------
-constexpr int BN_COLS = 32, BN_RG = 8;      // 32 columns x 8 row lanes per workgroup
+constexpr int BN_COLS = 16, BN_RG = 64, BN_NT = BN_COLS * BN_RG;      // 16 columns x 64 row lanes per workgroup (b = 512: 8 rows per thread)
 
 __device__ __forceinline__ float bn_col_sum(float v, float (*sh)[BN_COLS + 1], int cl, int rg) {
     __syncthreads();
     sh[rg][cl] = v;
     __syncthreads();
     float t = 0.f;
-#pragma unroll
+#pragma unroll 8
     for (int g = 0; g < BN_RG; g++) t += sh[g][cl];
     return t;
 }
@@ -1079,14 +1079,14 @@ __device__ __forceinline__ float bn_col_sum(float v, float (*sh)[BN_COLS + 1], i
 // y = leaky((x + lb - mean) invstd gamma + beta, slope); batch statistics over the b rows; running statistics
 // updated like nn.BatchNorm1d (momentum, unbiased running variance); lb = bias of the preceding Linear or null.
 template <typename TX>
-__global__ __launch_bounds__(256) void k_bn_act_fwd(const TX *__restrict__ x, const float *__restrict__ lb,
+__global__ __launch_bounds__(BN_NT) void k_bn_act_fwd(const TX *__restrict__ x, const float *__restrict__ lb,
                                                     const float *__restrict__ gamma, const float *__restrict__ beta,
                                                     float *__restrict__ run_mean, float *__restrict__ run_var,
                                                     long long *__restrict__ nbt, int b, int F, float momentum, float eps,
                                                     float slope, float *__restrict__ y, float *__restrict__ save_mean,
                                                     float *__restrict__ save_invstd) {
     __shared__ float sh[BN_RG][BN_COLS + 1];
-    const int cl = threadIdx.x & (BN_COLS - 1), rg = threadIdx.x >> 5;
+    const int cl = threadIdx.x & (BN_COLS - 1), rg = threadIdx.x / BN_COLS;
     const int c = blockIdx.x * BN_COLS + cl;
     const bool on = c < F;
     const float add = (on && lb) ? lb[c] : 0.f;
@@ -1118,14 +1118,14 @@ __global__ __launch_bounds__(256) void k_bn_act_fwd(const TX *__restrict__ x, co
 }
 
 template <typename TX>
-__global__ __launch_bounds__(256) void k_bn_act_bwd(const float *__restrict__ dy, const float *__restrict__ y,
+__global__ __launch_bounds__(BN_NT) void k_bn_act_bwd(const float *__restrict__ dy, const float *__restrict__ y,
                                                     const TX *__restrict__ x, const float *__restrict__ lb,
                                                     const float *__restrict__ gamma, const float *__restrict__ save_mean,
                                                     const float *__restrict__ save_invstd, int b, int F, float slope,
                                                     TX *__restrict__ dx, float *__restrict__ dgamma,
                                                     float *__restrict__ dbeta) {
     __shared__ float sh[BN_RG][BN_COLS + 1];
-    const int cl = threadIdx.x & (BN_COLS - 1), rg = threadIdx.x >> 5;
+    const int cl = threadIdx.x & (BN_COLS - 1), rg = threadIdx.x / BN_COLS;
     const int c = blockIdx.x * BN_COLS + cl;
     const bool on = c < F;
     const float add = (on && lb) ? lb[c] : 0.f;
@@ -1199,12 +1199,12 @@ __global__ __launch_bounds__(256) void k_ln_act_bwd_rows(const float *__restrict
 }
 
 // dgamma[c] = sum_i dz x_hat, dbeta[c] = sum_i dz  (column reduction, same geometry as the BatchNorm kernels)
-__global__ __launch_bounds__(256) void k_ln_act_bwd_cols(const float *__restrict__ dy, const float *__restrict__ y,
+__global__ __launch_bounds__(BN_NT) void k_ln_act_bwd_cols(const float *__restrict__ dy, const float *__restrict__ y,
                                                          const float *__restrict__ x, const float *__restrict__ save_mean,
                                                          const float *__restrict__ save_invstd, int b, int F, float slope,
                                                          float *__restrict__ dgamma, float *__restrict__ dbeta) {
     __shared__ float sh[BN_RG][BN_COLS + 1];
-    const int cl = threadIdx.x & (BN_COLS - 1), rg = threadIdx.x >> 5;
+    const int cl = threadIdx.x & (BN_COLS - 1), rg = threadIdx.x / BN_COLS;
     const int c = blockIdx.x * BN_COLS + cl;
     const bool on = c < F;
     float sb = 0.f, sg = 0.f;
@@ -1228,41 +1228,61 @@ __global__ __launch_bounds__(256) void k_ln_act_bwd_cols(const float *__restrict
 // Reparameterised samples of both branches, GAT KL and the alignment term (SpaDOT.py:78-93).
 //   zg [b, 2*Lg] = GAT_fc output (mu | logvar), p_m / p_v [b, Ls] fp64 = SVGP posterior, eps [b, Ls+Lg].
 //   latent [b, Ls+Lg] = (p_m + eps sqrt(p_v) | mu + eps sqrt(var)),  scal = (GAT_KL, alignment).
-__global__ __launch_bounds__(512) void k_latent_head_fwd(const float *__restrict__ zg, const double *__restrict__ p_m,
+// 32 lanes per row (Ls + Lg <= 32 columns): coalesced accesses, row norms by shuffles inside the half wave.
+__device__ __forceinline__ float half_wave_sum(float x) {
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) x += __shfl_xor(x, off, WAVE);
+    return x;
+}
+
+// 8 rows per 256-thread workgroup; the two scalars go through per-workgroup partials and the LAST workgroup to finish
+// (device counter, reset for the next launch) adds them in workgroup order: one launch, reproducible.
+__global__ __launch_bounds__(256) void k_latent_head_fwd(const float *__restrict__ zg, const double *__restrict__ p_m,
                                                          const double *__restrict__ p_v, const float *__restrict__ eps,
                                                          int b, int Ls, int Lg, float *__restrict__ latent,
-                                                         float *__restrict__ scal) {
+                                                         float *__restrict__ scal, double *__restrict__ partials,
+                                                         unsigned *__restrict__ counter) {
     __shared__ double sh[16];
+    __shared__ bool last;
     const int D = Ls + Lg;
-    double kl = 0.0, al = 0.0;
-    for (int i = threadIdx.x; i < b; i += blockDim.x) {
-        float ns = 0.f, ng = 0.f;
-#pragma unroll 5
-        for (int l = 0; l < Ls; l++) {
-            const double s = p_m[(size_t)i * Ls + l] + (double)eps[(size_t)i * D + l] * sqrt(p_v[(size_t)i * Ls + l]);
-            const float sf = (float)s;
-            latent[(size_t)i * D + l] = sf;
-            ns += sf * sf;
-        }
-#pragma unroll 5
-        for (int l = 0; l < Lg; l++) {
-            const float mu = zg[(size_t)i * 2 * Lg + l], lv = zg[(size_t)i * 2 * Lg + Lg + l];
-            const float var = expf(lv);
-            const float g = mu + eps[(size_t)i * D + Ls + l] * sqrtf(var);
-            latent[(size_t)i * D + Ls + l] = g;
-            ng += g * g;
-            kl += 1.0 + (double)logf(var) - (double)mu * mu - (double)var;
-        }
-        const float d = sqrtf(ns) / (float)Ls - sqrtf(ng) / (float)Lg;
-        al += (double)d * d;
+    const int c = threadIdx.x & 31, i = blockIdx.x * 8 + (threadIdx.x >> 5);
+    float val = 0.f, klt = 0.f;
+    if (i < b && c < Ls) {
+        val = (float)(p_m[(size_t)i * Ls + c] + (double)eps[(size_t)i * D + c] * sqrt(p_v[(size_t)i * Ls + c]));
+    } else if (i < b && c < D) {
+        const int l = c - Ls;
+        const float mu = zg[(size_t)i * 2 * Lg + l], lv = zg[(size_t)i * 2 * Lg + Lg + l];
+        const float var = expf(lv);
+        val = mu + eps[(size_t)i * D + c] * sqrtf(var);
+        klt = 1.f + logf(var) - mu * mu - var;
     }
-    kl = block_sum_d(kl, sh);
+    if (i < b && c < D) latent[(size_t)i * D + c] = val;
+    const float ns = half_wave_sum(c < Ls ? val * val : 0.f), ng = half_wave_sum(c >= Ls && c < D ? val * val : 0.f);
+    double al = 0.0;
+    if (c == 0 && i < b) { const float d = sqrtf(ns) / (float)Ls - sqrtf(ng) / (float)Lg; al = (double)d * d; }
+    const double kl = block_sum_d((double)klt, sh);
     al = block_sum_d(al, sh);
-    if (threadIdx.x == 0) { scal[0] = (float)(-0.5 * kl / Lg); scal[1] = (float)al; }
+    if (threadIdx.x == 0) {
+        partials[2 * blockIdx.x] = kl;
+        partials[2 * blockIdx.x + 1] = al;
+        __threadfence();
+        last = atomicAdd(counter, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    double k2 = 0.0, a2 = 0.0;
+    for (int g = threadIdx.x; g < (int)gridDim.x; g += blockDim.x) {
+        k2 += __builtin_nontemporal_load(partials + 2 * g);
+        a2 += __builtin_nontemporal_load(partials + 2 * g + 1);
+    }
+    k2 = block_sum_d(k2, sh);
+    a2 = block_sum_d(a2, sh);
+    if (threadIdx.x == 0) { scal[0] = (float)(-0.5 * k2 / Lg); scal[1] = (float)a2; *counter = 0u; }
 }
 
 // g_latent [b, Ls+Lg] (may be null), g_scal = device scalars (d loss / d GAT_KL, d loss / d alignment).
-__global__ __launch_bounds__(512) void k_latent_head_bwd(const float *__restrict__ zg, const double *__restrict__ p_v,
+__global__ __launch_bounds__(256) void k_latent_head_bwd(const float *__restrict__ zg, const double *__restrict__ p_v,
                                                          const float *__restrict__ eps, const float *__restrict__ latent,
                                                          const float *__restrict__ g_latent, const float *__restrict__ g_kl,
                                                          const float *__restrict__ g_al, int b, int Ls, int Lg,
@@ -1270,32 +1290,27 @@ __global__ __launch_bounds__(512) void k_latent_head_bwd(const float *__restrict
                                                          double *__restrict__ d_pv) {
     const int D = Ls + Lg;
     const float gk = g_kl ? g_kl[0] : 0.f, ga = g_al ? g_al[0] : 0.f;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < b; i += gridDim.x * blockDim.x) {
-        float ns = 0.f, ng = 0.f;
-#pragma unroll 5
-        for (int l = 0; l < Ls; l++) { const float s = latent[(size_t)i * D + l]; ns += s * s; }
-#pragma unroll 5
-        for (int l = 0; l < Lg; l++) { const float g = latent[(size_t)i * D + Ls + l]; ng += g * g; }
-        const float rs = sqrtf(ns), rg = sqrtf(ng);
-        const float d = rs / (float)Ls - rg / (float)Lg;
+    const int c = threadIdx.x & 31, i = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const bool on = i < b && c < D;
+    const float lat = on ? latent[(size_t)i * D + c] : 0.f;
+    const float ns = half_wave_sum(c < Ls ? lat * lat : 0.f), ng = half_wave_sum(c >= Ls && c < D ? lat * lat : 0.f);
+    if (!on) return;
+    const float rs = sqrtf(ns), rg = sqrtf(ng);
+    const float d = rs / (float)Ls - rg / (float)Lg;
+    const float gl = g_latent ? g_latent[(size_t)i * D + c] : 0.f;
+    if (c < Ls) {
         const float cs = rs > 0.f ? ga * 2.f * d / ((float)Ls * rs) : 0.f;      // d align / d s = cs * s
+        const double ds = (double)gl + (double)cs * lat;
+        d_pm[(size_t)i * Ls + c] = ds;
+        d_pv[(size_t)i * Ls + c] = ds * (double)eps[(size_t)i * D + c] * 0.5 / sqrt(p_v[(size_t)i * Ls + c]);
+    } else {
+        const int l = c - Ls;
         const float cg = rg > 0.f ? -ga * 2.f * d / ((float)Lg * rg) : 0.f;
-#pragma unroll 5
-        for (int l = 0; l < Ls; l++) {
-            const float gl = g_latent ? g_latent[(size_t)i * D + l] : 0.f;
-            const double ds = (double)gl + (double)cs * latent[(size_t)i * D + l];
-            d_pm[(size_t)i * Ls + l] = ds;
-            d_pv[(size_t)i * Ls + l] = ds * (double)eps[(size_t)i * D + l] * 0.5 / sqrt(p_v[(size_t)i * Ls + l]);
-        }
-#pragma unroll 5
-        for (int l = 0; l < Lg; l++) {
-            const float gl = g_latent ? g_latent[(size_t)i * D + Ls + l] : 0.f;
-            const float dg = gl + cg * latent[(size_t)i * D + Ls + l];
-            const float mu = zg[(size_t)i * 2 * Lg + l], var = expf(zg[(size_t)i * 2 * Lg + Lg + l]);
-            const float dvar = dg * eps[(size_t)i * D + Ls + l] * 0.5f / sqrtf(var) - gk * 0.5f / (float)Lg * (1.f / var - 1.f);
-            d_zg[(size_t)i * 2 * Lg + l] = dg + gk * mu / (float)Lg;
-            d_zg[(size_t)i * 2 * Lg + Lg + l] = dvar * var;
-        }
+        const float dg = gl + cg * lat;
+        const float mu = zg[(size_t)i * 2 * Lg + l], var = expf(zg[(size_t)i * 2 * Lg + Lg + l]);
+        const float dvar = dg * eps[(size_t)i * D + c] * 0.5f / sqrtf(var) - gk * 0.5f / (float)Lg * (1.f / var - 1.f);
+        d_zg[(size_t)i * 2 * Lg + l] = dg + gk * mu / (float)Lg;
+        d_zg[(size_t)i * 2 * Lg + Lg + l] = dvar * var;
     }
 }
 
@@ -1303,7 +1318,7 @@ __global__ __launch_bounds__(512) void k_latent_head_bwd(const float *__restrict
 //   z [b, D] latent of the seeds; labels_all[seed_ids[i]] = cluster of seed i; centres [K, D] of this time point;
 //   prev [Kp, D] centres of the previous time point; gamma [Kp, Kl] row-normalised plan; cluster_list [Kl].
 //   work (saved for the backward): means [K*D] | cnt [K] | n_distinct | lab [b] (as floats).
-constexpr int CL_MAXK = 64, CL_MAXD = 64;
+constexpr int CL_MAXK = 64, CL_MAXD = 64, CL_KREG = 16;
 __global__ __launch_bounds__(512) void k_cluster_losses_fwd(const float *__restrict__ z, const long long *__restrict__ labels_all,
                                                             const long long *__restrict__ seed_ids, const float *__restrict__ centres,
                                                             const float *__restrict__ prev, const float *__restrict__ gamma,
@@ -1316,8 +1331,9 @@ __global__ __launch_bounds__(512) void k_cluster_losses_fwd(const float *__restr
     __shared__ float s_means[CL_MAXK * CL_MAXD];  // centres first, batch means once the sums are complete
     __shared__ int s_cnt[CL_MAXK];
     extern __shared__ float s_dyn[];              // chunk_rows * D latent values (>= CL_MAXK * D: reused for the
-    float *s_z = s_dyn;                           // previous centres), then chunk_rows labels
+    float *s_z = s_dyn;                           // previous centres), then chunk_rows labels, then segment partials
     int *s_lab = (int *)(s_dyn + (size_t)chunk_rows * D);
+    float *s_part = s_dyn + (size_t)chunk_rows * D + chunk_rows;       // [512 / D][K][D + 1] (fast path)
     float *w_means = work, *w_cnt = work + (size_t)K * D, *w_nd = w_cnt + K, *w_lab = w_nd + 1;
     const int t = threadIdx.x;
     for (int e = t; e < K * D; e += blockDim.x) s_means[e] = centres[e];
@@ -1330,13 +1346,52 @@ __global__ __launch_bounds__(512) void k_cluster_losses_fwd(const float *__restr
     for (int r0 = 0; r0 < b; r0 += chunk_rows) {           // one chunk when the batch fits (b = 512, D = 20: 40 KB)
         const int rows = min(chunk_rows, b - r0);
         __syncthreads();
-        for (int e = t; e < rows * D; e += blockDim.x) s_z[e] = z[(size_t)r0 * D + e];
+#pragma unroll 5
+        for (int e = t; e < rows * D; e += blockDim.x) s_z[e] = z[(size_t)r0 * D + e];      // (unrolled: loads in flight together)
         for (int i = t; i < chunk_rows; i += blockDim.x) {
             const int lab = i < rows ? (int)labels_all[seed_ids[r0 + i]] : -1;      // -1: matches no cluster
             s_lab[i] = lab;
             if (i < rows) w_lab[r0 + i] = (float)lab;
         }
         __syncthreads();
+        if (K <= CL_KREG && D <= (int)blockDim.x) {
+            // fast path: thread = (row segment, column) keeps the K partial sums of its segment in registers;
+            // the segments are then added in order (fixed order => reproducible), far fewer serial LDS reads
+            const int segs = (int)blockDim.x / D, seg = t / D, d = t - seg * D;
+            const int per = (rows + segs - 1) / segs;
+            float av[CL_KREG];
+            int cv[CL_KREG];
+#pragma unroll
+            for (int k = 0; k < CL_KREG; k++) { av[k] = 0.f; cv[k] = 0; }
+            if (seg < segs) {
+                const int i1 = min(rows, (seg + 1) * per);
+                for (int i = seg * per; i < i1; i++) {
+                    const int lab = s_lab[i];
+                    const float zv = s_z[i * D + d];
+#pragma unroll
+                    for (int k = 0; k < CL_KREG; k++) { av[k] += lab == k ? zv : 0.f; cv[k] += lab == k ? 1 : 0; }
+                }
+                float *pp = s_part + (size_t)seg * K * (D + 1);
+                for (int k = 0; k < K; k++) {
+                    float a = 0.f; int c = 0;
+#pragma unroll
+                    for (int kk = 0; kk < CL_KREG; kk++) if (kk == k) { a = av[kk]; c = cv[kk]; }
+                    pp[k * (D + 1) + d] = a;
+                    if (d == 0) pp[k * (D + 1) + D] = (float)c;
+                }
+            }
+            __syncthreads();
+            if (t < K * D) {                                 // PAIRS slot 0 owns pair t
+                const int k = t / D, dd = t - k * D;
+                float sacc = ps[0];
+                int cacc = pc[0];
+                for (int sg = 0; sg < segs; sg++) {
+                    sacc += s_part[(size_t)sg * K * (D + 1) + k * (D + 1) + dd];
+                    cacc += (int)s_part[(size_t)sg * K * (D + 1) + k * (D + 1) + D];
+                }
+                ps[0] = sacc; pc[0] = cacc;
+            }
+        } else {
         // per-cluster sums: one (cluster, column) pair per thread slot, rows in order
 #pragma unroll
         for (int u = 0; u < PAIRS; u++) {
@@ -1353,6 +1408,7 @@ __global__ __launch_bounds__(512) void k_cluster_losses_fwd(const float *__restr
                 }
                 ps[u] = s; pc[u] = c;
             }
+        }
         }
         // K-means term of this chunk's rows (centres still in s_means)
         if (do_km)
@@ -1406,30 +1462,42 @@ __global__ __launch_bounds__(512) void k_cluster_losses_bwd(const float *__restr
                                                             int D, int K, int Kp, int Kl, int do_km, int do_ot,
                                                             float *__restrict__ dz) {
     __shared__ float s_dm[CL_MAXK * CL_MAXD];     // d OT / d means[k, d], already divided by cnt[k]
+    __shared__ float s_mean[CL_MAXK * CL_MAXD], s_prev[CL_MAXK * CL_MAXD], s_cen[CL_MAXK * CL_MAXD];
+    __shared__ float s_dist[CL_MAXK * CL_MAXK];
     const float *w_means = work, *w_cnt = work + (size_t)K * D, *w_nd = w_cnt + K, *w_lab = w_nd + 1;
     const int t = threadIdx.x;
     const float gk = (do_km && g_km) ? g_km[0] : 0.f, go = (do_ot && g_ot) ? g_ot[0] : 0.f;
-    for (int pq = t; pq < K * D; pq += blockDim.x) s_dm[pq] = 0.f;
-    __syncthreads();
+    for (int pq = t; pq < K * D; pq += blockDim.x) { s_dm[pq] = 0.f; s_mean[pq] = w_means[pq]; s_cen[pq] = centres[pq]; }
     if (do_ot)
+        for (int pq = t; pq < Kp * D; pq += blockDim.x) s_prev[pq] = prev[pq];
+    __syncthreads();
+    if (do_ot) {
+        for (int pq = t; pq < Kp * Kl; pq += blockDim.x) {                  // distances once, not once per column
+            const int p = pq / Kl, q = pq - p * Kl, k = (int)cluster_list[q];
+            float a = 0.f;
+#pragma unroll 4
+            for (int e = 0; e < D; e++) { const float df = s_mean[k * D + e] - s_prev[p * D + e]; a += df * df; }
+            s_dist[pq] = sqrtf(a);
+        }
+        __syncthreads();
         for (int qd = t; qd < Kl * D; qd += blockDim.x) {
             const int q = qd / D, d = qd - q * D, k = (int)cluster_list[q];
             if (w_cnt[k] <= 0.f) continue;                      // the stored centre stands in: no gradient
             float acc = 0.f;
             for (int p = 0; p < Kp; p++) {
-                float a = 0.f;
-                for (int e = 0; e < D; e++) { const float df = w_means[k * D + e] - prev[(size_t)p * D + e]; a += df * df; }
-                const float dist = sqrtf(a);
-                if (dist > 0.f) acc += gamma[p * Kl + q] * (w_means[k * D + d] - prev[(size_t)p * D + d]) / dist;
+                const float dist = s_dist[p * Kl + q];
+                if (dist > 0.f) acc += gamma[p * Kl + q] * (s_mean[k * D + d] - s_prev[p * D + d]) / dist;
             }
             s_dm[k * D + d] = go * acc / ((float)Kp * Kl) / w_cnt[k];
         }
+    }
     __syncthreads();
     const float nd = w_nd[0] > 0.f ? w_nd[0] : 1.f;
-    for (int i = t; i < b; i += blockDim.x) {
-        const int k = (int)w_lab[i];
-        for (int d = 0; d < D; d++)
-            dz[(size_t)i * D + d] = gk * 2.f * (z[(size_t)i * D + d] - centres[(size_t)k * D + d]) / ((float)D * nd) + s_dm[k * D + d];
+    const float ck = gk * 2.f / ((float)D * nd);
+#pragma unroll 4
+    for (int e = t; e < b * D; e += blockDim.x) {               // element-parallel: coalesced over the [b, D] arrays
+        const int i = e / D, d = e - i * D, k = (int)w_lab[i];
+        dz[e] = ck * (z[e] - s_cen[k * D + d]) + s_dm[k * D + d];
     }
 }
 
@@ -1667,10 +1735,10 @@ int spadot_bn_act_forward(const void *x, int x_dtype, const float *lin_bias, con
     hipStream_t st_ = (hipStream_t)stream;
     dim3 g((F + BN_COLS - 1) / BN_COLS);
     if (x_dtype == SPADOT_DT_F32)
-        hipLaunchKernelGGL(k_bn_act_fwd<float>, g, dim3(256), 0, st_, (const float *)x, lin_bias, gamma, beta, running_mean,
+        hipLaunchKernelGGL(k_bn_act_fwd<float>, g, dim3(BN_NT), 0, st_, (const float *)x, lin_bias, gamma, beta, running_mean,
                            running_var, num_batches_tracked, b, F, (float)momentum, (float)eps, (float)slope, y, save_mean, save_invstd);
     else if (x_dtype == SPADOT_DT_BF16)
-        hipLaunchKernelGGL(k_bn_act_fwd<__bf16>, g, dim3(256), 0, st_, (const __bf16 *)x, lin_bias, gamma, beta, running_mean,
+        hipLaunchKernelGGL(k_bn_act_fwd<__bf16>, g, dim3(BN_NT), 0, st_, (const __bf16 *)x, lin_bias, gamma, beta, running_mean,
                            running_var, num_batches_tracked, b, F, (float)momentum, (float)eps, (float)slope, y, save_mean, save_invstd);
     else
         return -22;
@@ -1684,10 +1752,10 @@ int spadot_bn_act_backward(const float *dy, const float *y, const void *x, int x
     hipStream_t st_ = (hipStream_t)stream;
     dim3 g((F + BN_COLS - 1) / BN_COLS);
     if (x_dtype == SPADOT_DT_F32)
-        hipLaunchKernelGGL(k_bn_act_bwd<float>, g, dim3(256), 0, st_, dy, y, (const float *)x, lin_bias, gamma, save_mean,
+        hipLaunchKernelGGL(k_bn_act_bwd<float>, g, dim3(BN_NT), 0, st_, dy, y, (const float *)x, lin_bias, gamma, save_mean,
                            save_invstd, b, F, (float)slope, (float *)dx, dgamma, dbeta);
     else if (x_dtype == SPADOT_DT_BF16)
-        hipLaunchKernelGGL(k_bn_act_bwd<__bf16>, g, dim3(256), 0, st_, dy, y, (const __bf16 *)x, lin_bias, gamma, save_mean,
+        hipLaunchKernelGGL(k_bn_act_bwd<__bf16>, g, dim3(BN_NT), 0, st_, dy, y, (const __bf16 *)x, lin_bias, gamma, save_mean,
                            save_invstd, b, F, (float)slope, (__bf16 *)dx, dgamma, dbeta);
     else
         return -22;
@@ -1709,7 +1777,7 @@ int spadot_ln_act_backward(const float *dy, const float *y, const float *x, cons
     hipStream_t st_ = (hipStream_t)stream;
     hipLaunchKernelGGL(k_ln_act_bwd_rows, dim3((b + 3) / 4), dim3(256), 0, st_, dy, y, x, gamma, save_mean, save_invstd, b, F,
                        (float)slope, dx);
-    hipLaunchKernelGGL(k_ln_act_bwd_cols, dim3((F + BN_COLS - 1) / BN_COLS), dim3(256), 0, st_, dy, y, x, save_mean,
+    hipLaunchKernelGGL(k_ln_act_bwd_cols, dim3((F + BN_COLS - 1) / BN_COLS), dim3(BN_NT), 0, st_, dy, y, x, save_mean,
                        save_invstd, b, F, (float)slope, dgamma, dbeta);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
@@ -1756,9 +1824,11 @@ int spadot_svgp_pre(const float *z, int b, int L, double *mu, double *var, doubl
 }
 
 int spadot_latent_head_forward(const float *zg, const double *p_m, const double *p_v, const float *eps, int b, int Ls,
-                               int Lg, float *latent, float *scal2, void *stream) {
-    if (b <= 0 || Ls <= 0 || Lg <= 0) return -22;
-    hipLaunchKernelGGL(k_latent_head_fwd, dim3(1), dim3(512), 0, (hipStream_t)stream, zg, p_m, p_v, eps, b, Ls, Lg, latent, scal2);
+                               int Lg, float *latent, float *scal2, double *partials, unsigned *counter, void *stream) {
+    if (b <= 0 || Ls <= 0 || Lg <= 0 || !partials || !counter) return -22;
+    if (Ls + Lg > 32) return -22;                 // one half wave (32 lanes) per row
+    hipLaunchKernelGGL(k_latent_head_fwd, dim3((b + 7) / 8), dim3(256), 0, (hipStream_t)stream, zg, p_m, p_v, eps, b, Ls, Lg,
+                       latent, scal2, partials, counter);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
@@ -1766,7 +1836,8 @@ int spadot_latent_head_backward(const float *zg, const double *p_v, const float 
                                 const float *g_latent, const float *g_kl, const float *g_align, int b, int Ls, int Lg,
                                 float *d_zg, double *d_pm, double *d_pv, void *stream) {
     if (b <= 0 || Ls <= 0 || Lg <= 0) return -22;
-    hipLaunchKernelGGL(k_latent_head_bwd, dim3((b + 255) / 256), dim3(256), 0, (hipStream_t)stream, zg, p_v, eps, latent,
+    if (Ls + Lg > 32) return -22;
+    hipLaunchKernelGGL(k_latent_head_bwd, dim3((b + 7) / 8), dim3(256), 0, (hipStream_t)stream, zg, p_v, eps, latent,
                        g_latent, g_kl, g_align, b, Ls, Lg, d_zg, d_pm, d_pv);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
@@ -1782,7 +1853,10 @@ int spadot_cluster_losses_forward(const float *z, const long long *labels_all, c
     if (chunk > b) chunk = b;
     if (chunk < CL_MAXK) chunk = CL_MAXK;
     chunk = (chunk + 7) / 8 * 8;
-    const size_t lds = sizeof(float) * (size_t)chunk * D + sizeof(int) * (size_t)chunk;
+    size_t lds = sizeof(float) * (size_t)chunk * D + sizeof(int) * (size_t)chunk;
+    if (K <= CL_KREG && D <= 512) lds += sizeof(float) * (size_t)(512 / D) * K * (D + 1);
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_cluster_losses_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); attr_set = true; }
     hipLaunchKernelGGL(k_cluster_losses_fwd, dim3(1), dim3(512), lds, (hipStream_t)stream, z, labels_all, seed_ids, centres,
                        prev_centres, gamma, cluster_list, b, D, K, Kp, Kl, do_km, do_ot, out2, work, chunk);
     return hipGetLastError() == hipSuccess ? 0 : -5;

@@ -267,6 +267,17 @@ def ln_act(x, ln, slope=0.01):
 
 # ----------------------------------------------------------------------------- loss tail (single-workgroup kernels)
 
+_counters = {}
+
+
+def _zero_counter(device):
+    """One device word per device that the last-workgroup-finishes kernels count on (they leave it at 0)."""
+    key = str(device)
+    if key not in _counters:
+        _counters[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return _counters[key]
+
+
 class _LatentHead(torch.autograd.Function):
     @staticmethod
     def forward(ctx, zg, p_m, p_v, eps, Ls, Lg):
@@ -277,8 +288,10 @@ class _LatentHead(torch.autograd.Function):
         assert zg.shape == (b, 2 * Lg) and p_m.shape == (b, Ls) and p_v.shape == (b, Ls) and eps.shape == (b, Ls + Lg)
         latent = torch.empty((b, Ls + Lg), dtype=torch.float32, device=zg.device)
         scal = torch.empty(2, dtype=torch.float32, device=zg.device)
+        partials = torch.empty(2 * ((b + 7) // 8), dtype=torch.float64, device=zg.device)
         _check(model_lib().spadot_latent_head_forward(_p(zg), _p(p_m), _p(p_v), _p(eps), b, Ls, Lg, _p(latent), _p(scal),
-                                                      _stream()), "spadot_latent_head_forward")
+                                                      _p(partials), _p(_zero_counter(zg.device)), _stream()),
+               "spadot_latent_head_forward")
         ctx.save_for_backward(zg, p_v, eps, latent)
         ctx.dims = (b, Ls, Lg)
         return latent, scal[0], scal[1]
