@@ -4,7 +4,7 @@ usage: pmc_summary.py <fetch_dir> <write_dir> <out.csv>"""
 import csv, glob, sys, collections
 
 def means(d, counter):
-    f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
+    f = max(glob.glob(d + "/**/*counter_collection.csv", recursive=True), key=__import__("os").path.getmtime)
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == counter:

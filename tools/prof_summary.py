@@ -2,7 +2,7 @@
 `steps` graph replays are taken as the timed region)."""
 import csv, glob, collections, sys
 d = sys.argv[1]; steps = int(sys.argv[2]) if len(sys.argv) > 2 else 40
-f = glob.glob(d + '/**/*kernel_trace.csv', recursive=True)[0]
+f = max(glob.glob(d + '/**/*kernel_trace.csv', recursive=True), key=__import__('os').path.getmtime)
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
 # the timed region: the last `steps` occurrences of the AdamW kernel close a step each
 idx = [i for i, r in enumerate(rows) if 'k_adamw' in r['Kernel_Name']]

@@ -1,7 +1,7 @@
 """Timeline of the last training step in a rocprofv3 kernel trace (start us, duration us, '||' when it
 started before an earlier kernel ended, idle gap before it)."""
 import csv, glob, re, sys
-f = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]
+f = max(glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True), key=__import__('os').path.getmtime)
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
 idx = [i for i, r in enumerate(rows) if 'k_adamw' in r['Kernel_Name']]
 sel = rows[idx[-2] + 1:idx[-1] + 1]
