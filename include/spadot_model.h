@@ -80,6 +80,10 @@ int spadot_gat_att_grad(const void *h, int dtype, const float *ds_src, const flo
                         int C, float *scratch, int scratch_floats, float *datt_src, float *datt_dst,
                         const void *g_pre, int n_pre, void *stream);
 
+/* out[c] = sum_r x[r, c] for a row-major fp32 [rows, width] array, rows added in a fixed order (bias gradients of the
+ * dense maps: no semaphore-based library reduction inside the replayed graphs). */
+int spadot_colsum(const float *x, int rows, int width, float *out, void *stream);
+
 /* ---------------------------------------------------------------- SVGP pieces */
 
 /* K[i,j] = k(|x_i - z_j|^2 / scale), x [n,d], z [m,d], K [n,m]; dtype F32 or F64 for all three.

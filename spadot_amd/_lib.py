@@ -130,6 +130,7 @@ def model_lib():
         "spadot_sqerr_backward": [vp, vp, vp, ll, cd, ci, vp, vp],
         "spadot_kmeans_assign": [vp, vp, ci, ci, ci, ci, vp, vp],
         "spadot_lloyd_step": [vp, vp, ci, ci, ci, ci, cd, vp, vp, vp, vp, ci, vp],
+        "spadot_colsum": [vp, ci, ci, vp, vp],
         "spadot_knn": [vp, ci, ci, ci, vp, vp],
         "spadot_grad_sumsq": [vp, ll, vp, vp, vp],
         "spadot_adamw_step": [vp, vp, vp, vp, vp, ll, cd, cd, cd, cd, cd, cd, ci, vp],

@@ -1622,6 +1622,12 @@ int spadot_gat_att_grad(const void *h, int dtype, const float *ds_src, const flo
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
+int spadot_colsum(const float *x, int rows, int width, float *out, void *stream) {
+    if (rows <= 0 || width <= 0) return -22;
+    hipLaunchKernelGGL(k_colsum_parts, dim3((width + 63) / 64), dim3(1024), 0, (hipStream_t)stream, x, rows, width, out);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
 int spadot_gat_backward_source(const void *g_pre, int dtype, const float *alpha, const float *dz,
                                const int *rowptr_t, const int *col_t, const int *eid_t, int n, int H, int C,
                                void *dh, float *ds_src, const float *ds_dst, const float *att_src,

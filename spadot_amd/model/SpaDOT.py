@@ -99,6 +99,33 @@ class SpaDOT(nn.Module):
         recon_loss = sqerr_sum(yb.float(), self.decoder(final_latent), 1.0 / self.input_dim)
         return recon_loss, SVGP_KL, GAT_KL, alignment_loss, final_latent
 
+    # ---- the three parts of forward() on their own (GraphedStepper's staged mode replays them as separate graphs:
+    #      the two branches on two streams, then the tail) ------------------------------------------------------
+    def branch_gat(self, y, edge_index, batch_size):
+        """GAT branch: (mu | logvar) of the seeds [b, 2 Lg]."""
+        return self.GATEncoder.pre_head(y, edge_index, rows=batch_size)
+
+    def branch_svgp(self, x, y, tp, batch_size, batch_key=None):
+        """SVGP branch: posterior mean / variance at the seeds [b, Ls] (fp64) and SVGP_KL."""
+        b = batch_size
+        svgp = self.svgp_dict[str(tp)]
+        z_enc = self.SVGPEncoder.pre_head(y[:b])
+        bc = svgp.batch_constants(x[:b], key=batch_key)
+        return svgp.elbo_finish(bc, svgp.elbo_start(bc, z_enc))
+
+    def tail(self, zg, p_m, p_v, y, batch_size, noise=None):
+        """Latent head + decoder + reconstruction: (recon, GAT_KL, alignment, final_latent)."""
+        b = batch_size
+        Ls, Lg = self.SVGP_z_dim, self.GAT_z_dim
+        if noise is None:
+            eps = torch.randn((b, Ls + Lg), dtype=torch.float32, device=zg.device)
+        else:
+            eps = torch.cat([noise[0].float(), noise[1].float()], dim=1)
+        final_latent, GAT_KL, alignment_loss = latent_head(zg, p_m, p_v, eps, Ls, Lg)
+        yb = y[:b, :self.input_dim]
+        recon_loss = sqerr_sum(yb.float(), self.decoder(final_latent), 1.0 / self.input_dim)
+        return recon_loss, GAT_KL, alignment_loss, final_latent
+
     def _side_stream(self):
         st = getattr(self, "_svgp_stream", None)
         if st is None:

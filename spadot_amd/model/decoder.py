@@ -9,7 +9,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..ops import ln_act
+from ..ops import linear_bias, ln_act
 
 
 def _hidden_stage(fan_in, fan_out):
@@ -34,9 +34,7 @@ class Decoder(nn.Module):
         h = latent_sample
         for i in range(0, len(stages) - 1, 3):
             dense, norm, act = stages[i], stages[i + 1], stages[i + 2]
-            h = ln_act(dense(h), norm, act.negative_slope)                  # LayerNorm + LeakyReLU: one launch
-        last, cd = stages[-1], self.compute_dtype
-        if cd == torch.float32:
-            return last(h)
+            h = ln_act(linear_bias(h, dense.weight, dense.bias), norm, act.negative_slope)     # LN + LeakyReLU: one launch
+        last = stages[-1]
         # hidden -> G is the only large GEMM here: compute dtype on MFMA (fp32 accumulate), fp32 result
-        return F.linear(h.to(cd), last.weight.to(cd), last.bias.to(cd)).float()
+        return linear_bias(h, last.weight, last.bias, self.compute_dtype)

@@ -11,7 +11,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..graph import build_batch_graph
-from ..ops import BatchGraph, bn_act, dense_cd, gat_edge
+from ..ops import BatchGraph, bn_act, dense_cd, gat_edge, linear_bias
 
 
 class SVGPEncoder(nn.Module):
@@ -58,7 +58,7 @@ class SVGPEncoder(nn.Module):
             else:
                 h = F.linear(h[:, :lin.in_features].float(), lin.weight)
             h = bn_act(h, lin.bias, bn, act.negative_slope)
-        return self.SVGP_fc(h)
+        return linear_bias(h, self.SVGP_fc.weight, self.SVGP_fc.bias)
 
 
 class GATConv(nn.Module):
@@ -141,4 +141,4 @@ class GATEncoder(nn.Module):
             h = self.gat3(h, edge_index, act=False)
             if rows is not None:
                 h = h[:rows]
-        return self.GAT_fc(h.float())
+        return linear_bias(h.float(), self.GAT_fc.weight, self.GAT_fc.bias)

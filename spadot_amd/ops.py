@@ -178,6 +178,41 @@ class _DenseCD(torch.autograd.Function):
         return dx, dW, None
 
 
+class _LinearBias(torch.autograd.Function):
+    """y = x W^T + b (fp32, or the compute dtype given by `cd`) with the bias gradient as a fixed-order column
+    sum (k_colsum_parts) instead of the library's semaphore-based reduction."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, cd):
+        ctx.save_for_backward(x, W)
+        ctx.cd = cd
+        if cd is None or cd == torch.float32:
+            return torch.addmm(b, x, W.t())
+        return torch.nn.functional.linear(x.to(cd), W.to(cd), b.to(cd)).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W = ctx.saved_tensors
+        g = g.contiguous().float()
+        db = torch.empty(g.shape[1], dtype=torch.float32, device=g.device)
+        _check(model_lib().spadot_colsum(_p(g), g.shape[0], g.shape[1], _p(db), _stream()), "spadot_colsum")
+        cd = ctx.cd
+        if cd is None or cd == torch.float32:
+            dx = g @ W if ctx.needs_input_grad[0] else None
+            dW = g.t() @ x
+        else:
+            gc = g.to(cd)
+            dx = (gc @ W.to(cd)).float() if ctx.needs_input_grad[0] else None
+            dW = torch.mm(gc.t(), x.to(cd), out_dtype=torch.float32)
+        return dx, dW, db, None
+
+
+def linear_bias(x, W, b, compute_dtype=None):
+    """F.linear(x, W, b) for 2-D x with a reproducible bias gradient (see _LinearBias)."""
+    _need_cuda(x, W, b)
+    return _LinearBias.apply(x.contiguous(), W, b, compute_dtype)
+
+
 def dense_cd(x, W, holder, tag="_wpad"):
     """x [n, Kp >= K] in the compute dtype, W fp32 [N, K]; `holder` (a module) keeps the padded compute-dtype
     image of W between calls."""
@@ -638,6 +673,25 @@ class FlatAdamW:
             if g is None:
                 p.grad.zero_()
         torch._foreach_copy_(dst, src)
+
+    def backward_partial(self, outputs, grad_outputs, params, extra_inputs=()):
+        """One stage of a backward pass that is issued in pieces (GraphedStepper's staged mode): gradients of
+        `outputs` (weighted by grad_outputs; None for a scalar loss) w.r.t. `params` go to their views of the flat
+        buffer (written, not accumulated; zeros where unreachable), those w.r.t. `extra_inputs` are returned."""
+        ins = list(params) + list(extra_inputs)
+        _DIRECT_GRAD[0] = True
+        try:
+            grads = torch.autograd.grad(outputs, ins, grad_outputs=grad_outputs, allow_unused=True)
+        finally:
+            _DIRECT_GRAD[0] = False
+        pg = grads[:len(params)]
+        pairs = [(p.grad, g) for p, g in zip(params, pg) if g is not None and g.data_ptr() != p.grad.data_ptr()]
+        for p, g in zip(params, pg):
+            if g is None:
+                p.grad.zero_()
+        if pairs:
+            torch._foreach_copy_([d for d, _ in pairs], [s for _, s in pairs])
+        return grads[len(params):]
 
     def grad_norm_sq(self):
         """Device scalar: squared global gradient norm (deterministic reduction)."""

@@ -11,6 +11,7 @@ What differs from the reference, on purpose (SURVEY 7 "hard parts", App. D):
   * backward(retain_graph=True) is not replicated (App. D.11);
   * only the first growth solve of compute_transport_map is run (it is the one returned, App. D.1).
 """
+import os
 import random
 from collections import OrderedDict
 from time import time
@@ -307,7 +308,9 @@ class GraphedStepper:
         self.beta1_t = _loss_weights(model, model_config, 0.0)     # (lambda1, -beta1, beta2, omiga1..3); entry 1 rewritten per step
         self.graphs, self.seen = {}, set()
         self.opt_graph = None
-        self.pool = None
+        self.pool = self.pool_side = None
+        self._groups = None
+        self.staged = bool(model_config.get("staged_graphs", os.environ.get("SPADOT_STAGED_GRAPHS", "1") == "1"))
         self.version = getattr(model, "_state_version", 0)
 
     def _body(self, tp_i, tp, bi, epoch, with_update=True):
@@ -344,6 +347,8 @@ class GraphedStepper:
             self.graphs.clear()
             self.version = getattr(self.model, "_state_version", 0)
         self.beta1_t[1].fill_(-float(beta1))
+        if self.staged:
+            return self._run_staged(tp_i, tp, bi, epoch, with_update)
         key = (tp, bi, epoch >= 1, epoch >= self.cfg["ot_epoch"] and tp_i != 0, with_update)
         if key in self.graphs:
             g, out = self.graphs[key]
@@ -356,6 +361,105 @@ class GraphedStepper:
         self.graphs[key] = (g, out)
         g.replay()
         return out.clone()
+
+    # ---- staged mode: the step as SIX graphs instead of one.  A replayed hipGraph runs its two branches mostly
+    # one after the other (tools/graph_probe.py); two graphs replayed on two streams do overlap.  So: GAT forward
+    # (main stream) || SVGP forward (side stream), tail forward + backward, GAT backward || SVGP backward, optimizer.
+    # Graphs that may run at the same time capture into different memory pools.
+    def _stages(self, tp_i, tp, bi, epoch):
+        model, cfg, dd, opt = self.model, self.cfg, self.dd, self.opt
+        batch = dd["dataloaders"][tp][bi]
+        if batch.y is not None:
+            x_b, y_b = batch.x, batch.y
+        else:
+            loc, Y, _ = dd["datasets"][tp]
+            x_b, y_b = loc[batch.n_id], Y[batch.n_id]
+        b = batch.batch_size
+        seeds = batch.n_id[:b]
+        do_km = epoch >= 1
+        do_ot = bool(epoch >= cfg["ot_epoch"] and tp_i != 0)
+        P = self._param_groups()
+        st = {}
+
+        def gat_fwd():
+            st["zg"] = model.branch_gat(y_b, batch.graph, b)
+
+        def svgp_fwd():
+            st["pm"], st["pv"], st["skl"] = model.branch_svgp(x_b, y_b, tp, b, batch_key=(tp, bi))
+
+        def tail():
+            leaves = [st[k].detach().requires_grad_(True) for k in ("zg", "pm", "pv", "skl")]
+            recon, gkl, align, z = model.tail(leaves[0], leaves[1], leaves[2], y_b, b)
+            km, ot = _cluster_terms(model, cfg, tp, tp_i, seeds, z, do_km, do_ot)
+            elbo, losses = mix_losses(self.beta1_t, (recon, leaves[3], gkl, align, km, ot))
+            st["g"] = opt.backward_partial(elbo, None, P["tail"], extra_inputs=leaves)
+            return losses
+
+        def svgp_bwd():
+            g = st["g"]
+            opt.backward_partial([st["pm"], st["pv"], st["skl"]], [g[1], g[2], g[3]], P["svgp"])
+
+        def gat_bwd():
+            opt.backward_partial([st["zg"]], [st["g"][0]], P["gat"])
+
+        return gat_fwd, svgp_fwd, tail, svgp_bwd, gat_bwd
+
+    def _param_groups(self):
+        if self._groups is None:
+            own = {id(p) for p in self.opt.params}
+            gat = [p for p in self.model.GATEncoder.parameters() if id(p) in own]
+            svgp = [p for p in self.model.SVGPEncoder.parameters() if id(p) in own]
+            taken = {id(p) for p in gat + svgp}
+            self._groups = {"gat": gat, "svgp": svgp, "tail": [p for p in self.opt.params if id(p) not in taken]}
+        return self._groups
+
+    def _replay_staged(self, graphs):
+        main = torch.cuda.current_stream()
+        side = self.model._side_stream()
+        g_gat_f, g_svgp_f, g_tail, g_svgp_b, g_gat_b = graphs
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            g_svgp_f.replay()
+        g_gat_f.replay()
+        main.wait_stream(side)
+        g_tail.replay()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            g_svgp_b.replay()
+        g_gat_b.replay()
+        main.wait_stream(side)
+
+    def _run_staged(self, tp_i, tp, bi, epoch, with_update):
+        key = (tp, bi, epoch >= 1, epoch >= self.cfg["ot_epoch"] and tp_i != 0, "staged")
+        if key in self.graphs:
+            graphs, out = self.graphs[key]
+            self._replay_staged(graphs)
+            res = out.clone()
+        elif key not in self.seen:                                          # warm-up visit: eager, same stages
+            self.seen.add(key)
+            gat_f, svgp_f, tail, svgp_b, gat_b = self._stages(tp_i, tp, bi, epoch)
+            gat_f(); svgp_f(); res = tail(); svgp_b(); gat_b()
+        else:
+            gat_f, svgp_f, tail, svgp_b, gat_b = self._stages(tp_i, tp, bi, epoch)
+            if self.pool is None:
+                self.pool, self.pool_side = torch.cuda.graph_pool_handle(), torch.cuda.graph_pool_handle()
+            torch.cuda.synchronize()
+            graphs = []
+            out = None
+            for fn, pool in ((gat_f, self.pool), (svgp_f, self.pool_side), (tail, self.pool), (svgp_b, self.pool_side),
+                             (gat_b, self.pool)):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
+                    r = fn()
+                if fn is tail:
+                    out = r
+                graphs.append(g)
+            self.graphs[key] = (graphs, out)
+            self._replay_staged(graphs)
+            res = out.clone()
+        if with_update:
+            self.update()
+        return res
 
     def fb(self, tp_i, tp, bi, epoch, beta1):
         """Forward + backward of one batch into the flat gradient buffer, no parameter update (data-parallel

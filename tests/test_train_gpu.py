@@ -119,8 +119,9 @@ def test_graphed_steps_match_eager_steps(monkeypatch):
     cfg.update(input_dim=40, timepoints=[0, 1], device=torch.device(DEV))
     results = []
     sync = lambda flat: flat.mul_(1.0)                 # stands in for the replicas' all-reduce (identity)
-    for graphed in (False, True, "split"):             # "split": forward+backward graph | gradient exchange | optimizer graph
-        _utils.set_seed(7)
+    for graphed in (False, True, "split", "staged"):   # "split": forward+backward graph | gradient exchange | optimizer graph;
+        _utils.set_seed(7)                             # "staged": six graphs per step, the two branches on two streams
+        cfg["staged_graphs"] = graphed == "staged"
         dd = tu.prepare_dataloader(data, cfg)
         model = SpaDOT.SpaDOT(cfg, dd).to(DEV)
         opt = FlatAdamW(model.parameters(), lr=cfg["lr"])
@@ -139,7 +140,7 @@ def test_graphed_steps_match_eager_steps(monkeypatch):
         results.append((torch.stack(losses).cpu().numpy(), opt.flat_param.detach().cpu().numpy().copy(), int(opt.step_dev.item())))
         if graphed:
             assert len(stepper.graphs) == 2
-            assert (stepper.opt_graph is not None and stepper.opt_graph is not False) == (graphed == "split")
+            assert (stepper.opt_graph is not None and stepper.opt_graph is not False) == (graphed in ("split", "staged"))
     (l0, p0, s0) = results[0]
     for l1, p1, s1 in results[1:]:
         assert s0 == s1 == 8

@@ -44,3 +44,34 @@ t0 = time.perf_counter()
 for _ in range(20): g.replay()
 torch.cuda.synchronize()
 print(order, f"{(time.perf_counter()-t0)/20*1e3:.3f} ms per replay")
+
+# ---- the same two branches as TWO graphs replayed on two streams (real stream-level concurrency)
+def time_it(fn, n=20):
+    for _ in range(5): fn()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+torch.cuda.synchronize()
+gA, gB = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+with torch.cuda.graph(gA):
+    ra = branch_a()
+with torch.cuda.graph(gB):
+    rb = branch_b()
+print(f"A alone {time_it(gA.replay):.3f} ms   B alone {time_it(gB.replay):.3f} ms")
+def both():
+    main = torch.cuda.current_stream()
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        gA.replay()
+    gB.replay()
+    main.wait_stream(side)
+print(f"two graphs on two streams {time_it(both):.3f} ms")
+def both_rev():
+    main = torch.cuda.current_stream()
+    side.wait_stream(main)
+    gB.replay()
+    with torch.cuda.stream(side):
+        gA.replay()
+    main.wait_stream(side)
+print(f"two graphs, B launched first {time_it(both_rev):.3f} ms")
