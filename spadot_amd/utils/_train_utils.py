@@ -310,7 +310,12 @@ class GraphedStepper:
         self.opt_graph = None
         self.pool = self.pool_side = None
         self._groups = None
-        self.staged = bool(model_config.get("staged_graphs", os.environ.get("SPADOT_STAGED_GRAPHS", "1") == "1"))
+        # staged (six-graph) replay: default for a single replica.  Replicas keep the two-graph form by default: with two
+        # processes sharing one GPU (the only multi-rank set-up that could be measured here) the multi-stream replays
+        # of the processes time-slice against each other (2 steps/s against 97)
+        import torch.distributed as dist
+        multi = grad_sync is not None or (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+        self.staged = bool(model_config.get("staged_graphs", os.environ.get("SPADOT_STAGED_GRAPHS", "0" if multi else "1") == "1"))
         self.version = getattr(model, "_state_version", 0)
 
     def _body(self, tp_i, tp, bi, epoch, with_update=True):
