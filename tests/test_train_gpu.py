@@ -187,6 +187,43 @@ def test_flat_backward_with_in_place_weight_gradients_matches_autograd():
         np.testing.assert_allclose(p.grad.cpu().numpy(), want.float().cpu().numpy(), rtol=1e-5, atol=1e-7)
 
 
+def test_staged_replay_gives_the_single_graph_gradients_bf16(monkeypatch):
+    """bf16 compute at a moderately large shape (4000 spots, 1200 genes: multi-workgroup reductions everywhere): the
+    flat gradient left by the staged replay (six graphs, two streams) equals the single-graph replay's, parameter by
+    parameter, over repeated replays of several batches -- the regression that bit here was a library reduction whose
+    memset node misbehaved inside the small graphs from the second replay on."""
+    from spadot_amd.model import SpaDOT
+    from spadot_amd.ops import FlatAdamW
+    from spadot_amd.synthetic import make_dataset
+    from spadot_amd.utils import _train_utils as tu, _utils
+    monkeypatch.setattr(torch, "randn", lambda *a, **k: torch.zeros(*a, **k))      # same (no) reparameterisation noise
+    data = make_dataset(2, 4000, 1200, seed=9)
+    cfg = _utils.load_model_config(types.SimpleNamespace(config=None))
+    cfg.update(input_dim=1200, timepoints=[0, 1], device=torch.device(DEV), compute_dtype=torch.bfloat16,
+               inducing_point_nums=300, n_clusters=6)
+    _utils.set_seed(3)
+    dd = tu.prepare_dataloader(data, cfg)
+    model = SpaDOT.SpaDOT(cfg, dd).to(DEV)
+    opt = FlatAdamW(model.parameters(), lr=cfg["lr"])
+    tu._update_Kmeans(model, cfg, dd)
+    tu._update_OT_matrix(model, cfg)
+    model.train()
+    single = tu.GraphedStepper(model, opt, dict(cfg, staged_graphs=False), dd)
+    staged = tu.GraphedStepper(model, opt, dict(cfg, staged_graphs=True), dd)
+    assert staged.staged and not single.staged
+    for rep in range(4):                                   # eager, capture + replay, replay, replay
+        for bi in range(3):
+            la = single.fb(1, 1, bi, cfg["ot_epoch"], 0.5)
+            ga = opt.flat_grad.clone()
+            opt.flat_grad.fill_(7.0)
+            lb = staged.fb(1, 1, bi, cfg["ot_epoch"], 0.5)
+            gb = opt.flat_grad
+            assert torch.isfinite(gb).all()
+            np.testing.assert_allclose(lb.cpu().numpy(), la.cpu().numpy(), rtol=1e-5, atol=1e-6)
+            scale = float(ga.abs().max())
+            np.testing.assert_allclose(gb.cpu().numpy(), ga.cpu().numpy(), rtol=2e-3, atol=2e-4 * scale)
+
+
 def _dp_worker(rank, world, port, q):
     """One data-parallel rank on cuda:0 (both ranks share the one GPU of the test box; gloo carries the
     collectives, on a real node the backend is nccl = RCCL)."""
