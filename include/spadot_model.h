@@ -175,10 +175,13 @@ int spadot_svgp_pre(const float *z, int b, int L, double *mu, double *var, doubl
  * posterior, eps [b, Ls+Lg] fp32 standard normal.  latent [b, Ls+Lg] = (p_m + eps sqrt(p_v) | mu + eps
  * sqrt(exp(logvar))); scal2 = (GAT_KL = -1/2 sum(1 + logvar - mu^2 - var) / Lg,
  * alignment = sum_i (|s_i| / Ls - |g_i| / Lg)^2); Ls + Lg <= 32; partials: 2 * ceil(b/8) doubles of work space, counter: one
- * unsigned that is 0 before the first launch (the kernel leaves it 0).  backward: g_latent [b, Ls+Lg] or NULL, g_kl / g_align device
+ * unsigned that is 0 before the first launch (the kernel leaves it 0).  rng_state NULL: eps is an input; else eps is
+ * WRITTEN by the kernel (counter-based standard normals from rng_state = (seed, launch count); the count advances by
+ * one per launch), so that no library RNG launch sits in the replayed graph.  backward: g_latent [b, Ls+Lg] or NULL, g_kl / g_align device
  * scalars or NULL -> d_zg [b, 2 Lg], d_pm, d_pv [b, Ls] fp64. */
-int spadot_latent_head_forward(const float *zg, const double *p_m, const double *p_v, const float *eps, int b, int Ls,
-                               int Lg, float *latent, float *scal2, double *partials, unsigned *counter, void *stream);
+int spadot_latent_head_forward(const float *zg, const double *p_m, const double *p_v, float *eps, int b, int Ls,
+                               int Lg, float *latent, float *scal2, double *partials, unsigned *counter,
+                               unsigned long long *rng_state, void *stream);
 int spadot_latent_head_backward(const float *zg, const double *p_v, const float *eps, const float *latent,
                                 const float *g_latent, const float *g_kl, const float *g_align, int b, int Ls, int Lg,
                                 float *d_zg, double *d_pm, double *d_pv, void *stream);
@@ -235,6 +238,12 @@ int spadot_grad_sumsq(const float *grad, long long count, double *scratch, float
  * correction, eps outside the sqrt):  coef = min(1, max_norm / (sqrt(sumsq) + 1e-6)); g = coef * grad;
  * p -= lr*wd*p; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr/(1-b1^t) * m / (sqrt(v/(1-b2^t)) + eps).
  * sumsq is read on the device (no host round trip). */
+/* clip_grad_norm_ + AdamW with the step count on the device, TWO launches: the gradient's sum of squares (per-workgroup
+ * partials in `scratch` (>= 2048 doubles), the last workgroup adds them in order, writes sumsq[0] and advances
+ * step_dev[0]; `counter` is one unsigned that is 0 before the first call and left 0), then the update. */
+int spadot_clip_adamw_dev(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long long count, double lr,
+                          double beta1, double beta2, double eps, double weight_decay, double max_norm, double *scratch,
+                          float *sumsq, int *step_dev, unsigned *counter, void *stream);
 int spadot_adamw_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
                       const float *sumsq, long long count, double lr, double beta1, double beta2,
                       double eps, double weight_decay, double max_norm, int step, void *stream);

@@ -120,7 +120,7 @@ def model_lib():
         "spadot_svgp_post_backward": [vp] * 13 + [ci, ci, ci, cd, cd] + [vp] * 8,
         "spadot_svgp_grad_tail": [vp] * 11 + [ci, ci, cd] + [vp] * 4,
         "spadot_svgp_pre": [vp, ci, ci, vp, vp, vp, vp, vp],
-        "spadot_latent_head_forward": [vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, vp],
+        "spadot_latent_head_forward": [vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, vp, vp],
         "spadot_latent_head_backward": [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp],
         "spadot_cluster_losses_forward": [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp],
         "spadot_cluster_losses_backward": [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp],
@@ -133,6 +133,7 @@ def model_lib():
         "spadot_colsum": [vp, ci, ci, vp, vp],
         "spadot_knn": [vp, ci, ci, ci, vp, vp],
         "spadot_grad_sumsq": [vp, ll, vp, vp, vp],
+        "spadot_clip_adamw_dev": [vp, vp, vp, vp, ll, cd, cd, cd, cd, cd, cd, vp, vp, vp, vp, vp],
         "spadot_adamw_step": [vp, vp, vp, vp, vp, ll, cd, cd, cd, cd, cd, cd, ci, vp],
         "spadot_adamw_step_dev": [vp, vp, vp, vp, vp, ll, cd, cd, cd, cd, cd, cd, vp, vp],
     }

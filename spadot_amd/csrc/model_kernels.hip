@@ -1035,6 +1035,37 @@ __global__ __launch_bounds__(256) void k_sumsq_part(const float *__restrict__ g,
     if (threadIdx.x == 0) part[blockIdx.x] = acc;
 }
 
+// Gradient sum of squares in ONE launch: per-workgroup partials, and the last workgroup to finish (device counter,
+// reset for the next launch) adds them in workgroup order, writes the total and advances the optimizer's step count.
+__global__ __launch_bounds__(256) void k_sumsq_last(const float *__restrict__ g, long long count, double *__restrict__ part,
+                                                    float *__restrict__ sumsq, int *__restrict__ step_dev,
+                                                    unsigned *__restrict__ counter) {
+    __shared__ double sh[16];
+    __shared__ bool last;
+    double acc = 0.0;
+    const long long n4 = count / 4;
+    const float4 *g4 = reinterpret_cast<const float4 *>(g);
+    for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < n4; k += (long long)gridDim.x * 256) {
+        const float4 v = g4[k];
+        acc += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    }
+    if (blockIdx.x == 0)
+        for (long long k = n4 * 4 + threadIdx.x; k < count; k += 256) acc += (double)g[k] * g[k];
+    acc = block_sum_d(acc, sh);
+    if (threadIdx.x == 0) {
+        part[blockIdx.x] = acc;
+        __threadfence();
+        last = atomicAdd(counter, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    double t = 0.0;
+    for (int b = threadIdx.x; b < (int)gridDim.x; b += blockDim.x) t += __builtin_nontemporal_load(part + b);
+    t = block_sum_d(t, sh);
+    if (threadIdx.x == 0) { sumsq[0] = (float)t; if (step_dev) step_dev[0] += 1; *counter = 0u; }
+}
+
 __global__ void k_step_inc(int *step) { step[0] += 1; }
 
 __global__ __launch_bounds__(256) void k_adamw(float *__restrict__ p, const float *__restrict__ g,
@@ -1235,25 +1266,41 @@ __device__ __forceinline__ float half_wave_sum(float x) {
     return x;
 }
 
+// Counter-based standard normal: splitmix64 of (seed, launch counter, element index) -> two uniforms -> Box-Muller.
+__device__ __forceinline__ float counter_randn(unsigned long long seed, unsigned long long ctr, unsigned long long idx) {
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (ctr * 0x100000001B3ull + idx + 1ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    const float u1 = ((float)(unsigned)(z >> 40) + 1.0f) * (1.0f / 16777216.0f);        // (0, 1]
+    const float u2 = (float)(unsigned)((z >> 8) & 0xFFFFFFu) * (1.0f / 16777216.0f);     // [0, 1)
+    return sqrtf(-2.0f * logf(u1)) * cosf(6.2831853071795865f * u2);
+}
+
 // 8 rows per 256-thread workgroup; the two scalars go through per-workgroup partials and the LAST workgroup to finish
 // (device counter, reset for the next launch) adds them in workgroup order: one launch, reproducible.
 __global__ __launch_bounds__(256) void k_latent_head_fwd(const float *__restrict__ zg, const double *__restrict__ p_m,
-                                                         const double *__restrict__ p_v, const float *__restrict__ eps,
+                                                         const double *__restrict__ p_v, float *__restrict__ eps,
                                                          int b, int Ls, int Lg, float *__restrict__ latent,
                                                          float *__restrict__ scal, double *__restrict__ partials,
-                                                         unsigned *__restrict__ counter) {
+                                                         unsigned *__restrict__ counter,
+                                                         unsigned long long *__restrict__ rng /* (seed, launches) or null */) {
     __shared__ double sh[16];
     __shared__ bool last;
     const int D = Ls + Lg;
     const int c = threadIdx.x & 31, i = blockIdx.x * 8 + (threadIdx.x >> 5);
-    float val = 0.f, klt = 0.f;
+    float val = 0.f, klt = 0.f, e = 0.f;
+    if (i < b && c < D) {
+        if (rng) { e = counter_randn(rng[0], rng[1], (unsigned long long)i * D + c); eps[(size_t)i * D + c] = e; }
+        else e = eps[(size_t)i * D + c];
+    }
     if (i < b && c < Ls) {
-        val = (float)(p_m[(size_t)i * Ls + c] + (double)eps[(size_t)i * D + c] * sqrt(p_v[(size_t)i * Ls + c]));
+        val = (float)(p_m[(size_t)i * Ls + c] + (double)e * sqrt(p_v[(size_t)i * Ls + c]));
     } else if (i < b && c < D) {
         const int l = c - Ls;
         const float mu = zg[(size_t)i * 2 * Lg + l], lv = zg[(size_t)i * 2 * Lg + Lg + l];
         const float var = expf(lv);
-        val = mu + eps[(size_t)i * D + c] * sqrtf(var);
+        val = mu + e * sqrtf(var);
         klt = 1.f + logf(var) - mu * mu - var;
     }
     if (i < b && c < D) latent[(size_t)i * D + c] = val;
@@ -1278,7 +1325,7 @@ __global__ __launch_bounds__(256) void k_latent_head_fwd(const float *__restrict
     }
     k2 = block_sum_d(k2, sh);
     a2 = block_sum_d(a2, sh);
-    if (threadIdx.x == 0) { scal[0] = (float)(-0.5 * k2 / Lg); scal[1] = (float)a2; *counter = 0u; }
+    if (threadIdx.x == 0) { scal[0] = (float)(-0.5 * k2 / Lg); scal[1] = (float)a2; *counter = 0u; if (rng) rng[1] += 1ull; }
 }
 
 // g_latent [b, Ls+Lg] (may be null), g_scal = device scalars (d loss / d GAT_KL, d loss / d alignment).
@@ -1829,12 +1876,13 @@ int spadot_svgp_pre(const float *z, int b, int L, double *mu, double *var, doubl
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
-int spadot_latent_head_forward(const float *zg, const double *p_m, const double *p_v, const float *eps, int b, int Ls,
-                               int Lg, float *latent, float *scal2, double *partials, unsigned *counter, void *stream) {
-    if (b <= 0 || Ls <= 0 || Lg <= 0 || !partials || !counter) return -22;
+int spadot_latent_head_forward(const float *zg, const double *p_m, const double *p_v, float *eps, int b, int Ls,
+                               int Lg, float *latent, float *scal2, double *partials, unsigned *counter,
+                               unsigned long long *rng_state, void *stream) {
+    if (b <= 0 || Ls <= 0 || Lg <= 0 || !partials || !counter || !eps) return -22;
     if (Ls + Lg > 32) return -22;                 // one half wave (32 lanes) per row
     hipLaunchKernelGGL(k_latent_head_fwd, dim3((b + 7) / 8), dim3(256), 0, (hipStream_t)stream, zg, p_m, p_v, eps, b, Ls, Lg,
-                       latent, scal2, partials, counter);
+                       latent, scal2, partials, counter, rng_state);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
@@ -1967,6 +2015,23 @@ int spadot_adamw_step_dev(float *param, const float *grad, float *exp_avg, float
     const int nb = (int)(want < 4096 ? want : 4096);
     hipLaunchKernelGGL(k_step_inc, dim3(1), dim3(1), 0, st_, step_dev);
     hipLaunchKernelGGL(k_adamw, dim3(nb), dim3(256), 0, st_, param, grad, exp_avg, exp_avg_sq, sumsq, count,
+                       (float)lr, (float)beta1, (float)beta2, (float)eps, (float)weight_decay, (float)max_norm,
+                       1.f, 1.f, (const int *)step_dev);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+int spadot_clip_adamw_dev(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long long count, double lr,
+                          double beta1, double beta2, double eps, double weight_decay, double max_norm, double *scratch,
+                          float *sumsq, int *step_dev, unsigned *counter, void *stream) {
+    if (count <= 0 || !step_dev || !scratch || !sumsq || !counter) return -22;
+    if (((uintptr_t)grad & 15) != 0) return -22;
+    hipStream_t st_ = (hipStream_t)stream;
+    const long long want4 = (count / 4 + 255) / 256;
+    const int nbs = (int)(want4 < 1 ? 1 : (want4 < 2048 ? want4 : 2048));
+    hipLaunchKernelGGL(k_sumsq_last, dim3(nbs), dim3(256), 0, st_, grad, count, scratch, sumsq, step_dev, counter);
+    const long long want = (count + 255) / 256;
+    const int nb = (int)(want < 4096 ? want : 4096);
+    hipLaunchKernelGGL(k_adamw, dim3(nb), dim3(256), 0, st_, param, grad, exp_avg, exp_avg_sq, (const float *)sumsq, count,
                        (float)lr, (float)beta1, (float)beta2, (float)eps, (float)weight_decay, (float)max_norm,
                        1.f, 1.f, (const int *)step_dev);
     return hipGetLastError() == hipSuccess ? 0 : -5;

@@ -87,15 +87,13 @@ class SpaDOT(nn.Module):
             p_m, p_v, SVGP_KL = svgp.elbo_finish(state["bc"], state["started"])
 
         Ls, Lg = self.SVGP_z_dim, self.GAT_z_dim
-        if noise is None:
-            eps = torch.randn((b, Ls + Lg), dtype=torch.float32, device=zg.device)
-        else:
-            eps = torch.cat([noise[0].float(), noise[1].float()], dim=1)
+        noise = noise if noise is not None else getattr(self, "fixed_noise", None)      # (tests: a pinned draw)
+        eps = None if noise is None else torch.cat([noise[0].float(), noise[1].float()], dim=1)
         main.wait_stream(side)
         for t in (p_m, p_v, SVGP_KL):
             t.record_stream(main)
-        # both reparameterised samples, GAT KL and the alignment term: one launch (ops.latent_head)
-        final_latent, GAT_KL, alignment_loss = latent_head(zg, p_m, p_v, eps, Ls, Lg)
+        # both reparameterised samples (noise drawn in the kernel), GAT KL and the alignment term: one launch
+        final_latent, GAT_KL, alignment_loss = latent_head(zg, p_m, p_v, eps, Ls, Lg, self._rng_state())
         recon_loss = sqerr_sum(yb.float(), self.decoder(final_latent), 1.0 / self.input_dim)
         return recon_loss, SVGP_KL, GAT_KL, alignment_loss, final_latent
 
@@ -117,14 +115,23 @@ class SpaDOT(nn.Module):
         """Latent head + decoder + reconstruction: (recon, GAT_KL, alignment, final_latent)."""
         b = batch_size
         Ls, Lg = self.SVGP_z_dim, self.GAT_z_dim
-        if noise is None:
-            eps = torch.randn((b, Ls + Lg), dtype=torch.float32, device=zg.device)
-        else:
-            eps = torch.cat([noise[0].float(), noise[1].float()], dim=1)
-        final_latent, GAT_KL, alignment_loss = latent_head(zg, p_m, p_v, eps, Ls, Lg)
+        noise = noise if noise is not None else getattr(self, "fixed_noise", None)
+        eps = None if noise is None else torch.cat([noise[0].float(), noise[1].float()], dim=1)
+        final_latent, GAT_KL, alignment_loss = latent_head(zg, p_m, p_v, eps, Ls, Lg, self._rng_state())
         yb = y[:b, :self.input_dim]
         recon_loss = sqerr_sum(yb.float(), self.decoder(final_latent), 1.0 / self.input_dim)
         return recon_loss, GAT_KL, alignment_loss, final_latent
+
+    def _rng_state(self):
+        """(seed, launch count) of the reparameterisation noise, on the device: the latent-head kernel draws its
+        own standard normals (counter-based), so a replayed graph contains no library RNG launch.  Seeded from
+        torch's generator at first use (torch.manual_seed / set_seed before the first step decides the stream)."""
+        st = getattr(self, "_noise_state", None)
+        if st is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            st = torch.tensor([seed, 0], dtype=torch.int64, device=self.device)
+            self._noise_state = st
+        return st
 
     def _side_stream(self):
         st = getattr(self, "_svgp_stream", None)

@@ -315,17 +315,23 @@ def _zero_counter(device):
 
 class _LatentHead(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, zg, p_m, p_v, eps, Ls, Lg):
-        _need_cuda(zg, p_m, p_v, eps)
-        zg, eps = zg.contiguous().float(), eps.contiguous().float()
+    def forward(ctx, zg, p_m, p_v, eps, Ls, Lg, rng_state=None):
+        _need_cuda(zg, p_m, p_v)
+        zg = zg.contiguous().float()
         p_m, p_v = p_m.contiguous().double(), p_v.contiguous().double()
         b = zg.shape[0]
+        if eps is None:             # drawn inside the kernel from rng_state = (seed, launch count) on the device
+            assert rng_state is not None and rng_state.dtype == torch.int64 and rng_state.numel() == 2
+            eps = torch.empty((b, Ls + Lg), dtype=torch.float32, device=zg.device)
+        else:
+            eps, rng_state = eps.contiguous().float(), None
         assert zg.shape == (b, 2 * Lg) and p_m.shape == (b, Ls) and p_v.shape == (b, Ls) and eps.shape == (b, Ls + Lg)
         latent = torch.empty((b, Ls + Lg), dtype=torch.float32, device=zg.device)
         scal = torch.empty(2, dtype=torch.float32, device=zg.device)
         partials = torch.empty(2 * ((b + 7) // 8), dtype=torch.float64, device=zg.device)
         _check(model_lib().spadot_latent_head_forward(_p(zg), _p(p_m), _p(p_v), _p(eps), b, Ls, Lg, _p(latent), _p(scal),
-                                                      _p(partials), _p(_zero_counter(zg.device)), _stream()),
+                                                      _p(partials), _p(_zero_counter(zg.device)),
+                                                      None if rng_state is None else _p(rng_state), _stream()),
                "spadot_latent_head_forward")
         ctx.save_for_backward(zg, p_v, eps, latent)
         ctx.dims = (b, Ls, Lg)
@@ -342,14 +348,15 @@ class _LatentHead(torch.autograd.Function):
         _check(model_lib().spadot_latent_head_backward(_p(zg), _p(p_v), _p(eps), _p(latent),
                                                        *(None if t is None else _p(t) for t in keep), b, Ls, Lg,
                                                        _p(d_zg), _p(d_pm), _p(d_pv), _stream()), "spadot_latent_head_backward")
-        return d_zg, d_pm, d_pv, None, None, None
+        return d_zg, d_pm, d_pv, None, None, None, None
 
 
-def latent_head(zg, p_m, p_v, eps, Ls, Lg):
+def latent_head(zg, p_m, p_v, eps, Ls, Lg, rng_state=None):
     """Reparameterised samples of both branches + GAT KL + alignment (SpaDOT.py:78-93) in one launch.
     zg [b, 2 Lg] = GAT_fc output (mu | logvar); p_m, p_v [b, Ls] SVGP posterior; eps [b, Ls+Lg] ~ N(0, 1).
+    eps None: the kernel draws the noise itself from `rng_state` (int64 [2] on the device: seed, launch count).
     Returns (final_latent [b, Ls+Lg] fp32, GAT_KL, alignment)."""
-    return _LatentHead.apply(zg, p_m, p_v, eps, Ls, Lg)
+    return _LatentHead.apply(zg, p_m, p_v, eps, Ls, Lg, rng_state)
 
 
 class _ClusterLosses(torch.autograd.Function):
@@ -652,6 +659,7 @@ class FlatAdamW:
         self.lr, self.betas, self.eps, self.weight_decay, self.max_norm = lr, betas, eps, weight_decay, max_norm
         self.t = 0
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)   # device-side step count (graph replays)
+        self._counter = torch.zeros(1, dtype=torch.int32, device=dev)   # last-workgroup-finishes counter of k_sumsq_last
 
     def zero_grad(self):
         self.flat_grad.zero_()
@@ -700,11 +708,10 @@ class FlatAdamW:
         return self.sumsq
 
     def step(self):
-        """clip + AdamW; the step count lives on the device, so the same launches can be captured in a
-        hipGraph and replayed."""
+        """clip + AdamW in two launches; the step count lives on the device, so the same launches can be captured in
+        a hipGraph and replayed."""
         self.t += 1
-        self.grad_norm_sq()
-        _check(model_lib().spadot_adamw_step_dev(_p(self.flat_param), _p(self.flat_grad), _p(self.exp_avg),
-                                                 _p(self.exp_avg_sq), _p(self.sumsq), self.count, self.lr,
-                                                 self.betas[0], self.betas[1], self.eps, self.weight_decay,
-                                                 self.max_norm, _p(self.step_dev), _stream()), "spadot_adamw_step_dev")
+        _check(model_lib().spadot_clip_adamw_dev(_p(self.flat_param), _p(self.flat_grad), _p(self.exp_avg),
+                                                 _p(self.exp_avg_sq), self.count, self.lr, self.betas[0], self.betas[1],
+                                                 self.eps, self.weight_decay, self.max_norm, _p(self.scratch), _p(self.sumsq),
+                                                 _p(self.step_dev), _p(self._counter), _stream()), "spadot_clip_adamw_dev")

@@ -453,6 +453,24 @@ def test_latent_head_vs_torch_formulas(ops, b, Ls, Lg):
         np.testing.assert_allclose(d.grad.cpu().numpy(), ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max(), err_msg=name)
 
 
+def test_latent_head_draws_its_own_standard_normals(ops):
+    """eps=None: the kernel fills eps from (seed, launch count) on the device -- standard normal moments, a new draw per
+    launch, the same draws for the same state, and the sample it returns is mu + eps * sigma of those eps."""
+    b, Ls, Lg = 4096, 10, 10
+    zg = torch.zeros((b, 2 * Lg), device=DEV); pm = torch.zeros((b, Ls), device=DEV, dtype=torch.float64); pv = torch.ones_like(pm)
+    st = torch.tensor([1234, 0], dtype=torch.int64, device=DEV)
+    lat1, _, _ = ops.latent_head(zg, pm, pv, None, Ls, Lg, st)
+    lat2, _, _ = ops.latent_head(zg, pm, pv, None, Ls, Lg, st)
+    assert st.cpu().tolist() == [1234, 2]
+    x1, x2 = lat1.cpu().numpy().ravel(), lat2.cpu().numpy().ravel()      # mu = 0, sigma = 1: the latent IS eps
+    assert abs(x1.mean()) < 0.02 and abs(x1.std() - 1.0) < 0.02 and abs((x1 ** 3).mean()) < 0.05 and abs((x1 ** 4).mean() - 3.0) < 0.15
+    assert abs(np.corrcoef(x1, x2)[0, 1]) < 0.02 and not np.array_equal(x1, x2)
+    assert abs(np.corrcoef(x1[:-1], x1[1:])[0, 1]) < 0.02
+    st2 = torch.tensor([1234, 0], dtype=torch.int64, device=DEV)
+    lat3, _, _ = ops.latent_head(zg, pm, pv, None, Ls, Lg, st2)
+    assert torch.equal(lat3, lat1)
+
+
 @pytest.mark.parametrize("b,K,absent", [(512, 10, False), (64, 10, True), (700, 7, True)])
 def test_cluster_losses_vs_oracle_and_torch_gradient(ops, b, K, absent):
     """ops.cluster_losses: values against the oracle's restatement of _train_utils.py:240-253/272-307, the

@@ -41,8 +41,7 @@ if mode in ("svgp", "gat", "decoder"):
                 zg = (self.GATEncoder.GAT_fc.weight.sum() * 0 + torch.zeros((bb, 2 * Lg), device=y.device))
             else:
                 zg = self.GATEncoder.pre_head(y, edge_index, rows=bb)
-        eps = torch.randn((bb, Ls + Lg), dtype=torch.float32, device=y.device)
-        final_latent, GAT_KL, al = latent_head(zg, p_m, p_v, eps, Ls, Lg)
+        final_latent, GAT_KL, al = latent_head(zg, p_m, p_v, None, Ls, Lg, self._rng_state())
         if mode == "decoder":
             recon = (final_latent ** 2).sum()
         else:

@@ -7,8 +7,6 @@ from spadot_amd.utils import _train_utils as tu, _utils
 from spadot_amd.model import SpaDOT
 from spadot_amd.ops import FlatAdamW
 dev = "cuda:0"
-_randn = torch.randn
-torch.randn = lambda *a, **k: torch.zeros(*a, **k)       # same noise (none) in both modes
 T, N, G = 5, 10000, 3000
 cfg = _utils.load_model_config(types.SimpleNamespace(config=None))
 data = make_dataset(T, N, G, seed=1993)
@@ -19,6 +17,7 @@ model = SpaDOT.SpaDOT(cfg, dd).to(dev)
 opt = FlatAdamW(model.parameters(), lr=cfg["lr"])
 tu._update_Kmeans(model, cfg, dd); tu._update_OT_matrix(model, cfg)
 model.train()
+model.fixed_noise = (torch.zeros((512, 10), device=dev), torch.zeros((512, 10), device=dev))   # same noise (none) in both modes
 cfg_s = dict(cfg); cfg_s["staged_graphs"] = True
 single = tu.GraphedStepper(model, opt, cfg, dd)
 staged = tu.GraphedStepper(model, opt, cfg_s, dd)
