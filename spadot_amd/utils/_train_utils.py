@@ -316,6 +316,14 @@ class GraphedStepper:
         import torch.distributed as dist
         multi = grad_sync is not None or (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
         self.staged = bool(model_config.get("staged_graphs", os.environ.get("SPADOT_STAGED_GRAPHS", "0" if multi else "1") == "1"))
+        # Capturable only while every launch of the step is ours or a plain library GEMM: with more inducing points per
+        # time point than the sweep kernel takes (ops.SWEEP_MAX_M) the SPD inverse goes through the library's batched
+        # Cholesky, which cannot be captured -- such runs take eager steps (same arithmetic, one launch at a time).
+        from ..ops import SWEEP_MAX_M
+        self.capturable = all(int(s.inducing_index_points.shape[0]) <= SWEEP_MAX_M for s in model.svgp_dict.values())
+        if not self.capturable:
+            print("[spadot_amd] more than %d inducing points in a time point: training steps run eagerly, not as replayed "
+                  "hipGraphs" % SWEEP_MAX_M)
         self.version = getattr(model, "_state_version", 0)
 
     def _body(self, tp_i, tp, bi, epoch, with_update=True):
@@ -338,7 +346,9 @@ class GraphedStepper:
     def update(self):
         """clip + AdamW as its own graph (data-parallel path: after the gradient exchange): eager once, then one
         replayed graph shared by all keys."""
-        if self.opt_graph is None:
+        if not self.capturable:
+            self.opt.step()
+        elif self.opt_graph is None:
             self.opt.step()
             self.opt_graph = False                  # warmed up; capture on the next call
         elif self.opt_graph is False:
@@ -352,6 +362,8 @@ class GraphedStepper:
             self.graphs.clear()
             self.version = getattr(self.model, "_state_version", 0)
         self.beta1_t[1].fill_(-float(beta1))
+        if not self.capturable:
+            return self._body(tp_i, tp, bi, epoch, with_update=with_update)
         if self.staged:
             return self._run_staged(tp_i, tp, bi, epoch, with_update)
         key = (tp, bi, epoch >= 1, epoch >= self.cfg["ot_epoch"] and tp_i != 0, with_update)

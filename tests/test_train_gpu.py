@@ -299,6 +299,22 @@ def test_device_kmeans_vs_sklearn():
     assert kmh.inertia_ <= 1.01 * skh.inertia_
 
 
+def test_training_with_more_inducing_points_than_the_sweep_kernel_takes(tmp_path, capsys):
+    """> 310 inducing points in a time point: the SPD inverse goes through the library (not capturable), the trainer
+    must notice and take eager steps instead of failing in a graph capture (the default 1200 points over two time
+    points is exactly this case)."""
+    import spadot_amd, yaml
+    from spadot_amd.synthetic import make_dataset
+    cfg = _small_config(); cfg["inducing_point_nums"] = 700; cfg["maxiter"] = 3
+    p = tmp_path / "cfg.yaml"; yaml.safe_dump(cfg, open(p, "w"))
+    args = types.SimpleNamespace(data=make_dataset(2, 1200, 40, seed=11), output_dir=str(tmp_path / "o"), prefix="",
+                                 config=str(p), save_model=False, device=DEV)
+    model, loss = spadot_amd.train(args)
+    assert np.isfinite(loss.values).all()
+    assert max(int(s.inducing_index_points.shape[0]) for s in model.svgp_dict.values()) > 310
+    assert "run eagerly" in capsys.readouterr().out
+
+
 def test_training_with_device_kmeans_and_knn_backends(tmp_path):
     """Everything after the h5ad read on the device: spatial kNN graph, K-means fits, training (bf16 compute)."""
     import spadot_amd, yaml
