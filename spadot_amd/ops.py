@@ -477,19 +477,44 @@ def rowdot(A, B):
 
 
 SWEEP_MAX_M = 310      # largest matrix the register/LDS-resident sweep kernel takes (include/spadot_model.h)
+SWEEP_MAX_M2 = 2 * SWEEP_MAX_M   # with one level of blocking (two sweeps + five batched GEMMs), still capturable
+
+
+def _sweep_kernel(A):
+    L, m, _ = A.shape
+    X = torch.empty_like(A)
+    logdet = torch.empty(L, dtype=torch.float64, device=A.device)
+    _check(model_lib().spadot_spd_inverse_logdet(_p(A), L, m, _p(X), _p(logdet), _stream()), "spadot_spd_inverse_logdet")
+    return X, logdet
 
 
 def _spd_inverse_logdet_nograd(A, need_logdet=True):
     """A [L, m, m] SPD fp64 -> (A^-1, log|A|).  m <= SWEEP_MAX_M: ONE launch of the sweep kernel gives both.
-    Larger m: the library's batched Cholesky (potrf + potri), which is just as stable but costs ~100 small
-    launches -- a block/Schur split through an explicit inverse was tried and loses cond(A) digits."""
+    m <= 2 SWEEP_MAX_M: the same elimination in two blocks -- sweep the leading block, form the Schur complement with
+    batched GEMMs, sweep it, back-substitute (Gauss-Jordan in block order: what the kernel would do pivot by pivot;
+    no library factorisation, so the step stays capturable in a hipGraph).  Larger m: the library's batched Cholesky."""
     L, m, _ = A.shape
     if m <= SWEEP_MAX_M:
+        return _sweep_kernel(A)
+    if m <= SWEEP_MAX_M2:
+        m1 = m // 2
+        A11 = A[:, :m1, :m1].contiguous()
+        A12 = A[:, :m1, m1:]
+        S11, ld1 = _sweep_kernel(A11)
+        B = S11 @ A12                                               # A11^-1 A12            [L, m1, m2]
+        # one refinement step: entries of B are O(1) while S11's are O(cond), so the product with the explicit
+        # inverse alone carries an eps * cond * |S11||A12| error that the Schur complement's inverse would amplify
+        B = B + S11 @ (A12 - A11 @ B)
+        C = A[:, m1:, m1:] - A12.transpose(1, 2) @ B                # Schur complement      [L, m2, m2]
+        C = 0.5 * (C + C.transpose(1, 2))
+        Ci, ld2 = _sweep_kernel(C.contiguous())
+        X12 = -(B @ Ci)
         X = torch.empty_like(A)
-        logdet = torch.empty(L, dtype=torch.float64, device=A.device)
-        _check(model_lib().spadot_spd_inverse_logdet(_p(A), L, m, _p(X), _p(logdet), _stream()),
-               "spadot_spd_inverse_logdet")
-        return X, logdet
+        X[:, :m1, :m1] = S11 - X12 @ B.transpose(1, 2)
+        X[:, :m1, m1:] = X12
+        X[:, m1:, :m1] = X12.transpose(1, 2)
+        X[:, m1:, m1:] = Ci
+        return X, ld1 + ld2
     Lc = torch.linalg.cholesky_ex(A, check_errors=False)[0]
     X = torch.cholesky_inverse(Lc)
     logdet = 2.0 * torch.log(torch.diagonal(Lc, dim1=-2, dim2=-1)).sum(-1)
@@ -498,7 +523,7 @@ def _spd_inverse_logdet_nograd(A, need_logdet=True):
 
 class _SPDInverse(torch.autograd.Function):
     """(A^-1, log|A|) of a batch of SPD matrices [L, m, m] (fp64).  Forward: the register-resident symmetric
-    sweep kernel (one launch, m <= 310; library Cholesky above).  Backward (A symmetric):
+    sweep kernel (one launch, m <= 310; two blocked sweeps to 620; library Cholesky above).  Backward (A symmetric):
     dA = -X G_X X + g_logdet X with X = A^-1 -- two batched GEMMs."""
 
     @staticmethod
