@@ -311,7 +311,8 @@ def _main(real_stdout):
             out.update(value=sk_res["value"], unit="Sinkhorn iters/s", ms_per_step=sk_res["ms_per_iter"] * ITERS_PER_STEP)
         out["dtype"] = (f"{args.compute_dtype} GAT branch + linears, f32 parameters/optimizer, f64 SVGP algebra; "
                         f"Sinkhorn {args.ot_storage} kernel matrix with f64 scalings")
-        out["config"] = {"workload": f"cfg3: {T} time points x {N} spots x {G} genes, batch 512, k=30, 1200 inducing points; "
+        name = "cfg3" if (T, N, G) == (5, 10000, 3000) else "custom shape"
+        out["config"] = {"workload": f"{name}: {T} time points x {N} spots x {G} genes, batch 512, k=30, 1200 inducing points; "
                                      f"Sinkhorn pair problem {N}x{N}",
                          "train": {k: v for k, v in (train_res or {}).items() if k != "cpu_baseline"},
                          "parallelism": "1 GPU" if world == 1 else f"{world} ranks: time points / pair problems sharded, "

@@ -93,7 +93,7 @@ int spadot_kernel_matrix(const void *x, const void *z, int n, int m, int d, doub
 
 /* Batched SPD inverse and log-determinant (fp64): A [L, m, m] symmetric positive definite ->
  * Ainv [L, m, m], logdet [L].  One workgroup per matrix, symmetric sweep operator, matrix resident in
- * registers + LDS (m <= 310; returns -34 beyond: the caller uses the library's batched Cholesky).  Replaces the
+ * registers + LDS (m <= 310; returns -34 beyond: the host splits larger matrices into blocks, spadot_amd/ops.py).  Replaces the
  * torch.linalg.inv / cholesky calls of svgp.py:50,75,87-88 on the L latent dimensions at once. */
 int spadot_spd_inverse_logdet(const double *A, int L, int m, double *Ainv, double *logdet, void *stream);
 

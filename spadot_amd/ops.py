@@ -477,7 +477,11 @@ def rowdot(A, B):
 
 
 SWEEP_MAX_M = 310      # largest matrix the register/LDS-resident sweep kernel takes (include/spadot_model.h)
-SWEEP_MAX_M2 = 2 * SWEEP_MAX_M   # with one level of blocking (two sweeps + five batched GEMMs), still capturable
+
+# sizes up to this go to one sweep launch, larger ones are split in two (measured, 10 matrices, graph replay: one launch
+# 0.204 ms at m = 236 but 0.54 / 0.56 ms at 300 / 310, where two blocks take 0.26 / 0.27 ms; m = 600: 0.68 ms as 4 blocks
+# against 1.26 ms as 2; tools/spd_split.py)
+_SPLIT = [256]
 
 
 def _sweep_kernel(A):
@@ -490,40 +494,35 @@ def _sweep_kernel(A):
 
 def _spd_inverse_logdet_nograd(A, need_logdet=True):
     """A [L, m, m] SPD fp64 -> (A^-1, log|A|).  m <= SWEEP_MAX_M: ONE launch of the sweep kernel gives both.
-    m <= 2 SWEEP_MAX_M: the same elimination in two blocks -- sweep the leading block, form the Schur complement with
-    batched GEMMs, sweep it, back-substitute (Gauss-Jordan in block order: what the kernel would do pivot by pivot;
-    no library factorisation, so the step stays capturable in a hipGraph).  Larger m: the library's batched Cholesky."""
+    Larger m: the same elimination in two blocks, recursively -- invert the leading block, form the Schur complement
+    with batched GEMMs, invert it, back-substitute (Gauss-Jordan in block order: what the kernel would do pivot by
+    pivot).  No library factorisation anywhere, so the step stays capturable in a hipGraph at every m."""
     L, m, _ = A.shape
-    if m <= SWEEP_MAX_M:
-        return _sweep_kernel(A)
-    if m <= SWEEP_MAX_M2:
-        m1 = m // 2
-        A11 = A[:, :m1, :m1].contiguous()
-        A12 = A[:, :m1, m1:]
-        S11, ld1 = _sweep_kernel(A11)
-        B = S11 @ A12                                               # A11^-1 A12            [L, m1, m2]
-        # one refinement step: entries of B are O(1) while S11's are O(cond), so the product with the explicit
-        # inverse alone carries an eps * cond * |S11||A12| error that the Schur complement's inverse would amplify
-        B = B + S11 @ (A12 - A11 @ B)
-        C = A[:, m1:, m1:] - A12.transpose(1, 2) @ B                # Schur complement      [L, m2, m2]
-        C = 0.5 * (C + C.transpose(1, 2))
-        Ci, ld2 = _sweep_kernel(C.contiguous())
-        X12 = -(B @ Ci)
-        X = torch.empty_like(A)
-        X[:, :m1, :m1] = S11 - X12 @ B.transpose(1, 2)
-        X[:, :m1, m1:] = X12
-        X[:, m1:, :m1] = X12.transpose(1, 2)
-        X[:, m1:, m1:] = Ci
-        return X, ld1 + ld2
-    Lc = torch.linalg.cholesky_ex(A, check_errors=False)[0]
-    X = torch.cholesky_inverse(Lc)
-    logdet = 2.0 * torch.log(torch.diagonal(Lc, dim1=-2, dim2=-1)).sum(-1)
-    return X, logdet
+    if m <= _SPLIT[0]:
+        return _sweep_kernel(A.contiguous())
+    m1 = (m + 1) // 2
+    A11 = A[:, :m1, :m1]
+    A12 = A[:, :m1, m1:]
+    S11, ld1 = _spd_inverse_logdet_nograd(A11)
+    B = S11 @ A12                                               # A11^-1 A12            [L, m1, m2]
+    # one refinement step: entries of B are O(1) while S11's are O(cond), so the product with the explicit
+    # inverse alone carries an eps * cond * |S11||A12| error that the Schur complement's inverse would amplify
+    B = B + S11 @ (A12 - A11 @ B)
+    C = A[:, m1:, m1:] - A12.transpose(1, 2) @ B                # Schur complement      [L, m2, m2]
+    C = 0.5 * (C + C.transpose(1, 2))
+    Ci, ld2 = _spd_inverse_logdet_nograd(C)
+    X12 = -(B @ Ci)
+    X = torch.empty_like(A)
+    X[:, :m1, :m1] = S11 - X12 @ B.transpose(1, 2)
+    X[:, :m1, m1:] = X12
+    X[:, m1:, :m1] = X12.transpose(1, 2)
+    X[:, m1:, m1:] = Ci
+    return X, ld1 + ld2
 
 
 class _SPDInverse(torch.autograd.Function):
     """(A^-1, log|A|) of a batch of SPD matrices [L, m, m] (fp64).  Forward: the register-resident symmetric
-    sweep kernel (one launch, m <= 310; two blocked sweeps to 620; library Cholesky above).  Backward (A symmetric):
+    sweep kernel (one launch for m <= 310, recursive two-block elimination above).  Backward (A symmetric):
     dA = -X G_X X + g_logdet X with X = A^-1 -- two batched GEMMs."""
 
     @staticmethod

@@ -316,14 +316,9 @@ class GraphedStepper:
         import torch.distributed as dist
         multi = grad_sync is not None or (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
         self.staged = bool(model_config.get("staged_graphs", os.environ.get("SPADOT_STAGED_GRAPHS", "0" if multi else "1") == "1"))
-        # Capturable only while every launch of the step is ours or a plain library GEMM: with more inducing points per
-        # time point than two blocked sweeps take (ops.SWEEP_MAX_M2) the SPD inverse goes through the library's batched
-        # Cholesky, which cannot be captured -- such runs take eager steps (same arithmetic, one launch at a time).
-        from ..ops import SWEEP_MAX_M2 as SWEEP_MAX_M
-        self.capturable = all(int(s.inducing_index_points.shape[0]) <= SWEEP_MAX_M for s in model.svgp_dict.values())
-        if not self.capturable:
-            print("[spadot_amd] more than %d inducing points in a time point: training steps run eagerly, not as replayed "
-                  "hipGraphs" % SWEEP_MAX_M)
+        # every launch of the step is ours or a plain library GEMM (the SPD inverse has no library factorisation at
+        # any number of inducing points: ops._spd_inverse_logdet_nograd), so the step is always capturable
+        self.capturable = True
         self.version = getattr(model, "_state_version", 0)
 
     def _body(self, tp_i, tp, bi, epoch, with_update=True):

@@ -299,34 +299,20 @@ def test_device_kmeans_vs_sklearn():
     assert kmh.inertia_ <= 1.01 * skh.inertia_
 
 
-def test_training_with_more_inducing_points_than_the_sweep_kernel_takes(tmp_path, capsys):
-    """> 620 inducing points in a time point: the SPD inverse goes through the library (not capturable), the trainer
-    must notice and take eager steps instead of failing in a graph capture."""
+@pytest.mark.parametrize("n_ind", [1100, 1500])
+def test_training_with_more_inducing_points_than_one_sweep_takes(tmp_path, capsys, n_ind):
+    """The default inducing-point load (1200 over two time points -> m ~ 600 each; here ~550 and ~750) is beyond one
+    sweep launch: the blocked elimination keeps the step capturable, graphs are replayed, losses stay finite."""
     import spadot_amd, yaml
     from spadot_amd.synthetic import make_dataset
-    cfg = _small_config(); cfg["inducing_point_nums"] = 1400; cfg["maxiter"] = 3
-    p = tmp_path / "cfg.yaml"; yaml.safe_dump(cfg, open(p, "w"))
-    args = types.SimpleNamespace(data=make_dataset(2, 1200, 40, seed=11), output_dir=str(tmp_path / "o"), prefix="",
-                                 config=str(p), save_model=False, device=DEV)
-    model, loss = spadot_amd.train(args)
-    assert np.isfinite(loss.values).all()
-    assert max(int(s.inducing_index_points.shape[0]) for s in model.svgp_dict.values()) > 620
-    assert "run eagerly" in capsys.readouterr().out
-
-
-def test_training_with_the_default_inducing_point_count_replays_graphs(tmp_path, capsys):
-    """About the default inducing-point load (1200 over two time points; here 1100 -> m ~ 550 each) is the blocked two-sweep range: graphs
-    are captured and replayed, losses stay finite."""
-    import spadot_amd, yaml
-    from spadot_amd.synthetic import make_dataset
-    cfg = _small_config(); cfg["inducing_point_nums"] = 1100; cfg["maxiter"] = 3
+    cfg = _small_config(); cfg["inducing_point_nums"] = n_ind; cfg["maxiter"] = 3
     p = tmp_path / "cfg.yaml"; yaml.safe_dump(cfg, open(p, "w"))
     args = types.SimpleNamespace(data=make_dataset(2, 1200, 40, seed=11), output_dir=str(tmp_path / "o"), prefix="",
                                  config=str(p), save_model=False, device=DEV)
     model, loss = spadot_amd.train(args)
     assert np.isfinite(loss.values).all()
     m = max(int(s.inducing_index_points.shape[0]) for s in model.svgp_dict.values())
-    assert 310 < m <= 620
+    assert m > 310
     assert "run eagerly" not in capsys.readouterr().out
 
 

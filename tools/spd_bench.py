@@ -2,7 +2,7 @@ import sys, time, torch, numpy as np
 sys.path.insert(0, '/root/repo')
 from spadot_amd import ops
 dev='cuda:0'
-for m in (236, 310, 330, 400, 480, 600, 620, 640):
+for m in (236, 310, 330, 600, 621, 870, 1200, 1300):
     rng=np.random.default_rng(m)
     # matrices shaped like the SVGP's Sigma_l: K_mm + c K_mn diag(w) K_nm + 1e-2 I, Gaussian kernel scale 0.1
     z=torch.as_tensor(rng.normal(size=(m,2))).to(dev); x=torch.as_tensor(rng.normal(size=(512,2))).to(dev)
