@@ -73,6 +73,30 @@ __device__ __forceinline__ double wave_sum(double x) {
     return x;   // valid in lane 0
 }
 
+// The same sum by DPP moves (register to register: no LDS crossbar round trip per step as with ds_bpermute):
+// inclusive scan inside each row of 16 lanes (row_shr 1, 2, 4, 8), then row_bcast:15 / row_bcast:31 carry the row
+// totals upwards.  Result valid in lane 63.  (In the fused pass the bpermute form took 0.60 us of the 2.64 us a
+// group of rows cost.)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double x) {
+    const int lo = __double2loint(x), hi = __double2hiint(x);
+    const int l2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+    const int h2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    return x + __hiloint2double(h2, l2);
+}
+__device__ __forceinline__ double wave_sum63(double x) {
+    x = dpp_add<0x111, 0xf>(x);   // row_shr:1
+    x = dpp_add<0x112, 0xf>(x);   // row_shr:2
+    x = dpp_add<0x114, 0xf>(x);   // row_shr:4
+    x = dpp_add<0x118, 0xf>(x);   // row_shr:8
+    x = dpp_add<0x142, 0xa>(x);   // row_bcast:15 into rows 1 and 3
+    x = dpp_add<0x143, 0xc>(x);   // row_bcast:31 into rows 2 and 3
+    return x;   // valid in lane 63
+}
+__device__ __forceinline__ double read_lane(double x, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
+}
+
 // Sum over a 256..1024-thread block; every thread gets the result.  `sh` needs 16 doubles.
 __device__ __forceinline__ double block_sum(double x, double *sh) {
     x = wave_sum(x);
@@ -339,14 +363,15 @@ __device__ __forceinline__ void fused_load(FusedRows<T, VPT, R> &buf, const T *_
     }
 }
 
-template <typename T, int VPT, int R, typename WT>
+template <typename T, int VPT, int R, typename WT, int PAR>
 __device__ __forceinline__ void fused_group(FusedRows<T, VPT, R> &buf, int row0, int row_end,
-                                            const WT *wl, double *red, double *arow,
+                                            const WT *wl, double *red,
                                             double *colacc, double *__restrict__ a,
                                             double *__restrict__ old_a, double *__restrict__ adx,
                                             const double *rowc, int band0, int band_rows, double alpha1,
                                             double inv_l1e, double tau, int ld, int *flag) {
     constexpr int V = Vec<T>::N;
+    constexpr int NW = FUSED_THREADS / 64;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     double s[R];
 #pragma unroll
@@ -364,48 +389,53 @@ __device__ __forceinline__ void fused_group(FusedRows<T, VPT, R> &buf, int row0,
 #pragma unroll
             for (int e = 0; e < V; e++) s[r] = fma(kv[e], wv[e], s[r]);
         }
+        __builtin_amdgcn_sched_barrier(0);     // one vector slot at a time: bounds the live fp64 temporaries
     }
-    // keep the band in its storage type across the barriers: without this the compiler keeps the
+    // keep the band in its storage type across the barrier: without this the compiler keeps the
     // widened fp64 copies of an fp32 band live for the accumulate phase (2x the registers)
 #pragma unroll
     for (int r = 0; r < R; r++)
 #pragma unroll
         for (int k = 0; k < VPT; k++) asm volatile("" : "+v"(buf.v[r][k]));
+    // wave partials -> LDS (two images, used by alternate groups: ONE barrier per group is enough, a wave that runs
+    // ahead into the next group writes the other image)
+    double *redp = red + PAR * (NW * R);
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        s[r] = wave_sum(s[r]);
-        if (lane == 0) red[wid * R + r] = s[r];
+        s[r] = wave_sum63(s[r]);
+        if (lane == 63) redp[wid * R + r] = s[r];
     }
     __syncthreads();
-    if (tid < R) {
-        const int row = row0 + tid;
-        double x = 0.0;
-        if (row < row_end) {
-            double t = 0.0;
+    // every wave finishes a_i itself (lane l takes row l mod R: same latency as one thread doing it, but no second
+    // barrier and no LDS round trip for the result); wave 0 stores.  p, dx, u and the previous a of the band were
+    // staged in LDS at kernel entry: a global load here would sit behind the whole prefetch in the vmcnt queue.
+    const int lr = lane & (R - 1);
+    const int row = row0 + lr;
+    double x = 0.0;
+    if (row < row_end) {
+        double t = 0.0;
 #pragma unroll
-            for (int wv = 0; wv < FUSED_THREADS / 64; wv++) t += red[wv * R + tid];
-            // p, dx, u and the previous a of the band were staged in LDS at kernel entry: a global load
-            // here would sit behind the whole prefetch in the vmcnt queue and serialise the pipeline
-            const int lr = row - band0;
-            const double an = scale_update(rowc[lr], t, alpha1, rowc[2 * band_rows + lr] * inv_l1e);
-            old_a[row] = rowc[3 * band_rows + lr];
+        for (int wv = 0; wv < NW; wv++) t += redp[wv * R + lr];
+        const int br = row - band0;
+        const double an = scale_update(rowc[br], t, alpha1, rowc[2 * band_rows + br] * inv_l1e);
+        x = an * rowc[band_rows + br];
+        if (tid < R) {
+            old_a[row] = rowc[3 * band_rows + br];
             a[row] = an;
-            x = an * rowc[band_rows + lr];
             adx[row] = x;
             if (an > tau) *flag = 1;
         }
-        arow[tid] = x;
     }
-    __syncthreads();
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        const double x = arow[r];
+        const double xr = read_lane(x, r);
 #pragma unroll
         for (int k = 0; k < VPT; k++) {
             double kv[V];
             unpack<T>(buf.v[r][k], kv);
 #pragma unroll
-            for (int e = 0; e < V; e++) colacc[k * V + e] = fma(kv[e], x, colacc[k * V + e]);
+            for (int e = 0; e < V; e++) colacc[k * V + e] = fma(kv[e], xr, colacc[k * V + e]);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
@@ -420,16 +450,36 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_fused_pass(
     extern __shared__ double smem[];
     constexpr int WPAD = VPT * FUSED_THREADS * V;    // w image padded with zeros to the register tile
     WT *wl = reinterpret_cast<WT *>(smem);   // WPAD entries of WT (double, or float for the widest fp32 rows)
-    double *red = smem + (WPAD * sizeof(WT) + 7) / 8;   // (FUSED_THREADS/64) * R
-    double *arow = red + (FUSED_THREADS / 64) * R;   // R
-    double *rowc = arow + R;                         // 4 x rows_per_block: p, dx, u, previous a
+    double *red = smem + (WPAD * sizeof(WT) + 7) / 8;   // 2 images of (FUSED_THREADS/64) * R wave partials
+    double *rowc = red + 2 * (FUSED_THREADS / 64) * R;  // 4 x rows_per_block: p, dx, u, previous a
     const int tid = threadIdx.x;
     const int r0 = blockIdx.x * rows_per_block;
     const int r1 = min(I, r0 + rows_per_block);
     FusedRows<T, VPT, R> bufA, bufB;
+    // Request order = arrival order (one in-order queue per wave): first the w image and the band's row constants
+    // (small, cache hits), then both register buffers of K.  The LDS images are filled while K is on its way; the
+    // other way round they would sit behind 160 KB of K per workgroup.
+    constexpr int WSLOTS = WPAD / FUSED_THREADS;      // VPT * V
+    double wreg[WSLOTS];
+#pragma unroll
+    for (int q = 0; q < WSLOTS; q++) {
+        const int j = tid + q * FUSED_THREADS;
+        wreg[q] = (j < ld) ? w[j] : 0.0;
+    }
+    double rc[4] = {0.0, 0.0, 0.0, 0.0};
+    const bool has_row = tid < r1 - r0;
+    if (has_row) { rc[0] = p[r0 + tid]; rc[1] = dx[r0 + tid]; rc[2] = u[r0 + tid]; rc[3] = a[r0 + tid]; }
     fused_load<T, VPT, R>(bufA, K, r0, r1, ld, tid);
-    for (int j = tid; j < WPAD; j += FUSED_THREADS) wl[j] = (j < ld) ? (WT)w[j] : (WT)0;
-    for (int t = tid; t < r1 - r0; t += FUSED_THREADS) {
+    fused_load<T, VPT, R>(bufB, K, r0 + R, r1, ld, tid);            // rows >= r1: clamped, weight 0
+#pragma unroll
+    for (int q = 0; q < WSLOTS; q++) wl[tid + q * FUSED_THREADS] = (WT)wreg[q];
+    if (has_row) {
+        rowc[tid] = rc[0];
+        rowc[rows_per_block + tid] = rc[1];
+        rowc[2 * rows_per_block + tid] = rc[2];
+        rowc[3 * rows_per_block + tid] = rc[3];
+    }
+    for (int t = tid + FUSED_THREADS; t < r1 - r0; t += FUSED_THREADS) {      // bands longer than the workgroup (rare)
         rowc[t] = p[r0 + t];
         rowc[rows_per_block + t] = dx[r0 + t];
         rowc[2 * rows_per_block + t] = u[r0 + t];
@@ -439,16 +489,26 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_fused_pass(
 #pragma unroll
     for (int k = 0; k < VPT * V; k++) colacc[k] = 0.0;
     __syncthreads();
-    for (int g = r0; g < r1; g += 2 * R) {
-        fused_load<T, VPT, R>(bufB, K, g + R, r1, ld, tid);          // rows >= r1: clamped, weight 0
-        fused_group<T, VPT, R, WT>(bufA, g, r1, wl, red, arow, colacc, a, old_a, adx, rowc, r0, rows_per_block,
-                                   alpha1, inv_l1e, tau, ld, flag);
-        if (g + R < r1) {
-            fused_load<T, VPT, R>(bufA, K, g + 2 * R, r1, ld, tid);
-            fused_group<T, VPT, R, WT>(bufB, g + R, r1, wl, red, arow, colacc, a, old_a, adx, rowc, r0,
-                                       rows_per_block, alpha1, inv_l1e, tau, ld, flag);
-        }
+#define FUSED_GROUP(PAR, BUF, G) fused_group<T, VPT, R, WT, PAR>(BUF, G, r1, wl, red, colacc, a, old_a, adx, rowc, r0, \
+                                                               rows_per_block, alpha1, inv_l1e, tau, ld, flag)
+    int g = r0;
+    // steady state: both loads unconditional (a conditional load would make the compiler wait for ALL outstanding
+    // loads at the join, i.e. undo the double buffering); the loop ends while both buffers still hold valid rows
+    for (; g + 3 * R < r1; g += 2 * R) {
+        FUSED_GROUP(0, bufA, g);
+        fused_load<T, VPT, R>(bufA, K, g + 2 * R, r1, ld, tid);
+        FUSED_GROUP(1, bufB, g + R);
+        fused_load<T, VPT, R>(bufB, K, g + 3 * R, r1, ld, tid);      // last round: a partial group, rows clamped
     }
+    // tail: one to three groups left, nothing is requested beyond the band
+    FUSED_GROUP(0, bufA, g);
+    if (g + R < r1) {
+        const bool third = g + 2 * R < r1;
+        if (third) fused_load<T, VPT, R>(bufA, K, g + 2 * R, r1, ld, tid);
+        FUSED_GROUP(1, bufB, g + R);
+        if (third) FUSED_GROUP(0, bufA, g + 2 * R);
+    }
+#undef FUSED_GROUP
     T *o = part + (size_t)blockIdx.x * ld;        // partials in the storage type: fp32 K => fp32 partials
 #pragma unroll
     for (int k = 0; k < VPT; k++) {
@@ -1228,7 +1288,7 @@ void choose_fused(spadot_ot_solver *s) {
     if (vpt > max_vpt) return;
     const size_t wbytes = (s->storage == SPADOT_F32 && vpt > 8) ? 4 : 8;   // fp32 w image for the widest rows
     const int R = vpt <= (s->storage == SPADOT_F32 ? 5 : 6) ? 2 : 1;     // must match the FUSED_CASE table
-    size_t lds = wbytes * (size_t)vpt * FUSED_THREADS * V + sizeof(double) * ((FUSED_THREADS / 64) * R + R) + 8;
+    size_t lds = wbytes * (size_t)vpt * FUSED_THREADS * V + sizeof(double) * (2 * (FUSED_THREADS / 64) * R) + 8;
     if (lds + 4096 > 160 * 1024) return;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) {
