@@ -1037,6 +1037,7 @@ __global__ __launch_bounds__(256) void k_sumsq_part(const float *__restrict__ g,
 
 // Gradient sum of squares in ONE launch: per-workgroup partials, and the last workgroup to finish (device counter,
 // reset for the next launch) adds them in workgroup order, writes the total and advances the optimizer's step count.
+template <int U>
 __global__ __launch_bounds__(256) void k_sumsq_last(const float *__restrict__ g, long long count, double *__restrict__ part,
                                                     float *__restrict__ sumsq, int *__restrict__ step_dev,
                                                     unsigned *__restrict__ counter) {
@@ -1045,9 +1046,16 @@ __global__ __launch_bounds__(256) void k_sumsq_last(const float *__restrict__ g,
     double acc = 0.0;
     const long long n4 = count / 4;
     const float4 *g4 = reinterpret_cast<const float4 *>(g);
-    for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < n4; k += (long long)gridDim.x * 256) {
-        const float4 v = g4[k];
-        acc += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    // U independent 16-byte loads in flight per thread, fp64 accumulation in a fixed order
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < n4; k += U * stride) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            v[u] = (k + u * stride < n4) ? g4[k + u * stride] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            acc += ((double)v[u].x * v[u].x + (double)v[u].y * v[u].y) + ((double)v[u].z * v[u].z + (double)v[u].w * v[u].w);
     }
     if (blockIdx.x == 0)
         for (long long k = n4 * 4 + threadIdx.x; k < count; k += 256) acc += (double)g[k] * g[k];
@@ -1061,7 +1069,15 @@ __global__ __launch_bounds__(256) void k_sumsq_last(const float *__restrict__ g,
     if (!last) return;
     __threadfence();
     double t = 0.0;
-    for (int b = threadIdx.x; b < (int)gridDim.x; b += blockDim.x) t += __builtin_nontemporal_load(part + b);
+    {   // gridDim.x <= 2048 (launcher): at most eight partials per thread, loaded together, added in a fixed order
+        double q[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int b = threadIdx.x + u * 256;
+            q[u] = b < (int)gridDim.x ? __builtin_nontemporal_load(part + b) : 0.0;
+        }
+        t = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
+    }
     t = block_sum_d(t, sh);
     if (threadIdx.x == 0) { sumsq[0] = (float)t; if (step_dev) step_dev[0] += 1; *counter = 0u; }
 }
@@ -2027,8 +2043,10 @@ int spadot_clip_adamw_dev(float *param, const float *grad, float *exp_avg, float
     if (((uintptr_t)grad & 15) != 0) return -22;
     hipStream_t st_ = (hipStream_t)stream;
     const long long want4 = (count / 4 + 255) / 256;
-    const int nbs = (int)(want4 < 1 ? 1 : (want4 < 2048 ? want4 : 2048));
-    hipLaunchKernelGGL(k_sumsq_last, dim3(nbs), dim3(256), 0, st_, grad, count, scratch, sumsq, step_dev, counter);
+    // 512 workgroups: every workgroup ends with an agent-scope release (L2 write-back) before its counter add, so
+    // the launch got SLOWER with more of them (2048: 56 us, 512: 31 us for 64 MB; tools/adamw_bench.py)
+    const int nbs = (int)(want4 < 1 ? 1 : (want4 < 512 ? want4 : 512));
+    hipLaunchKernelGGL(k_sumsq_last<4>, dim3(nbs), dim3(256), 0, st_, grad, count, scratch, sumsq, step_dev, counter);
     const long long want = (count + 255) / 256;
     const int nb = (int)(want < 4096 ? want : 4096);
     hipLaunchKernelGGL(k_adamw, dim3(nb), dim3(256), 0, st_, param, grad, exp_avg, exp_avg_sq, (const float *)sumsq, count,
