@@ -265,26 +265,42 @@ __global__ __launch_bounds__(256) void k_gat_datt_part(const T *__restrict__ h, 
         for (int it = 0; it < NITER; it++)
 #pragma unroll
             for (int k = 0; k < VEC; k++) { as[it][k] = 0.f; ad[it][k] = 0.f; ab[it][k] = 0.f; }
-        for (int j = j0; j < j1; j++) {
-            const float ws = ds_src[(size_t)j * H + hd], wd = ds_dst[(size_t)j * H + hd];
-            const T *row = h + (size_t)j * HC + (size_t)hd * C;
-            const bool with_g = g_pre != nullptr && j < n_pre;
-            const T *grow = g_pre + (size_t)(with_g ? j : 0) * HC + (size_t)hd * C;
+        // four nodes per trip, all their row loads issued before the first is used (one node per trip left the
+        // slab latency-bound: 34 us for 82 MB)
+        constexpr int UJ = 4;
+        for (int jb = j0; jb < j1; jb += UJ) {
+            float ws[UJ], wd[UJ], v[UJ][NITER][VEC], gv[UJ][NITER][VEC];
+            bool with_g[UJ];
 #pragma unroll
-            for (int it = 0; it < NITER; it++) {
-                const int c = (it * WAVE + lane) * VEC;
-                if (c < C) {
-                    float v[VEC];
-                    ldv<T, VEC>(row + c, v);
+            for (int u = 0; u < UJ; u++) {
+                const int j = min(jb + u, j1 - 1);
+                const bool live = jb + u < j1;
+                ws[u] = live ? ds_src[(size_t)j * H + hd] : 0.f;
+                wd[u] = live ? ds_dst[(size_t)j * H + hd] : 0.f;
+                with_g[u] = live && g_pre != nullptr && j < n_pre;
+                const T *row = h + (size_t)j * HC + (size_t)hd * C;
+                const T *grow = g_pre + (size_t)(with_g[u] ? j : 0) * HC + (size_t)hd * C;
 #pragma unroll
-                    for (int k = 0; k < VEC; k++) { as[it][k] = fmaf(ws, v[k], as[it][k]); ad[it][k] = fmaf(wd, v[k], ad[it][k]); }
-                    if (with_g) {
-                        ldv<T, VEC>(grow + c, v);
+                for (int it = 0; it < NITER; it++) {
+                    const int c = (it * WAVE + lane) * VEC;
 #pragma unroll
-                        for (int k = 0; k < VEC; k++) ab[it][k] += v[k];
+                    for (int k = 0; k < VEC; k++) { v[u][it][k] = 0.f; gv[u][it][k] = 0.f; }
+                    if (c < C) {
+                        ldv<T, VEC>(row + c, v[u][it]);
+                        if (with_g[u]) ldv<T, VEC>(grow + c, gv[u][it]);
                     }
                 }
             }
+#pragma unroll
+            for (int u = 0; u < UJ; u++)
+#pragma unroll
+                for (int it = 0; it < NITER; it++)
+#pragma unroll
+                    for (int k = 0; k < VEC; k++) {
+                        as[it][k] = fmaf(ws[u], v[u][it][k], as[it][k]);
+                        ad[it][k] = fmaf(wd[u], v[u][it][k], ad[it][k]);
+                        ab[it][k] += gv[u][it][k];
+                    }
         }
         const int nblk = g_pre ? 3 : 2;
         float *ps = part + (size_t)blockIdx.x * nblk * HC + (size_t)hd * C;
@@ -310,7 +326,13 @@ __global__ __launch_bounds__(1024) void k_colsum_parts(const float *__restrict__
     if (c < width) {
         const int per = (nslab + 15) / 16;
         const int s0 = gy * per, s1 = min(nslab, s0 + per);
-        for (int s = s0; s < s1; s++) acc += part[(size_t)s * width + c];
+        for (int sb = s0; sb < s1; sb += 8) {              // eight loads in flight, added in ascending order
+            float q[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) q[u] = (sb + u < s1) ? part[(size_t)(sb + u) * width + c] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; u++) acc += q[u];
+        }
     }
     sh[gy][cx] = acc;
     __syncthreads();
@@ -1668,7 +1690,7 @@ int spadot_gat_att_grad(const void *h, int dtype, const float *ds_src, const flo
     if (g_pre && (n_pre <= 0 || n_pre > n)) return -22;
     hipStream_t st_ = (hipStream_t)stream;
     const int width = (g_pre ? 3 : 2) * H * C;
-    int nslab = (n + 63) / 64;
+    int nslab = (n + 15) / 16;       // 16 nodes per workgroup: enough workgroups to keep the row loads of ~80 MB in flight
     if ((long long)nslab * width > scratch_floats) nslab = scratch_floats / width;
     if (nslab < 1) return -22;
     const int per = (n + nslab - 1) / nslab;

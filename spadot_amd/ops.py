@@ -123,7 +123,7 @@ class _GATEdge(torch.autograd.Function):
                                               _p(ds_dst), _p(a_s), _p(a_d), _stream()), "spadot_gat_backward_source")
         # attention-vector gradients and the bias gradient (column sums of g_pre) in one slab pass over the nodes
         datt = torch.empty((3, H * C), dtype=torch.float32, device=h.device)
-        floats = 3 * H * C * max(1, min((n + 63) // 64, 512))
+        floats = 3 * H * C * max(1, min((n + 15) // 16, 1024))
         scratch = _gat_att_scratch(h.device, floats)
         _check(lib.spadot_gat_att_grad(_p(h), _DT[h.dtype], _p(ds_src), _p(ds_dst), n, H, C, _p(scratch), floats,
                                        _p(datt), ctypes.c_void_p(datt.data_ptr() + 4 * H * C), _p(g_pre), nt, _stream()),
