@@ -99,9 +99,9 @@ class SpaDOT(nn.Module):
 
     # ---- the three parts of forward() on their own (GraphedStepper's staged mode replays them as separate graphs:
     #      the two branches on two streams, then the tail) ------------------------------------------------------
-    def branch_gat(self, y, edge_index, batch_size):
-        """GAT branch: (mu | logvar) of the seeds [b, 2 Lg]."""
-        return self.GATEncoder.pre_head(y, edge_index, rows=batch_size)
+    def branch_gat(self, y, edge_index, batch_size, taps=None):
+        """GAT branch: (mu | logvar) of the seeds [b, 2 Lg]; taps: see GATEncoder.pre_head."""
+        return self.GATEncoder.pre_head(y, edge_index, rows=batch_size, taps=taps)
 
     def branch_svgp(self, x, y, tp, batch_size, batch_key=None):
         """SVGP branch: posterior mean / variance at the seeds [b, Ls] (fp64) and SVGP_KL."""

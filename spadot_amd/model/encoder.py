@@ -112,15 +112,21 @@ class GATEncoder(nn.Module):
         self.GAT_fc = nn.Linear(hidden_dim, GAT_z_dim * 2)
         nn.init.xavier_uniform_(self.GAT_fc.weight)
 
+    def first_layer_parameters(self):
+        """The parameters whose gradients a backward pass produces last (ops.FlatAdamW `last`)."""
+        return list(self.gat1.parameters())
+
     def forward(self, x, edge_index, rows=None):
         """`rows` (optional int): only the first `rows` nodes of the output are needed (the seeds)."""
         mu, logvar = torch.chunk(self.pre_head(x, edge_index, rows), 2, dim=1)
         return mu, torch.exp(logvar)
 
-    def pre_head(self, x, edge_index, rows=None, after_first_dense=None):
+    def pre_head(self, x, edge_index, rows=None, after_first_dense=None, taps=None):
         """GAT_fc output (mu | logvar) [rows or n, 2 z]: what ops.latent_head consumes.
         after_first_dense: optional callable run right after the first (largest) GEMM has been issued -- the
-        composite model issues the start of its SVGP branch there, on another stream."""
+        composite model issues the start of its SVGP branch there, on another stream.
+        taps: optional dict; receives 'h1', the first layer's output (where a backward pass issued in pieces cuts:
+        everything above it is differentiated first, the first layer's own gradients last)."""
         lg = getattr(edge_index, "layer_graphs", None) if rows is not None else None
         g3 = getattr(edge_index, "seed_graph", None) if rows is not None else None
         if not isinstance(edge_index, BatchGraph):
@@ -129,6 +135,8 @@ class GATEncoder(nn.Module):
         if after_first_dense is not None:
             after_first_dense()
         h = self.gat1.edge(h, edge_index, act=True)
+        if taps is not None:
+            taps["h1"] = h
         if lg is not None and lg[1].n_tgt == rows:
             # only what the seeds' rows of layer 3 depend on: layer 2 for seeds + hop 1, layer 3 for the seeds
             h = self.gat2(h, lg[0], act=True)

@@ -658,8 +658,15 @@ class FlatAdamW:
     flat fp32 parameter buffer.  Parameters of `module` are re-pointed into the flat buffer (so the
     gradient all-reduce of the data-parallel path is a single collective over `flat_grad`)."""
 
-    def __init__(self, params, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_norm=0.3):
+    def __init__(self, params, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_norm=0.3, last=None):
+        """last: parameters to place at the END of the flat buffers (the update is element-wise, so the order is free).
+        The data-parallel path puts the parameters whose gradients arrive last in the backward pass there -- the
+        first GAT layer's -- so that `flat_grad[:tail_offset]` can be all-reduced while they are still being
+        computed (GraphedStepper, bucketed exchange)."""
         params = [p for p in params if p.requires_grad]
+        tail_ids = {id(p) for p in (last or [])}
+        params = [p for p in params if id(p) not in tail_ids] + [p for p in params if id(p) in tail_ids]
+        n_tail = sum(1 for p in params if id(p) in tail_ids)
         assert params and all(p.is_cuda and p.dtype == torch.float32 for p in params), \
             "FlatAdamW needs fp32 parameters on the MI355X"
         dev = params[0].device
@@ -680,6 +687,8 @@ class FlatAdamW:
             p.data = self.flat_param[o:o + s].view_as(p.data)
             p.grad = self.flat_grad[o:o + s].view_as(p.data)
         self.params, self.count = params, tot
+        self.tail_offset = offs[len(params) - n_tail] if n_tail else None     # start of the `last` group (16-byte aligned)
+        self.tail_params = params[len(params) - n_tail:] if n_tail else []
         self.lr, self.betas, self.eps, self.weight_decay, self.max_norm = lr, betas, eps, weight_decay, max_norm
         self.t = 0
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)   # device-side step count (graph replays)

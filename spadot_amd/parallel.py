@@ -65,6 +65,28 @@ def allreduce_flat_grad(flat_grad):
     return flat_grad
 
 
+def make_grad_sync(opt):
+    """(blocking, async) exchange of an ops.FlatAdamW's flat gradient.  When the optimizer keeps a tail group
+    (`last=`: the first GAT layer's parameters) the buffer travels as TWO buckets, [0, tail_offset) and the tail, in
+    that order on every rank and every path -- GraphedStepper issues them beside the end of the backward pass,
+    everything else one after the other."""
+    cut = opt.tail_offset
+
+    def sync(flat):
+        if world()[1] > 1:
+            if cut:
+                dist.all_reduce(flat[:cut], op=dist.ReduceOp.SUM)
+                dist.all_reduce(flat[cut:], op=dist.ReduceOp.SUM)
+            else:
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        return flat
+
+    def sync_async(view):
+        return dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True)
+
+    return sync, sync_async
+
+
 def average_buffers(module):
     """BatchNorm running_mean / running_var averaged over ranks (each replica saw different batches)."""
     _, P = world()
@@ -110,18 +132,25 @@ def gather_small_plans(local_plans, plan, shape, device):
     return {p: out[i] for i, p in enumerate(pairs)}
 
 
-def run_epoch(plan, batches_per_tp, order, compute_grad, zero_grad, flat_grad, apply_update):
+def run_epoch(plan, batches_per_tp, order, compute_grad, zero_grad, flat_grad, apply_update, exchange=None):
     """One synchronous data-parallel epoch.
         compute_grad(tp_i, tp, bi): backward of this rank's batch into flat_grad (after zero_grad())
+        exchange(did_work):         the step's gradient exchange (default: one all-reduce of flat_grad); told whether
+                                    this rank had a batch, because a stepper with the bucketed exchange has already
+                                    issued its collectives inside compute_grad
         apply_update():             clip + AdamW on the (now global) flat_grad
-    Every rank calls the collective the same number of times (n_steps), whatever its own item count."""
+    Every rank calls the collectives the same number of times (n_steps), whatever its own item count."""
     per_rank, n_steps = epoch_schedule(plan, batches_per_tp, order)
     mine = per_rank[plan.rank]
     for s in range(n_steps):
         zero_grad()
-        if s < len(mine):
+        did = s < len(mine)
+        if did:
             compute_grad(*mine[s])
-        allreduce_flat_grad(flat_grad)
+        if exchange is not None:
+            exchange(did)
+        else:
+            allreduce_flat_grad(flat_grad)
         apply_update()
     return n_steps
 
@@ -144,7 +173,8 @@ def train_SpaDOT_parallel(dataloader_dict, model_config, verbose=False):
     if P > 1:
         for t in list(model.parameters()) + [b for b in model.buffers()]:
             dist.broadcast(t.data, src=0)
-    opt = FlatAdamW(model.parameters(), lr=model_config["lr"])
+    opt = FlatAdamW(model.parameters(), lr=model_config["lr"], last=model.GATEncoder.first_layer_parameters())
+    sync, sync_async = make_grad_sync(opt)
     beta1s = tu._beta_cycle_linear(model_config["maxiter"], stop=model_config["beta1"])
     order = list(enumerate(model_config["timepoints"]))
     batches_per_tp = {tp: 0 for tp in model_config["timepoints"]}
@@ -157,7 +187,17 @@ def train_SpaDOT_parallel(dataloader_dict, model_config, verbose=False):
     losses = {}
     # replayed hipGraphs, as in the single-replica trainer: one forward+backward graph per (time point, batch),
     # the all-reduce of the flat gradient between replays (not captured), one clip + AdamW graph
-    stepper = tu.GraphedStepper(model, opt, model_config, dataloader_dict) if model_config.get("use_hip_graphs", True) else None
+    stepper = (tu.GraphedStepper(model, opt, model_config, dataloader_dict, grad_sync=sync,
+                                 grad_sync_async=sync_async if P > 1 else None)
+               if model_config.get("use_hip_graphs", True) else None)
+
+    def exchange(did_work):
+        if stepper is not None and stepper.overlap:        # bucketed: a rank with a batch has exchanged inside fb()
+            if not did_work:
+                stepper.exchange_idle()
+        else:
+            sync(opt.flat_grad)
+
     for epoch in range(model_config["maxiter"]):
         beta1 = float(beta1s[epoch])
         model.train()
@@ -172,7 +212,7 @@ def train_SpaDOT_parallel(dataloader_dict, model_config, verbose=False):
                                                optimizer=opt))
 
         run_epoch(plan, batches_per_tp, order, compute_grad, opt.zero_grad, opt.flat_grad,
-                  stepper.update if stepper is not None else opt.step)
+                  stepper.update if stepper is not None else opt.step, exchange=exchange)
         losses[epoch] = torch.stack(acc).mean(0).cpu().tolist() if acc else None
         average_buffers(model)
         tu._update_Kmeans(model, model_config, dataloader_dict)

@@ -287,6 +287,21 @@ def forward_backward(model, model_config, dataloader_dict, tp_i, tp, bi, epoch, 
     return losses
 
 
+def _ranks_share_a_device(device):
+    """True when two ranks of the process group run on the same GPU (one-GPU rehearsals).  Collective: every rank
+    calls it."""
+    import socket
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() < 2:
+        return False
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    prop = torch.cuda.get_device_properties(idx)
+    me = (socket.gethostname(), getattr(prop, "pci_domain_id", 0), getattr(prop, "pci_bus_id", idx), getattr(prop, "pci_device_id", 0))
+    everyone = [None] * dist.get_world_size()
+    dist.all_gather_object(everyone, me)
+    return len(set(everyone)) < len(everyone)
+
+
 class GraphedStepper:
     """Training steps as replayed hipGraphs (torch.cuda.CUDAGraph on ROCm = hipGraph).
 
@@ -299,23 +314,34 @@ class GraphedStepper:
     (a 0-dim tensor), K-means labels/centres and OT plans (copied in place), the optimizer's step count.
     """
 
-    def __init__(self, model, optimizer, model_config, dataloader_dict, grad_sync=None):
-        """grad_sync (data-parallel replicas): callable on the flat gradient buffer, e.g. an RCCL all-reduce.  The
-        step is then TWO graphs -- forward + backward per key, and one clip + AdamW graph shared by all keys -- with
-        the collective issued between their replays (nothing of the collective is captured)."""
+    def __init__(self, model, optimizer, model_config, dataloader_dict, grad_sync=None, grad_sync_async=None):
+        """grad_sync (data-parallel replicas): callable on the flat gradient buffer, e.g. an RCCL all-reduce, issued
+        between the replay of the forward + backward graph(s) and the clip + AdamW graph (nothing of the collective is
+        captured).
+        grad_sync_async: callable on a slice of the flat gradient buffer returning a handle with .wait() (e.g.
+        `dist.all_reduce(view, async_op=True)`).  With it, staged graphs and an optimizer built with
+        `last=model.GATEncoder.first_layer_parameters()`, the exchange is BUCKETED and overlapped: everything but the
+        first GAT layer's gradients is all-reduced while that layer's backward (its edge kernels and the largest
+        weight-gradient GEMM, the last thing a backward pass computes) is still running, the rest right after.
+        Every rank issues the same two collectives per step in the same order, whatever path it takes."""
         self.model, self.opt, self.cfg, self.dd = model, optimizer, model_config, dataloader_dict
-        self.grad_sync = grad_sync
+        self.grad_sync, self.grad_sync_async = grad_sync, grad_sync_async
         self.beta1_t = _loss_weights(model, model_config, 0.0)     # (lambda1, -beta1, beta2, omiga1..3); entry 1 rewritten per step
         self.graphs, self.seen = {}, set()
         self.opt_graph = None
         self.pool = self.pool_side = None
         self._groups = None
-        # staged (six-graph) replay: default for a single replica.  Replicas keep the two-graph form by default: with two
-        # processes sharing one GPU (the only multi-rank set-up that could be measured here) the multi-stream replays
-        # of the processes time-slice against each other (2 steps/s against 97)
+        # staged (six-graph) replay: the default, except for replicas that SHARE a device (the one-GPU rehearsal of the
+        # multi-rank path): there the multi-stream replays of the processes time-slice against each other
+        # (2 steps/s against 97), so those keep the two-graph form
         import torch.distributed as dist
         multi = grad_sync is not None or (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
-        self.staged = bool(model_config.get("staged_graphs", os.environ.get("SPADOT_STAGED_GRAPHS", "0" if multi else "1") == "1"))
+        shared = multi and _ranks_share_a_device(torch.device(model_config["device"]))
+        self.staged = bool(model_config.get("staged_graphs", os.environ.get("SPADOT_STAGED_GRAPHS", "0" if shared else "1") == "1"))
+        first = {id(p) for p in model.GATEncoder.first_layer_parameters()}
+        self.overlap = bool(self.staged and grad_sync_async is not None and optimizer.tail_offset is not None
+                            and {id(p) for p in optimizer.tail_params} == first
+                            and model_config.get("overlap_grad_sync", os.environ.get("SPADOT_OVERLAP_GRAD_SYNC", "1") == "1"))
         # every launch of the step is ours or a plain library GEMM (the SPD inverse has no library factorisation at
         # any number of inducing points: ops._spd_inverse_logdet_nograd), so the step is always capturable
         self.capturable = True
@@ -394,7 +420,7 @@ class GraphedStepper:
         st = {}
 
         def gat_fwd():
-            st["zg"] = model.branch_gat(y_b, batch.graph, b)
+            st["zg"] = model.branch_gat(y_b, batch.graph, b, taps=st if self.overlap else None)
 
         def svgp_fwd():
             st["pm"], st["pv"], st["skl"] = model.branch_svgp(x_b, y_b, tp, b, batch_key=(tp, bi))
@@ -414,6 +440,14 @@ class GraphedStepper:
         def gat_bwd():
             opt.backward_partial([st["zg"]], [st["g"][0]], P["gat"])
 
+        def gat_bwd_hi():           # layers 3, 2 and the head; stops at the first layer's output
+            st["gh1"] = opt.backward_partial([st["zg"]], [st["g"][0]], P["gat_hi"], extra_inputs=[st["h1"]])[0]
+
+        def gat_bwd_lo():           # the first layer: its edge backward and the largest weight gradient
+            opt.backward_partial([st["h1"]], [st["gh1"]], P["gat_lo"])
+
+        if self.overlap:
+            return gat_fwd, svgp_fwd, tail, svgp_bwd, gat_bwd_hi, gat_bwd_lo
         return gat_fwd, svgp_fwd, tail, svgp_bwd, gat_bwd
 
     def _param_groups(self):
@@ -422,52 +456,77 @@ class GraphedStepper:
             gat = [p for p in self.model.GATEncoder.parameters() if id(p) in own]
             svgp = [p for p in self.model.SVGPEncoder.parameters() if id(p) in own]
             taken = {id(p) for p in gat + svgp}
-            self._groups = {"gat": gat, "svgp": svgp, "tail": [p for p in self.opt.params if id(p) not in taken]}
+            lo = {id(p) for p in self.model.GATEncoder.first_layer_parameters()}
+            self._groups = {"gat": gat, "svgp": svgp, "tail": [p for p in self.opt.params if id(p) not in taken],
+                            "gat_lo": [p for p in gat if id(p) in lo], "gat_hi": [p for p in gat if id(p) not in lo]}
         return self._groups
 
-    def _replay_staged(self, graphs):
+    def _issue_staged(self, fns, two_streams=True):
+        """The stages in order: `fns` are the replay methods of their graphs (GAT stages on the main stream, SVGP
+        stages beside them on the side stream) or, on the eager warm-up visit, the stage callables themselves (one
+        stream).  Five stages end with the whole GAT backward; six (bucketed exchange) with the GAT backward above
+        the first layer, the all-reduce of everything but the first layer's gradients, the first layer's backward
+        beside it, and the all-reduce of the rest."""
         main = torch.cuda.current_stream()
-        side = self.model._side_stream()
-        g_gat_f, g_svgp_f, g_tail, g_svgp_b, g_gat_b = graphs
-        side.wait_stream(main)
+        side = self.model._side_stream() if two_streams else main
+        if two_streams:
+            side.wait_stream(main)
         with torch.cuda.stream(side):
-            g_svgp_f.replay()
-        g_gat_f.replay()
-        main.wait_stream(side)
-        g_tail.replay()
-        side.wait_stream(main)
+            fns[1]()
+        fns[0]()
+        if two_streams:
+            main.wait_stream(side)
+        res = fns[2]()
+        if two_streams:
+            side.wait_stream(main)
         with torch.cuda.stream(side):
-            g_svgp_b.replay()
-        g_gat_b.replay()
-        main.wait_stream(side)
+            fns[3]()
+        fns[4]()
+        if two_streams:
+            main.wait_stream(side)
+        if len(fns) == 6:
+            cut = self.opt.tail_offset
+            w1 = self.grad_sync_async(self.opt.flat_grad[:cut])
+            fns[5]()
+            w2 = self.grad_sync_async(self.opt.flat_grad[cut:])
+            w1.wait()
+            w2.wait()
+        return res
+
+    def exchange_idle(self):
+        """A replica without a batch in this step (its flat gradient is zero) joins the step's two collectives."""
+        cut = self.opt.tail_offset
+        w1 = self.grad_sync_async(self.opt.flat_grad[:cut])
+        w2 = self.grad_sync_async(self.opt.flat_grad[cut:])
+        w1.wait()
+        w2.wait()
 
     def _run_staged(self, tp_i, tp, bi, epoch, with_update):
         key = (tp, bi, epoch >= 1, epoch >= self.cfg["ot_epoch"] and tp_i != 0, "staged")
         if key in self.graphs:
             graphs, out = self.graphs[key]
-            self._replay_staged(graphs)
+            self._issue_staged([g.replay for g in graphs])
             res = out.clone()
         elif key not in self.seen:                                          # warm-up visit: eager, same stages
             self.seen.add(key)
-            gat_f, svgp_f, tail, svgp_b, gat_b = self._stages(tp_i, tp, bi, epoch)
-            gat_f(); svgp_f(); res = tail(); svgp_b(); gat_b()
+            res = self._issue_staged(list(self._stages(tp_i, tp, bi, epoch)), two_streams=False)
         else:
-            gat_f, svgp_f, tail, svgp_b, gat_b = self._stages(tp_i, tp, bi, epoch)
+            fns = self._stages(tp_i, tp, bi, epoch)
             if self.pool is None:
                 self.pool, self.pool_side = torch.cuda.graph_pool_handle(), torch.cuda.graph_pool_handle()
             torch.cuda.synchronize()
             graphs = []
             out = None
-            for fn, pool in ((gat_f, self.pool), (svgp_f, self.pool_side), (tail, self.pool), (svgp_b, self.pool_side),
-                             (gat_b, self.pool)):
+            for k, fn in enumerate(fns):
                 g = torch.cuda.CUDAGraph()
+                pool = self.pool_side if k in (1, 3) else self.pool          # the SVGP stages run beside the GAT ones
                 with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
                     r = fn()
-                if fn is tail:
+                if k == 2:
                     out = r
                 graphs.append(g)
             self.graphs[key] = (graphs, out)
-            self._replay_staged(graphs)
+            self._issue_staged([g.replay for g in graphs])
             res = out.clone()
         if with_update:
             self.update()
@@ -482,7 +541,8 @@ class GraphedStepper:
         if self.grad_sync is None:                  # single replica: the optimizer step is part of the step graph
             return self._run(tp_i, tp, bi, epoch, beta1, True)
         res = self.fb(tp_i, tp, bi, epoch, beta1)
-        self.grad_sync(self.opt.flat_grad)
+        if not self.overlap:                        # (bucketed exchange: already done beside the backward pass)
+            self.grad_sync(self.opt.flat_grad)
         self.update()
         return res
 

@@ -224,7 +224,59 @@ def test_staged_replay_gives_the_single_graph_gradients_bf16(monkeypatch):
             np.testing.assert_allclose(gb.cpu().numpy(), ga.cpu().numpy(), rtol=2e-3, atol=2e-4 * scale)
 
 
-def _dp_worker(rank, world, port, q):
+def test_bucketed_exchange_splits_the_backward_without_changing_the_gradient():
+    """Optimizer built with the first GAT layer's parameters last + an async exchange hook: the staged replay cuts
+    the GAT backward at the first layer's output, hands `flat_grad[:tail_offset]` to the exchange BEFORE that layer's
+    backward and the tail after it; the flat gradient must equal the unsplit staged replay's, bit for bit, and the
+    first bucket must already be final when it is handed over."""
+    from spadot_amd.model import SpaDOT
+    from spadot_amd.ops import FlatAdamW
+    from spadot_amd.synthetic import make_dataset
+    from spadot_amd.utils import _train_utils as tu, _utils
+    data = make_dataset(2, 2000, 300, seed=9)
+    cfg = _utils.load_model_config(types.SimpleNamespace(config=None))
+    cfg.update(input_dim=300, timepoints=[0, 1], device=torch.device(DEV), compute_dtype=torch.bfloat16,
+               inducing_point_nums=200, n_clusters=6)
+    _utils.set_seed(3)
+    dd = tu.prepare_dataloader(data, cfg)
+    model = SpaDOT.SpaDOT(cfg, dd).to(DEV)
+    first = model.GATEncoder.first_layer_parameters()
+    opt = FlatAdamW(model.parameters(), lr=cfg["lr"], last=first)
+    cut = opt.tail_offset
+    assert cut is not None and opt.count - cut >= sum(p.numel() for p in first)
+    assert all(p.grad.data_ptr() >= opt.flat_grad.data_ptr() + 4 * cut for p in first)
+    tu._update_Kmeans(model, cfg, dd)
+    tu._update_OT_matrix(model, cfg)
+    model.train()
+    model.fixed_noise = (torch.zeros((512, 10), device=DEV), torch.zeros((512, 10), device=DEV))
+    seen = []
+
+    class Handle:
+        def wait(self):
+            pass
+
+    def fake_async(view):
+        seen.append((view.data_ptr() - opt.flat_grad.data_ptr(), view.numel(), view.clone()))
+        return Handle()
+
+    plain = tu.GraphedStepper(model, opt, dict(cfg, staged_graphs=True), dd)
+    split = tu.GraphedStepper(model, opt, dict(cfg, staged_graphs=True), dd, grad_sync=lambda f: f, grad_sync_async=fake_async)
+    assert split.overlap and not plain.overlap
+    for rep in range(4):                                   # eager, capture + replay, replay, replay
+        for bi in range(2):
+            la = plain.fb(1, 1, bi, cfg["ot_epoch"], 0.5)
+            ga = opt.flat_grad.clone()
+            opt.flat_grad.fill_(7.0)
+            del seen[:]
+            lb = split.fb(1, 1, bi, cfg["ot_epoch"], 0.5)
+            torch.cuda.synchronize()
+            np.testing.assert_array_equal(lb.cpu().numpy(), la.cpu().numpy())
+            np.testing.assert_array_equal(opt.flat_grad.cpu().numpy(), ga.cpu().numpy())
+            assert [(o_, n_) for o_, n_, _ in seen] == [(0, cut), (4 * cut, opt.count - cut)]
+            np.testing.assert_array_equal(seen[0][2].cpu().numpy(), ga[:cut].cpu().numpy())    # final when handed over
+
+
+def _dp_worker(rank, world, port, q, staged=None):
     """One data-parallel rank on cuda:0 (both ranks share the one GPU of the test box; gloo carries the
     collectives, on a real node the backend is nccl = RCCL)."""
     import os
@@ -237,6 +289,8 @@ def _dp_worker(rank, world, port, q):
         from spadot_amd.utils import _train_utils as tu, _utils
         cfg = _small_config()
         cfg.update(maxiter=2, input_dim=40, timepoints=[0, 1, 2], device=torch.device(DEV))
+        if staged is not None:
+            cfg["staged_graphs"] = staged
         plan = par.ShardPlan(cfg["timepoints"], world, rank)
         cfg["owned_timepoints"] = plan.data_timepoints()
         data = make_dataset(3, 1200, 40, seed=11)
@@ -249,13 +303,17 @@ def _dp_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_data_parallel_training_two_ranks_one_gpu():
+@pytest.mark.parametrize("staged", [None, True])
+def test_data_parallel_training_two_ranks_one_gpu(staged):
+    """staged=None: what two ranks sharing a device get by default (two graphs per step, one exchange in two
+    buckets); staged=True: what ranks on their own devices get -- staged graphs with the bucketed exchange issued
+    beside the first GAT layer's backward (here forced onto the shared GPU, gloo carrying the async collectives)."""
     import socket
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q, staged)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda r: r[0])
