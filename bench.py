@@ -14,7 +14,8 @@ The metric has two halves and both are measured, inputs resident in HBM:
   * Sinkhorn iters/s  -- `sinkhorn.value`: one iteration = one update_a_b (ot_func.cpp:586-687) of the
     N_t x N_t coupling between consecutive time points (fp32 kernel matrix, fp64 scalings).
 Multi-GPU ("weak"): rank r owns time point r mod 5 (its data, graph, SVGP constants) and the pair
-problem (r mod 4, r mod 4 + 1); every step all-reduces the flat gradient buffer over RCCL; pair
+problem (r mod 4, r mod 4 + 1); every step all-reduces the flat gradient buffer over RCCL (two buckets, the first
+beside the end of the backward pass); pair
 solves need no collective.  `value` = steps of all ranks / max-over-ranks wall time.
 
 Prints ONE JSON line on rank 0.
@@ -319,7 +320,7 @@ def _main(real_stdout):
                                      f"Sinkhorn pair problem {N}x{N}",
                          "train": {k: v for k, v in (train_res or {}).items() if k != "cpu_baseline"},
                          "parallelism": "1 GPU" if world == 1 else f"{world} ranks: time points / pair problems sharded, "
-                                                                   "flat-gradient all-reduce (RCCL)"}
+                                                                   "flat-gradient all-reduce (RCCL) in two buckets, the first overlapped with the backward pass"}
         if sk_res is not None:
             out["sinkhorn"] = {k: v for k, v in sk_res.items() if k != "cpu_baseline"}
             out["roofline"] = roof
