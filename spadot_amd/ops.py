@@ -178,17 +178,34 @@ class _DenseCD(torch.autograd.Function):
         return dx, dW, None
 
 
+def _small_weight_grad(g, x):
+    """g^T x for the MLP stages' weight gradients (g [M, N], x [M, K], fp32).  For a mid-sized output over a long
+    batch axis (256 x 64 from M = 512: the decoder's and the SVGP encoder's middle stage) the library picks ONE
+    64 x 256 tile, i.e. one CU walks all of M: 33 us.  Eight slices of M as a batched GEMM + a fixed-order sum:
+    12 us (tools/small_gemm_probe.py); everything else goes to the library as it is."""
+    M, N = g.shape
+    K = x.shape[1]
+    if M >= 256 and M % 8 == 0 and min(N, K) >= 64 and N * K <= 65536:
+        return torch.bmm(g.view(8, M // 8, N).transpose(1, 2), x.view(8, M // 8, K)).sum(0)
+    return g.t() @ x
+
+
 class _LinearBias(torch.autograd.Function):
     """y = x W^T + b (fp32, or the compute dtype given by `cd`) with the bias gradient as a fixed-order column
     sum (k_colsum_parts) instead of the library's semaphore-based reduction."""
 
     @staticmethod
     def forward(ctx, x, W, b, cd):
-        ctx.save_for_backward(x, W)
         ctx.cd = cd
         if cd is None or cd == torch.float32:
+            ctx.save_for_backward(x, W)
             return torch.addmm(b, x, W.t())
-        return torch.nn.functional.linear(x.to(cd), W.to(cd), b.to(cd)).float()
+        # compute-dtype operands, fp32 accumulate AND fp32 result (no rounding of the output to the compute dtype,
+        # no cast launch after the GEMM); the images are kept for the backward pass.  Small dependent launches cost
+        # ~5 us each inside a replayed graph, so this stage is counted in launches: 4 forward, 4 backward.
+        xc, Wc = x.to(cd), W.to(cd)
+        ctx.save_for_backward(xc, Wc)
+        return torch.mm(xc, Wc.t(), out_dtype=torch.float32).add_(b)
 
     @staticmethod
     def backward(ctx, g):
@@ -199,11 +216,11 @@ class _LinearBias(torch.autograd.Function):
         cd = ctx.cd
         if cd is None or cd == torch.float32:
             dx = g @ W if ctx.needs_input_grad[0] else None
-            dW = g.t() @ x
+            dW = _small_weight_grad(g, x)
         else:
             gc = g.to(cd)
-            dx = (gc @ W.to(cd)).float() if ctx.needs_input_grad[0] else None
-            dW = torch.mm(gc.t(), x.to(cd), out_dtype=torch.float32)
+            dx = torch.mm(gc, W, out_dtype=torch.float32) if ctx.needs_input_grad[0] else None
+            dW = torch.mm(gc.t(), x, out_dtype=torch.float32)
         return dx, dW, db, None
 
 
