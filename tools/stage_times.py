@@ -35,4 +35,16 @@ for n, g in zip(names, graphs):
     t = timeit(g.replay); tot += t
     print(f"{n:10s} {t:8.1f} us")
 t = timeit(st.opt_graph.replay); print(f"{'optimizer':10s} {t:8.1f} us")
+side = model._side_stream()
+def pair(a, b):
+    def run():
+        main = torch.cuda.current_stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            b.replay()
+        a.replay()
+        main.wait_stream(side)
+    return run
+print(f"gat_fwd || svgp_fwd {timeit(pair(graphs[0], graphs[1])):8.1f} us   (alone: max of the two above)")
+print(f"gat_bwd || svgp_bwd {timeit(pair(graphs[4], graphs[3])):8.1f} us")
 print(f"sum of the five {tot:.0f} us; whole step {timeit(lambda: st.step(1, 1, 0, ep, 0.5), 30):.0f} us")
