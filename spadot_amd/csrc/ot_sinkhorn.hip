@@ -520,6 +520,83 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_fused_pass(
     }
 }
 
+// Row dots only, on the fused pass's machinery (same band geometry, w image in LDS, double-buffered register tiles,
+// DPP wave sums): sdot_i = sum_j K_ij w_j for the solver's duality-gap check, which needs nothing else from K.
+// One wave per row with w read from global (k_row_dot) streams at 5.0 TB/s; this form at the fused pass's rate.
+template <typename T, int VPT, int R, typename WT = double>
+__global__ __launch_bounds__(FUSED_THREADS) void k_fused_rowdot(const T *__restrict__ K, const double *__restrict__ w,
+                                                                double *__restrict__ sdot, int I, int ld,
+                                                                int rows_per_block) {
+    constexpr int V = Vec<T>::N;
+    constexpr int NW = FUSED_THREADS / 64;
+    extern __shared__ double smem[];
+    constexpr int WPAD = VPT * FUSED_THREADS * V;
+    WT *wl = reinterpret_cast<WT *>(smem);
+    double *red = smem + (WPAD * sizeof(WT) + 7) / 8;            // 2 images of NW * R wave partials
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(I, r0 + rows_per_block);
+    FusedRows<T, VPT, R> bufA, bufB;
+    constexpr int WSLOTS = WPAD / FUSED_THREADS;
+    double wreg[WSLOTS];
+#pragma unroll
+    for (int q = 0; q < WSLOTS; q++) {
+        const int j = tid + q * FUSED_THREADS;
+        wreg[q] = (j < ld) ? w[j] : 0.0;
+    }
+    fused_load<T, VPT, R>(bufA, K, r0, r1, ld, tid);
+    fused_load<T, VPT, R>(bufB, K, r0 + R, r1, ld, tid);
+#pragma unroll
+    for (int q = 0; q < WSLOTS; q++) wl[tid + q * FUSED_THREADS] = (WT)wreg[q];
+    __syncthreads();
+    auto group = [&](FusedRows<T, VPT, R> &buf, int row0, int par) {
+        double s[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) s[r] = 0.0;
+#pragma unroll
+        for (int k = 0; k < VPT; k++) {
+            const int j = (tid + k * FUSED_THREADS) * V;
+            double wv[V];
+#pragma unroll
+            for (int e = 0; e < V; e++) wv[e] = (double)wl[j + e];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                double kv[V];
+                unpack<T>(buf.v[r][k], kv);
+#pragma unroll
+                for (int e = 0; e < V; e++) s[r] = fma(kv[e], wv[e], s[r]);
+            }
+        }
+        double *redp = red + par * (NW * R);
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            s[r] = wave_sum63(s[r]);
+            if (lane == 63) redp[wid * R + r] = s[r];
+        }
+        __syncthreads();
+        if (tid < R && row0 + tid < r1) {
+            double t = 0.0;
+#pragma unroll
+            for (int wv = 0; wv < NW; wv++) t += redp[wv * R + tid];
+            sdot[row0 + tid] = t;
+        }
+    };
+    int g = r0;
+    for (; g + 3 * R < r1; g += 2 * R) {          // as k_fused_pass: unconditional loads in the steady state
+        group(bufA, g, 0);
+        fused_load<T, VPT, R>(bufA, K, g + 2 * R, r1, ld, tid);
+        group(bufB, g + R, 1);
+        fused_load<T, VPT, R>(bufB, K, g + 3 * R, r1, ld, tid);
+    }
+    group(bufA, g, 0);
+    if (g + R < r1) {
+        const bool third = g + 2 * R < r1;
+        if (third) fused_load<T, VPT, R>(bufA, K, g + 2 * R, r1, ld, tid);
+        group(bufB, g + R, 1);
+        if (third) group(bufA, g + 2 * R, 0);
+    }
+}
+
 // Column finalise for many partial rows: 64 columns x 16 partial-groups per block; partials are
 // summed in ascending block order within a group and groups in ascending order (deterministic).
 // mode 0: b update (ot_func.cpp:657-668) ; mode 1: t_out[j] = sum only.
@@ -1110,6 +1187,38 @@ template <> void fused_pass_T<double>(spadot_ot_solver *s, const IterParams &P, 
 }
 #undef FUSED_CASE
 
+template <typename T, int VPT, int R, typename WT = double>
+void launch_fused_rowdot(spadot_ot_solver *s) {
+    static bool attr_set = false;
+    auto kern = k_fused_rowdot<T, VPT, R, WT>;
+    if (!attr_set) {
+        HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(s->fused_blocks), dim3(FUSED_THREADS), s->fused_lds, s->stream, (const T *)s->K,
+                       s->w, s->rt, s->I, s->ld, s->fused_rows_per_block);
+}
+template <typename T> void fused_rowdot_T(spadot_ot_solver *s);
+#define FUSED_CASE(T, VPT, R) case VPT: launch_fused_rowdot<T, VPT, R>(s); break;
+template <> void fused_rowdot_T<float>(spadot_ot_solver *s) {
+    switch (s->fused_vpt) {
+        FUSED_CASE(float, 1, 2) FUSED_CASE(float, 2, 2) FUSED_CASE(float, 3, 2) FUSED_CASE(float, 4, 2)
+        FUSED_CASE(float, 5, 2) FUSED_CASE(float, 6, 1) FUSED_CASE(float, 7, 1) FUSED_CASE(float, 8, 1)
+        case 9: launch_fused_rowdot<float, 9, 1, float>(s); break;
+        case 10: launch_fused_rowdot<float, 10, 1, float>(s); break;
+        default: abort();
+    }
+}
+template <> void fused_rowdot_T<double>(spadot_ot_solver *s) {
+    switch (s->fused_vpt) {
+        FUSED_CASE(double, 1, 2) FUSED_CASE(double, 2, 2) FUSED_CASE(double, 3, 2) FUSED_CASE(double, 4, 2)
+        FUSED_CASE(double, 5, 2) FUSED_CASE(double, 6, 2) FUSED_CASE(double, 7, 1) FUSED_CASE(double, 8, 1)
+        FUSED_CASE(double, 9, 1) FUSED_CASE(double, 10, 1) FUSED_CASE(double, 11, 1) FUSED_CASE(double, 12, 1)
+        default: abort();
+    }
+}
+#undef FUSED_CASE
+
 void absorb_if_flagged(spadot_ot_solver *s, const IterParams &P, int *flag) {
     const int mx = std::max(s->I, s->J);
     hipLaunchKernelGGL(k_absorb_vec, dim3((mx + 255) / 256), dim3(256), 0, s->stream, s->a, s->b, s->u,
@@ -1183,7 +1292,10 @@ void drift_measure(spadot_ot_solver *s, double eps) {
 void gap_measure_fast(spadot_ot_solver *s, const IterParams &P) {
     const int I = s->I, J = s->J, ld = s->ld;
     dim3 g((I + ROW_WAVES - 1) / ROW_WAVES);
-    if (s->storage == SPADOT_F32)
+    if (s->fused_vpt > 0) {
+        if (s->storage == SPADOT_F32) fused_rowdot_T<float>(s);
+        else fused_rowdot_T<double>(s);
+    } else if (s->storage == SPADOT_F32)
         hipLaunchKernelGGL(k_row_dot<float>, g, dim3(256), 0, s->stream, (const float *)s->K, s->w, s->rt, I, ld);
     else
         hipLaunchKernelGGL(k_row_dot<double>, g, dim3(256), 0, s->stream, (const double *)s->K, s->w, s->rt, I, ld);
