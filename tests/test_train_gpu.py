@@ -224,6 +224,45 @@ def test_staged_replay_gives_the_single_graph_gradients_bf16(monkeypatch):
             np.testing.assert_allclose(gb.cpu().numpy(), ga.cpu().numpy(), rtol=2e-3, atol=2e-4 * scale)
 
 
+def test_full_size_step_staged_replay_matches_the_eager_step_bf16():
+    """BASELINE.json's bench shape for one time-point pair (10 000 spots x 3 000 genes, batches of 512 seeds whose
+    two-hop closure is the whole time point, ~240 inducing points, bf16 compute): the flat gradient and the loss
+    terms of the staged graph replay equal the eager step's on the same batches, replay after replay."""
+    from spadot_amd.model import SpaDOT
+    from spadot_amd.ops import FlatAdamW
+    from spadot_amd.synthetic import make_dataset
+    from spadot_amd.utils import _train_utils as tu, _utils
+    data = make_dataset(2, 10000, 3000, seed=1993)
+    cfg = _utils.load_model_config(types.SimpleNamespace(config=None))
+    cfg.update(input_dim=3000, timepoints=[0, 1], device=torch.device(DEV), compute_dtype=torch.bfloat16,
+               inducing_point_nums=480)
+    _utils.set_seed(cfg["seed"])
+    dd = tu.prepare_dataloader(data, cfg)
+    del data
+    model = SpaDOT.SpaDOT(cfg, dd).to(DEV)
+    opt = FlatAdamW(model.parameters(), lr=cfg["lr"])
+    tu._update_Kmeans(model, cfg, dd)
+    tu._update_OT_matrix(model, cfg)
+    model.train()
+    model.fixed_noise = (torch.zeros((512, 10), device=DEV), torch.zeros((512, 10), device=DEV))
+    b0 = dd["dataloaders"][1][0]
+    assert b0.graph.n > 9000 and b0.graph.E > 250000            # the closure really is (almost) the whole time point
+    staged = tu.GraphedStepper(model, opt, dict(cfg, staged_graphs=True), dd)
+    ep = cfg["ot_epoch"]
+    for rep in range(3):                                         # eager, capture + replay, replay
+        for bi in (0, 7):
+            staged.beta1_t[1].fill_(-0.5)                        # the weight the stepper sets for beta1 = 0.5
+            la = tu.forward_backward(model, cfg, dd, 1, 1, bi, ep, staged.beta1_t, optimizer=opt)
+            ga = opt.flat_grad.clone()
+            opt.flat_grad.fill_(7.0)
+            lb = staged.fb(1, 1, bi, ep, 0.5)
+            gb = opt.flat_grad
+            assert torch.isfinite(gb).all()
+            np.testing.assert_allclose(lb.cpu().numpy(), la.cpu().numpy(), rtol=1e-4, atol=1e-5)
+            scale = float(ga.abs().max())
+            np.testing.assert_allclose(gb.cpu().numpy(), ga.cpu().numpy(), rtol=2e-3, atol=2e-4 * scale)
+
+
 def test_bucketed_exchange_splits_the_backward_without_changing_the_gradient():
     """Optimizer built with the first GAT layer's parameters last + an async exchange hook: the staged replay cuts
     the GAT backward at the first layer's output, hands `flat_grad[:tail_offset]` to the exchange BEFORE that layer's
