@@ -243,7 +243,10 @@ int spadot_grad_sumsq(const float *grad, long long count, double *scratch, float
  * step_dev[0]; `counter` is one unsigned that is 0 before the first call and left 0), then the update. */
 int spadot_clip_adamw_dev(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long long count, double lr,
                           double beta1, double beta2, double eps, double weight_decay, double max_norm, double *scratch,
-                          float *sumsq, int *step_dev, unsigned *counter, void *stream);
+                          float *sumsq, int *step_dev, unsigned *counter, const float *grad_scale_dev, void *stream);
+/* grad_scale_dev (device scalar, may be NULL = 1): `grad` stands for grad_scale * grad -- the data-parallel step
+ * all-reduces a SUM over replicas and passes 1 / (number of replicas that had a batch in this step), so that the clip
+ * threshold and the update see the MEAN gradient, as a single replica would (spadot_amd/parallel.py). */
 int spadot_adamw_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
                       const float *sumsq, long long count, double lr, double beta1, double beta2,
                       double eps, double weight_decay, double max_norm, int step, void *stream);

@@ -210,6 +210,17 @@ def main():
     print("ot_entry_points: primal", pri, "dual", dua, "gap", gap, "step1 absorb ret", s_ab["ret"],
           "ret_max", ret_max, "pm gap", pm["gap"], "pl gap", pl["gap"])
 
+    # ---------------- (3) added in round 2, own RNG so that the fixtures above keep their bytes -------------
+    # last-stage batches LONGER than the device solver's 64-iteration chunk, with a tau small enough that the
+    # stabilisation fires inside such a batch (regression: a per-chunk flag clear used to lose it)
+    rng2 = np.random.default_rng(2024)
+    # (lambda 1 / 50: the scalings keep growing through the last stage; with tau = 2.4 the stabilisation fires at
+    # iteration 85 of the first 200-iteration batch of the last stage, i.e. in its second 64-iteration chunk, and not in
+    # the chunks after it -- traced with oracle/ot_oracle.py step by step; stages 0 and 4 stabilise too)
+    cfg_long = dict(base_cfg); cfg_long.update(tau=2.4, batch_size=200, lambda1=1.0, lambda2=50.0)
+    xa, cen = mixture(rng2, 90); xb, _ = mixture(rng2, 110, centres=cen + 0.3)
+    solve_case("longbatch90x110", xa, xb, cfg_long)
+
 
 if __name__ == "__main__":
     main()

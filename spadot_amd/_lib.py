@@ -133,7 +133,7 @@ def model_lib():
         "spadot_colsum": [vp, ci, ci, vp, vp],
         "spadot_knn": [vp, ci, ci, ci, vp, vp],
         "spadot_grad_sumsq": [vp, ll, vp, vp, vp],
-        "spadot_clip_adamw_dev": [vp, vp, vp, vp, ll, cd, cd, cd, cd, cd, cd, vp, vp, vp, vp, vp],
+        "spadot_clip_adamw_dev": [vp, vp, vp, vp, ll, cd, cd, cd, cd, cd, cd, vp, vp, vp, vp, vp, vp],
         "spadot_adamw_step": [vp, vp, vp, vp, vp, ll, cd, cd, cd, cd, cd, cd, ci, vp],
         "spadot_adamw_step_dev": [vp, vp, vp, vp, vp, ll, cd, cd, cd, cd, cd, cd, vp, vp],
     }

@@ -1110,14 +1110,18 @@ __global__ __launch_bounds__(256) void k_adamw(float *__restrict__ p, const floa
                                                float *__restrict__ m, float *__restrict__ v,
                                                const float *__restrict__ sumsq, long long count, float lr,
                                                float b1, float b2, float eps, float wd, float max_norm,
-                                               float bc1, float bc2_sqrt, const int *__restrict__ step_dev) {
+                                               float bc1, float bc2_sqrt, const int *__restrict__ step_dev,
+                                               const float *__restrict__ grad_scale) {
     if (step_dev) {   // step count lives on the device (hipGraph replays): bias corrections computed here
         const double t = (double)step_dev[0];
         bc1 = (float)(1.0 - pow((double)b1, t));
         bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, t));
     }
-    const float total = sqrtf(sumsq[0]);
-    const float coef = fminf(1.f, max_norm / (total + 1e-6f));
+    // grad_scale (device scalar, optional): the buffer holds a SUM over replicas and stands for scale * g
+    // (data-parallel steps: 1 / number of replicas that had a batch); the norm is clipped on the scaled gradient
+    const float gs = grad_scale ? grad_scale[0] : 1.f;
+    const float total = sqrtf(sumsq[0]) * gs;
+    const float coef = fminf(1.f, max_norm / (total + 1e-6f)) * gs;
     for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < count; k += (long long)gridDim.x * 256) {
         const float gg = g[k] * coef;
         float pp = p[k] * (1.f - lr * wd);
@@ -2054,13 +2058,13 @@ int spadot_adamw_step_dev(float *param, const float *grad, float *exp_avg, float
     hipLaunchKernelGGL(k_step_inc, dim3(1), dim3(1), 0, st_, step_dev);
     hipLaunchKernelGGL(k_adamw, dim3(nb), dim3(256), 0, st_, param, grad, exp_avg, exp_avg_sq, sumsq, count,
                        (float)lr, (float)beta1, (float)beta2, (float)eps, (float)weight_decay, (float)max_norm,
-                       1.f, 1.f, (const int *)step_dev);
+                       1.f, 1.f, (const int *)step_dev, (const float *)nullptr);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
 int spadot_clip_adamw_dev(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long long count, double lr,
                           double beta1, double beta2, double eps, double weight_decay, double max_norm, double *scratch,
-                          float *sumsq, int *step_dev, unsigned *counter, void *stream) {
+                          float *sumsq, int *step_dev, unsigned *counter, const float *grad_scale_dev, void *stream) {
     if (count <= 0 || !step_dev || !scratch || !sumsq || !counter) return -22;
     if (((uintptr_t)grad & 15) != 0) return -22;
     hipStream_t st_ = (hipStream_t)stream;
@@ -2073,7 +2077,7 @@ int spadot_clip_adamw_dev(float *param, const float *grad, float *exp_avg, float
     const int nb = (int)(want < 4096 ? want : 4096);
     hipLaunchKernelGGL(k_adamw, dim3(nb), dim3(256), 0, st_, param, grad, exp_avg, exp_avg_sq, (const float *)sumsq, count,
                        (float)lr, (float)beta1, (float)beta2, (float)eps, (float)weight_decay, (float)max_norm,
-                       1.f, 1.f, (const int *)step_dev);
+                       1.f, 1.f, (const int *)step_dev, grad_scale_dev);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
@@ -2088,7 +2092,7 @@ int spadot_adamw_step(float *param, const float *grad, float *exp_avg, float *ex
     const double bc2 = 1.0 - pow(beta2, (double)step);
     hipLaunchKernelGGL(k_adamw, dim3(nb), dim3(256), 0, st_, param, grad, exp_avg, exp_avg_sq, sumsq, count,
                        (float)lr, (float)beta1, (float)beta2, (float)eps, (float)weight_decay, (float)max_norm,
-                       (float)bc1, (float)sqrt(bc2), (const int *)nullptr);
+                       (float)bc1, (float)sqrt(bc2), (const int *)nullptr, (const float *)nullptr);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 

@@ -22,20 +22,36 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <stdexcept>
 #include <type_traits>
 #include <vector>
 
 #include "../../include/spadot_ot.h"
 
-#define HIP_CHECK(expr)                                                                         \
-    do {                                                                                        \
-        hipError_t _e = (expr);                                                                 \
-        if (_e != hipSuccess) {                                                                 \
-            fprintf(stderr, "libspadot_ot: HIP error %s at %s:%d (%s) -- there is no CPU path\n", \
-                    hipGetErrorString(_e), __FILE__, __LINE__, #expr);                          \
-            abort();                                                                            \
-        }                                                                                       \
+// Error handling: no HIP failure ends the host process.  Every HIP call is checked; a failure unwinds to the C entry
+// point, which reports it on stderr and returns SPADOT_EHIP (part B: int results), NaN (part A: double / float results,
+// which the reference's driver turns into a RuntimeError, ot_solvers.py:446-447) or -2 (step1_process_double).
+struct hip_failure { hipError_t err; const char *file; int line; const char *expr; };
+#define HIP_CHECK(expr)                                                        \
+    do {                                                                       \
+        hipError_t _e = (expr);                                                \
+        if (_e != hipSuccess) throw hip_failure{_e, __FILE__, __LINE__, #expr}; \
     } while (0)
+#define SPADOT_EHIP (-5)
+static void report_failure(const hip_failure &f) {
+    fprintf(stderr, "libspadot_ot: HIP error %s at %s:%d (%s) -- there is no CPU path\n", hipGetErrorString(f.err),
+            f.file, f.line, f.expr);
+    (void)hipGetLastError();      // clear the sticky error so that a later call reports its own
+}
+#define SPADOT_ENTER try {
+#define SPADOT_LEAVE(ret)                                                        \
+    } catch (const hip_failure &f_) {                                            \
+        report_failure(f_);                                                      \
+        return ret;                                                              \
+    } catch (const std::exception &e_) {                                         \
+        fprintf(stderr, "libspadot_ot: %s\n", e_.what());                        \
+        return ret;                                                              \
+    }
 
 namespace {
 
@@ -1116,11 +1132,8 @@ dim3 grid_cols(const spadot_ot_solver *s, int V) {
 void require_device() {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
-    if (e != hipSuccess || n <= 0) {
-        fprintf(stderr, "libspadot_ot: no HIP device available (%s); this library has no CPU path\n",
-                hipGetErrorString(e));
-        abort();
-    }
+    if (e != hipSuccess || n <= 0)      // this library has no CPU path
+        throw hip_failure{e != hipSuccess ? e : hipErrorNoDevice, __FILE__, __LINE__, "hipGetDeviceCount: no HIP device"};
 }
 
 template <typename T> void launch_build_K(spadot_ot_solver *s, double eps, const int *flag) {
@@ -1174,7 +1187,7 @@ template <> void fused_pass_T<float>(spadot_ot_solver *s, const IterParams &P, i
         // wider rows (J up to 20 480, e.g. cfg5's 20k): w.dy is staged as fp32 so that it still fits LDS
         case 9: launch_fused<float, 9, 1, float>(s, P, flag); break;
         case 10: launch_fused<float, 10, 1, float>(s, P, flag); break;
-        default: abort();
+        default: throw std::logic_error("fused geometry outside the instantiated table");
     }
 }
 template <> void fused_pass_T<double>(spadot_ot_solver *s, const IterParams &P, int *flag) {
@@ -1182,7 +1195,7 @@ template <> void fused_pass_T<double>(spadot_ot_solver *s, const IterParams &P, 
         FUSED_CASE(double, 1, 2) FUSED_CASE(double, 2, 2) FUSED_CASE(double, 3, 2) FUSED_CASE(double, 4, 2)
         FUSED_CASE(double, 5, 2) FUSED_CASE(double, 6, 2) FUSED_CASE(double, 7, 1) FUSED_CASE(double, 8, 1)
         FUSED_CASE(double, 9, 1) FUSED_CASE(double, 10, 1) FUSED_CASE(double, 11, 1) FUSED_CASE(double, 12, 1)
-        default: abort();
+        default: throw std::logic_error("fused geometry outside the instantiated table");
     }
 }
 #undef FUSED_CASE
@@ -1206,7 +1219,7 @@ template <> void fused_rowdot_T<float>(spadot_ot_solver *s) {
         FUSED_CASE(float, 5, 2) FUSED_CASE(float, 6, 1) FUSED_CASE(float, 7, 1) FUSED_CASE(float, 8, 1)
         case 9: launch_fused_rowdot<float, 9, 1, float>(s); break;
         case 10: launch_fused_rowdot<float, 10, 1, float>(s); break;
-        default: abort();
+        default: throw std::logic_error("fused geometry outside the instantiated table");
     }
 }
 template <> void fused_rowdot_T<double>(spadot_ot_solver *s) {
@@ -1214,7 +1227,7 @@ template <> void fused_rowdot_T<double>(spadot_ot_solver *s) {
         FUSED_CASE(double, 1, 2) FUSED_CASE(double, 2, 2) FUSED_CASE(double, 3, 2) FUSED_CASE(double, 4, 2)
         FUSED_CASE(double, 5, 2) FUSED_CASE(double, 6, 2) FUSED_CASE(double, 7, 1) FUSED_CASE(double, 8, 1)
         FUSED_CASE(double, 9, 1) FUSED_CASE(double, 10, 1) FUSED_CASE(double, 11, 1) FUSED_CASE(double, 12, 1)
-        default: abort();
+        default: throw std::logic_error("fused geometry outside the instantiated table");
     }
 }
 #undef FUSED_CASE
@@ -1254,9 +1267,14 @@ template <typename T> void one_iteration_T(spadot_ot_solver *s, const IterParams
 //     scaling exceeds tau, and the CALLER must check it and redo the batch in safe mode from a snapshot
 //     (K, u, v are untouched in fast mode, so the snapshot is the six mutable vectors only).
 void run_iterations(spadot_ot_solver *s, const IterParams &P, int iters, bool absorb = true) {
+    bool first = true;
     while (iters > 0) {
         const int nb = std::min(iters, MAX_BATCH);
-        HIP_CHECK(hipMemsetAsync(s->flags, 0, sizeof(int) * MAX_BATCH, s->stream));
+        // safe mode uses one flag per iteration of the chunk; fast mode's single flag (flags[0]) is STICKY over the
+        // whole call -- a batch longer than MAX_BATCH must not lose a tau overflow raised in an earlier chunk
+        if (absorb || first)
+            HIP_CHECK(hipMemsetAsync(s->flags, 0, sizeof(int) * MAX_BATCH, s->stream));
+        first = false;
         for (int t = 0; t < nb; t++) {
             int *flag = absorb ? s->flags + t : s->flags;
             if (s->storage == SPADOT_F32) one_iteration_T<float>(s, P, flag, absorb);
@@ -1331,7 +1349,7 @@ void gap_measure(spadot_ot_solver *s, const IterParams &P, void *Rout) {
 // The reference's cur_iter bookkeeping (including its -1 quirk, :821-824 + :869) is kept on the host.
 double process_stage(spadot_ot_solver *s, const IterParams &P, bool last_stage, int batch_size,
                      double threshold, int cur_iter, int max_iter, void *Rout, int *iters_done,
-                     int *checks, bool fast = false) {
+                     int *checks, bool fast = false, int *cur_iter_out = nullptr) {
     double gap = 1e100;
     int done = 0, nchecks = 0;
     auto measure = [&]() {
@@ -1376,6 +1394,7 @@ double process_stage(spadot_ot_solver *s, const IterParams &P, bool last_stage, 
     }
     if (iters_done) *iters_done = done;
     if (checks) *checks += nchecks;
+    if (cur_iter_out) *cur_iter_out = cur_iter;
     return gap;
 }
 
@@ -1442,6 +1461,7 @@ extern "C" {
 const char *spadot_ot_version(void) { return "spadot_ot 0.1 (gfx950)"; }
 
 int spadot_ot_create(spadot_ot_solver **out, int I, int J, int storage, void *stream) {
+    SPADOT_ENTER
     if (!out) return -22;
     *out = nullptr;
     if (I <= 0 || J <= 0 || (storage != SPADOT_F64 && storage != SPADOT_F32)) return -22;
@@ -1481,9 +1501,11 @@ int spadot_ot_create(spadot_ot_solver **out, int I, int J, int storage, void *st
     HIP_CHECK(hipEventCreate(&s->ev1));
     *out = s;
     return 0;
+    SPADOT_LEAVE(SPADOT_EHIP)
 }
 
 void spadot_ot_destroy(spadot_ot_solver *s) {
+    SPADOT_ENTER
     if (!s) return;
     (void)hipStreamSynchronize(s->stream);
     void *dev[] = {s->C, s->K, s->a, s->backup, s->red, s->part, s->rt, s->scal, s->flags};
@@ -1491,38 +1513,48 @@ void spadot_ot_destroy(spadot_ot_solver *s) {
     (void)hipHostFree(s->h_scal); (void)hipHostFree(s->h_flags);
     (void)hipEventDestroy(s->ev0); (void)hipEventDestroy(s->ev1);
     delete s;
+    SPADOT_LEAVE()
 }
 
 int spadot_ot_ld(const spadot_ot_solver *s) { return s ? s->ld : -22; }
 
 void spadot_ot_fused_geometry(const spadot_ot_solver *s, int *out) {
+    SPADOT_ENTER
     if (!s || !out) return;
     out[0] = s->fused_vpt; out[1] = s->fused_r; out[2] = s->fused_blocks; out[3] = s->fused_rows_per_block;
+    SPADOT_LEAVE()
 }
 
 void *spadot_ot_matrix_dev(spadot_ot_solver *s, int which) {
+    SPADOT_ENTER
     if (!s) return nullptr;
     return which == 0 ? s->C : (which == 1 ? s->K : nullptr);
+    SPADOT_LEAVE(nullptr)
 }
 
 double *spadot_ot_vector_dev(spadot_ot_solver *s, int which) {
+    SPADOT_ENTER
     if (!s) return nullptr;
     switch (which) {
         case 0: return s->a; case 1: return s->b; case 2: return s->u; case 3: return s->v;
         case 4: return s->old_a; case 5: return s->old_b; default: return nullptr;
     }
+    SPADOT_LEAVE(nullptr)
 }
 
 int spadot_ot_vector_host(spadot_ot_solver *s, int which, double *out) {
+    SPADOT_ENTER
     double *src = spadot_ot_vector_dev(s, which);
     if (!src || !out) return -22;
     const int n = (which == 0 || which == 2 || which == 4) ? s->I : s->J;
     download_vec(s, out, src, n);
     HIP_CHECK(hipStreamSynchronize(s->stream));
     return 0;
+    SPADOT_LEAVE(SPADOT_EHIP)
 }
 
 int spadot_ot_matrix_host(spadot_ot_solver *s, int which, double *out) {
+    SPADOT_ENTER
     void *src = spadot_ot_matrix_dev(s, which);
     if (!src || !out) return -22;
     const size_t n = (size_t)s->I * s->J;
@@ -1536,9 +1568,11 @@ int spadot_ot_matrix_host(spadot_ot_solver *s, int which, double *out) {
     HIP_CHECK(hipStreamSynchronize(s->stream));
     HIP_CHECK(hipFree(tmp));
     return 0;
+    SPADOT_LEAVE(SPADOT_EHIP)
 }
 
 int spadot_ot_set_cost_dev(spadot_ot_solver *s, const void *C_dev, int dtype, int ldc) {
+    SPADOT_ENTER
     if (!s || !C_dev || ldc < s->J) return -22;
     dim3 g((s->ld + 255) / 256, (unsigned)std::min(s->I, 8192));
     if (dtype == SPADOT_F64 && s->storage == SPADOT_F64)
@@ -1553,9 +1587,11 @@ int spadot_ot_set_cost_dev(spadot_ot_solver *s, const void *C_dev, int dtype, in
         return -22;
     s->sum_kbar_eps = -1.0;
     return 0;
+    SPADOT_LEAVE(SPADOT_EHIP)
 }
 
 int spadot_ot_set_cost_host(spadot_ot_solver *s, const double *C_host) {
+    SPADOT_ENTER
     if (!s || !C_host) return -22;
     double *tmp = (double *)dmalloc(sizeof(double) * (size_t)s->I * s->J);
     HIP_CHECK(hipMemcpyAsync(tmp, C_host, sizeof(double) * (size_t)s->I * s->J, hipMemcpyHostToDevice, s->stream));
@@ -1563,6 +1599,7 @@ int spadot_ot_set_cost_host(spadot_ot_solver *s, const double *C_host) {
     HIP_CHECK(hipStreamSynchronize(s->stream));
     HIP_CHECK(hipFree(tmp));
     return rc;
+    SPADOT_LEAVE(SPADOT_EHIP)
 }
 
 }  // extern "C"
@@ -1599,6 +1636,7 @@ double select_kth(spadot_ot_solver *s, const double *D, size_t n, size_t k) {
 
 extern "C" int spadot_ot_set_cost_from_latents_dev(spadot_ot_solver *s, const double *x_dev,
                                                    const double *y_dev, int d, int divide_by_median) {
+    SPADOT_ENTER
     if (!s || !x_dev || !y_dev || d < 1 || d > MAX_LATENT_DIM) return -22;
     const int I = s->I, J = s->J;
     const size_t n = (size_t)I * J;
@@ -1621,6 +1659,7 @@ extern "C" int spadot_ot_set_cost_from_latents_dev(spadot_ot_solver *s, const do
     HIP_CHECK(hipFree(D));
     s->sum_kbar_eps = -1.0;
     return 0;
+    SPADOT_LEAVE(SPADOT_EHIP)
 }
 
 extern "C" {
@@ -1628,6 +1667,7 @@ extern "C" {
 // ot_solvers.py:164-449 with everything resident in HBM.
 int spadot_ot_solve(spadot_ot_solver *s, const double *G_host, const spadot_ot_config *cfg,
                     spadot_ot_info *info) {
+    SPADOT_ENTER
     if (!s || !cfg) return -22;
     const int I = s->I, J = s->J, ld = s->ld, S = 5;
     if (cfg->batch_size < 1 || cfg->batch_size > MAX_BATCH * 64) return -22;
@@ -1666,6 +1706,10 @@ int spadot_ot_solve(spadot_ot_solver *s, const double *G_host, const spadot_ot_c
         const double thr = (e == S) ? cfg->tolerance : 1e-6;
         build_K(s, eps_i, nullptr);
         if (e == S) sum_kbar(s, s->C, eps_i, true);   // only the last stage's gap needs sum(Kbar)
+        // cur_iter = 0 in EVERY stage, as on the reference's live path: with c_for_v2 = True (ot_solvers.py:17,282-289)
+        // each stage is one update_process_c call that receives current_iter, and Python never updates that
+        // variable on this path (it is only threaded through step1_process_c on the c_for_v2 = False branch,
+        // :345-350) -- so max_iter is a per-stage budget there and here
         gap = process_stage(s, P, e == S, cfg->batch_size, thr, 0, cfg->max_iter, nullptr,
                             &rep.stage_iters[e], &rep.gap_checks, /*fast=*/spec);
     }
@@ -1675,9 +1719,11 @@ int spadot_ot_solve(spadot_ot_solver *s, const double *G_host, const spadot_ot_c
     rep.gap = gap;
     if (info) *info = rep;
     return std::isnan(gap) ? 1 : 0;
+    SPADOT_LEAVE(SPADOT_EHIP)
 }
 
 int spadot_ot_plan_dev(spadot_ot_solver *s, void *plan_dev, int dtype, int ldp) {
+    SPADOT_ENTER
     if (!s || !plan_dev || ldp < s->J) return -22;
     dim3 g((s->J + 255) / 256, (unsigned)std::min(s->I, 8192));
     const double sc = 1.0 / s->J;
@@ -1692,9 +1738,11 @@ int spadot_ot_plan_dev(spadot_ot_solver *s, void *plan_dev, int dtype, int ldp) 
     else
         return -22;
     return 0;
+    SPADOT_LEAVE(SPADOT_EHIP)
 }
 
 int spadot_ot_plan_group_sums_dev(spadot_ot_solver *s, const int *col_labels_dev, int ngroups, double *Q_dev) {
+    SPADOT_ENTER
     if (!s || !col_labels_dev || !Q_dev || ngroups < 1 || ngroups > 64) return -22;
     const size_t lds = sizeof(double) * ROW_WAVES * (size_t)ngroups * WAVE;
     dim3 g((s->I + ROW_WAVES - 1) / ROW_WAVES);
@@ -1704,9 +1752,11 @@ int spadot_ot_plan_group_sums_dev(spadot_ot_solver *s, const int *col_labels_dev
     else
         hipLaunchKernelGGL(k_plan_group_sums<double>, g, dim3(256), lds, s->stream, (const double *)s->K, s->a, s->b, col_labels_dev, ngroups, sc, Q_dev, s->I, s->J, s->ld);
     return hipGetLastError() == hipSuccess ? 0 : -5;
+    SPADOT_LEAVE(SPADOT_EHIP)
 }
 
 int spadot_ot_plan_host(spadot_ot_solver *s, double *plan_host) {
+    SPADOT_ENTER
     if (!s || !plan_host) return -22;
     double *tmp = (double *)dmalloc(sizeof(double) * (size_t)s->I * s->J);
     int rc = spadot_ot_plan_dev(s, tmp, SPADOT_F64, s->J);
@@ -1715,10 +1765,12 @@ int spadot_ot_plan_host(spadot_ot_solver *s, double *plan_host) {
     HIP_CHECK(hipStreamSynchronize(s->stream));
     HIP_CHECK(hipFree(tmp));
     return rc;
+    SPADOT_LEAVE(SPADOT_EHIP)
 }
 
 // rowsum_i = a_i * sum_j K_ij b_j / J  == (row pass with weights b) -- reuses k_gap_rows' rs slot
 int spadot_ot_plan_rowsums_host(spadot_ot_solver *s, double *rowsums_host) {
+    SPADOT_ENTER
     if (!s || !rowsums_host) return -22;
     // dy-weighted row sums with dy := 1/J are exactly the plan's row sums
     hipLaunchKernelGGL(k_fill, dim3((s->J + 255) / 256), dim3(256), 0, s->stream, s->tcol, 1.0 / s->J, s->J);
@@ -1730,10 +1782,12 @@ int spadot_ot_plan_rowsums_host(spadot_ot_solver *s, double *rowsums_host) {
     download_vec(s, rowsums_host, s->rt, s->I);
     HIP_CHECK(hipStreamSynchronize(s->stream));
     return 0;
+    SPADOT_LEAVE(SPADOT_EHIP)
 }
 
 int spadot_ot_run_iterations(spadot_ot_solver *s, const spadot_ot_config *cfg, double eps_stage,
                              int iters, float *ms_out) {
+    SPADOT_ENTER
     if (!s || !cfg || iters < 0) return -22;
     IterParams P{eps_stage, cfg->tau, cfg->lambda1, cfg->lambda2, cfg->lambda1 / (cfg->lambda1 + eps_stage),
                  cfg->lambda2 / (cfg->lambda2 + eps_stage)};
@@ -1759,6 +1813,7 @@ int spadot_ot_run_iterations(spadot_ot_solver *s, const spadot_ot_config *cfg, d
         if (s->h_flags[0] != 0) return 2;
     }
     return 0;
+    SPADOT_LEAVE(SPADOT_EHIP)
 }
 
 // The solver's real inner loop, `nbatches` times, ignoring the threshold: snapshot, batch_size (last stage)
@@ -1766,6 +1821,7 @@ int spadot_ot_run_iterations(spadot_ot_solver *s, const spadot_ot_config *cfg, d
 // iters_out = scaling iterations run; ms_out = host wall time of the whole call in milliseconds.
 int spadot_ot_run_checked(spadot_ot_solver *s, const spadot_ot_config *cfg, double eps_stage, int last_stage,
                           int nbatches, int *iters_out, float *ms_out) {
+    SPADOT_ENTER
     if (!s || !cfg || nbatches < 1) return -22;
     IterParams P{eps_stage, cfg->tau, cfg->lambda1, cfg->lambda2, cfg->lambda1 / (cfg->lambda1 + eps_stage),
                  cfg->lambda2 / (cfg->lambda2 + eps_stage)};
@@ -1790,6 +1846,7 @@ int spadot_ot_run_checked(spadot_ot_solver *s, const spadot_ot_config *cfg, doub
     if (ms_out) HIP_CHECK(hipEventElapsedTime(ms_out, s->ev0, s->ev1));
     if (iters_out) *iters_out = nbatches * iters;
     return 0;
+    SPADOT_LEAVE(SPADOT_EHIP)
 }
 
 // Per-kernel live timing: each kernel of one scaling iteration launched `reps` times back to back
@@ -1798,6 +1855,7 @@ int spadot_ot_run_checked(spadot_ot_solver *s, const spadot_ot_config *cfg, doub
 // single-sweep path -- ms_out[4] = fused pass, ms_out[5] = its column finalise (else 0).
 int spadot_ot_time_kernels(spadot_ot_solver *s, const spadot_ot_config *cfg, double eps_stage, int reps,
                            float *ms_out) {
+    SPADOT_ENTER
     if (!s || !cfg || !ms_out || reps < 1) return -22;
     IterParams P{eps_stage, cfg->tau, cfg->lambda1, cfg->lambda2, cfg->lambda1 / (cfg->lambda1 + eps_stage),
                  cfg->lambda2 / (cfg->lambda2 + eps_stage)};
@@ -1867,6 +1925,7 @@ int spadot_ot_time_kernels(spadot_ot_solver *s, const spadot_ot_config *cfg, dou
         for (auto &e : ev) (void)hipEventDestroy(e);
     }
     return 0;
+    SPADOT_LEAVE(SPADOT_EHIP)
 }
 
 // ============================================================================================
@@ -1879,10 +1938,8 @@ namespace {
 struct Tmp {
     spadot_ot_solver *s = nullptr;
     Tmp(int m, int n, int storage) {
-        if (spadot_ot_create(&s, m, n, storage, nullptr) != 0) {
-            fprintf(stderr, "libspadot_ot: cannot create a %d x %d device problem\n", m, n);
-            abort();
-        }
+        if (spadot_ot_create(&s, m, n, storage, nullptr) != 0)
+            throw std::runtime_error("cannot create the temporary device problem of a libot-compatible call");
     }
     ~Tmp() { spadot_ot_destroy(s); }
 };
@@ -1960,46 +2017,62 @@ double compat_gap(int which, T *C, T *Kbar, T *R, const double *dx, const double
 extern "C" {
 
 void update_k_double(double *K, double *K_, double *C, double *u, double *v, double epsilon, int m, int n) {
+    SPADOT_ENTER
     compat_update_k<double>(K, K_, C, u, v, epsilon, m, n);
+    SPADOT_LEAVE()
 }
 void update_k_float(float *K, float *K_, float *C, float *u, float *v, float epsilon, int m, int n) {
+    SPADOT_ENTER
     auto uu = widen(u, m), vv = widen(v, n);
     compat_update_k<float>(K, K_, C, uu.data(), vv.data(), (double)epsilon, m, n);
+    SPADOT_LEAVE()
 }
 void update_R_double(double *R, double *K, double *a, double *b, int m, int n) {
+    SPADOT_ENTER
     compat_update_R<double>(R, K, a, b, m, n);
+    SPADOT_LEAVE()
 }
 void update_R_float(float *R, float *K, float *a, float *b, int m, int n) {
+    SPADOT_ENTER
     auto aa = widen(a, m), bb = widen(b, n);
     compat_update_R<float>(R, K, aa.data(), bb.data(), m, n);
+    SPADOT_LEAVE()
 }
 
 double primal_double(double *C, double *K, double *R, double *dx, double *dy, double *p, double *q,
                      double *a, double *b, double epsilon, double lambda1, double lambda2, int m, int n) {
+    SPADOT_ENTER
     return compat_gap<double>(1, C, K, R, dx, dy, p, q, a, b, epsilon, lambda1, lambda2, m, n);
+    SPADOT_LEAVE(NAN)
 }
 double dual_double(double *C, double *K, double *R, double *dx, double *dy, double *p, double *q,
                    double *a, double *b, double epsilon, double lambda1, double lambda2, int m, int n) {
+    SPADOT_ENTER
     return compat_gap<double>(2, C, K, R, dx, dy, p, q, a, b, epsilon, lambda1, lambda2, m, n);
+    SPADOT_LEAVE(NAN)
 }
 double compute_duality_gap_double(double *C, double *K, double *R, double *dx, double *dy, double *p,
                                   double *q, double *a, double *b, double epsilon, double lambda1,
                                   double lambda2, int m, int n) {
+    SPADOT_ENTER
     return compat_gap<double>(0, C, K, R, dx, dy, p, q, a, b, epsilon, lambda1, lambda2, m, n);
+    SPADOT_LEAVE(NAN)
 }
 #define FLOAT_GAP(which)                                                                              \
+    SPADOT_ENTER                                                                                      \
     auto dx_ = widen(dx, m), dy_ = widen(dy, n), p_ = widen(p, m), q_ = widen(q, n), a_ = widen(a, m), \
          b_ = widen(b, n);                                                                            \
     return (float)compat_gap<float>(which, C, K, R, dx_.data(), dy_.data(), p_.data(), q_.data(),     \
                                     a_.data(), b_.data(), (double)epsilon, (double)lambda1,           \
-                                    (double)lambda2, m, n)
+                                    (double)lambda2, m, n);                                           \
+    SPADOT_LEAVE(NAN)
 float primal_float(float *C, float *K, float *R, float *dx, float *dy, float *p, float *q, float *a,
-                   float *b, float epsilon, float lambda1, float lambda2, int m, int n) { FLOAT_GAP(1); }
+                   float *b, float epsilon, float lambda1, float lambda2, int m, int n) { FLOAT_GAP(1) }
 float dual_float(float *C, float *K, float *R, float *dx, float *dy, float *p, float *q, float *a,
-                 float *b, float epsilon, float lambda1, float lambda2, int m, int n) { FLOAT_GAP(2); }
+                 float *b, float epsilon, float lambda1, float lambda2, int m, int n) { FLOAT_GAP(2) }
 float compute_duality_gap_float(float *C, float *K, float *R, float *dx, float *dy, float *p, float *q,
                                 float *a, float *b, float epsilon, float lambda1, float lambda2, int m,
-                                int n) { FLOAT_GAP(0); }
+                                int n) { FLOAT_GAP(0) }
 #undef FLOAT_GAP
 
 float dummy_float(float *, float *, float *, float *, float *, float *, float *, float *, float *, float,
@@ -2039,6 +2112,7 @@ int step1_process_double(double *a, double *b, double *old_a, double *old_b, dou
                          double *dx, double *dy, double *p, double *q, double *u, double *v,
                          int cur_iter, int max_iter, int iters, double tau, double lambda1,
                          double lambda2, double alpha1, double alpha2, double epsilon, int m, int n) {
+    SPADOT_ENTER
     Tmp t(m, n, SPADOT_F64);
     spadot_ot_solver *s = t.s;
     compat_load_state(s, a, b, old_a, old_b, K, C, dx, dy, p, q, u, v);
@@ -2053,6 +2127,7 @@ int step1_process_double(double *a, double *b, double *old_a, double *old_b, dou
     HIP_CHECK(hipStreamSynchronize(s->stream));
     if (ret == -1) printf("Reached max_iter with duality gap still above threshold. Returning");
     return ret;
+    SPADOT_LEAVE(SPADOT_EHIP)
 }
 
 double update_process_double(double *R, double *a, double *b, double *old_a, double *old_b, double *K,
@@ -2061,6 +2136,7 @@ double update_process_double(double *R, double *a, double *b, double *old_a, dou
                              int batch_size, double epsilon, double threshold, double tau,
                              double lambda1, double lambda2, double alpha1, double alpha2,
                              int cur_iter, int max_iter, int m, int n) {
+    SPADOT_ENTER
     Tmp t(m, n, SPADOT_F64);
     spadot_ot_solver *s = t.s;
     const bool last = (cur_epsilon_scaling == epsilon_scalings);
@@ -2079,6 +2155,7 @@ double update_process_double(double *R, double *a, double *b, double *old_a, dou
     HIP_CHECK(hipStreamSynchronize(s->stream));
     if (Rdev) HIP_CHECK(hipFree(Rdev));
     return gap;
+    SPADOT_LEAVE(NAN)
 }
 
 }  // extern "C"

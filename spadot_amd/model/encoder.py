@@ -79,9 +79,14 @@ class GATConv(nn.Module):
         self.att_src = nn.Parameter(torch.empty(1, heads, out_channels))
         self.att_dst = nn.Parameter(torch.empty(1, heads, out_channels))
         self.bias = nn.Parameter(torch.zeros(heads * out_channels if concat else out_channels))
-        nn.init.xavier_uniform_(self.lin.weight)     # PyG: glorot on lin and att; zeros on bias
-        nn.init.xavier_uniform_(self.att_src)
-        nn.init.xavier_uniform_(self.att_dst)
+        # PyG's reset_parameters: glorot on lin and on the attention vectors, zeros on bias.  Its glorot() draws from
+        # U(-s, s) with s = sqrt(6 / (size(-2) + size(-1))): for att_* [1, H, C] that is sqrt(6 / (H + C)) -- NOT
+        # nn.init.xavier_uniform_'s fan computation on a 3-D tensor (which would give sqrt(6 / (H C + C))).
+        # (encoder.py:42-46 of the reference then re-draws lin.weight with xavier_uniform_: same distribution.)
+        nn.init.xavier_uniform_(self.lin.weight)
+        bound = (6.0 / (heads + out_channels)) ** 0.5
+        nn.init.uniform_(self.att_src, -bound, bound)
+        nn.init.uniform_(self.att_dst, -bound, bound)
 
     def forward(self, x, graph, act=False):
         H, C = self.heads, self.out_channels

@@ -709,6 +709,9 @@ class FlatAdamW:
         self.lr, self.betas, self.eps, self.weight_decay, self.max_norm = lr, betas, eps, weight_decay, max_norm
         self.t = 0
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)   # device-side step count (graph replays)
+        # device scalar: what one entry of flat_grad has to be multiplied by to be THE gradient (1 on one replica;
+        # data-parallel steps sum over replicas and set 1 / number of replicas that had a batch: parallel.run_epoch)
+        self.grad_scale = torch.ones(1, dtype=torch.float32, device=dev)
         self._counter = torch.zeros(1, dtype=torch.int32, device=dev)   # last-workgroup-finishes counter of k_sumsq_last
 
     def zero_grad(self):
@@ -764,4 +767,5 @@ class FlatAdamW:
         _check(model_lib().spadot_clip_adamw_dev(_p(self.flat_param), _p(self.flat_grad), _p(self.exp_avg),
                                                  _p(self.exp_avg_sq), self.count, self.lr, self.betas[0], self.betas[1],
                                                  self.eps, self.weight_decay, self.max_norm, _p(self.scratch), _p(self.sumsq),
-                                                 _p(self.step_dev), _p(self._counter), _stream()), "spadot_clip_adamw_dev")
+                                                 _p(self.step_dev), _p(self._counter), _p(self.grad_scale), _stream()),
+               "spadot_clip_adamw_dev")

@@ -7,8 +7,10 @@ process / single device); the design follows SURVEY 8(e):
   * Training: time points are dealt round-robin to ranks (data, graph, SVGP constants and K-means state
     of a time point live on its owner); the model is replicated; each global step every rank computes
     the gradient of ITS next batch into the flat gradient buffer, ONE all-reduce (sum) of that buffer
-    crosses xGMI, and every replica applies the same clip + AdamW update.  Ranks that have run out of
-    batches in an epoch contribute zeros.  Per epoch: BatchNorm running statistics are averaged and the
+    crosses xGMI, and every replica applies the same clip + AdamW update to the MEAN over the replicas that
+    had a batch in that step (the 1/n sits in the update kernel's `grad_scale`).  Ranks that have run out of
+    batches in an epoch contribute zeros.  Per epoch: BatchNorm running statistics are averaged, weighted by
+    the number of steps each replica ran, and the
     K-means centres (T x 10 x 20 floats) are all-gathered (the OT term of time point t needs the
     centres of t-1, which may live on another rank).
     This turns the reference's sequential one-step-per-batch schedule into synchronous steps with P
@@ -87,17 +89,24 @@ def make_grad_sync(opt):
     return sync, sync_async
 
 
-def average_buffers(module):
-    """BatchNorm running_mean / running_var averaged over ranks (each replica saw different batches)."""
+def average_buffers(module, weight=1.0):
+    """BatchNorm running_mean / running_var averaged over ranks, each replica weighted by `weight` = the number of
+    training steps it ran since the last call (each replica saw different batches; a rank that ran none -- more
+    ranks than time points, or a short time point -- would otherwise drag the statistics back towards the last
+    average).  If no rank ran a step the buffers are left alone."""
     _, P = world()
     if P == 1:
         return
     bufs = [b for n, b in module.named_buffers() if b.is_floating_point()]
     if not bufs:
         return
-    flat = torch.cat([b.reshape(-1).float() for b in bufs])
+    w = float(weight)
+    flat = torch.cat([b.reshape(-1).float() for b in bufs] + [torch.ones(1, device=bufs[0].device)]) * w
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-    flat /= P
+    total = float(flat[-1])
+    if total <= 0.0:
+        return
+    flat = flat[:-1] / total
     off = 0
     for b in bufs:
         n = b.numel()
@@ -132,16 +141,23 @@ def gather_small_plans(local_plans, plan, shape, device):
     return {p: out[i] for i, p in enumerate(pairs)}
 
 
-def run_epoch(plan, batches_per_tp, order, compute_grad, zero_grad, flat_grad, apply_update, exchange=None):
+def run_epoch(plan, batches_per_tp, order, compute_grad, zero_grad, flat_grad, apply_update, exchange=None,
+              set_grad_scale=None):
     """One synchronous data-parallel epoch.
         compute_grad(tp_i, tp, bi): backward of this rank's batch into flat_grad (after zero_grad())
         exchange(did_work):         the step's gradient exchange (default: one all-reduce of flat_grad); told whether
                                     this rank had a batch, because a stepper with the bucketed exchange has already
                                     issued its collectives inside compute_grad
         apply_update():             clip + AdamW on the (now global) flat_grad
-    Every rank calls the collectives the same number of times (n_steps), whatever its own item count."""
+        set_grad_scale(x):          told 1 / (number of ranks that had a batch in this step) before apply_update: the
+                                    exchange SUMS, the update is made with the MEAN over the contributing replicas, so
+                                    the fixed clip threshold (0.3) and the step size mean what they mean on one GPU
+                                    whatever the number of ranks (known from the schedule: no extra collective)
+    Every rank calls the collectives the same number of times (n_steps), whatever its own item count.
+    Returns (n_steps, number of steps this rank computed)."""
     per_rank, n_steps = epoch_schedule(plan, batches_per_tp, order)
     mine = per_rank[plan.rank]
+    last_scale = None
     for s in range(n_steps):
         zero_grad()
         did = s < len(mine)
@@ -151,8 +167,13 @@ def run_epoch(plan, batches_per_tp, order, compute_grad, zero_grad, flat_grad, a
             exchange(did)
         else:
             allreduce_flat_grad(flat_grad)
+        if set_grad_scale is not None:
+            scale = 1.0 / max(1, sum(1 for items in per_rank if s < len(items)))
+            if scale != last_scale:
+                set_grad_scale(scale)
+                last_scale = scale
         apply_update()
-    return n_steps
+    return n_steps, len(mine)
 
 
 # ------------------------------------------------------------------------------ training driver
@@ -211,10 +232,11 @@ def train_SpaDOT_parallel(dataloader_dict, model_config, verbose=False):
                 acc.append(tu.forward_backward(model, model_config, dataloader_dict, tp_i, tp, bi, epoch, beta1,
                                                optimizer=opt))
 
-        run_epoch(plan, batches_per_tp, order, compute_grad, opt.zero_grad, opt.flat_grad,
-                  stepper.update if stepper is not None else opt.step, exchange=exchange)
+        _, n_mine = run_epoch(plan, batches_per_tp, order, compute_grad, opt.zero_grad, opt.flat_grad,
+                              stepper.update if stepper is not None else opt.step, exchange=exchange,
+                              set_grad_scale=lambda x: opt.grad_scale.fill_(x))
         losses[epoch] = torch.stack(acc).mean(0).cpu().tolist() if acc else None
-        average_buffers(model)
+        average_buffers(model, weight=n_mine)
         tu._update_Kmeans(model, model_config, dataloader_dict)
         centres = gather_centres({tp: model.kmeans_center_dict[tp] for tp in dataloader_dict["datasets"]},
                                  plan, model_config["n_clusters"], model_config["z_dim"], device)

@@ -28,7 +28,7 @@ def solve_cfg(g):
 
 
 SOLVE_CASES = ["train10x10", "ragged7x13", "edge1x5", "growth64x48", "spots300x400",
-               "absorb120x150", "outlier40x56"]
+               "absorb120x150", "outlier40x56", "longbatch90x110"]
 
 
 @pytest.fixture(scope="session")

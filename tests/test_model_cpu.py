@@ -72,3 +72,24 @@ def test_csr_round_trip():
     s_t = np.repeat(np.arange(n), np.diff(rowptr_t))
     np.testing.assert_array_equal(col[eid_t], s_t)
     np.testing.assert_array_equal(tgt[eid_t], col_t)
+
+
+def test_gatconv_initialisation_bounds_follow_pyg_glorot():
+    """torch_geometric's GATConv.reset_parameters: glorot(att_src / att_dst) draws U(-s, s) with
+    s = sqrt(6 / (size(-2) + size(-1))) = sqrt(6 / (H + C)) on the [1, H, C] tensors, and the
+    reference re-draws lin.weight Xavier-uniform (encoder.py:42-46): bound sqrt(6 / (fan_in + fan_out))."""
+    from spadot_amd.model.encoder import GATConv
+    torch.manual_seed(0)
+    H, C, fin = 4, 512, 300
+    layer = GATConv(fin, C, heads=H, concat=True)
+    s_att = (6.0 / (H + C)) ** 0.5
+    for att in (layer.att_src, layer.att_dst):
+        a = att.detach()
+        assert a.shape == (1, H, C)
+        assert float(a.abs().max()) <= s_att
+        assert float(a.abs().max()) > 0.95 * s_att            # 2048 draws: the maximum sits next to the bound
+        assert abs(float(a.std()) - s_att / 3 ** 0.5) < 0.05 * s_att
+    s_lin = (6.0 / (fin + H * C)) ** 0.5
+    w = layer.lin.weight.detach()
+    assert float(w.abs().max()) <= s_lin and float(w.abs().max()) > 0.99 * s_lin
+    assert float(layer.bias.abs().max()) == 0.0

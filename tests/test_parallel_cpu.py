@@ -69,8 +69,16 @@ def _worker(rank, world, port, q):
             x, y = _data(tp, bi)
             ((m(x) - y) ** 2).mean().backward()
 
-        steps = par.run_epoch(plan, BATCHES, ORDER, compute_grad, grad.zero_, grad, opt.step)
-        par.average_buffers(m)
+        scale = [1.0]              # stands in for FlatAdamW.grad_scale (a device scalar the update kernel reads)
+
+        def apply_update():
+            grad.mul_(scale[0])
+            opt.step()
+
+        steps, n_mine = par.run_epoch(plan, BATCHES, ORDER, compute_grad, grad.zero_, grad, apply_update,
+                                      set_grad_scale=lambda x: scale.__setitem__(0, x))
+        own_bufs = [b.clone().numpy() for b in m.buffers() if b.is_floating_point()]
+        par.average_buffers(m, weight=n_mine)
         centres = par.gather_centres({tp: np.full((4, 3), float(tp + 1)) for tp in plan.owned_timepoints()}, plan, 4, 3, "cpu")
         # pair-sharded Sinkhorn: each rank solves its own pairs with no collective, plans gathered after
         from oracle import ot_oracle
@@ -83,7 +91,7 @@ def _worker(rank, world, port, q):
         plans = par.gather_small_plans(local, plan, (4, 4), "cpu")
         q.put((rank, steps, flat.clone().numpy(), [b.clone().numpy() for b in m.buffers() if b.is_floating_point()],
                {k: v.copy() for k, v in centres.items()}, {k: v.copy() for k, v in plans.items()},
-               sorted(local)))
+               sorted(local), own_bufs, n_mine))
     finally:
         dist.destroy_process_group()
 
@@ -100,13 +108,15 @@ def test_data_parallel_epoch_over_gloo():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, s0, f0, b0, c0, p0, l0), (r1, s1, f1, b1, c1, p1, l1) = res
+    (r0, s0, f0, b0, c0, p0, l0, ob0, n0), (r1, s1, f1, b1, c1, p1, l1, ob1, n1) = res
     # rank 0 owns time points 0 and 2 (3 + 2 batches), rank 1 owns 1 (1 batch): 5 global steps on both
     assert s0 == s1 == 5
     np.testing.assert_array_equal(f0, f1)                       # replicas stay identical
-    for x, y in zip(b0, b1):
-        np.testing.assert_array_equal(x, y)                      # averaged BatchNorm statistics
-    # single-process emulation of the same schedule: per step the SUM of both ranks' gradients
+    assert (n0, n1) == (5, 1)
+    for x, y, o0, o1 in zip(b0, b1, ob0, ob1):
+        np.testing.assert_array_equal(x, y)                      # averaged BatchNorm statistics ...
+        np.testing.assert_allclose(x, (5.0 * o0 + 1.0 * o1) / 6.0, rtol=1e-6)   # ... weighted by the steps each rank ran
+    # single-process emulation of the same schedule: per step the MEAN of the gradients of the ranks that had a batch
     m, flat, grad = _make_model(0)
     opt = torch.optim.SGD(m.parameters(), lr=0.1)
     plan0, plan1 = par.ShardPlan([0, 1, 2], 2, 0), par.ShardPlan([0, 1, 2], 2, 1)
@@ -115,11 +125,14 @@ def test_data_parallel_epoch_over_gloo():
     bn_states = []
     for s in range(n):
         grad.zero_()
+        contributors = 0
         for r in range(2):
             if s < len(per_rank[r]):
                 tp_i, tp, bi = per_rank[r][s]
                 x, y = _data(tp, bi)
                 ((m(x) - y) ** 2).mean().backward()
+                contributors += 1
+        grad.div_(contributors)
         opt.step()
     # (BatchNorm running stats differ between the emulation and the replicas by construction; the
     # parameters only depend on batch statistics in train mode, so they must match exactly)
