@@ -342,24 +342,36 @@ def induced_batch(edge_index, n_nodes, seeds, hops=2):
 
 # ----------------------------------------------------------------------------- one optimizer step
 
-def training_step(P, svgp, x, y, edge_index, batch_size, heads, noise_svgp, noise_gat, weights,
-                  km=None, ot=None, lr=3e-4, max_norm=0.3, opt_state=None):
-    """_train_utils.py:187-217 on the CPU in fp64: forward, composite loss, backward (torch autograd),
-    clip_grad_norm_(0.3), AdamW(lr) step.  P: dict name -> leaf tensor (requires_grad for parameters).
-    weights = (lambda1, beta1, beta2, omiga1, omiga2, omiga3); km = (centers, labels) or None;
-    ot = (labels, all_labels, cur_centers, prev_centers, gamma) or None.
-    Returns (loss terms dict, optimizer) -- the optimizer can be passed back in as opt_state."""
-    params = [v for k, v in P.items() if v.requires_grad]
-    opt = opt_state if opt_state is not None else torch.optim.AdamW(params, lr=lr)
+def step_loss(P, svgp, x, y, edge_index, batch_size, heads, noise_svgp, noise_gat, weights, km=None, ot=None):
+    """Forward + composite loss of one batch (_train_utils.py:193-212).  Returns (loss, terms dict of 0-dim
+    tensors, final_latent)."""
     (recon, skl, gkl, align, z), _ = spadot_forward(P, svgp, x, y, edge_index, batch_size, heads, noise_svgp,
                                                     noise_gat, train=True)
     l1, b1, b2, o1, o2, o3 = weights
     kml = kmeans_loss(z, km[0], km[1]) if km is not None else torch.zeros((), dtype=z.dtype)
     otl = ot_loss(z, *ot) if ot is not None else torch.zeros((), dtype=z.dtype)
     loss = l1 * recon - b1 * skl + b2 * gkl + o1 * align + o2 * kml + o3 * otl
+    return loss, dict(elbo=loss, Recon=recon, SVGP_KL=skl, GAT_KL=gkl, alignment=align, KMeans=kml, OT=otl), z
+
+
+def training_step(P, svgp, x, y, edge_index, batch_size, heads, noise_svgp, noise_gat, weights,
+                  km=None, ot=None, lr=3e-4, max_norm=0.3, opt_state=None, detail=None):
+    """_train_utils.py:187-217 on the CPU in fp64: forward, composite loss, backward (torch autograd),
+    clip_grad_norm_(0.3), AdamW(lr) step.  P: dict name -> leaf tensor (requires_grad for parameters).
+    weights = (lambda1, beta1, beta2, omiga1, omiga2, omiga3); km = (centers, labels) or None;
+    ot = (labels, all_labels, cur_centers, prev_centers, gamma) or None.
+    detail (optional dict): receives 'latent' (final_latent, detached) and 'grads' (name -> gradient BEFORE the
+    clip, detached clones) -- what a parity check of the device step compares against.
+    Returns (loss terms dict, optimizer) -- the optimizer can be passed back in as opt_state."""
+    params = [v for k, v in P.items() if v.requires_grad]
+    opt = opt_state if opt_state is not None else torch.optim.AdamW(params, lr=lr)
+    loss, terms, z = step_loss(P, svgp, x, y, edge_index, batch_size, heads, noise_svgp, noise_gat, weights, km, ot)
     opt.zero_grad()
     loss.backward()
+    if detail is not None:
+        detail["latent"] = z.detach().clone()
+        detail["grads"] = {k: (v.grad.detach().clone() if v.grad is not None else torch.zeros_like(v))
+                           for k, v in P.items() if v.requires_grad}
     torch.nn.utils.clip_grad_norm_(params, max_norm)
     opt.step()
-    return dict(elbo=float(loss), Recon=float(recon), SVGP_KL=float(skl), GAT_KL=float(gkl),
-                alignment=float(align), KMeans=float(kml), OT=float(otl)), opt
+    return {k: float(v.detach()) for k, v in terms.items()}, opt

@@ -88,7 +88,7 @@ class SpaDOT(nn.Module):
 
         Ls, Lg = self.SVGP_z_dim, self.GAT_z_dim
         noise = noise if noise is not None else getattr(self, "fixed_noise", None)      # (tests: a pinned draw)
-        eps = None if noise is None else torch.cat([noise[0].float(), noise[1].float()], dim=1)
+        eps = None if noise is None else torch.cat([noise[0][:b].float(), noise[1][:b].float()], dim=1)
         main.wait_stream(side)
         for t in (p_m, p_v, SVGP_KL):
             t.record_stream(main)
@@ -116,7 +116,7 @@ class SpaDOT(nn.Module):
         b = batch_size
         Ls, Lg = self.SVGP_z_dim, self.GAT_z_dim
         noise = noise if noise is not None else getattr(self, "fixed_noise", None)
-        eps = None if noise is None else torch.cat([noise[0].float(), noise[1].float()], dim=1)
+        eps = None if noise is None else torch.cat([noise[0][:b].float(), noise[1][:b].float()], dim=1)
         final_latent, GAT_KL, alignment_loss = latent_head(zg, p_m, p_v, eps, Ls, Lg, self._rng_state())
         yb = y[:b, :self.input_dim]
         recon_loss = sqerr_sum(yb.float(), self.decoder(final_latent), 1.0 / self.input_dim)

@@ -262,11 +262,15 @@ def _loss_weights(model, model_config, beta1):
                         device=next(model.parameters()).device)
 
 
-def forward_backward(model, model_config, dataloader_dict, tp_i, tp, bi, epoch, beta1, optimizer=None):
+def forward_backward(model, model_config, dataloader_dict, tp_i, tp, bi, epoch, beta1, optimizer=None, noise=None,
+                     latent_out=None):
     """Forward of batch `bi` of time point `tp`, composite loss (_train_utils.py:193-212) and backward
     into the parameters' .grad (the flat gradient buffer; with `optimizer` a FlatAdamW, through its
     backward(), which overwrites the buffer and so needs no zero_grad()).  Returns the seven loss terms
-    as a device tensor (no host sync)."""
+    as a device tensor (no host sync).
+    noise = (eps_svgp, eps_gat), each [b, L]: replaces the two reparameterisation draws (SpaDOT.py:78,83) so that
+    the step can be compared with a host restatement fed the same numbers; latent_out (a list) receives the
+    batch's final_latent.  Both are for parity checks; training passes neither."""
     batch = dataloader_dict["dataloaders"][tp][bi]
     loc, Y, _ = dataloader_dict["datasets"][tp]
     if batch.y is not None:                                    # gathered once in prepare_dataloader
@@ -275,7 +279,9 @@ def forward_backward(model, model_config, dataloader_dict, tp_i, tp, bi, epoch, 
         x_b, y_b = loc[batch.n_id], Y[batch.n_id]
     seeds = batch.n_id[:batch.batch_size]
     recon, svgp_kl, gat_kl, align, z = model.forward(x=x_b, y=y_b, edge_index=batch.graph, tp=tp,
-                                                     batch_size=batch.batch_size, batch_key=(tp, bi))
+                                                     batch_size=batch.batch_size, batch_key=(tp, bi), noise=noise)
+    if latent_out is not None:
+        latent_out.append(z.detach())
     do_km = epoch >= 1
     do_ot = bool(epoch >= model_config["ot_epoch"] and tp_i != 0)
     km, ot = _cluster_terms(model, model_config, tp, tp_i, seeds, z, do_km, do_ot)

@@ -1,0 +1,184 @@
+"""GPU: the training step at BASELINE.json's shapes against the fp64 host oracle.
+
+  * cfg3 (the benchmarked shape: one time-point pair of 10 000 spots x 3 000 genes, batches of 512 seeds whose
+    two-hop closure is ~the whole time point, ~240 inducing points): ONE optimizer step's arithmetic --
+    the seven loss terms, final_latent and the gradient of every parameter -- in bf16 compute (what bench.py times)
+    and in fp32 compute, against oracle/model_oracle.training_step (the reference's formulas,
+    _train_utils.py:187-217 -> SpaDOT.py:52-94, (b, m, m) ELBO tensor and all) on the same weights, batch, graph,
+    noise, K-means state and OT plan.
+  * cfg2 (2 x 5 000 spots x 2 000 genes, fp32, 1 200 inducing points -> m ~ 600): graphed steps == eager steps and
+    one oracle-checked forward.
+  * cfg5 shape (20 000 spots x 5 000 genes per time point, 256 inducing points over 10 time points -> m ~ 26, k = 30):
+    the step runs, staged replay == eager, everything finite.
+
+Stated tolerances (the reference is fp64 on the CPU):
+  fp32 compute: loss terms rtol 1e-4, latent rtol 1e-4 / atol 1e-5 x scale, per-parameter gradient cosine >= 0.9999 and
+                relative L2 error <= 2e-3;
+  bf16 compute (GAT branch and the two G-sized linears in bf16, fp32 accumulate): loss terms rtol 2e-2, latent
+                relative L2 <= 2e-2, per-parameter gradient cosine >= 0.98 and relative L2 error <= 0.2, gradient as
+                a whole (the direction AdamW follows) cosine >= 0.995.
+"""
+import json
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _setup(T, N, G, n_ind, compute_dtype, bf16_exact_inputs=False, seed=1993, **over):
+    from spadot_amd.model import SpaDOT
+    from spadot_amd.ops import FlatAdamW
+    from spadot_amd.synthetic import make_dataset
+    from spadot_amd.utils import _train_utils as tu, _utils
+    data = make_dataset(T, N, G, seed=seed)
+    if bf16_exact_inputs:       # expression values representable in bf16: the fp32 and bf16 runs read the same numbers
+        data.X = torch.from_numpy(data.X).bfloat16().float().numpy()
+    cfg = _utils.load_model_config(types.SimpleNamespace(config=None))
+    cfg.update(input_dim=G, timepoints=list(range(T)), device=torch.device(DEV), compute_dtype=compute_dtype,
+               inducing_point_nums=n_ind, kmeans_backend="sklearn")
+    cfg.update(over)
+    _utils.set_seed(cfg["seed"])
+    dd = tu.prepare_dataloader(data, cfg)
+    del data
+    model = SpaDOT.SpaDOT(cfg, dd).to(DEV)
+    opt = FlatAdamW(model.parameters(), lr=cfg["lr"])
+    tu._update_Kmeans(model, cfg, dd)
+    tu._update_OT_matrix(model, cfg)
+    model.train()
+    return tu, cfg, dd, model, opt
+
+
+def _report(tag, rep):
+    """Keeps the numbers of the last run next to the other GPU artefacts (gpurun_out/ travels back from the box)."""
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, f"step_parity_{tag}.json"), "w") as f:
+            json.dump(rep, f, indent=1)
+    except OSError:
+        pass
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_cfg3_training_step_matches_the_fp64_oracle(dtype):
+    from oracle import step_parity as sp
+    cdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    tu, cfg, dd, model, opt = _setup(2, 10000, 3000, 480, cdt, bf16_exact_inputs=True)
+    tp, bi, epoch, beta1 = 1, 0, cfg["ot_epoch"], 0.5          # every loss term active
+    batch = dd["dataloaders"][tp][bi]
+    assert batch.graph.n > 9000 and batch.graph.E > 250000 and batch.batch_size == 512
+    noise = sp.make_noise(batch.batch_size, seed=0)
+    # the oracle's answer depends on the weights (same seed -> same initial weights in both dtypes), the data (bf16-exact
+    # here) and the K-means / OT state (fitted on the device latents, so it differs slightly between the two runs):
+    # one oracle step per run, ~30 s on the GPU box's cores
+    inp = sp.oracle_inputs(model, dd, cfg, tp, bi, tp - 1)
+    assert 200 <= inp["m"] <= 280
+    ref = sp.oracle_step(inp, cfg, beta1, noise)
+    dl, dz, dg = sp.device_step(model, opt, cfg, dd, tu, 1, tp, bi, epoch, beta1, noise)
+    rep = sp.compare(dl, dz, dg, ref)
+    rep["dtype"], rep["oracle_seconds"] = dtype, ref["seconds"]
+    _report(f"cfg3_{dtype}", rep)
+    print(json.dumps({k: v for k, v in rep.items() if k != "per_param"}))
+    assert np.isfinite(dl).all() and all(np.isfinite(v).all() for v in dg.values())
+    assert (np.asarray(rep["loss_ref"])[4:] > 0).all()         # alignment, K-means and OT terms are live
+    if dtype == "f32":
+        assert rep["max_rel_loss_err"] <= 1e-4, rep["loss_rel_err"]
+        assert rep["latent_max_abs_err"] <= 1e-4 * max(1.0, float(np.abs(ref["latent"]).max())) + 1e-5
+        assert rep["grad_cos_min"] >= 0.9999, (rep["grad_cos_min_param"], rep["grad_cos_min"])
+        assert rep["grad_rel_l2_max"] <= 2e-3, (rep["grad_rel_l2_max_param"], rep["grad_rel_l2_max"])
+    else:
+        assert rep["max_rel_loss_err"] <= 2e-2, rep["loss_rel_err"]
+        assert rep["latent_rel_l2_err"] <= 2e-2
+        assert rep["grad_cos_min"] >= 0.98, (rep["grad_cos_min_param"], rep["grad_cos_min"])
+        assert rep["grad_rel_l2_max"] <= 0.2, (rep["grad_rel_l2_max_param"], rep["grad_rel_l2_max"])
+        assert rep["grad_cos_global"] >= 0.995
+    # a Linear bias in front of BatchNorm has a zero gradient in exact arithmetic: zero on the device as well
+    assert len(rep["zero_grad_params"]) >= 2 and rep["zero_grad_dev_rel_norm_max"] <= 1e-6
+
+
+def test_cfg2_fp32_graphed_steps_match_eager_and_the_oracle_forward():
+    """BASELINE.json configs[1]: 2 time points x 5 000 spots x 2 000 genes, fp32 compute, the default 1 200 inducing
+    points (m ~ 600 per time point: the blocked SPD inverse), k = 30."""
+    from oracle import model_oracle as mo, step_parity as sp
+    tu, cfg, dd, model, opt = _setup(2, 5000, 2000, 1200, torch.float32)
+    m = int(dd["inducing_points"][1].shape[0])
+    assert 520 <= m <= 680
+    tp, epoch, beta1 = 1, cfg["ot_epoch"], 0.5
+    b0 = dd["dataloaders"][tp][0]
+    assert b0.graph.n > 4500
+
+    # (a) one forward against the oracle (no gradient on the host: its (b, m, m) tensor is 1.5 GB per latent dim)
+    noise = sp.make_noise(b0.batch_size, seed=3)
+    inp = sp.oracle_inputs(model, dd, cfg, tp, 0, tp - 1)
+    w = (cfg["lambda1"], beta1, cfg["beta2"], cfg["omiga1"], cfg["omiga2"], cfg["omiga3"])
+    with torch.no_grad():
+        _, terms, z_ref = mo.step_loss(inp["P"], inp["svgp"], inp["x"], inp["y"], inp["ei"], inp["b"],
+                                       cfg["gat_attention_heads"], noise[0], noise[1], w, km=inp["km"], ot=inp["ot"])
+    want = np.array([float(terms[n]) for n in sp.LOSS_NAMES])
+    dl, dz, dg = sp.device_step(model, opt, cfg, dd, tu, 1, tp, 0, epoch, beta1, noise)
+    np.testing.assert_allclose(dl, want, rtol=1e-4, err_msg=str(sp.LOSS_NAMES))
+    np.testing.assert_allclose(dz, z_ref.numpy(), rtol=1e-4, atol=1e-4)
+    assert all(np.isfinite(v).all() for v in dg.values())
+
+    # (b) replayed graphs == eager steps on the same batches (noise silenced in both)
+    model.fixed_noise = (torch.zeros((512, 10), device=DEV), torch.zeros((512, 10), device=DEV))
+    staged = tu.GraphedStepper(model, opt, dict(cfg, staged_graphs=True), dd)
+    assert staged.capturable
+    for rep in range(3):                                         # eager, capture + replay, replay
+        for bi in (0, 3):
+            staged.beta1_t[1].fill_(-beta1)
+            la = tu.forward_backward(model, cfg, dd, 1, tp, bi, epoch, staged.beta1_t, optimizer=opt)
+            ga = opt.flat_grad.clone()
+            opt.flat_grad.fill_(7.0)
+            lb = staged.fb(1, tp, bi, epoch, beta1)
+            gb = opt.flat_grad
+            assert torch.isfinite(gb).all()
+            np.testing.assert_allclose(lb.cpu().numpy(), la.cpu().numpy(), rtol=1e-4, atol=1e-5)
+            scale = float(ga.abs().max())
+            np.testing.assert_allclose(gb.cpu().numpy(), ga.cpu().numpy(), rtol=2e-3, atol=2e-4 * scale)
+    assert len(staged.graphs) == 2
+    # and a few real optimizer steps through the replayed graphs stay finite and move the parameters
+    p0 = opt.flat_param.clone()
+    for k in range(4):
+        out = staged.step(1, tp, k % 2 * 3, epoch, beta1)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all() and torch.isfinite(opt.flat_param).all()
+    assert float((opt.flat_param - p0).abs().max()) > 0
+
+
+def test_cfg5_shape_step_runs_staged_equals_eager():
+    """BASELINE.json configs[4] per-GPU shape: 20 000 spots x 5 000 genes per time point, 256 inducing points over 10
+    time points (here 2 time points with 52 -> m ~ 26 each), k = 30, bf16 compute.  Batches gather their rows per step
+    (batch_cache_gb = 0: at 40 batches x 20k rows x 5k genes the cache would be 8 GB per time point -- fine on the
+    device, just not worth filling for three batches)."""
+    tu, cfg, dd, model, opt = _setup(2, 20000, 5000, 52, torch.bfloat16, batch_cache_gb=0.0, kmeans_backend="device")
+    m = int(dd["inducing_points"][1].shape[0])
+    assert 15 <= m <= 40
+    tp, epoch, beta1 = 1, cfg["ot_epoch"], 0.5
+    b0 = dd["dataloaders"][tp][0]
+    assert b0.y is None and b0.graph.n > 18000 and b0.graph.E > 500000
+    model.fixed_noise = (torch.zeros((512, 10), device=DEV), torch.zeros((512, 10), device=DEV))
+    staged = tu.GraphedStepper(model, opt, dict(cfg, staged_graphs=True), dd)
+    for rep in range(3):
+        for bi in (0, 39):                                        # first and last (partial) batch
+            staged.beta1_t[1].fill_(-beta1)
+            la = tu.forward_backward(model, cfg, dd, 1, tp, bi, epoch, staged.beta1_t, optimizer=opt)
+            ga = opt.flat_grad.clone()
+            opt.flat_grad.fill_(7.0)
+            lb = staged.fb(1, tp, bi, epoch, beta1)
+            gb = opt.flat_grad
+            assert torch.isfinite(lb).all() and torch.isfinite(gb).all()
+            np.testing.assert_allclose(lb.cpu().numpy(), la.cpu().numpy(), rtol=1e-4, atol=1e-5)
+            scale = float(ga.abs().max())
+            np.testing.assert_allclose(gb.cpu().numpy(), ga.cpu().numpy(), rtol=2e-3, atol=2e-4 * scale)
+    la = la.cpu().numpy()
+    assert (la[[1, 3, 4, 5, 6]] > 0).all()                      # Recon, GAT_KL, alignment, K-means, OT are live
+    for k in range(3):
+        out = staged.step(1, tp, 0, epoch, beta1)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all() and torch.isfinite(opt.flat_param).all()

@@ -101,9 +101,15 @@ def test_train_end_to_end_writes_reference_outputs(tmp_path):
     assert "GATEncoder.gat1.lin.weight" in sd and "SVGPEncoder.SVGP_encoder_net.1.running_mean" in sd
     assert set(model.gammas) == {"0_1"} and model.gammas["0_1"].shape == (4, 4)
     assert set(model.kmeans_center_dict) == {0, 1}
-    # integer cluster assignments: the device assignment kernel reproduces sklearn's labels bit for bit
+    # integer cluster assignments: the device assignment kernel reproduces the labels sklearn's fit left for the
+    # same latents (no training step ran between the last _update_Kmeans and get_latent) bit for bit
     from spadot_amd import ops
-    lat0 = torch.as_tensor(z["X"][:1200], dtype=torch.float64, device=DEV)
+    for tp in (0, 1):
+        lat = torch.as_tensor(z["X"][1200 * tp:1200 * (tp + 1)], device=DEV)        # float32, as the host fit saw it
+        cen = torch.as_tensor(np.asarray(model.kmeans_center_dict[tp]), device=DEV)
+        got = ops.kmeans_assign(lat, cen).cpu().numpy()
+        assert got.dtype == np.int32
+        np.testing.assert_array_equal(got, np.asarray(model.kmeans_cluster_dict[tp], dtype=np.int32))
 
 
 def test_graphed_steps_match_eager_steps(monkeypatch):
