@@ -67,40 +67,156 @@ def cpu_sinkhorn(I, J, budget_s=10.0):
             "sample": f"{n} update_a_b iterations of one {I}x{J} fp64 problem (oracle/ot_oracle.c, 1 thread), {el:.1f} s"}
 
 
-def cpu_train_step(model, dd, cfg, tp, bi, tp_prev):
-    """ONE training step of the same batch on the host: oracle/model_oracle.training_step (fp64,
-    torch CPU with all cores), the reference's arithmetic including its (b, m, m) ELBO tensor."""
+def cpu_train_steps(model, opt, dd, cfg, tu, tp, bi, tp_prev, epoch, beta1, n_steps=3):
+    """`n_steps` training steps of the same batch on the host: oracle/model_oracle.training_step (fp64, torch CPU with
+    all cores), the reference's arithmetic including its (b, m, m) ELBO tensor (SURVEY 8d asks for >= 3 steps).
+    The first of them doubles as the PARITY CHECK of the benchmarked device step: the eager HIP step body is run on
+    the same weights / batch / graph / noise / K-means state / OT plan, and its seven loss terms, final_latent and
+    per-parameter gradients are compared with the oracle's (oracle/step_parity.py)."""
     import torch
-    from oracle import model_oracle as mo
+    from oracle import step_parity as sp
     batch = dd["dataloaders"][tp][bi]
-    loc, Y, _ = dd["datasets"][tp]
-    n_id = batch.n_id
-    x = loc[n_id].cpu().double()
-    y = Y[n_id].float().cpu().double()
-    g = batch.graph
-    tgt = torch.repeat_interleave(torch.arange(g.n), (g.rowptr[1:] - g.rowptr[:-1]).cpu().long())
-    ei = torch.stack([g.col.cpu().long(), tgt])
-    P = {k: v.detach().cpu().double().clone() for k, v in model.state_dict().items()}
-    for k in P:
-        if P[k].is_floating_point() and "running" not in k:
-            P[k].requires_grad_(True)
-    sv = mo.SVGPOracle(dd["inducing_points"][tp], dd["N_train"][tp])
-    b = batch.batch_size
-    gen = torch.Generator().manual_seed(0)
-    n1 = torch.randn((b, 10), dtype=torch.float64, generator=gen)
-    n2 = torch.randn((b, 10), dtype=torch.float64, generator=gen)
-    seeds = n_id[:b].cpu().numpy()
-    labels = np.asarray(model.kmeans_cluster_dict[tp])
-    km = (model.kmeans_center_dict[tp], labels[seeds])
-    ot = (labels[seeds], labels, model.kmeans_center_dict[tp], model.kmeans_center_dict[tp_prev],
-          model.gammas[f"{tp_prev}_{tp}"])
-    w = (cfg["lambda1"], 0.5, cfg["beta2"], cfg["omiga1"], cfg["omiga2"], cfg["omiga3"])
+    noise = sp.make_noise(batch.batch_size, seed=0)
+    inp = sp.oracle_inputs(model, dd, cfg, tp, bi, tp_prev)              # snapshot of the current weights
+    dl, dz, dg = sp.device_step(model, opt, cfg, dd, tu, 1, tp, bi, epoch, beta1, noise)
+    ref = sp.oracle_step(inp, cfg, beta1, noise, n_steps=n_steps)
+    rep = sp.compare(dl, dz, dg, ref)
+    secs = ref["seconds"]
+    med = float(np.median(secs))
+    cpu = {"value": 1.0 / med, "unit": "training steps/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"{len(secs)} training steps (batch of {inp['b']} seeds, n_sub={inp['n_sub']}, E={inp['E']}, m={inp['m']}) "
+                     f"in fp64 on torch-CPU, {', '.join(f'{t:.1f}' for t in secs)} s (median {med:.1f} s); oracle/model_oracle.py"}
+    keep = ("max_rel_loss_err", "loss_names", "loss_rel_err", "latent_rel_l2_err", "latent_max_abs_err", "grad_cos_min",
+            "grad_cos_min_param", "grad_rel_l2_max", "grad_rel_l2_max_param", "grad_cos_global", "zero_grad_dev_rel_norm_max")
+    parity = {k: rep[k] for k in keep}
+    parity["what"] = ("eager HIP step body vs the fp64 host oracle on the same weights, batch, noise, K-means state and OT "
+                      "plan: 7 loss terms, final_latent, gradient of every parameter (tests/test_step_parity_gpu.py holds "
+                      "the asserting version)")
+    return cpu, parity
+
+
+# ------------------------------------------------------------------------------ training-leg roofline, epoch block
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak (spec; the guide measures ~1.25-1.5 PF on random data)
+
+
+def newest_profile(name):
+    """Path of profiles/rNN/<name> of the highest round that has it, or None."""
+    base = os.path.join(ROOT, "profiles")
+    for d in sorted((x for x in os.listdir(base) if x.startswith("r")), reverse=True) if os.path.isdir(base) else []:
+        p = os.path.join(base, d, name)
+        if os.path.exists(p):
+            return p
+    return None
+
+
+def roofline_train(dd, tp, cfg, G, compute_dtype, n_params, live_ms_per_step):
+    """Where the training step stands against the machine, per kernel family.
+
+    ALGORITHMIC work per step comes from the shapes of the batch actually run (computed here, live); the MICROSECONDS
+    per family cannot be taken from inside a graph replay with events, so they are REPLAYED from the committed
+    rocprofv3 --kernel-trace summary of this same command (tools/prof_summary.py -> profiles/rNN/train_cfg3_<dtype>_families.json),
+    and the block says so.  Pricing (DESIGN.md "Measurement"):
+      gemm (compute dtype): 2 m n k per GEMM -- layer 1: forward + weight gradient (its input needs no gradient); layer 2
+          (all n_sub rows) and layer 3 (seeds + hop 1 rows): forward, input gradient, weight gradient; the two G-sized
+          MLP maps on the b seeds -- against the dense bf16 MFMA peak;
+      gat edge: SURVEY 8(d)'s minimum per layer, 2 n H C s + E (8 + 2 H s) bytes, once forward and twice backward (target
+          side and source side each read and write one n x H C image) -- against the 8 TB/s HBM peak;
+      optimizer: 8 fp32 streams over the flat buffers (p, g, m, v read; p, m, v written; g read once more for the norm);
+      everything else is latency (20 workgroups of fp64 sweep, ~90 launches of a few microseconds)."""
+    b0 = dd["dataloaders"][tp][0]
+    g1 = b0.graph
+    lg = g1.layer_graphs
+    H, C = cfg["gat_attention_heads"], cfg["gat_encoder_hidden"]
+    HC = H * C
+    s_el = 2 if compute_dtype == "bf16" else 4
+    n, b = g1.n, b0.batch_size
+    n1 = lg[1].n if lg is not None else n
+    layers = [(n, n, g1.E)] + ([(lg[0].n, lg[0].n_tgt, lg[0].E), (lg[1].n, lg[1].n_tgt, lg[1].E)] if lg is not None
+                              else [(n, n, g1.E), (n, n, g1.E)])
+    hid_s, hid_d = cfg["svgp_encoder_layers"][0], cfg["decoder_layers"][-1]
+    gemm_flops = (2 * 2.0 * n * G * HC            # layer 1: forward, weight gradient
+                  + 3 * 2.0 * n * HC * HC          # layer 2
+                  + 3 * 2.0 * n1 * HC * HC         # layer 3 (rows: seeds + hop 1)
+                  + 2 * 2.0 * b * G * hid_s        # SVGP encoder's G-sized map: forward, weight gradient
+                  + 3 * 2.0 * b * hid_d * G)       # decoder's G-sized map
+    gat_bytes = sum(3 * ((ns + nt) * HC * s_el + E * (8 + 2 * H * s_el)) for ns, nt, E in layers)
+    opt_bytes = 8.0 * 4 * n_params
+    out = {"workload": f"one step: n_sub={n}, seeds+hop1={n1}, b={b}, E={g1.E}, G={G}, H={H}, C={C}, {compute_dtype}",
+           "live_ms_per_step": live_ms_per_step,
+           "algorithmic": {"gemm_flops_per_step": gemm_flops, "gat_edge_bytes_per_step": gat_bytes, "optimizer_bytes_per_step": opt_bytes}}
+    fam_path = newest_profile(f"train_cfg3_{compute_dtype}_families.json")
+    if fam_path is None:
+        out["source"] = "no committed rocprofv3 family summary for this dtype: only the algorithmic work is reported"
+        return out
+    prof = json.load(open(fam_path))
+    fam = prof["families"]
+    us = lambda *names: sum(fam.get(k, {}).get("us_per_step", 0.0) for k in names)
+    gemm_us = us("gemm_bf16_library", "gemm_bf16_own") if compute_dtype == "bf16" else us("gemm_f32_library")
+    gat_us, opt_us = us("gat_edge"), us("optimizer")
+    out["source"] = (f"kernel microseconds REPLAYED from {os.path.relpath(fam_path, ROOT)} (rocprofv3 --kernel-trace of "
+                     f"`bench.py --leg train`, {prof['steps']} steps, {prof['wall_us_per_step']:.0f} us/step under the profiler); "
+                     "algorithmic flops / bytes computed live from this run's batch")
+    out["families"] = {
+        "gemm_" + compute_dtype: {"bound": "mfma", "us_per_step": gemm_us, "achieved": gemm_flops / max(gemm_us, 1e-9) / 1e6,
+                                  "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": gemm_flops / max(gemm_us, 1e-9) / 1e6 / MFMA_BF16_PEAK_TFLOPS},
+        "gat_edge": {"bound": "hbm", "us_per_step": gat_us, "achieved": gat_bytes / max(gat_us, 1e-9) / 1e3, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": gat_bytes / max(gat_us, 1e-9) / 1e3 / HBM_PEAK_GBS},
+        "optimizer": {"bound": "hbm", "us_per_step": opt_us, "achieved": opt_bytes / max(opt_us, 1e-9) / 1e3, "peak": HBM_PEAK_GBS,
+                      "unit": "GB/s", "frac": opt_bytes / max(opt_us, 1e-9) / 1e3 / HBM_PEAK_GBS},
+        "svgp_sweep": {"bound": "latency (2L = 20 workgroups, fp64 vector FMA)", "us_per_step": us("svgp_sweep")},
+        "gemm_f64_svgp": {"bound": "latency (m x m, b x m fp64 library GEMMs)", "us_per_step": us("gemm_f64_library")},
+        "small_kernels": {"bound": "launch latency", "us_per_step": us("own_small", "torch_glue"),
+                          "launches_per_step": sum(fam.get(k, {}).get("launches_per_step", 0.0) for k in ("own_small", "torch_glue")),
+                          "torch_glue_us_per_step": us("torch_glue")},
+    }
+    out["launches_per_step"] = prof["launches_per_step"]
+    out["under_12us"] = prof["under_12us"]
+    return out
+
+
+def epoch_block(tu, model, opt, cfg, dd, stepper, T, beta1, torch):
+    """One whole training epoch as train_SpaDOT runs it (_train_utils.py:174-231): every batch of every time point
+    (cfg3: 100 steps), then _update_Kmeans (per-time-point inference + K-means, kmeans_backend as configured) and
+    _update_OT_matrix -- the per-epoch work the steps/s headline does not contain.  Seconds, host wall clock."""
+    import random
+    epoch = cfg["ot_epoch"]
+    order = [(i, t) for i, t in enumerate(cfg["timepoints"]) if t in dd["dataloaders"]]
+    nsteps = sum(len(dd["dataloaders"][t]) for _, t in order)
+
+    def run_steps():
+        for tp_i, tp in order:
+            for bi in range(len(dd["dataloaders"][tp])):
+                if stepper is not None:
+                    stepper.step(tp_i, tp, bi, epoch, beta1)
+                else:
+                    tu.training_step(model, opt, cfg, dd, tp_i, tp, bi, epoch, beta1)
+
     t0 = time.perf_counter()
-    mo.training_step(P, sv, x, y, ei, b, cfg["gat_attention_heads"], n1, n2, w, km=km, ot=ot, lr=cfg["lr"])
-    el = time.perf_counter() - t0
-    return {"value": 1.0 / el, "unit": "training steps/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 training step (batch of {b} seeds, n_sub={g.n}, E={g.E}, m={sv.z.shape[0]}) in fp64 on torch-CPU, "
-                      f"{el:.1f} s; oracle/model_oracle.py"}
+    for _ in range(2 if stepper is not None else 0):      # first visits: eager, then capture (epochs 0 and 1 of a real run)
+        run_steps()
+    torch.cuda.synchronize()
+    warm_s = time.perf_counter() - t0
+    random.shuffle(order)
+    model.train()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_steps()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    tu._update_Kmeans(model, cfg, dd)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    tu._update_OT_matrix(model, cfg)
+    torch.cuda.synchronize()
+    t3 = time.perf_counter()
+    model.train()
+    return {"steps": nsteps, "steps_s": t1 - t0, "update_kmeans_s": t2 - t1, "update_ot_matrix_s": t3 - t2, "total_s": t3 - t0,
+            "steps_per_s_whole_epoch": nsteps / (t3 - t0), "kmeans_backend": cfg.get("kmeans_backend", "device"),
+            "graph_warmup_s": warm_s,
+            "note": "replayed-graph epoch (epoch >= 2 of a run): every (time point, batch) step, then the per-epoch K-means "
+                    "refit of all time points and the 10x10 OT plans (the reference refits the plans every 10th epoch)"}
 
 
 # ------------------------------------------------------------------------------ main
@@ -126,6 +242,9 @@ def _main(real_stdout):
     ap.add_argument("--compute-dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--ot-storage", default="f32", choices=["f32", "f64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; value = their median")
+    ap.add_argument("--cpu-steps", type=int, default=3, help="oracle training steps timed for cpu_baseline")
+    ap.add_argument("--no-epoch", action="store_true", help="skip the whole-epoch block (100 steps + K-means + OT update)")
     ap.add_argument("--leg", default="both", choices=["both", "train", "sinkhorn"])
     args = ap.parse_args()
 
@@ -148,6 +267,16 @@ def _main(real_stdout):
             dist.init_process_group("nccl", device_id=torch.device(dev))
         else:
             dist.init_process_group(backend)
+
+    # proof that the collectives ran over `world` ranks of the chosen backend: an all-reduce of ones
+    rccl_ranks, rank_devices = 1, [torch.cuda.get_device_name(torch.cuda.current_device())]
+    if world > 1:
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        rccl_ranks = int(ones.item())
+        assert rccl_ranks == world == dist.get_world_size(), (rccl_ranks, world)
+        rank_devices = [None] * world
+        dist.all_gather_object(rank_devices, f"{local_rank}:{torch.cuda.get_device_properties(local_rank).name}")
 
     def barrier():
         if world > 1:
@@ -185,6 +314,10 @@ def _main(real_stdout):
         data = make_dataset(T, N, G, seed=1993)
         cfg.update(input_dim=G, timepoints=list(range(T)), device=torch.device(dev), compute_dtype=cdt,
                    owned_timepoints=own)
+        owned_all = [own]
+        if world > 1:
+            owned_all = [None] * world
+            dist.all_gather_object(owned_all, own)
         _utils.set_seed(cfg["seed"])
         t_setup = time.perf_counter()
         dd = tu.prepare_dataloader(data, cfg)
@@ -199,6 +332,7 @@ def _main(real_stdout):
         if world > 1:       # two buckets, same order on every rank and path (spadot_amd.parallel.make_grad_sync)
             from spadot_amd.parallel import make_grad_sync
             grad_sync, grad_sync_async = make_grad_sync(opt)
+            opt.grad_scale.fill_(1.0 / world)       # every rank has a batch in every step: update on the MEAN gradient
         # schedule: (tp_i, batch) round robin over the time points that have a predecessor on this rank
         train_tps = [t for t in own if t >= 1 and (t - 1) in own]
         sched = [(t, bi) for bi in range(len(dd["dataloaders"][train_tps[0]])) for t in train_tps]
@@ -235,23 +369,36 @@ def _main(real_stdout):
             setup_s += time.perf_counter() - t_cap
         for i in range(args.warmup):
             step(i)
-        barrier()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            last = step(args.warmup + i)
-        barrier()
-        el = max_over_ranks(time.perf_counter() - t0)
+        # `repeats` timed regions of EXACTLY `steps` steps each, every one bracketed by barrier + synchronize and
+        # reduced with MAX over ranks; `value` is the median region (spread reported beside it)
+        regions = []
+        for rep in range(max(1, args.repeats)):
+            barrier()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                last = step(args.warmup + i)
+            barrier()
+            regions.append(max_over_ranks(time.perf_counter() - t0))
+        el = float(np.median(regions))
         b0 = dd["dataloaders"][train_tps[0]][0]
         train_res = {"value": world * args.steps / el, "ms_per_step": 1e3 * el / args.steps,
+                     "repeats": {"n": len(regions), "ms_per_step": [1e3 * r / args.steps for r in regions],
+                                 "min": 1e3 * min(regions) / args.steps, "max": 1e3 * max(regions) / args.steps,
+                                 "spread_pct": 100.0 * (max(regions) - min(regions)) / el},
                      "setup_s": setup_s, "n_sub": b0.graph.n, "E_sub": b0.graph.E,
                      "m_inducing": int(dd["inducing_points"][train_tps[0]].shape[0]),
                      "params": int(opt.count), "last_losses": [float(v) for v in last.cpu().tolist()],
                      "hip_graphs": state["stepper"] is not None,
                      "staged_graphs": bool(state["stepper"] is not None and state["stepper"].staged),
                      "bucketed_grad_exchange": bool(state["stepper"] is not None and state["stepper"].overlap)}
+        train_res["roofline_train"] = roofline_train(dd, train_tps[0], cfg, G, args.compute_dtype, int(opt.count),
+                                                     train_res["ms_per_step"])
+        if world == 1 and not args.no_epoch:
+            train_res["epoch"] = epoch_block(tu, model, opt, cfg, dd, state["stepper"], T, beta1, torch)
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             t, bi = sched[0]
-            train_res["cpu_baseline"] = cpu_train_step(model, dd, cfg, t, bi, t - 1)
+            train_res["cpu_baseline"], train_res["parity_check"] = cpu_train_steps(
+                model, opt, dd, cfg, tu, t, bi, t - 1, epoch, beta1, n_steps=max(1, args.cpu_steps))
         del model, opt, dd
         torch.cuda.empty_cache()
 
@@ -297,13 +444,14 @@ def _main(real_stdout):
         # HBM traffic per launch comes from separate rocprofv3 --pmc passes (FETCH_SIZE x2 for 16-byte/lane
         # streams on gfx950, + WRITE_SIZE; MI355X_MICROARCH.md "HBM"): taken from the committed summary of the
         # same workload, when there is one
-        pmc = os.path.join(ROOT, "profiles", "r01", "sinkhorn_cfg3_f32_pmc_summary.csv")
-        if dom == "fused_pass" and I == 10000 and args.ot_storage == "f32" and os.path.exists(pmc):
+        pmc = newest_profile("sinkhorn_cfg3_f32_pmc_summary.csv")
+        if dom == "fused_pass" and I == 10000 and args.ot_storage == "f32" and pmc:
             import csv
             for row in csv.reader(open(pmc)):
                 if row and "k_fused_pass<float, 5, 2" in row[0]:
                     roof["traffic"] = (2.0 * float(row[1]) + float(row[3])) * 1024.0
-                    roof["traffic_source"] = "profiles/r01/sinkhorn_cfg3_f32_pmc_summary.csv (2*FETCH_SIZE + WRITE_SIZE, bytes per launch)"
+                    roof["traffic_source"] = (f"replayed from {os.path.relpath(pmc, ROOT)} (separate rocprofv3 --pmc passes of this "
+                                              "command: 2*FETCH_SIZE + WRITE_SIZE, bytes per launch) -- not measured in this run")
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             sk_res["cpu_baseline"] = cpu_sinkhorn(I, J)
         solver.close()
@@ -318,9 +466,21 @@ def _main(real_stdout):
         name = "cfg3" if (T, N, G) == (5, 10000, 3000) else "custom shape"
         out["config"] = {"workload": f"{name}: {T} time points x {N} spots x {G} genes, batch 512, k=30, 1200 inducing points; "
                                      f"Sinkhorn pair problem {N}x{N}",
-                         "train": {k: v for k, v in (train_res or {}).items() if k != "cpu_baseline"},
-                         "parallelism": "1 GPU" if world == 1 else f"{world} ranks: time points / pair problems sharded, "
-                                                                   "flat-gradient all-reduce (RCCL) in two buckets, the first overlapped with the backward pass"}
+                         "train": {k: v for k, v in (train_res or {}).items()
+                                   if k not in ("cpu_baseline", "parity_check", "roofline_train", "epoch")},
+                         "parallelism": "1 GPU" if world == 1 else (
+                             f"{world} ranks (one per GPU, backend {backend}, all-reduce of ones = {rccl_ranks}): rank r trains time "
+                             f"point 1 + r mod {T - 1} (holding it and its predecessor) and solves pair problem (r mod {T - 1}, "
+                             f"r mod {T - 1} + 1)" + (f"; ranks >= {T - 1} repeat the data of rank r - {T - 1} (weak scaling: "
+                             "fixed work per rank)" if world > T - 1 else "") + "; flat-gradient all-reduce (sum, update on the mean) in two "
+                             "buckets, the first overlapped with the backward pass; no collective in the pair solves")}
+        out["rccl_ranks"] = rccl_ranks
+        if train_res is not None:
+            out["rank_timepoints"] = owned_all
+        out["rank_devices"] = rank_devices
+        for k in ("roofline_train", "epoch", "parity_check"):
+            if train_res is not None and k in train_res:
+                out[k] = train_res[k]
         if sk_res is not None:
             out["sinkhorn"] = {k: v for k, v in sk_res.items() if k != "cpu_baseline"}
             out["roofline"] = roof

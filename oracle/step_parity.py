@@ -35,9 +35,8 @@ def oracle_inputs(model, dd, cfg, tp, bi, tp_prev, do_km=True, do_ot=True):
     tgt = torch.repeat_interleave(torch.arange(g.n), (g.rowptr[1:] - g.rowptr[:-1]).cpu().long())
     ei = torch.stack([g.col.cpu().long(), tgt])
     P = {k: v.detach().cpu().double().clone() for k, v in model.state_dict().items()}
-    for k in P:
-        if P[k].is_floating_point() and "running" not in k:
-            P[k].requires_grad_(True)
+    for k, _ in model.named_parameters():          # (buffers -- running statistics, batch counters -- stay constants)
+        P[k].requires_grad_(True)
     sv = mo.SVGPOracle(dd["inducing_points"][tp], dd["N_train"][tp], kernel_type=cfg.get("kernel_type", "Gaussian"),
                        scale=cfg.get("kernel_scale", 0.1))
     b = batch.batch_size

@@ -9,7 +9,7 @@ that touches the data stays in HBM.
 Parity: sklearn's fit is third-party and not pinned bit for bit (its own chunked arithmetic decides ties and
 the exact iteration count); what IS exact is the assignment rule -- labels are produced by the
 spadot_kmeans_assign kernel (nearest centre, first minimum wins), the same rule sklearn's predict applies.
-It is therefore opt-in: model_config['kmeans_backend'] = 'device' (default 'sklearn' = reference behaviour).
+Selected by model_config['kmeans_backend']: 'device' (default) | 'sklearn' (the reference's host fit, the parity option).
 """
 import numpy as np
 import torch

@@ -23,7 +23,8 @@ class SpaDOT(nn.Module):
         self.SVGP_z_dim = model_config["z_dim"] // 2
         self.GAT_z_dim = model_config["z_dim"] // 2
         self.dtype = torch.float32
-        self.compute_dtype = model_config.get("compute_dtype", torch.float32)
+        from ..utils._utils import resolve_compute_dtype
+        self.compute_dtype = resolve_compute_dtype(model_config.get("compute_dtype"))
         self.svgp_issue = model_config.get("svgp_issue", __import__("os").environ.get("SPADOT_SVGP_ISSUE", "first"))
         self.device = torch.device(model_config["device"])
 

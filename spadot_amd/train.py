@@ -48,7 +48,11 @@ def train(args):
     if model_config["device"].type != "cuda":
         raise RuntimeError("spadot_amd trains on the MI355X only (device 'cuda:N'); there is no CPU path")
     model_config["dtype"] = torch.float32          # reference: float64 (train.py:27); see model/SpaDOT.py
-    model_config.setdefault("compute_dtype", getattr(args, "compute_dtype", torch.float32))
+    # compute dtype of the GAT branch and the G-sized dense maps: config.yaml's `compute_dtype` ('float32' |
+    # 'bfloat16'); an `args.compute_dtype` (string or torch dtype) overrides it
+    if getattr(args, "compute_dtype", None) is not None:
+        model_config["compute_dtype"] = args.compute_dtype
+    model_config["compute_dtype"] = _utils.resolve_compute_dtype(model_config.get("compute_dtype"))
 
     _utils.set_seed(model_config["seed"])
     print("Preparing data...")

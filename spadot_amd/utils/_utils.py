@@ -24,6 +24,26 @@ def seed_worker(worker_id=1993):
     random.seed(worker_id)
 
 
+_COMPUTE_DTYPES = {"float32": torch.float32, "fp32": torch.float32, "f32": torch.float32,
+                   "bfloat16": torch.bfloat16, "bf16": torch.bfloat16}
+
+
+def resolve_compute_dtype(value):
+    """config.yaml's `compute_dtype` ('float32' | 'bfloat16', also 'fp32' / 'bf16') or a torch dtype -> torch dtype.
+    None means float32.  The compute dtype covers the GAT branch and the G-sized dense maps; parameters and the
+    optimizer stay fp32, the SVGP m x m algebra fp64 (model/SpaDOT.py)."""
+    if value is None:
+        return torch.float32
+    if isinstance(value, torch.dtype):
+        if value not in (torch.float32, torch.bfloat16):
+            raise ValueError(f"compute_dtype {value} is not supported (float32 or bfloat16)")
+        return value
+    try:
+        return _COMPUTE_DTYPES[str(value).lower().replace("torch.", "")]
+    except KeyError:
+        raise ValueError(f"compute_dtype {value!r} is not supported (float32 or bfloat16)") from None
+
+
 def load_model_config(args):
     """yaml.safe_load of args.config, or of the packaged default (no merging, like the reference)."""
     path = args.config if getattr(args, "config", None) else os.path.join(

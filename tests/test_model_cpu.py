@@ -93,3 +93,30 @@ def test_gatconv_initialisation_bounds_follow_pyg_glorot():
     w = layer.lin.weight.detach()
     assert float(w.abs().max()) <= s_lin and float(w.abs().max()) > 0.99 * s_lin
     assert float(layer.bias.abs().max()) == 0.0
+
+
+def test_config_yaml_is_the_reference_schema_plus_three_documented_keys():
+    """The packaged config.yaml carries every key of the reference's SpaDOT/config.yaml with the same default
+    (values pinned here from /root/reference/SpaDOT/config.yaml:1-57, which does not travel) and exactly three keys of
+    its own; `compute_dtype` strings resolve to torch dtypes."""
+    import types
+    from spadot_amd.utils import _utils
+    cfg = _utils.load_model_config(types.SimpleNamespace(config=None))
+    ref = dict(maxiter=100, ot_epoch=50, batch_size=512, z_dim=20, n_clusters=10, seed=1993, lr=3e-4,
+               svgp_encoder_layers=[256, 64], gat_encoder_hidden=512, gat_attention_heads=4, decoder_layers=[64, 256],
+               kernel_type="Gaussian", kernel_scale=0.1, inducing_point_nums=1200, lambda1=0.1, beta1=1.0, beta2=1e-4,
+               knn_cutoff=6, max_neighbors=30, omiga1=0.1, omiga2=0.1, omiga3=1.0)
+    for k, v in ref.items():
+        assert cfg[k] == v, k
+    ot = dict(growth_iters=3, ot_epochs=10, epsilon=0.05, epsilon0=1, lambda1=0.1, lambda2=5.0, tau=1000, scaling_iter=3000,
+              inner_iter_max=50, tolerance=1e-8, max_iter=10000000, batch_size=5, extra_iter=1000, numItermax=1000000,
+              use_Py=False, use_C=True, profiling=False, method="waddington")
+    assert cfg["ot_config"] == ot
+    assert set(cfg) - set(ref) - {"ot_config"} == {"compute_dtype", "kmeans_backend", "knn_backend"}
+    assert (cfg["compute_dtype"], cfg["kmeans_backend"], cfg["knn_backend"]) == ("float32", "device", "sklearn")
+    assert _utils.resolve_compute_dtype(cfg["compute_dtype"]) is torch.float32
+    assert _utils.resolve_compute_dtype("bfloat16") is torch.bfloat16 and _utils.resolve_compute_dtype("bf16") is torch.bfloat16
+    assert _utils.resolve_compute_dtype(None) is torch.float32 and _utils.resolve_compute_dtype(torch.bfloat16) is torch.bfloat16
+    import pytest
+    with pytest.raises(ValueError):
+        _utils.resolve_compute_dtype("float16")

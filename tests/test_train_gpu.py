@@ -19,7 +19,7 @@ def _small_config():
     from spadot_amd.utils import _utils
     cfg = _utils.load_model_config(types.SimpleNamespace(config=None))
     cfg.update(maxiter=3, ot_epoch=1, batch_size=256, inducing_point_nums=60, svgp_encoder_layers=[32, 16],
-               gat_encoder_hidden=16, decoder_layers=[16, 32], n_clusters=4)
+               gat_encoder_hidden=16, decoder_layers=[16, 32], n_clusters=4, kmeans_backend="sklearn")
     cfg["ot_config"] = dict(cfg["ot_config"], ot_epochs=1)
     return cfg
 

@@ -22,11 +22,12 @@ for dt in (torch.bfloat16,):
     w = torch.randn((g.n, H * C), device=dev).to(dt)
     def fwd():
         return ops.gat_edge(h, a_s, a_d, bias, g, H, C, True, True)
-    for _ in range(30): out = fwd(); out.backward(w)
+    REPS = int(os.environ.get("GAT_BENCH_REPS", "100"))
+    for _ in range(min(30, REPS)): out = fwd(); out.backward(w)
     torch.cuda.synchronize()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     tf, tb = [], []
-    for _ in range(100):
+    for _ in range(REPS):
         ev[0].record(); out = fwd(); ev[1].record(); out.backward(w); ev[2].record()
         torch.cuda.synchronize()
         tf.append(ev[0].elapsed_time(ev[1])); tb.append(ev[1].elapsed_time(ev[2]))

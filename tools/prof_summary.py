@@ -1,20 +1,72 @@
 """Per-step kernel breakdown from a rocprofv3 --kernel-trace csv of `bench.py --leg train` (the last
-`steps` graph replays are taken as the timed region)."""
-import csv, glob, collections, sys
-d = sys.argv[1]; steps = int(sys.argv[2]) if len(sys.argv) > 2 else 40
-f = max(glob.glob(d + '/**/*kernel_trace.csv', recursive=True), key=__import__('os').path.getmtime)
-rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
-# the timed region: the last `steps` occurrences of the AdamW kernel close a step each
-idx = [i for i, r in enumerate(rows) if 'k_adamw' in r['Kernel_Name']]
-first = idx[-steps - 1] + 1
-sel = rows[first:idx[-1] + 1]
-wall = (int(sel[-1]['End_Timestamp']) - int(sel[0]['Start_Timestamp'])) / steps / 1e3
-c = collections.Counter(); t = collections.Counter()
-for r in sel:
-    n = r['Kernel_Name']; c[n] += 1; t[n] += int(r['End_Timestamp']) - int(r['Start_Timestamp'])
-tot = sum(t.values()) / steps / 1e3
-print(f"kernels/step {len(sel)/steps:.0f}  wall {wall:.0f} us/step  kernel sum {tot:.0f} us/step")
-small = sum(v for n, v in t.items() if v / c[n] < 12000) / steps / 1e3
-print(f"kernels < 12 us: {sum(c[n] for n in c if t[n]/c[n] < 12000)/steps:.0f}/step, {small:.0f} us/step")
-for n, v in sorted(t.items(), key=lambda x: -x[1])[:int(sys.argv[3]) if len(sys.argv) > 3 else 30]:
-    print(f"{c[n]/steps:6.1f}/step {v/c[n]/1e3:8.1f} us  {v/steps/1e3:7.1f} us/step  {n[:110]}")
+`steps` graph replays are taken as the timed region).
+usage: prof_summary.py <dir> [steps] [top_n] [families.json]
+With a fourth argument the per-family totals (us per step, launches per step) are also written as JSON: that file,
+committed under profiles/, is what bench.py's `roofline_train` block replays."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def family(name):
+    """Kernel family of one launch, by name (Tensile names: BBS/BSS/_B_ = bf16 inputs, _DB_ = fp64, _S_/SB = fp32)."""
+    n = name
+    if "k_gat_" in n:
+        return "gat_edge"
+    if "k_gemm_bf16" in n:
+        return "gemm_bf16_own"
+    if n.startswith("Cijk_") or n.startswith("Custom_Cijk") or "rocblas_gem" in n or "gemv" in n.lower():
+        if "_DB_" in n or "double" in n:
+            return "gemm_f64_library"
+        if "_BBS_" in n or "_BSS_" in n:          # bf16 operands (bf16 or fp32 result)
+            return "gemm_bf16_library"
+        return "gemm_f32_library"                 # "_S_B_Bias...": fp32 operands
+    if "k_spd_sweep" in n:
+        return "svgp_sweep"
+    if "k_adamw" in n or "k_sumsq" in n:
+        return "optimizer"
+    if "at::native" in n or "at_cuda_detail" in n or "elementwise_kernel" in n:
+        return "torch_glue"
+    return "own_small"
+
+
+def main():
+    d = sys.argv[1]
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+    top = int(sys.argv[3]) if len(sys.argv) > 3 else 30
+    f = max(glob.glob(d + '/**/*kernel_trace.csv', recursive=True), key=os.path.getmtime)
+    rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
+    # the timed region: the last `steps` occurrences of the AdamW kernel close a step each
+    idx = [i for i, r in enumerate(rows) if 'k_adamw' in r['Kernel_Name']]
+    first = idx[-steps - 1] + 1
+    sel = rows[first:idx[-1] + 1]
+    wall = (int(sel[-1]['End_Timestamp']) - int(sel[0]['Start_Timestamp'])) / steps / 1e3
+    c = collections.Counter(); t = collections.Counter()
+    for r in sel:
+        n = r['Kernel_Name']; c[n] += 1; t[n] += int(r['End_Timestamp']) - int(r['Start_Timestamp'])
+    tot = sum(t.values()) / steps / 1e3
+    print(f"kernels/step {len(sel)/steps:.0f}  wall {wall:.0f} us/step  kernel sum {tot:.0f} us/step")
+    small_n = sum(c[n] for n in c if t[n] / c[n] < 12000) / steps
+    small = sum(v for n, v in t.items() if v / c[n] < 12000) / steps / 1e3
+    print(f"kernels < 12 us: {small_n:.0f}/step, {small:.0f} us/step")
+    fam_t = collections.Counter(); fam_c = collections.Counter()
+    for n in t:
+        fam_t[family(n)] += t[n]; fam_c[family(n)] += c[n]
+    for k, v in sorted(fam_t.items(), key=lambda x: -x[1]):
+        print(f"family {k:20s} {fam_c[k]/steps:6.1f}/step {v/steps/1e3:8.1f} us/step")
+    for n, v in sorted(t.items(), key=lambda x: -x[1])[:top]:
+        print(f"{c[n]/steps:6.1f}/step {v/c[n]/1e3:8.1f} us  {v/steps/1e3:7.1f} us/step  {n[:110]}")
+    if len(sys.argv) > 4:
+        out = {"steps": steps, "wall_us_per_step": wall, "kernel_sum_us_per_step": tot, "launches_per_step": len(sel) / steps,
+               "under_12us": {"launches_per_step": small_n, "us_per_step": small},
+               "families": {k: {"us_per_step": fam_t[k] / steps / 1e3, "launches_per_step": fam_c[k] / steps} for k in fam_t},
+               "top_kernels": [{"name": n[:160], "per_step": c[n] / steps, "avg_us": v / c[n] / 1e3, "us_per_step": v / steps / 1e3}
+                               for n, v in sorted(t.items(), key=lambda x: -x[1])[:12]]}
+        json.dump(out, open(sys.argv[4], "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
