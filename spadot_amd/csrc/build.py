@@ -13,10 +13,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
-# source -> shared object
+# shared object -> translation units
 TARGETS = {
-    "ot_sinkhorn.hip": "libspadot_ot.so",
-    "model_kernels.hip": "libspadot_model.so",
+    "libspadot_ot.so": ["ot_sinkhorn.hip"],
+    "libspadot_model.so": ["model_kernels.hip", "gat_mfma.hip"],
 }
 
 # per-source extra flags.  ot_sinkhorn: the fused pass keeps its whole register budget (256 VGPRs) for the row band;
@@ -38,10 +38,20 @@ def build_all(force=False, verbose=True):
     inc = os.path.join(HERE, "..", "..", "include")
     headers = [os.path.join(inc, f) for f in os.listdir(inc)] if os.path.isdir(inc) else []
     built = []
-    for src, out in TARGETS.items():
-        s, o = os.path.join(HERE, src), os.path.join(HERE, out)
-        if force or _stale(s, o, headers):
-            cmd = [HIPCC] + FLAGS + EXTRA.get(src, []) + ["-o", o, s]
+    for out, srcs in TARGETS.items():
+        o = os.path.join(HERE, out)
+        paths = [os.path.join(HERE, s) for s in srcs]
+        if force or any(_stale(s, o, headers) for s in paths):
+            objs = []
+            for s, name in zip(paths, srcs):          # one object per translation unit, then one link
+                obj = s[:-4] + ".o"
+                if force or _stale(s, obj, headers):
+                    cmd = [HIPCC] + [f for f in FLAGS if f != "-shared"] + EXTRA.get(name, []) + ["-c", "-o", obj, s]
+                    if verbose:
+                        print(" ".join(cmd), flush=True)
+                    subprocess.check_call(cmd)
+                objs.append(obj)
+            cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", o] + objs
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)

@@ -163,3 +163,84 @@ def precompute_batches(edge_index, n_nodes, batch_size, device, hops=2, coords=N
         g = build_batch_graph(sub, n_id.size, device, seeds=seeds.size, tiers=tiers if hops == 2 else None)
         out.append(Batch(torch.from_numpy(n_id).to(device), g, seeds.size))
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Block plans for the matrix-core GAT edge kernels (csrc/model_kernels.hip: k_gat_agg / k_gat_edot).
+#
+# The edge phase of a GAT layer is out[i] = sum_j alpha[i, j] h[j]: per edge one 4 KB row gather.  Nodes that are
+# close in space share most of their neighbours, so a block of 32 consecutive targets (in Z-order) touches ~60-130
+# DISTINCT sources, not 32 x 31: the kernels therefore work on (32 rows) x (distinct columns of the block) tiles --
+# every distinct row is fetched once per block and the weighted sum becomes a small dense product
+# alpha_tile [32 x S] . h_rows [S x C] on the matrix cores, with zeros where there is no edge.
+# A plan is the host-side (one-off) description of those tiles.
+
+PLAN_ROWS = 32       # rows (targets, or sources on the transposed side) per block = the MFMA M dimension
+PLAN_KPAD = 32       # a block's column list is padded to a multiple of this (two 16-wide k-steps)
+
+
+class BlockPlan:
+    """rows  int32 [nb * 32]      row node id of every block slot (-1 = padding)
+       sptr  int32 [nb + 1]       start of each block's column list in `cols` (multiples of PLAN_KPAD)
+       cols  int32 [sptr[nb]]     distinct column node ids of the block, ascending; the padding repeats a valid id
+       cell  int32 [sptr[nb] * 32]  for chunk q = position // 16 and cell (r, kk) -> index r * 16 + kk:
+                                  alpha row (edge position in the by-target CSR) of edge (column slot 16 q + kk -> row r),
+                                  or -1 where the tile is zero
+       Built for a CSR in either direction: by target (rows = targets, cols = sources: forward and the target-side
+       backward) or transposed (rows = sources, cols = targets: the source-side backward)."""
+    __slots__ = ("rows", "sptr", "cols", "cell", "nb", "n_rows", "max_cols", "avg_cols")
+
+    def to(self, device):
+        p = BlockPlan()
+        for k in ("rows", "sptr", "cols", "cell"):
+            setattr(p, k, getattr(self, k).to(device))
+        p.nb, p.n_rows, p.max_cols, p.avg_cols = self.nb, self.n_rows, self.max_cols, self.avg_cols
+        return p
+
+
+def build_block_plan(rowptr, col, n_cols, order=None, eid=None):
+    """rowptr [n_rows + 1], col [E]: CSR by row; order: the rows in processing order (default 0..n_rows-1; pass a
+    spatial order -- consecutive rows should share columns); eid [E]: alpha row of every CSR position (default: the
+    position itself; the transposed CSR passes its eid_t).  Tensors on any device (the plan is built where they
+    live); returns None if the CSR holds a duplicate (row, column) pair (the tile has one cell per pair)."""
+    rowptr = torch.as_tensor(rowptr).long()
+    col = torch.as_tensor(col).long()
+    dev = col.device
+    n_rows = rowptr.numel() - 1
+    E = col.numel()
+    deg = rowptr[1:] - rowptr[:-1]
+    row_of = torch.repeat_interleave(torch.arange(n_rows, device=dev), deg)
+    if order is None:
+        order = torch.arange(n_rows, device=dev)
+    order = torch.as_tensor(order).long().to(dev)
+    pos = torch.empty(n_rows, dtype=torch.long, device=dev)
+    pos[order] = torch.arange(n_rows, device=dev)
+    nb = (n_rows + PLAN_ROWS - 1) // PLAN_ROWS
+    if torch.unique(row_of * n_cols + col).numel() != E:
+        return None
+    b_of = pos[row_of] // PLAN_ROWS
+    r_of = pos[row_of] % PLAN_ROWS
+    ukey, inv = torch.unique(b_of * n_cols + col, return_inverse=True)        # sorted by (block, column)
+    ub, uc = ukey // n_cols, ukey % n_cols
+    cnt = torch.bincount(ub, minlength=nb)
+    pc = (cnt + PLAN_KPAD - 1) // PLAN_KPAD * PLAN_KPAD
+    sptr = torch.zeros(nb + 1, dtype=torch.long, device=dev)
+    sptr[1:] = torch.cumsum(pc, 0)
+    first = torch.zeros(nb + 1, dtype=torch.long, device=dev)
+    first[1:] = torch.cumsum(cnt, 0)
+    slot = torch.arange(ukey.numel(), device=dev) - first[ub]
+    gpos = sptr[ub] + slot
+    last = uc[first[1:] - 1]                                                  # a valid column of every block (cnt >= 1)
+    cols = torch.repeat_interleave(last, pc)
+    cols[gpos] = uc
+    rows = torch.full((nb * PLAN_ROWS,), -1, dtype=torch.long, device=dev)
+    rows[:n_rows] = order
+    egpos = gpos[inv]                                                         # global column position of every edge
+    cell = torch.full((int(sptr[-1]) * PLAN_ROWS,), -1, dtype=torch.long, device=dev)
+    eid = torch.arange(E, device=dev) if eid is None else torch.as_tensor(eid).long().to(dev)
+    cell[(egpos // 16) * (16 * PLAN_ROWS) + r_of * 16 + egpos % 16] = eid
+    p = BlockPlan()
+    p.rows, p.sptr, p.cols, p.cell = rows.int(), sptr.int(), cols.int(), cell.int()
+    p.nb, p.n_rows = int(nb), int(n_rows)
+    p.max_cols, p.avg_cols = int(pc.max()), float(cnt.float().mean())
+    return p

@@ -416,27 +416,31 @@ class GraphedStepper:
     def _stages(self, tp_i, tp, bi, epoch):
         model, cfg, dd, opt = self.model, self.cfg, self.dd, self.opt
         batch = dd["dataloaders"][tp][bi]
-        if batch.y is not None:
-            x_b, y_b = batch.x, batch.y
-        else:
-            loc, Y, _ = dd["datasets"][tp]
-            x_b, y_b = loc[batch.n_id], Y[batch.n_id]
         b = batch.batch_size
         seeds = batch.n_id[:b]
+        cached = batch.y is not None
+        loc, Y, _ = dd["datasets"][tp]
         do_km = epoch >= 1
         do_ot = bool(epoch >= cfg["ot_epoch"] and tp_i != 0)
         P = self._param_groups()
         st = {}
 
+        # Batch inputs: the cached gathers (prepare_dataloader) live at fixed addresses.  Without the cache the rows
+        # are gathered INSIDE the stages, i.e. inside the captured graphs -- a gather made out here would hand the
+        # graphs the address of a temporary that is gone by the first replay.  Each branch gathers what it reads on
+        # its own stream: the GAT branch all n_sub rows, the SVGP branch (and the tail after it) the seeds' rows.
         def gat_fwd():
-            st["zg"] = model.branch_gat(y_b, batch.graph, b, taps=st if self.overlap else None)
+            y_all = batch.y if cached else Y[batch.n_id]
+            st["zg"] = model.branch_gat(y_all, batch.graph, b, taps=st if self.overlap else None)
 
         def svgp_fwd():
-            st["pm"], st["pv"], st["skl"] = model.branch_svgp(x_b, y_b, tp, b, batch_key=(tp, bi))
+            st["xs"] = batch.x[:b] if cached else loc[seeds]
+            st["ys"] = batch.y[:b] if cached else Y[seeds]
+            st["pm"], st["pv"], st["skl"] = model.branch_svgp(st["xs"], st["ys"], tp, b, batch_key=(tp, bi))
 
         def tail():
             leaves = [st[k].detach().requires_grad_(True) for k in ("zg", "pm", "pv", "skl")]
-            recon, gkl, align, z = model.tail(leaves[0], leaves[1], leaves[2], y_b, b)
+            recon, gkl, align, z = model.tail(leaves[0], leaves[1], leaves[2], st["ys"], b)
             km, ot = _cluster_terms(model, cfg, tp, tp_i, seeds, z, do_km, do_ot)
             elbo, losses = mix_losses(self.beta1_t, (recon, leaves[3], gkl, align, km, ot))
             st["g"] = opt.backward_partial(elbo, None, P["tail"], extra_inputs=leaves)

@@ -15,8 +15,10 @@ Stated tolerances (the reference is fp64 on the CPU):
   fp32 compute: loss terms rtol 1e-4, latent rtol 1e-4 / atol 1e-5 x scale, per-parameter gradient cosine >= 0.9999 and
                 relative L2 error <= 2e-3;
   bf16 compute (GAT branch and the two G-sized linears in bf16, fp32 accumulate): loss terms rtol 2e-2, latent
-                relative L2 <= 2e-2, per-parameter gradient cosine >= 0.98 and relative L2 error <= 0.2, gradient as
-                a whole (the direction AdamW follows) cosine >= 0.995.
+                relative L2 <= 2e-2, per-parameter gradient cosine >= 0.99 and relative L2 error <= 0.1, gradient as
+                a whole (the direction AdamW follows) cosine >= 0.995.  (Measured on the MI355X, round 2: loss terms
+                <= 3e-4, latent 1.6e-3, worst parameter cosine 0.998 / relative L2 0.063, whole gradient 0.9989;
+                fp32: loss terms <= 1e-7, worst parameter relative L2 4e-5.)
 """
 import json
 import os
@@ -94,8 +96,8 @@ def test_cfg3_training_step_matches_the_fp64_oracle(dtype):
     else:
         assert rep["max_rel_loss_err"] <= 2e-2, rep["loss_rel_err"]
         assert rep["latent_rel_l2_err"] <= 2e-2
-        assert rep["grad_cos_min"] >= 0.98, (rep["grad_cos_min_param"], rep["grad_cos_min"])
-        assert rep["grad_rel_l2_max"] <= 0.2, (rep["grad_rel_l2_max_param"], rep["grad_rel_l2_max"])
+        assert rep["grad_cos_min"] >= 0.99, (rep["grad_cos_min_param"], rep["grad_cos_min"])
+        assert rep["grad_rel_l2_max"] <= 0.1, (rep["grad_rel_l2_max_param"], rep["grad_rel_l2_max"])
         assert rep["grad_cos_global"] >= 0.995
     # a Linear bias in front of BatchNorm has a zero gradient in exact arithmetic: zero on the device as well
     assert len(rep["zero_grad_params"]) >= 2 and rep["zero_grad_dev_rel_norm_max"] <= 1e-6
