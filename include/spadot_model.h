@@ -231,6 +231,41 @@ int spadot_lloyd_step(const double *X, double *C, int n, int D, int K, int R, do
  * NearestNeighbors call of _Cal_Spatial_Net (_utils.py:66-75) when the coordinates already live in HBM. */
 int spadot_knn(const double *x, int n, int d, int kk, int *out, void *stream);
 
+/* ---------------------------------------------------------------- GAT edge phase on the matrix cores (bf16 rows)
+ * Same arithmetic as spadot_gat_forward / _backward_target / _backward_source (GATConv message passing of
+ * /root/reference/SpaDOT/model/encoder.py:41-58) for bf16 rows with C = 512 channels per head, H in
+ * {1, 2, 4, 8} and head concat, organised by BLOCK PLANS (spadot_amd/graph.py: BlockPlan): blocks of 32 rows, each
+ * with the list of its distinct columns (plan_cols, padded to a multiple of 32, offsets plan_sptr).  Every distinct
+ * source row of a block is fetched once (LDS-DMA) and the weighted sum is a dense product on v_mfma_f32_32x32x16_bf16.
+ * The weights travel as a dense image `acell` [chunk of 16 columns][head][hi | lo][512] of bf16 (weights = hi + lo, 16
+ * significant bits; zero where the tile has no edge; the 512 positions of a 32 x 16 tile are in MFMA fragment order),
+ * which the per-node kernels fill through cellq[e] = chunk * 512 + position of edge e.  The image must be ZERO before
+ * its first use and may then be reused: edges always overwrite the same cells.
+ *   spadot_gat_alpha             alpha[e, hd] = softmax over the incoming edges of each of the n_tgt targets, written as
+ *                                fp32 [E, H] and into the by-target plan's image (cellq = plan's cellq)
+ *   spadot_gat_aggregate         mode 0: out[row] = act?(sum_cols w x[col] + vec_a (bias));              plan by target
+ *                                mode 1: out[row] = sum_cols w x[col] + ds_src[row] vec_a + ds_dst[row] vec_b  (att_src,
+ *                                att_dst: the logits' own gradient path);                                plan by source
+ *   spadot_gat_edge_dot          g_pre = g_out * (act ? LeakyReLU'(out) : 1) (written), dz[e] = <g_pre[row], h[col]> through
+ *                                plan_cell [chunk][32 rows][16] -> edge position or -1
+ *   spadot_gat_softmax_backward  dz (raw d alpha) -> d logits in place, ds_dst[i] = sum over incoming edges; alpha also
+ *                                written into the by-SOURCE plan's image (cellq_s indexed by by-target edge position)
+ *   spadot_gat_ds_src            ds_src[j] = sum of dz over the outgoing edges of j (transposed CSR)
+ * spadot_gat_mfma_supported(dtype, H, C, max_cols) tells whether a plan whose longest column list is max_cols can run. */
+int spadot_gat_mfma_supported(int dtype, int H, int C, int max_cols);
+int spadot_gat_alpha(const float *s_src, const float *s_dst, const int *rowptr, const int *col, const int *cellq, int n_tgt,
+                     int H, float *alpha, void *acell, void *stream);
+int spadot_gat_aggregate(const void *x, int dtype, const void *acell, const int *plan_rows, const int *plan_sptr,
+                         const int *plan_cols, int nb, int max_cols, int H, int C, int mode, const float *vec_a,
+                         const float *vec_b, int act, const float *ds_src, const float *ds_dst, void *out, void *stream);
+int spadot_gat_edge_dot(const void *g_out, const void *out, const void *h, int dtype, const int *plan_rows,
+                        const int *plan_sptr, const int *plan_cols, const int *plan_cell, int nb, int max_cols, int H,
+                        int C, int act, void *g_pre, float *dz, void *stream);
+int spadot_gat_softmax_backward(const float *alpha, const float *s_src, const float *s_dst, const int *rowptr,
+                                const int *col, const int *cellq_s, int n_tgt, int H, float *dz, float *ds_dst,
+                                void *acell_s, void *stream);
+int spadot_gat_ds_src(const float *dz, const int *rowptr_t, const int *eid_t, int n, int H, float *ds_src, void *stream);
+
 /* ---------------------------------------------------------------- optimiser (one flat fp32 buffer)
  * sumsq[0] = sum g^2 over `count` gradients (deterministic two-stage reduction; scratch >= 2048 doubles). */
 int spadot_grad_sumsq(const float *grad, long long count, double *scratch, float *sumsq, void *stream);

@@ -105,7 +105,12 @@ def model_lib():
         "spadot_gat_backward_target": [vp, vp, vp, ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp],
         "spadot_gat_backward_source": [vp, ci, vp, vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, vp, vp],
         "spadot_gat_logits": [vp, ci, vp, vp, ci, ci, ci, vp, vp, vp],
-        "spadot_gat_att_grad": [vp, ci, vp, vp, ci, ci, ci, vp, ci, vp, vp, vp, ci, vp],
+        "spadot_gat_alpha": [vp, vp, vp, vp, vp, ci, ci, vp, vp, vp],
+        "spadot_gat_softmax_backward": [vp, vp, vp, vp, vp, vp, ci, ci, vp, vp, vp, vp],
+        "spadot_gat_ds_src": [vp, vp, vp, ci, ci, vp, vp],
+        "spadot_gat_mfma_supported": [ci, ci, ci, ci],
+        "spadot_gat_aggregate": [vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp, vp],
+        "spadot_gat_edge_dot": [vp, vp, vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp, vp],
         "spadot_kernel_matrix": [vp, vp, ci, ci, ci, cd, ci, ci, vp, vp],
         "spadot_spd_inverse_logdet": [vp, ci, ci, vp, vp, vp],
         "spadot_rowdot_forward": [vp, vp, ci, ci, ci, ci, vp, vp],

@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdint>
+#include <type_traits>
 
 #include "../../include/spadot_model.h"
 
@@ -32,12 +33,12 @@ constexpr float ACT_SLOPE = 0.01f;   // F.leaky_relu default (encoder.py:56-57)
 constexpr int ROWS = 32;             // rows per block (graph.py: PLAN_ROWS) = MFMA N (targets on the lanes)
 constexpr int KSTEP = 16;            // sources per chunk = MFMA K
 constexpr int NT = 256;              // threads per workgroup (4 waves)
-constexpr int MAX_COLS = 2048;       // longest column list a block may have (ids staged in LDS)
 
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 typedef short s4 __attribute__((ext_vector_type(4)));
 typedef short s8 __attribute__((ext_vector_type(8)));
 typedef float f16v __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));      // a native 16-byte value (HIP's uint4 class kept register sets in scratch)
 
 __device__ __forceinline__ float leaky(float z, float slope) { return z > 0.f ? z : slope * z; }
 __device__ __forceinline__ unsigned short bf16_bits(float x) { return __builtin_bit_cast(unsigned short, (__bf16)x); }
@@ -52,158 +53,244 @@ __device__ __forceinline__ int xcd_item(int total) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// alpha[e, hd] = softmax over the incoming edges e of target i of LeakyReLU_0.2(s_src[j] + s_dst[i])
-// (exp(e - max) / (sum + 1e-16): SURVEY App. A).  One thread per (target, head); neighbouring threads are the heads of
-// one target, so the index loads broadcast and the logit gathers are 16-byte runs.
+// Per-node kernels: one WAVE per node, lane = (edge slot, head) with head = lane % H (H in {1, 2, 4, 8}), so 64 / H
+// edges per pass and every per-edge array ([E, H] fp32) is read and written in whole 256-byte runs.  Reductions over
+// the edges of one head are butterflies over the lanes with equal lane % H.  The first four passes (64 * 4 / H edges:
+// every kNN graph here) keep their logits in registers; longer rows recompute them.
 // ------------------------------------------------------------------------------------------------------------------
+template <int H> __device__ __forceinline__ float head_max(float x) {
+#pragma unroll
+    for (int off = H; off < 64; off <<= 1) x = fmaxf(x, __shfl_xor(x, off, 64));
+    return x;
+}
+template <int H> __device__ __forceinline__ float head_sum(float x) {
+#pragma unroll
+    for (int off = H; off < 64; off <<= 1) x += __shfl_xor(x, off, 64);
+    return x;
+}
+
+// Element offset of edge cell `cq` (graph.py: BlockPlan.cellq) inside the dense weight image
+// acell [chunk][head][hi | lo][512] (bf16): cq = chunk * 512 + position inside the 32 x 16 tile in fragment order.
+__device__ __forceinline__ size_t acell_off(int cq, int H, int hd) {
+    return ((size_t)(cq >> 9) * H + hd) * 1024 + (size_t)(cq & 511);
+}
+__device__ __forceinline__ void acell_put(__bf16 *__restrict__ acell, size_t off, float a) {
+    const __bf16 hi = (__bf16)a;
+    acell[off] = hi;
+    acell[off + 512] = (__bf16)(a - (float)hi);
+}
+
+// alpha[e, hd] = softmax over the incoming edges e of target i of LeakyReLU_0.2(s_src[j] + s_dst[i])
+// (exp(e - max) / (sum + 1e-16): SURVEY App. A), also scattered as bf16 hi + lo into the plan's dense weight image.
+template <int H>
 __global__ __launch_bounds__(256) void k_gat_alpha(const float *__restrict__ s_src, const float *__restrict__ s_dst,
-                                                   const int *__restrict__ rowptr, const int *__restrict__ col, int n_tgt,
-                                                   int H, float *__restrict__ alpha) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= n_tgt * H) return;
-    const int i = idx / H, hd = idx - i * H;
-    const int p0 = rowptr[i], p1 = rowptr[i + 1];
+                                                   const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                   const int *__restrict__ cellq, int n_tgt, float *__restrict__ alpha,
+                                                   __bf16 *__restrict__ acell) {
+    constexpr int EP = 64 / H;
+    const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n_tgt) return;
+    const int hd = lane % H, es = lane / H;
+    const int p0 = rowptr[i], deg = rowptr[i + 1] - p0;
     const float sd = s_dst[(size_t)i * H + hd];
+    const int npass = (deg + EP - 1) / EP;
+    float ev[4];
     float m = -INFINITY;
-#pragma unroll 4
-    for (int p = p0; p < p1; p++) m = fmaxf(m, leaky(s_src[(size_t)col[p] * H + hd] + sd, ATT_SLOPE));
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const int p = p0 + t * EP + es;
+        ev[t] = -INFINITY;
+        if (t < npass && p < p0 + deg) ev[t] = leaky(s_src[(size_t)col[p] * H + hd] + sd, ATT_SLOPE);
+        m = fmaxf(m, ev[t]);
+    }
+    for (int t = 4; t < npass; t++) {
+        const int p = p0 + t * EP + es;
+        if (p < p0 + deg) m = fmaxf(m, leaky(s_src[(size_t)col[p] * H + hd] + sd, ATT_SLOPE));
+    }
+    m = head_max<H>(m);
     float ssum = 0.f;
-#pragma unroll 4
-    for (int p = p0; p < p1; p++) ssum += __expf(leaky(s_src[(size_t)col[p] * H + hd] + sd, ATT_SLOPE) - m);
-    const float inv = 1.f / (ssum + 1e-16f);
-#pragma unroll 4
-    for (int p = p0; p < p1; p++)
-        alpha[(size_t)p * H + hd] = __expf(leaky(s_src[(size_t)col[p] * H + hd] + sd, ATT_SLOPE) - m) * inv;
+#pragma unroll
+    for (int t = 0; t < 4; t++) ssum += __expf(ev[t] - m);          // exp(-inf) = 0 for the empty slots
+    for (int t = 4; t < npass; t++) {
+        const int p = p0 + t * EP + es;
+        if (p < p0 + deg) ssum += __expf(leaky(s_src[(size_t)col[p] * H + hd] + sd, ATT_SLOPE) - m);
+    }
+    const float inv = 1.f / (head_sum<H>(ssum) + 1e-16f);
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const int p = p0 + t * EP + es;
+        if (t < npass && p < p0 + deg) {
+            const float a = __expf(ev[t] - m) * inv;
+            alpha[(size_t)p * H + hd] = a;
+            acell_put(acell, acell_off(cellq[p], H, hd), a);
+        }
+    }
+    for (int t = 4; t < npass; t++) {
+        const int p = p0 + t * EP + es;
+        if (p < p0 + deg) {
+            const float a = __expf(leaky(s_src[(size_t)col[p] * H + hd] + sd, ATT_SLOPE) - m) * inv;
+            alpha[(size_t)p * H + hd] = a;
+            acell_put(acell, acell_off(cellq[p], H, hd), a);
+        }
+    }
 }
 
 // dz[e] holds the raw d(alpha[e]) on entry; on exit dz[e] = d(logit[e]) = alpha (d(alpha) - sum_k alpha_k d(alpha_k)) *
-// LeakyReLU'(z), and ds_dst[i] = sum_e dz[e].
+// LeakyReLU'(z) and ds_dst[i] = sum_e dz[e].  alpha is also scattered into the SOURCE-side plan's weight image (what the
+// backward product alpha^T g_pre reads).
+template <int H>
 __global__ __launch_bounds__(256) void k_gat_softmax_bwd(const float *__restrict__ alpha, const float *__restrict__ s_src,
                                                          const float *__restrict__ s_dst, const int *__restrict__ rowptr,
-                                                         const int *__restrict__ col, int n_tgt, int H,
-                                                         float *__restrict__ dz, float *__restrict__ ds_dst) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= n_tgt * H) return;
-    const int i = idx / H, hd = idx - i * H;
-    const int p0 = rowptr[i], p1 = rowptr[i + 1];
+                                                         const int *__restrict__ col, const int *__restrict__ cellq_s,
+                                                         int n_tgt, float *__restrict__ dz, float *__restrict__ ds_dst,
+                                                         __bf16 *__restrict__ acell_s) {
+    constexpr int EP = 64 / H;
+    const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n_tgt) return;
+    const int hd = lane % H, es = lane / H;
+    const int p0 = rowptr[i], deg = rowptr[i + 1] - p0;
     const float sd = s_dst[(size_t)i * H + hd];
+    const int npass = (deg + EP - 1) / EP;
+    float av[4], dv[4];
     float dsum = 0.f;
-#pragma unroll 4
-    for (int p = p0; p < p1; p++) dsum += alpha[(size_t)p * H + hd] * dz[(size_t)p * H + hd];
-    float dsd = 0.f;
-#pragma unroll 4
-    for (int p = p0; p < p1; p++) {
-        const size_t e = (size_t)p * H + hd;
-        const float z = s_src[(size_t)col[p] * H + hd] + sd;
-        const float d = alpha[e] * (dz[e] - dsum) * (z > 0.f ? 1.f : ATT_SLOPE);
-        dz[e] = d;
-        dsd += d;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const int p = p0 + t * EP + es;
+        av[t] = 0.f; dv[t] = 0.f;
+        if (t < npass && p < p0 + deg) { av[t] = alpha[(size_t)p * H + hd]; dv[t] = dz[(size_t)p * H + hd]; }
+        dsum += av[t] * dv[t];
     }
-    ds_dst[(size_t)i * H + hd] = dsd;
+    for (int t = 4; t < npass; t++) {
+        const int p = p0 + t * EP + es;
+        if (p < p0 + deg) dsum += alpha[(size_t)p * H + hd] * dz[(size_t)p * H + hd];
+    }
+    dsum = head_sum<H>(dsum);
+    float dsd = 0.f;
+    auto finish = [&](int p, float a, float da) __attribute__((always_inline)) {
+        const float z = s_src[(size_t)col[p] * H + hd] + sd;
+        const float d = a * (da - dsum) * (z > 0.f ? 1.f : ATT_SLOPE);
+        dz[(size_t)p * H + hd] = d;
+        dsd += d;
+        acell_put(acell_s, acell_off(cellq_s[p], H, hd), a);
+    };
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const int p = p0 + t * EP + es;
+        if (t < npass && p < p0 + deg) finish(p, av[t], dv[t]);
+    }
+    for (int t = 4; t < npass; t++) {
+        const int p = p0 + t * EP + es;
+        if (p < p0 + deg) finish(p, alpha[(size_t)p * H + hd], dz[(size_t)p * H + hd]);
+    }
+    dsd = head_sum<H>(dsd);
+    if (es == 0) ds_dst[(size_t)i * H + hd] = dsd;
+}
+
+// ds_src[j, hd] = sum of dz over the OUTGOING edges of j (transposed CSR; eid_t = position of the edge in the by-target order)
+template <int H>
+__global__ __launch_bounds__(256) void k_gat_dsrc(const float *__restrict__ dz, const int *__restrict__ rowptr_t,
+                                                  const int *__restrict__ eid_t, int n, float *__restrict__ ds_src) {
+    constexpr int EP = 64 / H;
+    const int lane = threadIdx.x & 63, j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= n) return;
+    const int hd = lane % H, es = lane / H;
+    const int p0 = rowptr_t[j], p1 = rowptr_t[j + 1];
+    float acc = 0.f;
+    for (int p = p0 + es; p < p1; p += EP) acc += dz[(size_t)eid_t[p] * H + hd];
+    acc = head_sum<H>(acc);
+    if (es == 0) ds_src[(size_t)j * H + hd] = acc;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// k_gat_agg: D^T [C x 32] = X^T [C x S] . A^T [S x 32] for one (block, head).
+// k_gat_agg: D^T [512 x 32] = X^T [512 x S] . A^T [S x 32] for one (block, head); C = 512 channels per head.
 //
-// LDS: a ring of 3 chunks of 16 source rows (row stride 2 C + 64 B: the transposed reads below are bank-conflict
-// free), 3 attention sub-tiles [32 rows x 16 sources] hi + lo (row stride 48 B), the block's column ids, 32 row scalars.
-// Pipeline (one barrier per chunk): chunk c's rows, cell indices and weights are requested 4 iterations before they are
-// used and wait in registers (3 rotating sets); iteration it writes chunk it + 1 into LDS, requests chunk it + 4,
-// barrier, multiplies chunk it.  MFMA operands: A operand = X^T fragment (lane: channel l & 31, sources 8 (l >> 5) ..+7)
-// by two ds_read_b64_tr_b16 of the row-major image; B operand = the weights (lane: row l & 31, same 8 sources).
-// The result has the row (target) on the lane and 16 channels in registers: four runs of four consecutive channels.
-// Epilogue through LDS (the ring is free by then) so that every global store is a whole 16-byte piece of a row.
+// Data path: every 16-source chunk is 16 rows x 1 KiB of X plus its 2 KiB weight tile (hi | lo, already in fragment
+// order: k_gat_alpha wrote it).  Both go global -> LDS by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave instruction,
+// no registers): per chunk every wave issues 4 row pieces (rows 4 wave .. 4 wave + 3) and one half-wave piece of the
+// weight tile, FIVE vector-memory operations, so "chunk c has landed" is s_waitcnt vmcnt(5) while chunk c + 1 is in
+// flight (vmcnt counts in issue order) and vmcnt(0) on the last chunk.  LDS: ring of 3 chunks (row stride 1088 B: the
+// transposed reads are bank-conflict free) + 3 weight tiles + the column ids.  One raw s_barrier per chunk:
+//     wait(chunk it) ; barrier ; request chunk it + 2 into the slot chunk it - 1 just left ; multiply chunk it
+// (__syncthreads() would drain the DMAs: its fence waits for vmcnt(0)).  No ordinary global load lives inside the loop
+// (hipcc waits vmcnt(0) for one while a DMA is in flight): the column ids are read from LDS.
+// MFMA operands: A operand = X^T fragment (lane: channel l & 31, sources 8 (l >> 5) .. + 7) by two ds_read_b64_tr_b16 of
+// the row-major image; B operand = the weights (lane: row l & 31, same 8 sources), hi then lo.  The result has the row
+// (target) on the lane and 16 channels in registers; it leaves through LDS so that every global store is a whole
+// 16-byte piece of a row.
 // MODE 0 (forward):         out = leaky?(D + bias)
-// MODE 1 (source backward): out = D + ds_src att_src + ds_dst att_dst, ds_src[row] = sum of dz over the row's cells
+// MODE 1 (source backward): out = D + ds_src att_src + ds_dst att_dst
 // ------------------------------------------------------------------------------------------------------------------
-template <int NTW> struct AggCfg {
-    static constexpr int C = 128 * NTW;                 // channels per head
-    static constexpr int PPR = C / 8;                   // 16-byte pieces per row
-    static constexpr int ROWB = 2 * C + 64;             // staged row stride (bytes), = 64 mod 256
-    static constexpr int CHUNKB = KSTEP * ROWB;
-    static constexpr int OUTB = 2 * C + 16;             // epilogue image row stride (bytes)
-    static constexpr int ATILEB = ROWS * 48;            // one hi (or lo) sub-tile
-    static constexpr int RING = 3;
-    static constexpr size_t lds_bytes() {
-        const size_t ring = (size_t)RING * CHUNKB, outimg = (size_t)ROWS * OUTB;
-        return (ring > outimg ? ring : outimg) + (size_t)RING * 2 * ATILEB + MAX_COLS * 4 + ROWS * 8;
-    }
-};
+namespace agg {
+constexpr int C = 512, PPR = C / 8;
+constexpr int ROWB = 2 * C + 64;                    // staged row stride (bytes), = 64 mod 256
+constexpr int CHUNKB = KSTEP * ROWB;                // 17408
+constexpr int OUTB = 2 * C + 16;                    // epilogue image row stride (bytes)
+constexpr int ATILEB = 2048;                        // hi (1 KiB) | lo (1 KiB)
+constexpr int RING = 3;
+constexpr int MAXC = 1024;                          // longest column list of a block
+constexpr int LDS_RING = RING * CHUNKB;             // 52224 >= 32 * OUTB
+constexpr int LDS_BYTES = LDS_RING + RING * ATILEB + MAXC * 4 + ROWS * 4;
+}  // namespace agg
 
-template <int NTW, int MODE>
+typedef __attribute__((address_space(3))) void *lds_ptr_t;
+
+template <int MODE>
 __global__ __launch_bounds__(NT, 2) void k_gat_agg(
-    const __bf16 *__restrict__ X, const float *__restrict__ alpha, const int *__restrict__ prow,
-    const int *__restrict__ sptr, const int *__restrict__ pcol, const int *__restrict__ cell, int nb, int H,
+    const __bf16 *__restrict__ X, const __bf16 *__restrict__ acell, const int *__restrict__ prow,
+    const int *__restrict__ sptr, const int *__restrict__ pcol, int nb, int H,
     const float *__restrict__ vec_a,      // MODE 0: bias [H*C]; MODE 1: att_src [H*C]
     const float *__restrict__ vec_b,      // MODE 1: att_dst [H*C]
-    int act, const float *__restrict__ dz, const float *__restrict__ ds_dst, float *__restrict__ ds_src,
-    __bf16 *__restrict__ out) {
-    using G = AggCfg<NTW>;
-    constexpr int C = G::C, PPR = G::PPR, ROWB = G::ROWB;
+    int act, const float *__restrict__ ds_src, const float *__restrict__ ds_dst, __bf16 *__restrict__ out) {
+    using namespace agg;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *ring = smem;
-    constexpr size_t ring_bytes = ((size_t)G::RING * G::CHUNKB > (size_t)ROWS * G::OUTB) ? (size_t)G::RING * G::CHUNKB : (size_t)ROWS * G::OUTB;
-    unsigned char *atile = smem + ring_bytes;                             // [RING][hi | lo][32 x 48 B]
-    int *sids = reinterpret_cast<int *>(atile + G::RING * 2 * G::ATILEB); // [MAX_COLS]
-    int *rid = sids + MAX_COLS;                                           // [32] row node ids
-    float *rsc = reinterpret_cast<float *>(rid + ROWS);                   // [32] row scalars (MODE 1: ds_src)
+    unsigned char *atile = smem + LDS_RING;
+    int *sids = reinterpret_cast<int *>(atile + RING * ATILEB);
+    int *rid = sids + MAXC;
 
     const int item = xcd_item(nb * H);
     if (item >= nb * H) return;
     const int b = item / H, hd = item - b * H;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int s0 = sptr[b], ncol = sptr[b + 1] - s0, nch = ncol / KSTEP;
     const int q0 = s0 / KSTEP;                                            // first global chunk of this block
-
     for (int k = tid; k < ncol; k += NT) sids[k] = pcol[s0 + k];
     if (tid < ROWS) rid[tid] = prow[b * ROWS + tid];
     __syncthreads();
 
-    // register sets of the chunks in flight
-    uint4 rows_r[3][NTW];
-    int2 cell_r[3];
-    float a_r[3][2], d_r[3][2];
-    float dzsum = 0.f;
     const size_t hoff = (size_t)hd * C;
     const size_t HC = (size_t)H * C;
+    const __bf16 *xlane = X + hoff + (size_t)lane * 8;                    // this lane's 16-byte piece of a row
 
-    auto request_cells = [&](int c, int u) {
-        cell_r[u] = reinterpret_cast<const int2 *>(cell + (size_t)(q0 + c) * (KSTEP * ROWS))[tid];
+    // LDS-DMA by inline asm (recipe of cdna_hip_programming.md 5.7): issued through the builtin, hipcc knows the DMA writes
+    // LDS and puts s_waitcnt vmcnt(0) in front of the next LDS read -- which drains the chunks that are meant to stay in
+    // flight.  The asm form is invisible to that bookkeeping; the counted waits below are ours.  M0 (LDS destination
+    // base) is saved and restored inside the statement.
+    auto dma16 = [&](const void *gsrc, unsigned lds_dst) __attribute__((always_inline)) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
     };
-    auto request_rows = [&](int c, int u) {
-        const int2 ce = cell_r[u];
-        a_r[u][0] = ce.x >= 0 ? alpha[(size_t)ce.x * H + hd] : 0.f;
-        a_r[u][1] = ce.y >= 0 ? alpha[(size_t)ce.y * H + hd] : 0.f;
-        if (MODE == 1) {      // (summed when the chunk is staged: an add here would wait for the load at once)
-            d_r[u][0] = ce.x >= 0 ? dz[(size_t)ce.x * H + hd] : 0.f;
-            d_r[u][1] = ce.y >= 0 ? dz[(size_t)ce.y * H + hd] : 0.f;
-        }
+    const unsigned lds0 = (unsigned)(size_t)smem;                         // LDS byte offset of the dynamic segment
+    auto request = [&](int c) __attribute__((always_inline)) {            // 5 vector-memory operations per wave
+        const unsigned slot = lds0 + (unsigned)(c % RING) * CHUNKB;
+        const int4 id4 = *reinterpret_cast<const int4 *>(sids + c * KSTEP + 4 * wave);      // rows 4 wave .. 4 wave + 3
+        const int ids[4] = {id4.x, id4.y, id4.z, id4.w};
 #pragma unroll
-        for (int m = 0; m < NTW; m++) {
-            const int pi = m * NT + tid, r = pi / PPR, pc = pi - r * PPR;
-            const int sid = sids[c * KSTEP + r];
-            rows_r[u][m] = *reinterpret_cast<const uint4 *>(X + (size_t)sid * HC + hoff + (size_t)pc * 8);
+        for (int m = 0; m < 4; m++) {
+            const int r = 4 * wave + m;
+            const int sid = __builtin_amdgcn_readfirstlane(ids[m]);
+            dma16(xlane + (size_t)sid * HC, __builtin_amdgcn_readfirstlane(slot + r * ROWB));
         }
-    };
-    auto stage = [&](int c, int u) {            // registers of chunk c -> LDS slot c % 3
-        unsigned char *slot = ring + (size_t)(c % G::RING) * G::CHUNKB;
-#pragma unroll
-        for (int m = 0; m < NTW; m++) {
-            const int pi = m * NT + tid, r = pi / PPR, pc = pi - r * PPR;
-            *reinterpret_cast<uint4 *>(slot + (size_t)r * ROWB + (size_t)pc * 16) = rows_r[u][m];
-        }
-        if (MODE == 1) dzsum += d_r[u][0] + d_r[u][1];
-        const float a0 = a_r[u][0], a1 = a_r[u][1];
-        const float h0 = bf16_to_f(bf16_bits(a0)), h1 = bf16_to_f(bf16_bits(a1));
-        unsigned char *at = atile + (size_t)(c % G::RING) * 2 * G::ATILEB;
-        const int r = tid >> 3, kk = (tid & 7) * 2;
-        *reinterpret_cast<unsigned *>(at + r * 48 + kk * 2) = pack2(h0, h1);
-        *reinterpret_cast<unsigned *>(at + G::ATILEB + r * 48 + kk * 2) = pack2(a0 - h0, a1 - h1);
+        if (lane < 32)       // half a wave: 512 B, quarter `wave` of the chunk's weight tile
+            dma16(acell + ((size_t)(q0 + c) * H + hd) * 1024 + wave * 256 + lane * 8,
+                  __builtin_amdgcn_readfirstlane(lds0 + LDS_RING + (unsigned)(c % RING) * ATILEB + wave * 512));
     };
 
-    f16v acc[NTW];
+    f16v acc[4];
 #pragma unroll
-    for (int t = 0; t < NTW; t++)
+    for (int t = 0; t < 4; t++)
 #pragma unroll
         for (int i = 0; i < 16; i++) acc[t][i] = 0.f;
 
@@ -211,77 +298,49 @@ __global__ __launch_bounds__(NT, 2) void k_gat_agg(
     // N-tile, lane 4 q + p of the group supplies row q, columns 4 p .. 4 p + 3; the two reads of a fragment are rows
     // 8 hh .. + 3 and 8 hh + 4 .. + 7
     const int hh = lane >> 5, g16 = (lane >> 4) & 1, qq = (lane & 15) >> 2, pp = lane & 3;
-    const int tr_off = (8 * hh + qq) * ROWB + (16 * g16 + 4 * pp) * 2;
+    const int tr_off = (8 * hh + qq) * ROWB + (16 * g16 + 4 * pp) * 2 + wave * 4 * 64;
+    const int a_off = (hh * 32 + (lane & 31)) * 16;      // weight fragment: piece hh * 32 + row (conflict-free b128 reads)
 
-    auto multiply = [&](int c) {
-        const unsigned char *slot = ring + (size_t)(c % G::RING) * G::CHUNKB;
-        const unsigned char *at = atile + (size_t)(c % G::RING) * 2 * G::ATILEB;
-        const bf8 a_hi = *reinterpret_cast<const bf8 *>(at + (lane & 31) * 48 + hh * 16);
-        const bf8 a_lo = *reinterpret_cast<const bf8 *>(at + G::ATILEB + (lane & 31) * 48 + hh * 16);
+    auto multiply = [&](int c) __attribute__((always_inline)) {
+        const unsigned char *slot = ring + (size_t)(c % RING) * CHUNKB + tr_off;
+        const unsigned char *at = atile + (c % RING) * ATILEB + a_off;
+        const bf8 a_hi = *reinterpret_cast<const bf8 *>(at);
+        const bf8 a_lo = *reinterpret_cast<const bf8 *>(at + 1024);
 #pragma unroll
-        for (int t = 0; t < NTW; t++) {
-            const int cb = (wave * NTW + t) * 32;
-            const unsigned char *base = slot + tr_off + cb * 2;
+        for (int t = 0; t < 4; t++) {
+            const unsigned char *base = slot + t * 64;
             const s4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4 __attribute__((address_space(3))) *)(base));
             const s4 x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4 __attribute__((address_space(3))) *)(base + 4 * ROWB));
-            const s8 xs = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
-            const bf8 xf = __builtin_bit_cast(bf8, xs);
+            const bf8 xf = __builtin_bit_cast(bf8, __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7));
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, a_hi, acc[t], 0, 0, 0);
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, a_lo, acc[t], 0, 0, 0);
         }
     };
 
-    // Pipeline.  Every chunk c goes through: request_cells(c) -> request_rows(c) (needs the cells: the weights are
-    // gathered through them) -> stage(c) (registers -> LDS) -> multiply(c), in iterations c - 5, c - 4, c - 1, c.
-    // Loads return in issue order, so inside an iteration the cells of chunk it + 5 are requested FIRST: waiting for
-    // them one iteration later then only waits for loads that are two iterations old.  Register sets rotate mod 3.
-    request_cells(0, 0);
-    if (1 < nch) request_cells(1, 1);
-    if (2 < nch) request_cells(2, 2);
-    request_rows(0, 0);
-    if (3 < nch) request_cells(3, 0);
-    if (1 < nch) request_rows(1, 1);
-    if (4 < nch) request_cells(4, 1);
-    if (2 < nch) request_rows(2, 2);
-    stage(0, 0);
-    if (3 < nch) request_rows(3, 0);
-#define AGG_ITER(U)                                                                        \
-    {                                                                                      \
-        const int it = it0 + (U);                                                          \
-        if (it < nch) {                                                                    \
-            if (it + 5 < nch) request_cells(it + 5, ((U) + 2) % 3);                        \
-            if (it + 1 < nch) stage(it + 1, ((U) + 1) % 3);                                \
-            if (it + 4 < nch) request_rows(it + 4, ((U) + 1) % 3);                         \
-            __syncthreads();                                                               \
-            multiply(it);                                                                  \
-        }                                                                                  \
+    if (0 < nch) request(0);
+    if (1 < nch) request(1);
+    for (int it = 0; it < nch; it++) {
+        if (it + 1 < nch) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (it + 2 < nch) request(it + 2);
+        multiply(it);
     }
-    for (int it0 = 0; it0 < nch; it0 += 3) {
-        AGG_ITER(0)
-        AGG_ITER(1)
-        AGG_ITER(2)
-    }
-#undef AGG_ITER
 
-    // ---- epilogue
-    if (MODE == 1) {       // ds_src[row] = sum of dz over the row's cells: 8 threads per row hold partial sums
-        float v = dzsum;
-        v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
-        if ((tid & 7) == 0) rsc[tid >> 3] = v;
-    }
-    __syncthreads();       // every wave is done with the ring; rsc visible
+    // ---- epilogue: accumulators -> bf16 image in LDS (the ring is free) -> whole 16-byte pieces to global memory
+    __syncthreads();
     {
         const int t = lane & 31;
         const int node = rid[t];
         float sa = 0.f, sb = 0.f;
-        if (MODE == 1) {
-            sa = rsc[t];
-            sb = node >= 0 ? ds_dst[(size_t)node * H + hd] : 0.f;
+        if (MODE == 1 && node >= 0) {
+            sa = ds_src[(size_t)node * H + hd];
+            sb = ds_dst[(size_t)node * H + hd];
         }
-        unsigned char *img = ring;
 #pragma unroll
-        for (int tt = 0; tt < NTW; tt++) {
-            const int cb = (wave * NTW + tt) * 32;
+        for (int tt = 0; tt < 4; tt++) {
+            const int cb = (wave * 4 + tt) * 32;
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 const int ch = cb + 8 * g + 4 * hh;
@@ -298,19 +357,18 @@ __global__ __launch_bounds__(NT, 2) void k_gat_agg(
                     v[0] += sa * va.x + sb * vb.x; v[1] += sa * va.y + sb * vb.y;
                     v[2] += sa * va.z + sb * vb.z; v[3] += sa * va.w + sb * vb.w;
                 }
-                *reinterpret_cast<uint2 *>(img + (size_t)t * G::OUTB + (size_t)ch * 2) = make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
+                *reinterpret_cast<uint2 *>(ring + (size_t)t * OUTB + (size_t)ch * 2) = make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
             }
         }
-        if (MODE == 1 && tid < ROWS && rid[tid] >= 0) ds_src[(size_t)rid[tid] * H + hd] = rsc[tid];
     }
     __syncthreads();
 #pragma unroll
-    for (int m = 0; m < 2 * NTW; m++) {
+    for (int m = 0; m < 8; m++) {
         const int pi = m * NT + tid, r = pi / PPR, pc = pi - r * PPR;
         const int node = rid[r];
         if (node >= 0)
             *reinterpret_cast<uint4 *>(out + (size_t)node * HC + hoff + (size_t)pc * 8) =
-                *reinterpret_cast<const uint4 *>(ring + (size_t)r * G::OUTB + (size_t)pc * 16);
+                *reinterpret_cast<const uint4 *>(ring + (size_t)r * OUTB + (size_t)pc * 16);
     }
 }
 
@@ -396,72 +454,77 @@ __global__ __launch_bounds__(NT, 4) void k_gat_edot(const __bf16 *__restrict__ g
 
 }  // namespace
 
+#define H_DISPATCH(KERNEL, ...)                                              \
+    do {                                                                     \
+        if (H == 1) hipLaunchKernelGGL(KERNEL<1>, __VA_ARGS__);              \
+        else if (H == 2) hipLaunchKernelGGL(KERNEL<2>, __VA_ARGS__);         \
+        else if (H == 4) hipLaunchKernelGGL(KERNEL<4>, __VA_ARGS__);         \
+        else hipLaunchKernelGGL(KERNEL<8>, __VA_ARGS__);                     \
+    } while (0)
+
 extern "C" {
 
-int spadot_gat_alpha(const float *s_src, const float *s_dst, const int *rowptr, const int *col, int n_tgt, int H,
-                     float *alpha, void *stream) {
-    if (n_tgt <= 0 || H <= 0) return -22;
-    const long long tot = (long long)n_tgt * H;
-    hipLaunchKernelGGL(k_gat_alpha, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, s_src, s_dst, rowptr,
-                       col, n_tgt, H, alpha);
+int spadot_gat_mfma_supported(int dtype, int H, int C, int max_cols) {
+    return dtype == SPADOT_DT_BF16 && C == agg::C && (H == 1 || H == 2 || H == 4 || H == 8) && max_cols >= 0 &&
+           max_cols <= agg::MAXC && max_cols % 32 == 0;
+}
+
+int spadot_gat_alpha(const float *s_src, const float *s_dst, const int *rowptr, const int *col, const int *cellq, int n_tgt,
+                     int H, float *alpha, void *acell, void *stream) {
+    if (n_tgt <= 0 || !(H == 1 || H == 2 || H == 4 || H == 8) || !cellq || !alpha || !acell) return -22;
+    H_DISPATCH(k_gat_alpha, dim3((unsigned)((n_tgt + 3) / 4)), dim3(256), 0, (hipStream_t)stream, s_src, s_dst, rowptr, col, cellq,
+               n_tgt, alpha, (__bf16 *)acell);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
 int spadot_gat_softmax_backward(const float *alpha, const float *s_src, const float *s_dst, const int *rowptr,
-                                const int *col, int n_tgt, int H, float *dz, float *ds_dst, void *stream) {
-    if (n_tgt <= 0 || H <= 0) return -22;
-    const long long tot = (long long)n_tgt * H;
-    hipLaunchKernelGGL(k_gat_softmax_bwd, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, alpha, s_src,
-                       s_dst, rowptr, col, n_tgt, H, dz, ds_dst);
+                                const int *col, const int *cellq_s, int n_tgt, int H, float *dz, float *ds_dst,
+                                void *acell_s, void *stream) {
+    if (n_tgt <= 0 || !(H == 1 || H == 2 || H == 4 || H == 8) || !cellq_s || !acell_s) return -22;
+    H_DISPATCH(k_gat_softmax_bwd, dim3((unsigned)((n_tgt + 3) / 4)), dim3(256), 0, (hipStream_t)stream, alpha, s_src, s_dst, rowptr,
+               col, cellq_s, n_tgt, dz, ds_dst, (__bf16 *)acell_s);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
-int spadot_gat_mfma_supported(int dtype, int C, int max_cols) {
-    return dtype == SPADOT_DT_BF16 && (C == 128 || C == 256 || C == 512) && max_cols > 0 && max_cols <= MAX_COLS && max_cols % 32 == 0;
+int spadot_gat_ds_src(const float *dz, const int *rowptr_t, const int *eid_t, int n, int H, float *ds_src, void *stream) {
+    if (n <= 0 || !(H == 1 || H == 2 || H == 4 || H == 8)) return -22;
+    H_DISPATCH(k_gat_dsrc, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dz, rowptr_t, eid_t, n, ds_src);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
-#define AGG_LAUNCH(NTW, MODE)                                                                                      \
+#define AGG_LAUNCH(MODE)                                                                                           \
     do {                                                                                                           \
-        auto kern = k_gat_agg<NTW, MODE>;                                                                          \
+        auto kern = k_gat_agg<MODE>;                                                                               \
         static bool attr_set = false;                                                                              \
-        const size_t lds = AggCfg<NTW>::lds_bytes();                                                               \
         if (!attr_set) {                                                                                           \
-            if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -5; \
+            if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, agg::LDS_BYTES) != hipSuccess) return -5; \
             attr_set = true;                                                                                       \
         }                                                                                                          \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, st_, (const __bf16 *)x, alpha, plan_rows, plan_sptr,    \
-                           plan_cols, plan_cell, nb, H, vec_a, vec_b, act, dz, ds_dst, ds_src, (__bf16 *)out);     \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), agg::LDS_BYTES, st_, (const __bf16 *)x, (const __bf16 *)acell, plan_rows, \
+                           plan_sptr, plan_cols, nb, H, vec_a, vec_b, act, ds_src, ds_dst, (__bf16 *)out);         \
     } while (0)
 
-int spadot_gat_aggregate(const void *x, int dtype, const float *alpha, const int *plan_rows, const int *plan_sptr,
-                         const int *plan_cols, const int *plan_cell, int nb, int max_cols, int H, int C, int mode,
-                         const float *vec_a, const float *vec_b, int act, const float *dz, const float *ds_dst,
-                         float *ds_src, void *out, void *stream) {
-    if (!spadot_gat_mfma_supported(dtype, C, max_cols) || nb <= 0 || H <= 0 || (mode != 0 && mode != 1)) return -22;
-    if (!x || !alpha || !plan_rows || !plan_sptr || !plan_cols || !plan_cell || !vec_a || !out) return -22;
-    if (mode == 1 && (!vec_b || !dz || !ds_dst || !ds_src)) return -22;
+int spadot_gat_aggregate(const void *x, int dtype, const void *acell, const int *plan_rows, const int *plan_sptr,
+                         const int *plan_cols, int nb, int max_cols, int H, int C, int mode, const float *vec_a,
+                         const float *vec_b, int act, const float *ds_src, const float *ds_dst, void *out, void *stream) {
+    if (!spadot_gat_mfma_supported(dtype, H, C, max_cols) || nb <= 0 || (mode != 0 && mode != 1)) return -22;
+    if (!x || !acell || !plan_rows || !plan_sptr || !plan_cols || !vec_a || !out) return -22;
+    if (mode == 1 && (!vec_b || !ds_src || !ds_dst)) return -22;
     hipStream_t st_ = (hipStream_t)stream;
     const unsigned grid = 8u * (unsigned)((nb * H + 7) / 8);
-    if (C == 512) { if (mode == 0) AGG_LAUNCH(4, 0); else AGG_LAUNCH(4, 1); }
-    else if (C == 256) { if (mode == 0) AGG_LAUNCH(2, 0); else AGG_LAUNCH(2, 1); }
-    else { if (mode == 0) AGG_LAUNCH(1, 0); else AGG_LAUNCH(1, 1); }
+    if (mode == 0) AGG_LAUNCH(0); else AGG_LAUNCH(1);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
 int spadot_gat_edge_dot(const void *g_out, const void *out, const void *h, int dtype, const int *plan_rows,
                         const int *plan_sptr, const int *plan_cols, const int *plan_cell, int nb, int max_cols, int H,
                         int C, int act, void *g_pre, float *dz, void *stream) {
-    if (!spadot_gat_mfma_supported(dtype, C, max_cols) || nb <= 0 || H <= 0) return -22;
+    if (!spadot_gat_mfma_supported(dtype, H, C, max_cols) || nb <= 0) return -22;
     if (!g_out || !h || !plan_rows || !plan_sptr || !plan_cols || !plan_cell || !g_pre || !dz || (act && !out)) return -22;
     hipStream_t st_ = (hipStream_t)stream;
     const unsigned grid = 8u * (unsigned)((nb * H + 7) / 8);
-#define EDOT_LAUNCH(NTW)                                                                                           \
-    hipLaunchKernelGGL(k_gat_edot<NTW>, dim3(grid), dim3(NT), 0, st_, (const __bf16 *)g_out, (const __bf16 *)out,    \
-                       (const __bf16 *)h, plan_rows, plan_sptr, plan_cols, plan_cell, nb, H, act, (__bf16 *)g_pre, dz)
-    if (C == 512) EDOT_LAUNCH(4);
-    else if (C == 256) EDOT_LAUNCH(2);
-    else EDOT_LAUNCH(1);
-#undef EDOT_LAUNCH
+    hipLaunchKernelGGL(k_gat_edot<4>, dim3(grid), dim3(NT), 0, st_, (const __bf16 *)g_out, (const __bf16 *)out,
+                       (const __bf16 *)h, plan_rows, plan_sptr, plan_cols, plan_cell, nb, H, act, (__bf16 *)g_pre, dz);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 

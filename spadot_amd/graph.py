@@ -55,7 +55,7 @@ def _csr_both(src, dst, n, n_tgt=None):
     return rowptr, col, rowptr_t, col_t, perm
 
 
-def build_batch_graph(edge_index, n, device, seeds=None, tiers=None):
+def build_batch_graph(edge_index, n, device, seeds=None, tiers=None, order_key=None, plans=False):
     """edge_index [2, E] (source, target) -> BatchGraph with GATConv's self-loop convention applied
     (existing self loops dropped, one per node appended: SURVEY App. A).
     seeds (optional int): also attach `.seed_graph`, the same graph with only the first `seeds` nodes as
@@ -86,6 +86,10 @@ def build_batch_graph(edge_index, n, device, seeds=None, tiers=None):
             g2 = BatchGraph(n, *dev(_csr_both(src[s2], dst[s2], n, n1)), n_tgt=n1)
             g3 = BatchGraph(n1, *dev(_csr_both(src[s3], dst[s3], n1, b)), n_tgt=b)
             g.layer_graphs = (g2, g3)
+            if plans:
+                attach_plans(g2, order_key)       # (the seeds-only last layer stays on the per-edge kernels)
+    if plans:                                     # plans=True / order_key: see attach_plans
+        attach_plans(g, order_key)
     return g
 
 
@@ -150,7 +154,7 @@ class Batch:
         self.y = None               # optional cache: expression rows in the compute dtype, K padded to 128
 
 
-def precompute_batches(edge_index, n_nodes, batch_size, device, hops=2, coords=None):
+def precompute_batches(edge_index, n_nodes, batch_size, device, hops=2, coords=None, plans=False):
     """All batches of one time point in loader order (consecutive seed blocks, last one partial).
     With `coords`, the nodes of each hop of every batch are stored in Z-order of their coordinates: the
     neighbours a GAT workgroup gathers are then close in memory and in launch order (L2 reuse per XCD).
@@ -160,7 +164,8 @@ def precompute_batches(edge_index, n_nodes, batch_size, device, hops=2, coords=N
     for s in range(0, n_nodes, batch_size):
         seeds = np.arange(s, min(n_nodes, s + batch_size))
         n_id, sub, tiers = induced_batch(edge_index, n_nodes, seeds, hops, order_key=key, return_tiers=True)
-        g = build_batch_graph(sub, n_id.size, device, seeds=seeds.size, tiers=tiers if hops == 2 else None)
+        g = build_batch_graph(sub, n_id.size, device, seeds=seeds.size, tiers=tiers if hops == 2 else None,
+                              order_key=None if key is None else key[n_id], plans=plans)
         out.append(Batch(torch.from_numpy(n_id).to(device), g, seeds.size))
     return out
 
@@ -185,17 +190,31 @@ class BlockPlan:
        cols  int32 [sptr[nb]]     distinct column node ids of the block, ascending; the padding repeats a valid id
        cell  int32 [sptr[nb] * 32]  for chunk q = position // 16 and cell (r, kk) -> index r * 16 + kk:
                                   alpha row (edge position in the by-target CSR) of edge (column slot 16 q + kk -> row r),
-                                  or -1 where the tile is zero
+                                  or -1 where the tile is zero (read by the target-side backward: d(alpha) scatter)
+       cellq int32 [E]            indexed by the edge's position in the BY-TARGET CSR: q * 512 + position of the edge's
+                                  cell inside the chunk's 32 x 16 weight tile in MFMA fragment order,
+                                  ((kk >> 3) * 32 + r) * 8 + (kk & 7) -- where the per-node kernels put alpha into the
+                                  dense weight image the aggregation kernel streams
        Built for a CSR in either direction: by target (rows = targets, cols = sources: forward and the target-side
        backward) or transposed (rows = sources, cols = targets: the source-side backward)."""
-    __slots__ = ("rows", "sptr", "cols", "cell", "nb", "n_rows", "max_cols", "avg_cols")
+    __slots__ = ("rows", "sptr", "cols", "cell", "cellq", "nb", "n_rows", "max_cols", "avg_cols", "_acell")
 
     def to(self, device):
         p = BlockPlan()
-        for k in ("rows", "sptr", "cols", "cell"):
+        for k in ("rows", "sptr", "cols", "cell", "cellq"):
             setattr(p, k, getattr(self, k).to(device))
         p.nb, p.n_rows, p.max_cols, p.avg_cols = self.nb, self.n_rows, self.max_cols, self.avg_cols
+        p._acell = {}
         return p
+
+    def weight_image(self, H):
+        """The plan's dense weight image [chunks][H][hi | lo][512] (bf16), zero where a tile has no edge.  Allocated once
+        per head count and reused by every call on this plan: edges always overwrite the same cells, the rest stays 0."""
+        img = self._acell.get(H)
+        if img is None:
+            img = torch.zeros(int(self.cols.numel()) // 16 * H * 1024, dtype=torch.bfloat16, device=self.cols.device)
+            self._acell[H] = img
+        return img
 
 
 def build_block_plan(rowptr, col, n_cols, order=None, eid=None):
@@ -238,9 +257,31 @@ def build_block_plan(rowptr, col, n_cols, order=None, eid=None):
     egpos = gpos[inv]                                                         # global column position of every edge
     cell = torch.full((int(sptr[-1]) * PLAN_ROWS,), -1, dtype=torch.long, device=dev)
     eid = torch.arange(E, device=dev) if eid is None else torch.as_tensor(eid).long().to(dev)
-    cell[(egpos // 16) * (16 * PLAN_ROWS) + r_of * 16 + egpos % 16] = eid
+    q, kk = egpos // 16, egpos % 16
+    cell[q * (16 * PLAN_ROWS) + r_of * 16 + kk] = eid
+    cellq = torch.empty(E, dtype=torch.long, device=dev)
+    cellq[eid] = q * 512 + ((kk >> 3) * 32 + r_of) * 8 + (kk & 7)
     p = BlockPlan()
-    p.rows, p.sptr, p.cols, p.cell = rows.int(), sptr.int(), cols.int(), cell.int()
+    p.rows, p.sptr, p.cols, p.cell, p.cellq = rows.int(), sptr.int(), cols.int(), cell.int(), cellq.int()
     p.nb, p.n_rows = int(nb), int(n_rows)
     p.max_cols, p.avg_cols = int(pc.max()), float(cnt.float().mean())
+    p._acell = {}
     return p
+
+
+def attach_plans(g, order_key=None):
+    """Block plans of a BatchGraph for the matrix-core edge kernels (built on the device the graph lives on).
+    order_key: one sortable value per node of the graph (e.g. the Morton key of its coordinates): blocks are runs of 32
+    rows in that order, so that the rows of a block share columns.  Without it blocks follow the node numbering."""
+    dev = g.col.device
+    n, nt = g.n, g.n_tgt
+    ot = os_ = None
+    if order_key is not None:
+        k = torch.as_tensor(np.asarray(order_key).astype(np.int64)).to(dev)
+        ot = torch.argsort(k[:nt], stable=True)
+        os_ = torch.argsort(k[:n], stable=True)
+    g.plan_t = build_block_plan(g.rowptr, g.col, n, order=ot)
+    g.plan_s = build_block_plan(g.rowptr_t, g.col_t, nt, order=os_, eid=g.eid_t)
+    if g.plan_t is None or g.plan_s is None:
+        g.plan_t = g.plan_s = None
+    return g

@@ -50,12 +50,16 @@ class BatchGraph:
         assert rowptr.numel() == self.n_tgt + 1 and rowptr_t.numel() == self.n + 1
         self.seed_graph = None      # optional: the same graph restricted to the seeds as targets (last GAT layer)
         self.layer_graphs = None    # optional: (g2, g3) of graph.build_batch_graph(tiers=...)
+        self.plan_t = None          # optional: graph.BlockPlan by target (matrix-core forward / target-side backward)
+        self.plan_s = None          # optional: graph.BlockPlan by source (matrix-core source-side backward)
 
     def to(self, device):
         g = BatchGraph(self.n, *(t.to(device) for t in (self.rowptr, self.col, self.rowptr_t, self.col_t, self.eid_t)),
                        n_tgt=self.n_tgt)
         g.seed_graph = self.seed_graph.to(device) if self.seed_graph is not None else None
         g.layer_graphs = tuple(t.to(device) for t in self.layer_graphs) if self.layer_graphs is not None else None
+        g.plan_t = self.plan_t.to(device) if self.plan_t is not None else None
+        g.plan_s = self.plan_s.to(device) if self.plan_s is not None else None
         return g
 
 
@@ -71,6 +75,88 @@ def _gat_att_scratch(device, floats):
         cur = torch.empty(floats, dtype=torch.float32, device=device)
         _gat_scratch[key] = cur
     return cur
+
+
+GAT_MFMA = [__import__("os").environ.get("SPADOT_GAT_MFMA", "1") == "1"]      # [False]: per-edge kernels everywhere (A/B runs)
+
+
+def _mfma_plans(h, graph, H, C, concat):
+    """The graph's block plans if the matrix-core edge kernels take this layer: bf16 rows, C = 512, H in {1, 2, 4, 8},
+    head concat, plans attached (graph.attach_plans) and every block's column list within the kernels' LDS budget."""
+    if not GAT_MFMA[0] or not concat or h.dtype != torch.bfloat16:
+        return None
+    pt, ps = getattr(graph, "plan_t", None), getattr(graph, "plan_s", None)
+    if pt is None or ps is None:
+        return None
+    lib = model_lib()
+    if not (lib.spadot_gat_mfma_supported(DT_BF16, H, C, pt.max_cols) and lib.spadot_gat_mfma_supported(DT_BF16, H, C, ps.max_cols)):
+        return None
+    return pt, ps
+
+
+class _GATEdgeMFMA(torch.autograd.Function):
+    """gat_edge on the matrix cores (csrc/gat_mfma.hip): logits, softmax per (target, head) written into the plan's dense
+    weight image, then per block of 32 targets one dense product weights . h_rows with every distinct source row
+    fetched once.  Backward: the mirror product for d(alpha) (k_gat_edot), softmax backward, and weights^T . g_pre on
+    the transposed plan."""
+
+    @staticmethod
+    def forward(ctx, h, att_src, att_dst, bias, graph, H, C, act, plans):
+        _need_cuda(h, att_src, att_dst, bias)
+        lib = model_lib()
+        pt, ps = plans
+        h = h.contiguous()
+        a_s = att_src.reshape(H, C).contiguous().float()
+        a_d = att_dst.reshape(H, C).contiguous().float()
+        bias_f = bias.contiguous().float()
+        n, nt = graph.n, graph.n_tgt
+        assert h.shape == (n, H * C), (h.shape, n, H, C)
+        dev = h.device
+        s_src = torch.empty((n, H), dtype=torch.float32, device=dev)
+        s_dst = torch.empty((n, H), dtype=torch.float32, device=dev)
+        _check(lib.spadot_gat_logits(_p(h), DT_BF16, _p(a_s), _p(a_d), n, H, C, _p(s_src), _p(s_dst), _stream()), "spadot_gat_logits")
+        alpha = torch.empty((graph.E, H), dtype=torch.float32, device=dev)
+        img = pt.weight_image(H)
+        _check(lib.spadot_gat_alpha(_p(s_src), _p(s_dst), _p(graph.rowptr), _p(graph.col), _p(pt.cellq), nt, H, _p(alpha), _p(img),
+                                    _stream()), "spadot_gat_alpha")
+        out = torch.empty((nt, H * C), dtype=h.dtype, device=dev)
+        _check(lib.spadot_gat_aggregate(_p(h), DT_BF16, _p(img), _p(pt.rows), _p(pt.sptr), _p(pt.cols), pt.nb, pt.max_cols, H, C, 0,
+                                        _p(bias_f), None, int(act), None, None, _p(out), _stream()), "spadot_gat_aggregate")
+        ctx.save_for_backward(h, s_src, s_dst, out, alpha, a_s, a_d)
+        ctx.graph, ctx.H, ctx.C, ctx.act, ctx.plans = graph, H, C, act, plans
+        ctx.bias_dtype, ctx.att_shape, ctx.att_dtype = bias.dtype, att_src.shape, att_src.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        lib = model_lib()
+        h, s_src, s_dst, out, alpha, a_s, a_d = ctx.saved_tensors
+        graph, H, C = ctx.graph, ctx.H, ctx.C
+        pt, ps = ctx.plans
+        n, nt = graph.n, graph.n_tgt
+        dev = h.device
+        g_out = g_out.contiguous().to(h.dtype)
+        g_pre = torch.empty((nt, H * C), dtype=h.dtype, device=dev)
+        dz = torch.empty((graph.E, H), dtype=torch.float32, device=dev)
+        ds_dst = (torch.empty if nt == n else torch.zeros)((n, H), dtype=torch.float32, device=dev)
+        _check(lib.spadot_gat_edge_dot(_p(g_out), _p(out), _p(h), DT_BF16, _p(pt.rows), _p(pt.sptr), _p(pt.cols), _p(pt.cell),
+                                       pt.nb, pt.max_cols, H, C, int(ctx.act), _p(g_pre), _p(dz), _stream()), "spadot_gat_edge_dot")
+        img = ps.weight_image(H)
+        _check(lib.spadot_gat_softmax_backward(_p(alpha), _p(s_src), _p(s_dst), _p(graph.rowptr), _p(graph.col), _p(ps.cellq), nt, H,
+                                               _p(dz), _p(ds_dst), _p(img), _stream()), "spadot_gat_softmax_backward")
+        ds_src = torch.empty((n, H), dtype=torch.float32, device=dev)
+        _check(lib.spadot_gat_ds_src(_p(dz), _p(graph.rowptr_t), _p(graph.eid_t), n, H, _p(ds_src), _stream()), "spadot_gat_ds_src")
+        dh = torch.empty_like(h)
+        _check(lib.spadot_gat_aggregate(_p(g_pre), DT_BF16, _p(img), _p(ps.rows), _p(ps.sptr), _p(ps.cols), ps.nb, ps.max_cols, H, C, 1,
+                                        _p(a_s), _p(a_d), 0, _p(ds_src), _p(ds_dst), _p(dh), _stream()), "spadot_gat_aggregate")
+        datt = torch.empty((3, H * C), dtype=torch.float32, device=dev)
+        floats = 3 * H * C * max(1, min((n + 15) // 16, 1024))
+        scratch = _gat_att_scratch(dev, floats)
+        _check(lib.spadot_gat_att_grad(_p(h), DT_BF16, _p(ds_src), _p(ds_dst), n, H, C, _p(scratch), floats,
+                                       _p(datt), ctypes.c_void_p(datt.data_ptr() + 4 * H * C), _p(g_pre), nt, _stream()),
+               "spadot_gat_att_grad")
+        return (dh, datt[0].view(ctx.att_shape).to(ctx.att_dtype), datt[1].view(ctx.att_shape).to(ctx.att_dtype),
+                datt[2].to(ctx.bias_dtype), None, None, None, None, None)
 
 
 class _GATEdge(torch.autograd.Function):
@@ -136,6 +222,9 @@ class _GATEdge(torch.autograd.Function):
 def gat_edge(h, att_src, att_dst, bias, graph, heads, channels, concat=True, act=False):
     """Everything of one GATConv layer after the dense map h = x W^T: attention logits, edge softmax,
     aggregation, bias, optional leaky_relu(0.01), head concat/mean.  att_src / att_dst: [1, H, C] parameters."""
+    plans = _mfma_plans(h, graph, heads, channels, concat) if h.is_cuda else None
+    if plans is not None:
+        return _GATEdgeMFMA.apply(h, att_src, att_dst, bias, graph, heads, channels, act, plans)
     return _GATEdge.apply(h, att_src, att_dst, bias, graph, heads, channels, concat, act)
 
 

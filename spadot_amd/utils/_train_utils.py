@@ -80,8 +80,11 @@ def prepare_dataloader(adata, model_config):
         print("The graph contains %d edges, %d cells." % (ei.shape[1] - n, n))
         Y = torch.as_tensor(np.ascontiguousarray(np.asarray(X[ix]))).to(device=device, dtype=store)
         datasets[tp] = (torch.as_tensor(loc[ix, :2]).to(device), Y, ix)
-        dataloaders[tp] = precompute_batches(ei, n, model_config["batch_size"], device, coords=spatial[ix])
-        graphs[tp] = build_batch_graph(ei, n, device)
+        # block plans for the matrix-core GAT edge kernels: bf16 rows only (fp32 compute keeps the per-edge kernels)
+        plans = store == torch.bfloat16 and model_config.get("gat_block_plans", True)
+        dataloaders[tp] = precompute_batches(ei, n, model_config["batch_size"], device, coords=spatial[ix], plans=plans)
+        from ..graph import morton_key
+        graphs[tp] = build_batch_graph(ei, n, device, order_key=morton_key(spatial[ix]), plans=plans)
     _cache_batch_inputs(dataloaders, datasets, model_config)
     return {"inducing_points": inducing_points_dict, "N_train": N_train_dict, "dataloaders": dataloaders,
             "datasets": datasets, "graphs": graphs}
