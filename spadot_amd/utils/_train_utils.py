@@ -357,6 +357,7 @@ class GraphedStepper:
         # every launch of the step is ours or a plain library GEMM (the SPD inverse has no library factorisation at
         # any number of inducing points: ops._spd_inverse_logdet_nograd), so the step is always capturable
         self.capturable = True
+        self.issue_main_first = os.environ.get("SPADOT_ISSUE_MAIN_FIRST", "1") == "1"
         self.version = getattr(model, "_state_version", 0)
 
     def _body(self, tp_i, tp, bi, epoch, with_update=True):
@@ -485,19 +486,34 @@ class GraphedStepper:
         beside it, and the all-reduce of the rest."""
         main = torch.cuda.current_stream()
         side = self.model._side_stream() if two_streams else main
+        # Issue order inside a pair: the GAT graph (main stream, the longer one) FIRST.  A graph launch costs the host
+        # ~2.5 us per node, and the graph launched second only starts once the first has been handed over: with the
+        # ~45-node SVGP graph in front, the main stream sat idle for 120 us (forward) and 190 us (backward) per step
+        # (rocprofv3 timeline, profiles/r02).  The side stream's wait on `main` is recorded before the GAT launch, so it
+        # covers the work in front of the pair, not the GAT graph itself.
         if two_streams:
             side.wait_stream(main)
-        with torch.cuda.stream(side):
-            fns[1]()
-        fns[0]()
+        if self.issue_main_first and two_streams:
+            fns[0]()
+            with torch.cuda.stream(side):
+                fns[1]()
+        else:
+            with torch.cuda.stream(side):
+                fns[1]()
+            fns[0]()
         if two_streams:
             main.wait_stream(side)
         res = fns[2]()
         if two_streams:
             side.wait_stream(main)
-        with torch.cuda.stream(side):
-            fns[3]()
-        fns[4]()
+        if self.issue_main_first and two_streams:
+            fns[4]()
+            with torch.cuda.stream(side):
+                fns[3]()
+        else:
+            with torch.cuda.stream(side):
+                fns[3]()
+            fns[4]()
         if two_streams:
             main.wait_stream(side)
         if len(fns) == 6:

@@ -59,6 +59,13 @@ def main():
         print(f"family {k:20s} {fam_c[k]/steps:6.1f}/step {v/steps/1e3:8.1f} us/step")
     for n, v in sorted(t.items(), key=lambda x: -x[1])[:top]:
         print(f"{c[n]/steps:6.1f}/step {v/c[n]/1e3:8.1f} us  {v/steps/1e3:7.1f} us/step  {n[:110]}")
+    if len(sys.argv) > 5:      # the launches of the last timed step, in start order (stream = queue id): who sits between whom
+        last = rows[idx[-2] + 1:idx[-1] + 1]
+        t0 = int(last[0]['Start_Timestamp'])
+        with open(sys.argv[5], "w") as fh:
+            for r in last:
+                fh.write(f"{(int(r['Start_Timestamp']) - t0) / 1e3:9.1f} us  +{(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:7.1f} us  "
+                         f"q{r.get('Queue_Id', '?')}  {r['Kernel_Name'][:150]}\n")
     if len(sys.argv) > 4:
         out = {"steps": steps, "wall_us_per_step": wall, "kernel_sum_us_per_step": tot, "launches_per_step": len(sel) / steps,
                "under_12us": {"launches_per_step": small_n, "us_per_step": small},
