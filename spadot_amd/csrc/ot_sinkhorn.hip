@@ -1109,6 +1109,9 @@ struct spadot_ot_solver {
     int fused_vpt = 0, fused_r = 0, fused_blocks = 0, fused_rows_per_block = 0;
     size_t fused_lds = 0;
     double sum_kbar_eps = -1.0;
+    long long cost_info[2] = {0, 0};   // last set_cost_from_latents: {path, candidates collected} (ot_cost.hip)
+    void *cost_ws = nullptr;           // its scratch (sample, bracket candidates, sort space), kept between calls
+    size_t cost_ws_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     size_t elt() const { return storage == SPADOT_F32 ? 4 : 8; }
 };
@@ -1508,7 +1511,7 @@ void spadot_ot_destroy(spadot_ot_solver *s) {
     SPADOT_ENTER
     if (!s) return;
     (void)hipStreamSynchronize(s->stream);
-    void *dev[] = {s->C, s->K, s->a, s->backup, s->red, s->part, s->rt, s->scal, s->flags};
+    void *dev[] = {s->C, s->K, s->a, s->backup, s->red, s->part, s->rt, s->scal, s->flags, s->cost_ws};
     for (void *p : dev) (void)hipFree(p);
     (void)hipHostFree(s->h_scal); (void)hipHostFree(s->h_flags);
     (void)hipEventDestroy(s->ev0); (void)hipEventDestroy(s->ev1);
@@ -1634,10 +1637,25 @@ double select_kth(spadot_ot_solver *s, const double *D, size_t n, size_t k) {
 }
 }  // namespace
 
+// ot_cost.hip: distances recomputed on the fly, exact median through a sampled bracket, no I x J temporary
+int spadot_cost_from_latents_impl(const double *x, const double *y, int d, int I, int J, int ld, int storage_f32, void *C,
+                                  int divide_by_median, hipStream_t st, void **ws_ptr, size_t *ws_bytes, double *denom_out,
+                                  long long *info_out);
+
 extern "C" int spadot_ot_set_cost_from_latents_dev(spadot_ot_solver *s, const double *x_dev,
                                                    const double *y_dev, int d, int divide_by_median) {
     SPADOT_ENTER
     if (!s || !x_dev || !y_dev || d < 1 || d > MAX_LATENT_DIM) return -22;
+    const char *legacy = getenv("SPADOT_OT_COST_LEGACY");       // round-1 path (materialised fp64 matrix + radix select): A/B runs
+    if (!(legacy && legacy[0] == '1')) {
+        const int rc = spadot_cost_from_latents_impl(x_dev, y_dev, d, s->I, s->J, s->ld, s->storage == SPADOT_F32, s->C,
+                                                     divide_by_median, s->stream, &s->cost_ws, &s->cost_ws_bytes, nullptr,
+                                                     s->cost_info);
+        if (rc >= 1000) throw hip_failure{(hipError_t)(rc - 1000), __FILE__, __LINE__, "spadot_cost_from_latents_impl"};
+        if (rc != 0) return rc;
+        s->sum_kbar_eps = -1.0;
+        return 0;
+    }
     const int I = s->I, J = s->J;
     const size_t n = (size_t)I * J;
     double *D = (double *)dmalloc(sizeof(double) * n);

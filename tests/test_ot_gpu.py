@@ -211,6 +211,32 @@ def test_cost_from_latents_matches_sklearn_arithmetic(OTSolver, oracle_ot, I, J)
     s.close()
 
 
+@pytest.mark.parametrize("I,J,storage", [(2300, 1900, "f64"), (2049, 2051, "f64"), (3000, 3000, "f32")])
+def test_cost_from_latents_sampled_bracket_is_the_exact_median(OTSolver, oracle_ot, I, J, storage):
+    """Above 2^22 entries the I x J distances are never stored: a sorted sample brackets the middle ranks, one pass
+    counts / collects, the collected entries give the EXACT np.median (even and odd element counts).  Mixture latents
+    (the real shape of the data: a multi-modal distance distribution)."""
+    rng = np.random.default_rng(I + J)
+    cen = rng.normal(size=(10, 20))
+    x = cen[rng.integers(0, 10, I)] + 0.3 * rng.normal(size=(I, 20))
+    y = cen[rng.integers(0, 10, J)] + 0.3 * rng.normal(size=(J, 20))
+    D = oracle_ot.sqeuclidean_cost(x, y)
+    med = np.median(D)
+    s = OTSolver(I, J, storage=storage)
+    s.set_cost_from_latents(x, y)
+    got = s.matrix("C")
+    if storage == "f64":
+        # the median itself is an order statistic of the device's own distances (fp64, other summation order than
+        # BLAS): identical up to the last bits of one entry
+        np.testing.assert_allclose(got, D / med, rtol=1e-12, atol=1e-14)
+    else:
+        np.testing.assert_allclose(got, D / med, rtol=3e-7, atol=1e-9)
+    assert abs(np.median(got) - 1.0) < (1e-12 if storage == "f64" else 1e-6)
+    s.set_cost_from_latents(x, y, divide_by_median=False)
+    np.testing.assert_allclose(s.matrix("C"), D, rtol=1e-12 if storage == "f64" else 3e-7, atol=1e-12)
+    s.close()
+
+
 @pytest.mark.parametrize("case", ["train10x10", "ragged7x13", "growth64x48"])
 def test_mirror_compute_transport_map(case, capsys):
     from spadot_amd.utils.OT_loss import ot_solvers
