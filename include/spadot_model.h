@@ -261,10 +261,16 @@ int spadot_gat_aggregate(const void *x, int dtype, const void *acell, const int 
 int spadot_gat_edge_dot(const void *g_out, const void *out, const void *h, int dtype, const int *plan_rows,
                         const int *plan_sptr, const int *plan_cols, const int *plan_cell, int nb, int max_cols, int H,
                         int C, int act, void *g_pre, float *dz, void *stream);
+/* (ds_dst has n_all >= n_tgt rows: the rows of nodes that are sources only are written as zeros) */
 int spadot_gat_softmax_backward(const float *alpha, const float *s_src, const float *s_dst, const int *rowptr,
-                                const int *col, const int *cellq_s, int n_tgt, int H, float *dz, float *ds_dst,
+                                const int *col, const int *cellq_s, int n_tgt, int n_all, int H, float *dz, float *ds_dst,
                                 void *acell_s, void *stream);
 int spadot_gat_ds_src(const float *dz, const int *rowptr_t, const int *eid_t, int n, int H, float *ds_src, void *stream);
+
+/* dst[t][r, 0:K[t]] = (bf16) src[t][r, 0:K[t]] for n <= 4 row-major matrices in one launch (fp32 weights -> their
+ * compute-dtype images; dst rows have Kp[t] >= K[t] elements, the padding is not touched; K, Kp multiples of 4). */
+int spadot_cast_rows_multi(const float *const *src, void *const *dst, const int *rows, const int *K, const int *Kp, int n,
+                           void *stream);
 
 /* ---------------------------------------------------------------- optimiser (one flat fp32 buffer)
  * sumsq[0] = sum g^2 over `count` gradients (deterministic two-stage reduction; scratch >= 2048 doubles). */

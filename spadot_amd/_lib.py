@@ -106,7 +106,7 @@ def model_lib():
         "spadot_gat_backward_source": [vp, ci, vp, vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, vp, vp],
         "spadot_gat_logits": [vp, ci, vp, vp, ci, ci, ci, vp, vp, vp],
         "spadot_gat_alpha": [vp, vp, vp, vp, vp, ci, ci, vp, vp, vp],
-        "spadot_gat_softmax_backward": [vp, vp, vp, vp, vp, vp, ci, ci, vp, vp, vp, vp],
+        "spadot_gat_softmax_backward": [vp, vp, vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp],
         "spadot_gat_ds_src": [vp, vp, vp, ci, ci, vp, vp],
         "spadot_gat_mfma_supported": [ci, ci, ci, ci],
         "spadot_gat_aggregate": [vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp, vp],
@@ -136,6 +136,7 @@ def model_lib():
         "spadot_kmeans_assign": [vp, vp, ci, ci, ci, ci, vp, vp],
         "spadot_lloyd_step": [vp, vp, ci, ci, ci, ci, cd, vp, vp, vp, vp, ci, vp],
         "spadot_colsum": [vp, ci, ci, vp, vp],
+        "spadot_cast_rows_multi": [vp, vp, vp, vp, vp, ci, vp],
         "spadot_knn": [vp, ci, ci, ci, vp, vp],
         "spadot_grad_sumsq": [vp, ll, vp, vp, vp],
         "spadot_clip_adamw_dev": [vp, vp, vp, vp, ll, cd, cd, cd, cd, cd, cd, vp, vp, vp, vp, vp, vp],

@@ -142,11 +142,14 @@ template <int H>
 __global__ __launch_bounds__(256) void k_gat_softmax_bwd(const float *__restrict__ alpha, const float *__restrict__ s_src,
                                                          const float *__restrict__ s_dst, const int *__restrict__ rowptr,
                                                          const int *__restrict__ col, const int *__restrict__ cellq_s,
-                                                         int n_tgt, float *__restrict__ dz, float *__restrict__ ds_dst,
-                                                         __bf16 *__restrict__ acell_s) {
+                                                         int n_tgt, int n_all, float *__restrict__ dz,
+                                                         float *__restrict__ ds_dst, __bf16 *__restrict__ acell_s) {
     constexpr int EP = 64 / H;
     const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= n_tgt) return;
+    if (i >= n_tgt) {        // nodes that are sources only (rows n_tgt .. n_all - 1): no incoming edge, zero gradient
+        if (i < n_all && lane < H) ds_dst[(size_t)i * H + lane] = 0.f;
+        return;
+    }
     const int hd = lane % H, es = lane / H;
     const int p0 = rowptr[i], deg = rowptr[i + 1] - p0;
     const float sd = s_dst[(size_t)i * H + hd];
@@ -478,11 +481,11 @@ int spadot_gat_alpha(const float *s_src, const float *s_dst, const int *rowptr, 
 }
 
 int spadot_gat_softmax_backward(const float *alpha, const float *s_src, const float *s_dst, const int *rowptr,
-                                const int *col, const int *cellq_s, int n_tgt, int H, float *dz, float *ds_dst,
+                                const int *col, const int *cellq_s, int n_tgt, int n_all, int H, float *dz, float *ds_dst,
                                 void *acell_s, void *stream) {
-    if (n_tgt <= 0 || !(H == 1 || H == 2 || H == 4 || H == 8) || !cellq_s || !acell_s) return -22;
-    H_DISPATCH(k_gat_softmax_bwd, dim3((unsigned)((n_tgt + 3) / 4)), dim3(256), 0, (hipStream_t)stream, alpha, s_src, s_dst, rowptr,
-               col, cellq_s, n_tgt, dz, ds_dst, (__bf16 *)acell_s);
+    if (n_tgt <= 0 || n_all < n_tgt || !(H == 1 || H == 2 || H == 4 || H == 8) || !cellq_s || !acell_s) return -22;
+    H_DISPATCH(k_gat_softmax_bwd, dim3((unsigned)((n_all + 3) / 4)), dim3(256), 0, (hipStream_t)stream, alpha, s_src, s_dst, rowptr,
+               col, cellq_s, n_tgt, n_all, dz, ds_dst, (__bf16 *)acell_s);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 

@@ -8,6 +8,7 @@
 // gradient uses the transposed CSR instead of scatter-add), so results are bitwise reproducible.
 #include <hip/hip_runtime.h>
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 
 #include "../../include/spadot_model.h"
@@ -1605,6 +1606,24 @@ __global__ void k_mix_losses_bwd(const float *__restrict__ g, const float *__res
     if (k < 6) g6[k] = g[0] * w[k];
 }
 
+// dst[r, 0:K] = (bf16) src[r, 0:K] for up to 4 matrices in ONE launch (the compute-dtype images of the fp32 weights:
+// one launch per stage instead of one per matrix); dst rows may be longer than K (zero padding written once, elsewhere).
+struct CastSeg { const float *src; __bf16 *dst; int rows, K, Kp; long long first; };     // first = start in the flat index space
+struct CastSegs { CastSeg s[4]; int n; long long total; };
+__global__ __launch_bounds__(256) void k_cast_rows_multi(CastSegs segs) {
+    for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < segs.total; q += (long long)gridDim.x * 256) {
+        int k = 0;
+#pragma unroll
+        for (int t = 1; t < 4; t++)
+            if (t < segs.n && q >= segs.s[t].first) k = t;
+        const CastSeg &S = segs.s[k];
+        const long long e = (q - S.first) * 4;                 // four consecutive elements of one row (K % 4 == 0)
+        const int r = (int)(e / S.K), c = (int)(e - (long long)r * S.K);
+        const float4 v = *reinterpret_cast<const float4 *>(S.src + (size_t)r * S.K + c);
+        *reinterpret_cast<uint2 *>(S.dst + (size_t)r * S.Kp + c) = make_uint2(bf16_pack2(v.x, v.y), bf16_pack2(v.z, v.w));
+    }
+}
+
 int pick_gat(int C, int &vec, int &niter, int dtype = -1) {
     // bf16 rows: 16-byte accesses (8 channels per lane) when a head's row is a multiple of 1 KiB
     if (dtype == SPADOT_DT_BF16 && C % 512 == 0 && C / 512 <= 2) { vec = 8; niter = C / 512; return 0; }
@@ -1708,6 +1727,25 @@ int spadot_gat_att_grad(const void *h, int dtype, const float *ds_src, const flo
     // scratch rows are [slab][src H*C | dst H*C (| g_pre column sums H*C)]: one column sum writes all outputs (adjacent)
     hipLaunchKernelGGL(k_colsum_parts, dim3((width + 63) / 64), dim3(1024), 0, st_, scratch, nslab, width, datt_src);
     (void)datt_dst;
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+int spadot_cast_rows_multi(const float *const *src, void *const *dst, const int *rows, const int *K, const int *Kp, int n,
+                           void *stream) {
+    if (n < 1 || n > 4 || !src || !dst || !rows || !K || !Kp) return -22;
+    CastSegs segs;
+    long long tot = 0;
+    for (int t = 0; t < n; t++) {
+        if (rows[t] <= 0 || K[t] <= 0 || K[t] % 4 != 0 || Kp[t] < K[t] || Kp[t] % 4 != 0) return -22;
+        if (((uintptr_t)src[t] & 15) != 0 || ((uintptr_t)dst[t] & 7) != 0) return -22;
+        segs.s[t] = CastSeg{src[t], (__bf16 *)dst[t], rows[t], K[t], Kp[t], tot};
+        tot += (long long)rows[t] * K[t] / 4;
+    }
+    for (int t = n; t < 4; t++) segs.s[t] = segs.s[0];
+    segs.n = n; segs.total = tot;
+    const long long want = (tot + 255) / 256;
+    const int nb = (int)(want < 4096 ? want : 4096);
+    hipLaunchKernelGGL(k_cast_rows_multi, dim3(nb), dim3(256), 0, (hipStream_t)stream, segs);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 

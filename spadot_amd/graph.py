@@ -152,6 +152,7 @@ class Batch:
         self.batch_size = int(batch_size)
         self.x = None               # optional cache: coordinates of the batch nodes [n_sub, 2]
         self.y = None               # optional cache: expression rows in the compute dtype, K padded to 128
+        self.y_seed32 = None        # optional cache: the seeds' expression rows in fp32 (reconstruction target)
 
 
 def precompute_batches(edge_index, n_nodes, batch_size, device, hops=2, coords=None, plans=False):

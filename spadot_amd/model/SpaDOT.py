@@ -112,15 +112,16 @@ class SpaDOT(nn.Module):
         bc = svgp.batch_constants(x[:b], key=batch_key)
         return svgp.elbo_finish(bc, svgp.elbo_start(bc, z_enc))
 
-    def tail(self, zg, p_m, p_v, y, batch_size, noise=None):
-        """Latent head + decoder + reconstruction: (recon, GAT_KL, alignment, final_latent)."""
+    def tail(self, zg, p_m, p_v, y, batch_size, noise=None, y_seed32=None):
+        """Latent head + decoder + reconstruction: (recon, GAT_KL, alignment, final_latent).  y_seed32: the seeds' rows
+        of y already in fp32 (cached batches keep them: no cast launch per step)."""
         b = batch_size
         Ls, Lg = self.SVGP_z_dim, self.GAT_z_dim
         noise = noise if noise is not None else getattr(self, "fixed_noise", None)
         eps = None if noise is None else torch.cat([noise[0][:b].float(), noise[1][:b].float()], dim=1)
         final_latent, GAT_KL, alignment_loss = latent_head(zg, p_m, p_v, eps, Ls, Lg, self._rng_state())
-        yb = y[:b, :self.input_dim]
-        recon_loss = sqerr_sum(yb.float(), self.decoder(final_latent), 1.0 / self.input_dim)
+        yb32 = y_seed32 if y_seed32 is not None else y[:b, :self.input_dim].float()
+        recon_loss = sqerr_sum(yb32, self.decoder(final_latent), 1.0 / self.input_dim)
         return recon_loss, GAT_KL, alignment_loss, final_latent
 
     def _rng_state(self):

@@ -11,7 +11,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..graph import build_batch_graph
-from ..ops import BatchGraph, bn_act, dense_cd, gat_edge, linear_bias
+from ..ops import BatchGraph, bn_act, cast_rows, dense_cd, gat_edge, linear_bias, weight_image
 
 
 class SVGPEncoder(nn.Module):
@@ -88,16 +88,16 @@ class GATConv(nn.Module):
         nn.init.uniform_(self.att_src, -bound, bound)
         nn.init.uniform_(self.att_dst, -bound, bound)
 
-    def forward(self, x, graph, act=False):
-        H, C = self.heads, self.out_channels
-        return self.edge(self.dense(x), graph, act)
+    def forward(self, x, graph, act=False, fresh=False):
+        return self.edge(self.dense(x, fresh), graph, act)
 
-    def dense(self, x):
-        """h = x W^T  [n, H*C] (MFMA GEMM in the compute dtype; x may be K-padded)."""
+    def dense(self, x, fresh=False):
+        """h = x W^T  [n, H*C] (MFMA GEMM in the compute dtype; x may be K-padded).  fresh: the compute-dtype image
+        of the weight is already current (GATEncoder casts the three layers' weights in one launch)."""
         cd = self.compute_dtype
         if cd == torch.float32:
             return F.linear(x[:, :self.in_channels].float(), self.lin.weight)
-        return dense_cd(x.to(cd), self.lin.weight, self)
+        return dense_cd(x.to(cd), self.lin.weight, self, fresh=fresh)
 
     def edge(self, h, graph, act=False):
         """Everything after the dense map (ops.gat_edge)."""
@@ -136,7 +136,15 @@ class GATEncoder(nn.Module):
         g3 = getattr(edge_index, "seed_graph", None) if rows is not None else None
         if not isinstance(edge_index, BatchGraph):
             edge_index = build_batch_graph(edge_index, x.shape[0], x.device)
-        h = self.gat1.dense(x)
+        # compute-dtype images of the three layers' weights: one cast launch for all of them
+        fresh = False
+        if self.gat1.compute_dtype == torch.bfloat16 and x.is_cuda:
+            HC = self.gat2.in_channels
+            cast_rows([(self.gat1.lin.weight.detach(), weight_image(self.gat1.lin.weight, x.shape[1], torch.bfloat16, self.gat1)),
+                       (self.gat2.lin.weight.detach(), weight_image(self.gat2.lin.weight, HC, torch.bfloat16, self.gat2)),
+                       (self.gat3.lin.weight.detach(), weight_image(self.gat3.lin.weight, HC, torch.bfloat16, self.gat3))])
+            fresh = True
+        h = self.gat1.dense(x, fresh)
         if after_first_dense is not None:
             after_first_dense()
         h = self.gat1.edge(h, edge_index, act=True)
@@ -144,14 +152,14 @@ class GATEncoder(nn.Module):
             taps["h1"] = h
         if lg is not None and lg[1].n_tgt == rows:
             # only what the seeds' rows of layer 3 depend on: layer 2 for seeds + hop 1, layer 3 for the seeds
-            h = self.gat2(h, lg[0], act=True)
-            h = self.gat3(h, lg[1], act=False)
+            h = self.gat2(h, lg[0], act=True, fresh=fresh)
+            h = self.gat3(h, lg[1], act=False, fresh=fresh)
         elif g3 is not None and g3.n_tgt == rows:
-            h = self.gat2(h, edge_index, act=True)
-            h = self.gat3(h, g3, act=False)          # edge phase for the seeds only: same rows, ~n/rows less work
+            h = self.gat2(h, edge_index, act=True, fresh=fresh)
+            h = self.gat3(h, g3, act=False, fresh=fresh)          # edge phase for the seeds only: same rows, ~n/rows less work
         else:
-            h = self.gat2(h, edge_index, act=True)
-            h = self.gat3(h, edge_index, act=False)
+            h = self.gat2(h, edge_index, act=True, fresh=fresh)
+            h = self.gat3(h, edge_index, act=False, fresh=fresh)
             if rows is not None:
                 h = h[:rows]
         return linear_bias(h.float(), self.GAT_fc.weight, self.GAT_fc.bias)

@@ -138,12 +138,12 @@ class _GATEdgeMFMA(torch.autograd.Function):
         g_out = g_out.contiguous().to(h.dtype)
         g_pre = torch.empty((nt, H * C), dtype=h.dtype, device=dev)
         dz = torch.empty((graph.E, H), dtype=torch.float32, device=dev)
-        ds_dst = (torch.empty if nt == n else torch.zeros)((n, H), dtype=torch.float32, device=dev)
+        ds_dst = torch.empty((n, H), dtype=torch.float32, device=dev)      # (rows >= nt zeroed by the softmax kernel)
         _check(lib.spadot_gat_edge_dot(_p(g_out), _p(out), _p(h), DT_BF16, _p(pt.rows), _p(pt.sptr), _p(pt.cols), _p(pt.cell),
                                        pt.nb, pt.max_cols, H, C, int(ctx.act), _p(g_pre), _p(dz), _stream()), "spadot_gat_edge_dot")
         img = ps.weight_image(H)
-        _check(lib.spadot_gat_softmax_backward(_p(alpha), _p(s_src), _p(s_dst), _p(graph.rowptr), _p(graph.col), _p(ps.cellq), nt, H,
-                                               _p(dz), _p(ds_dst), _p(img), _stream()), "spadot_gat_softmax_backward")
+        _check(lib.spadot_gat_softmax_backward(_p(alpha), _p(s_src), _p(s_dst), _p(graph.rowptr), _p(graph.col), _p(ps.cellq), nt, n,
+                                               H, _p(dz), _p(ds_dst), _p(img), _stream()), "spadot_gat_softmax_backward")
         ds_src = torch.empty((n, H), dtype=torch.float32, device=dev)
         _check(lib.spadot_gat_ds_src(_p(dz), _p(graph.rowptr_t), _p(graph.eid_t), n, H, _p(ds_src), _stream()), "spadot_gat_ds_src")
         dh = torch.empty_like(h)
@@ -233,17 +233,39 @@ def gat_edge(h, att_src, att_dst, bias, graph, heads, channels, concat=True, act
 _DIRECT_GRAD = [False]     # True only inside FlatAdamW.backward (a plain .backward() would ADD the returned view to itself)
 
 
+def cast_rows(pairs):
+    """[(src fp32 [R, K] contiguous, dst bf16 [R, Kp >= K] contiguous), ...] -> dst[:, :K] = src, ONE launch for up to
+    four matrices (csrc: k_cast_rows_multi) instead of one library cast launch each."""
+    ok = all(s_.dtype == torch.float32 and d_.dtype == torch.bfloat16 and s_.is_contiguous() and d_.is_contiguous()
+             and s_.dim() == 2 and s_.shape[1] % 4 == 0 and d_.shape[1] % 4 == 0 and s_.is_cuda for s_, d_ in pairs)
+    if not ok:
+        for s_, d_ in pairs:
+            d_[:, :s_.shape[1]].copy_(s_)
+        return
+    lib = model_lib()
+    for k0 in range(0, len(pairs), 4):
+        grp = pairs[k0:k0 + 4]
+        n = len(grp)
+        src = (ctypes.c_void_p * n)(*(s_.data_ptr() for s_, _ in grp))
+        dst = (ctypes.c_void_p * n)(*(d_.data_ptr() for _, d_ in grp))
+        rows = (ctypes.c_int * n)(*(s_.shape[0] for s_, _ in grp))
+        K = (ctypes.c_int * n)(*(s_.shape[1] for s_, _ in grp))
+        Kp = (ctypes.c_int * n)(*(d_.shape[1] for _, d_ in grp))
+        _check(lib.spadot_cast_rows_multi(src, dst, rows, K, Kp, n, _stream()), "spadot_cast_rows_multi")
+
+
 class _DenseCD(torch.autograd.Function):
     """h = x W^T with x already in the compute dtype (bf16) and possibly zero-padded along K (so that the
     G-sized GEMM gets a K that is a multiple of 128), W the fp32 parameter [N, K].  Backward writes the weight
     gradient in fp32 straight out of the GEMM (no bf16 round trip)."""
 
     @staticmethod
-    def forward(ctx, x, W, wbuf):
+    def forward(ctx, x, W, wbuf, fresh):
         N, K = W.shape
         Kp = x.shape[1]
         assert Kp >= K and wbuf.shape == (N, Kp) and wbuf.dtype == x.dtype
-        wbuf[:, :K].copy_(W)                       # cast into the persistent padded image (pad columns stay zero)
+        if not fresh:                              # (fresh: the caller has just cast W into wbuf, e.g. ops.cast_rows)
+            wbuf[:, :K].copy_(W)                   # cast into the persistent padded image (pad columns stay zero)
         ctx.save_for_backward(x, wbuf)
         ctx.K = K
         # FlatAdamW keeps W.grad as a view of its flat gradient buffer: the weight-gradient GEMM writes there
@@ -264,7 +286,7 @@ class _DenseCD(torch.autograd.Function):
                 dW = torch.mm(g.t(), x[:, :ctx.K], out_dtype=torch.float32, out=ctx.wgrad)
             else:
                 dW = torch.mm(g.t(), x[:, :ctx.K], out_dtype=torch.float32)
-        return dx, dW, None
+        return dx, dW, None, None
 
 
 def _small_weight_grad(g, x):
@@ -292,7 +314,12 @@ class _LinearBias(torch.autograd.Function):
         # compute-dtype operands, fp32 accumulate AND fp32 result (no rounding of the output to the compute dtype,
         # no cast launch after the GEMM); the images are kept for the backward pass.  Small dependent launches cost
         # ~5 us each inside a replayed graph, so this stage is counted in launches: 4 forward, 4 backward.
-        xc, Wc = x.to(cd), W.to(cd)
+        if cd == torch.bfloat16 and x.dtype == torch.float32 and x.shape[1] % 4 == 0:
+            xc = torch.empty(x.shape, dtype=cd, device=x.device)
+            Wc = torch.empty(W.shape, dtype=cd, device=W.device)
+            cast_rows([(x, xc), (W.detach().contiguous(), Wc)])        # both casts in one launch
+        else:
+            xc, Wc = x.to(cd), W.to(cd)
         ctx.save_for_backward(xc, Wc)
         return torch.mm(xc, Wc.t(), out_dtype=torch.float32).add_(b)
 
@@ -319,16 +346,22 @@ def linear_bias(x, W, b, compute_dtype=None):
     return _LinearBias.apply(x.contiguous(), W, b, compute_dtype)
 
 
-def dense_cd(x, W, holder, tag="_wpad"):
-    """x [n, Kp >= K] in the compute dtype, W fp32 [N, K]; `holder` (a module) keeps the padded compute-dtype
-    image of W between calls."""
+def weight_image(W, width, dtype, holder, tag="_wpad"):
+    """The persistent compute-dtype image [N, width >= K] of the fp32 weight W [N, K] kept on `holder` (a module);
+    one image per input width: training (padded) and inference (unpadded) keep theirs, addresses stay valid."""
     N, K = W.shape
-    tag = f"{tag}_{x.shape[1]}_{str(x.dtype).split('.')[-1]}"   # one image per input width: training (padded) and
-    buf = getattr(holder, tag, None)                            # inference (unpadded) keep theirs, addresses stay valid
-    if buf is None or buf.device != x.device:
-        buf = torch.zeros((N, x.shape[1]), dtype=x.dtype, device=x.device)
+    tag = f"{tag}_{width}_{str(dtype).split('.')[-1]}"
+    buf = getattr(holder, tag, None)
+    if buf is None or buf.device != W.device:
+        buf = torch.zeros((N, width), dtype=dtype, device=W.device)
         object.__setattr__(holder, tag, buf)       # plain attribute: not a parameter, not a buffer (state_dict unchanged)
-    return _DenseCD.apply(x, W, buf)
+    return buf
+
+
+def dense_cd(x, W, holder, tag="_wpad", fresh=False):
+    """x [n, Kp >= K] in the compute dtype, W fp32 [N, K]; `holder` (a module) keeps the padded compute-dtype
+    image of W between calls.  fresh=True: the image already holds the current W (cast by the caller)."""
+    return _DenseCD.apply(x, W, weight_image(W, x.shape[1], x.dtype, holder, tag), fresh)
 
 
 # ----------------------------------------------------------------------------- small-MLP stages
@@ -819,9 +852,7 @@ class FlatAdamW:
         pairs = [(p.grad, g) for p, g in zip(self.params, grads) if g is not None and g.data_ptr() != p.grad.data_ptr()]
         dst = [d for d, _ in pairs]
         src = [s for _, s in pairs]
-        for p, g in zip(self.params, grads):
-            if g is None:
-                p.grad.zero_()
+        self._zero_unreached(self.params, grads)
         torch._foreach_copy_(dst, src)
 
     def backward_partial(self, outputs, grad_outputs, params, extra_inputs=()):
@@ -836,12 +867,16 @@ class FlatAdamW:
             _DIRECT_GRAD[0] = False
         pg = grads[:len(params)]
         pairs = [(p.grad, g) for p, g in zip(params, pg) if g is not None and g.data_ptr() != p.grad.data_ptr()]
-        for p, g in zip(params, pg):
-            if g is None:
-                p.grad.zero_()
+        self._zero_unreached(params, pg)
         if pairs:
             torch._foreach_copy_([d for d, _ in pairs], [s for _, s in pairs])
         return grads[len(params):]
+
+    def _zero_unreached(self, params, grads):
+        """Slots of parameters the loss does not reach read zero afterwards (like backward() after zero_grad())."""
+        for p, g in zip(params, grads):
+            if g is None:
+                p.grad.zero_()
 
     def grad_norm_sq(self):
         """Device scalar: squared global gradient norm (deterministic reduction)."""

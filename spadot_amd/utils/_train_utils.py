@@ -115,6 +115,8 @@ def _cache_batch_inputs(dataloaders, datasets, model_config):
             else:
                 b.y = torch.zeros((b.n_id.numel(), Gp), dtype=Y.dtype, device=Y.device)
                 b.y[:, :G] = Y[b.n_id]
+            if Y.dtype != torch.float32:       # the seeds' rows once more in fp32: what the reconstruction term reads
+                b.y_seed32 = Y[b.n_id[:b.batch_size]].float()
     return True
 
 
@@ -444,7 +446,8 @@ class GraphedStepper:
 
         def tail():
             leaves = [st[k].detach().requires_grad_(True) for k in ("zg", "pm", "pv", "skl")]
-            recon, gkl, align, z = model.tail(leaves[0], leaves[1], leaves[2], st["ys"], b)
+            recon, gkl, align, z = model.tail(leaves[0], leaves[1], leaves[2], st["ys"], b,
+                                              y_seed32=getattr(batch, "y_seed32", None) if cached else None)
             km, ot = _cluster_terms(model, cfg, tp, tp_i, seeds, z, do_km, do_ot)
             elbo, losses = mix_losses(self.beta1_t, (recon, leaves[3], gkl, align, km, ot))
             st["g"] = opt.backward_partial(elbo, None, P["tail"], extra_inputs=leaves)
