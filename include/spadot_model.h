@@ -96,6 +96,11 @@ int spadot_kernel_matrix(const void *x, const void *z, int n, int m, int d, doub
  * registers + LDS (m <= 310; returns -34 beyond: the host splits larger matrices into blocks, spadot_amd/ops.py).  Replaces the
  * torch.linalg.inv / cholesky calls of svgp.py:50,75,87-88 on the L latent dimensions at once. */
 int spadot_spd_inverse_logdet(const double *A, int L, int m, double *Ainv, double *logdet, void *stream);
+/* Same for L matrices read as A[b mod Lsrc] + add0 (+ add1 for b >= Lsrc) (add0 / add1: m x m or NULL; Lsrc = 0: plain).
+ * The SVGP step stores G_l = c K_mn diag(1/var_l) K_nm once and inverts Sigma_l = G_l + (K_mm + jI) and
+ * Sigma_l + K_mm^2 / j (svgp.py:65-75 and the Sylvester form of :88) for every latent dimension in this one launch. */
+int spadot_spd_inverse_logdet2(const double *A, int Lsrc, int L, int m, const double *add0, const double *add1, double *Ainv,
+                               double *logdet, void *stream);
 
 /* Batched row-wise dot products: out[l, i] = sum_k A[l, i, k] * B[i, k]   (A [L,n,m], B [n,m]).
  * dtype F32 or F64. */
@@ -152,7 +157,7 @@ int spadot_ln_act_backward(const float *dy, const float *y, const float *x, cons
 int spadot_svgp_post_forward(const double *raw, const double *rd, const double *r, const double *Mr, const double *ld,
                              const double *sm, const double *mu, const double *var, const double *ktilde, int b, int L,
                              int m, double c, double kl_const, double b_over_N, double *p_m, double *mv, double *p_v,
-                             double *tr, double *out4, void *stream);
+                             double *tr, double *out4, float *skl32 /* may be NULL: SVGP_KL once more in fp32 */, void *stream);
 int spadot_svgp_post_backward(const float *g_skl, const double *out4, const double *G_pm, const double *G_pv,
                               const double *mu, const double *var, const double *mv, const double *tr, const double *p_m,
                               const double *p_v, const double *ktilde, const double *Mr, const double *M, int b, int L,
@@ -166,6 +171,13 @@ int spadot_svgp_grad_tail(const double *q1, const double *q2, const double *Kdt,
  * (encoder.py:31-34 + the first element-wise steps of svgp.py:62-70).  grad_tail's dz [b, 2L] fp32 is the matching
  * gradient (d/dlogvar = d/dvar * var); dmu/dvar may then be NULL. */
 int spadot_svgp_pre(const float *z, int b, int L, double *mu, double *var, double *w, double *muw, void *stream);
+/* ... and A[l, i, :] = K_nm[i, :] / var[i, l]  ([L, b, m] fp64) in the same launch */
+int spadot_svgp_pre2(const float *z, const double *Kn, int b, int L, int m, double *mu, double *var, double *w, double *muw,
+                     double *A, void *stream);
+/* The small products behind the inverse for all L latent dimensions in two launches: r_l = S_l t_l, Mr_l = M r_l,
+ * raw[:, l] = X2 r_l (X2 [rows2, m]) and sm_l = <S_l, M>; smpart: scratch of >= L * 4 * ceil(m / 4) doubles. */
+int spadot_svgp_mid(const double *S, const double *t, const double *M, const double *X2, int L, int m, int rows2,
+                    double *r, double *Mr, double *raw, double *sm, double *smpart, int smpart_doubles, void *stream);
 
 /* ---------------------------------------------------------------- loss tail of a training step
  * Single-workgroup kernels for the b x 20 / 10 x 10 arithmetic after the encoders (each replaces a few dozen

@@ -121,10 +121,13 @@ def model_lib():
         "spadot_bn_act_backward": [vp, vp, vp, ci, vp, vp, vp, vp, ci, ci, cd, vp, vp, vp, vp],
         "spadot_ln_act_forward": [vp, vp, vp, ci, ci, cd, cd, vp, vp, vp, vp],
         "spadot_ln_act_backward": [vp, vp, vp, vp, vp, vp, ci, ci, cd, vp, vp, vp, vp],
-        "spadot_svgp_post_forward": [vp] * 9 + [ci, ci, ci, cd, cd, cd] + [vp] * 6,
+        "spadot_svgp_post_forward": [vp] * 9 + [ci, ci, ci, cd, cd, cd] + [vp] * 7,
         "spadot_svgp_post_backward": [vp] * 13 + [ci, ci, ci, cd, cd] + [vp] * 8,
         "spadot_svgp_grad_tail": [vp] * 11 + [ci, ci, cd] + [vp] * 4,
         "spadot_svgp_pre": [vp, ci, ci, vp, vp, vp, vp, vp],
+        "spadot_svgp_pre2": [vp, vp, ci, ci, ci, vp, vp, vp, vp, vp, vp],
+        "spadot_svgp_mid": [vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp],
+        "spadot_spd_inverse_logdet2": [vp, ci, ci, ci, vp, vp, vp, vp, vp],
         "spadot_latent_head_forward": [vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, vp, vp],
         "spadot_latent_head_backward": [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp],
         "spadot_cluster_losses_forward": [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp],

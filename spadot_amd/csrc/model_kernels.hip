@@ -583,12 +583,18 @@ struct SweepTile {
 template <int TS, int RSMAX = SWEEP_RS>
 __global__ __launch_bounds__(SWEEP_NT) void k_spd_sweep(const double *__restrict__ A, int m, int T,
                                                         double *__restrict__ Ainv,
-                                                        double *__restrict__ logdet) {
+                                                        double *__restrict__ logdet, int Lsrc = 0,
+                                                        const double *__restrict__ add0 = nullptr,
+                                                        const double *__restrict__ add1 = nullptr) {
     extern __shared__ double colbuf[];          // 2 x (T*TS + 1) column buffers (+ 1/pivot), m pivots, 16 scratch, tile borders
     constexpr int CS = TS + ((TS & 1) ? 0 : 1);   // column-buffer stride per tile: odd, so lanes of consecutive tiles spread over the LDS banks
     const int mp = T * CS;
     double *piv = colbuf + 2 * (mp + 1);
-    const double *Am = A + (size_t)blockIdx.x * m * m;
+    // matrix b = A[b mod Lsrc] + add0 (+ add1 for b >= Lsrc): the SVGP step inverts Sigma_l = G_l + (K + jI) and
+    // Sigma_l + K^2/j for every latent dimension from ONE stored G (no copy / add launches in front of the sweep)
+    const int src = Lsrc > 0 ? (int)(blockIdx.x % (unsigned)Lsrc) : (int)blockIdx.x;
+    const bool hi = Lsrc > 0 && (int)blockIdx.x >= Lsrc;
+    const double *Am = A + (size_t)src * m * m;
     double *Om = Ainv + (size_t)blockIdx.x * m * m;
     const int t = threadIdx.x;
     const int ntiles = T * (T + 1) / 2;
@@ -602,12 +608,17 @@ __global__ __launch_bounds__(SWEEP_NT) void k_spd_sweep(const double *__restrict
 #pragma unroll
     for (int r = 0; r < TS; r++) {
         const int i = ti * TS + r;
-        const double *rowp = Am + (size_t)min(i, m - 1) * m + tj * TS;   // one base pointer per tile row
+        const size_t roff = (size_t)min(i, m - 1) * m + tj * TS;          // one base offset per tile row
+        const double *rowp = Am + roff;
 #pragma unroll
         for (int c = 0; c < TS; c++) {
             const int j = tj * TS + c;
             double v = (i == j) ? 1.0 : 0.0;                             // padding: identity
-            if (live && i < m && j < m) v = rowp[c];
+            if (live && i < m && j < m) {
+                v = rowp[c];
+                if (add0) v += add0[roff + c];
+                if (hi && add1) v += add1[roff + c];
+            }
             tile.set(r, c, v);
         }
     }
@@ -743,7 +754,8 @@ __global__ __launch_bounds__(1024) void k_svgp_post_fwd(const double *__restrict
                                                         const double *__restrict__ kt, int b, int L, int m, double c,
                                                         double kl_const, double b_over_N, double *__restrict__ p_m,
                                                         double *__restrict__ mv, double *__restrict__ p_v,
-                                                        double *__restrict__ tr, double *__restrict__ out4) {
+                                                        double *__restrict__ tr, double *__restrict__ out4,
+                                                        float *__restrict__ skl32) {
     __shared__ double sh[16];
     double l3 = 0.0, ce = 0.0, kl = 0.0;
     const int tot = b * L;
@@ -766,6 +778,7 @@ __global__ __launch_bounds__(1024) void k_svgp_post_fwd(const double *__restrict
     if (threadIdx.x == 0) {
         out4[0] = l3; out4[1] = ce; out4[2] = kl;
         out4[3] = -fabs(ce - (l3 - b_over_N * kl)) / L;
+        if (skl32) skl32[0] = (float)out4[3];
     }
 }
 
@@ -808,6 +821,70 @@ __global__ __launch_bounds__(256) void k_svgp_post_bwd(const float *__restrict__
 }
 
 // z [b, 2L] fp32 = SVGP_fc output (mu | logvar)  ->  mu, var = exp(logvar), w = 1/var, mu*w  (all [b, L] fp64)
+// k_svgp_pre plus A[l, i, :] = K_nm[i, :] / var[i, l] (the left factor of Sigma_l's batch term): one wave per (i, l)
+__global__ __launch_bounds__(256) void k_svgp_pre2(const float *__restrict__ z, const double *__restrict__ Kn, int b, int L,
+                                                   int m, double *__restrict__ mu, double *__restrict__ var,
+                                                   double *__restrict__ w, double *__restrict__ muw, double *__restrict__ A) {
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (e >= b * L) return;
+    const int i = e / L, l = e - i * L;
+    const double m_ = (double)z[(size_t)i * 2 * L + l];
+    const double v = (double)expf(z[(size_t)i * 2 * L + L + l]);       // torch.exp in fp32, like the encoder's own
+    const double wi = 1.0 / v;
+    if (lane == 0) { mu[e] = m_; var[e] = v; w[e] = wi; muw[e] = m_ / v; }
+    const double *kr = Kn + (size_t)i * m;
+    double *ar = A + ((size_t)l * b + i) * m;
+    for (int k = lane; k < m; k += 64) ar[k] = kr[k] * wi;
+}
+
+// The small products after the inverse, all latent dimensions at once (they were five library launches):
+//   mid1: r_l = S_l t_l and the row parts of <S_l, M>            (one wave per row of S_l)
+//   mid2: Mr_l = M r_l, raw[:, l] = X2 r_l, sm_l = <S_l, M>       (one wave per row of M / X2)
+__global__ __launch_bounds__(256) void k_svgp_mid1(const double *__restrict__ S, const double *__restrict__ t,
+                                                   const double *__restrict__ M, int m, double *__restrict__ r,
+                                                   double *__restrict__ smpart) {
+    const int l = blockIdx.y, i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    double ar = 0.0, as = 0.0;
+    if (i < m) {
+        const double *srow = S + ((size_t)l * m + i) * m, *mrow = M + (size_t)i * m, *tl = t + (size_t)l * m;
+#pragma unroll 4
+        for (int j = lane; j < m; j += 64) {
+            const double sv = srow[j];
+            ar = fma(sv, tl[j], ar);
+            as = fma(sv, mrow[j], as);
+        }
+    }
+    ar = wave_sum_d(ar); as = wave_sum_d(as);
+    if (lane == 0) {
+        if (i < m) r[(size_t)l * m + i] = ar;
+        smpart[(size_t)l * gridDim.x * 4 + blockIdx.x * 4 + (threadIdx.x >> 6)] = as;      // 0 for the rows past m
+    }
+}
+__global__ __launch_bounds__(256) void k_svgp_mid2(const double *__restrict__ M, const double *__restrict__ X2,
+                                                   const double *__restrict__ r, const double *__restrict__ smpart,
+                                                   int nparts, int m, int rows2, int L, double *__restrict__ Mr,
+                                                   double *__restrict__ raw, double *__restrict__ sm) {
+    const int l = blockIdx.y, q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const double *rl = r + (size_t)l * m;
+    if (q < m + rows2) {
+        const double *row = q < m ? M + (size_t)q * m : X2 + (size_t)(q - m) * m;
+        double acc = 0.0;
+#pragma unroll 4
+        for (int j = lane; j < m; j += 64) acc = fma(row[j], rl[j], acc);
+        acc = wave_sum_d(acc);
+        if (lane == 0) {
+            if (q < m) Mr[(size_t)l * m + q] = acc;
+            else raw[(size_t)(q - m) * L + l] = acc;
+        }
+    }
+    if (blockIdx.x == 0 && (threadIdx.x >> 6) == 0) {
+        double a = 0.0;
+        for (int k = lane; k < nparts; k += 64) a += smpart[(size_t)l * nparts + k];
+        a = wave_sum_d(a);
+        if (lane == 0) sm[l] = a;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_svgp_pre(const float *__restrict__ z, int b, int L, double *__restrict__ mu,
                                                   double *__restrict__ var, double *__restrict__ w,
                                                   double *__restrict__ muw) {
@@ -1791,8 +1868,9 @@ int spadot_kernel_matrix(const void *x, const void *z, int n, int m, int d, doub
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
-int spadot_spd_inverse_logdet(const double *A, int L, int m, double *Ainv, double *logdet, void *stream) {
-    if (L <= 0 || m <= 0) return -22;
+int spadot_spd_inverse_logdet2(const double *A, int Lsrc, int L, int m, const double *add0, const double *add1, double *Ainv,
+                               double *logdet, void *stream) {
+    if (L <= 0 || m <= 0 || Lsrc < 0 || Lsrc > L) return -22;
     hipStream_t st_ = (hipStream_t)stream;
     // smallest tile edge whose lower-triangular tile grid fits the workgroup: T <= 31 (T(T+1)/2 <= 512)
     const int TS = (m + 30) / 31;
@@ -1805,7 +1883,7 @@ int spadot_spd_inverse_logdet(const double *A, int L, int m, double *Ainv, doubl
     case N: {                                                                                                 \
         static bool attr_set = false;                                                                         \
         if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_spd_sweep<N>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; } \
-        hipLaunchKernelGGL(k_spd_sweep<N>, dim3(L), dim3(SWEEP_NT), lds, st_, A, m, T, Ainv, logdet);         \
+        hipLaunchKernelGGL(k_spd_sweep<N>, dim3(L), dim3(SWEEP_NT), lds, st_, A, m, T, Ainv, logdet, Lsrc, add0, add1);         \
     } break;
     switch (TS) {
         SWEEP_CASE(1) SWEEP_CASE(2) SWEEP_CASE(3) SWEEP_CASE(4) SWEEP_CASE(5) SWEEP_CASE(6) SWEEP_CASE(7)
@@ -1814,6 +1892,10 @@ int spadot_spd_inverse_logdet(const double *A, int L, int m, double *Ainv, doubl
     }
 #undef SWEEP_CASE
     return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+int spadot_spd_inverse_logdet(const double *A, int L, int m, double *Ainv, double *logdet, void *stream) {
+    return spadot_spd_inverse_logdet2(A, 0, L, m, nullptr, nullptr, Ainv, logdet, stream);
 }
 
 int spadot_rowdot_forward(const void *A, const void *B, int L, int n, int m, int dtype, void *out, void *stream) {
@@ -1918,10 +2000,27 @@ int spadot_ln_act_backward(const float *dy, const float *y, const float *x, cons
 int spadot_svgp_post_forward(const double *raw, const double *rd, const double *r, const double *Mr, const double *ld,
                              const double *sm, const double *mu, const double *var, const double *ktilde, int b, int L,
                              int m, double c, double kl_const, double b_over_N, double *p_m, double *mv, double *p_v,
-                             double *tr, double *out4, void *stream) {
+                             double *tr, double *out4, float *skl32, void *stream) {
     if (b <= 0 || L <= 0 || m <= 0) return -22;
     hipLaunchKernelGGL(k_svgp_post_fwd, dim3(1), dim3(1024), 0, (hipStream_t)stream, raw, rd, r, Mr, ld, sm, mu, var, ktilde,
-                       b, L, m, c, kl_const, b_over_N, p_m, mv, p_v, tr, out4);
+                       b, L, m, c, kl_const, b_over_N, p_m, mv, p_v, tr, out4, skl32);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+int spadot_svgp_pre2(const float *z, const double *Kn, int b, int L, int m, double *mu, double *var, double *w, double *muw,
+                     double *A, void *stream) {
+    if (b <= 0 || L <= 0 || m <= 0 || !Kn || !A) return -22;
+    hipLaunchKernelGGL(k_svgp_pre2, dim3((b * L + 3) / 4), dim3(256), 0, (hipStream_t)stream, z, Kn, b, L, m, mu, var, w, muw, A);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+int spadot_svgp_mid(const double *S, const double *t, const double *M, const double *X2, int L, int m, int rows2,
+                    double *r, double *Mr, double *raw, double *sm, double *smpart, int smpart_doubles, void *stream) {
+    if (L <= 0 || m <= 0 || rows2 <= 0 || !smpart) return -22;
+    const int gx = (m + 3) / 4, nparts = gx * 4;
+    if ((long long)L * nparts > smpart_doubles) return -22;
+    hipStream_t st_ = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_svgp_mid1, dim3(gx, L), dim3(256), 0, st_, S, t, M, m, r, smpart);
+    hipLaunchKernelGGL(k_svgp_mid2, dim3((m + rows2 + 3) / 4, L), dim3(256), 0, st_, M, X2, (const double *)r,
+                       (const double *)smpart, nparts, m, rows2, L, Mr, raw, sm);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 

@@ -47,13 +47,14 @@ class SpaDOT(nn.Module):
         self.kmeans_cluster_dict = {}
         self.kmeans_index_dict = {}
 
-    def forward(self, x, y, edge_index, tp, batch_size, noise=None, batch_key=None):
+    def forward(self, x, y, edge_index, tp, batch_size, noise=None, batch_key=None, y_seed32=None):
         """x: coordinates [n_sub, 2]; y: expression [n_sub, G] (or [n_sub, G'] with G' - G zero pad columns,
         see prepare_dataloader's batch cache); edge_index: BatchGraph (or [2, E] tensor);
         the first `batch_size` rows are the seeds.  Returns (recon, SVGP_KL, GAT_KL, alignment,
         final_latent) like SpaDOT.py:52-94.  `noise` = (eps_svgp, eps_gat), each [b, L], replaces the
         two torch.randn_like draws (SpaDOT.py:78,83) for parity tests; `batch_key` lets the SVGP cache
-        the coordinate-only constants of a recurring batch."""
+        the coordinate-only constants of a recurring batch; `y_seed32`: the seeds' rows of y in fp32 when the batch
+        keeps them (read by the SVGP encoder's first map and the reconstruction term instead of casting y[:b])."""
         b = batch_size
         svgp = self.svgp_dict[str(tp)]
         yb = y[:b, :self.input_dim]                 # y may carry zero pad columns (cached batch inputs)
@@ -73,7 +74,7 @@ class SpaDOT(nn.Module):
 
         def svgp_first_half():
             with torch.cuda.stream(s_svgp):
-                z_enc = self.SVGPEncoder.pre_head(y[:b])           # (mu | logvar); pad columns, if any, meet zero weights
+                z_enc = self.SVGPEncoder.pre_head(y_seed32 if y_seed32 is not None else y[:b])   # (mu | logvar); pad columns, if any, meet zero weights
                 state["bc"] = svgp.batch_constants(x[:b], key=batch_key)
                 state["started"] = svgp.elbo_start(state["bc"], z_enc)
 
@@ -95,7 +96,7 @@ class SpaDOT(nn.Module):
             t.record_stream(main)
         # both reparameterised samples (noise drawn in the kernel), GAT KL and the alignment term: one launch
         final_latent, GAT_KL, alignment_loss = latent_head(zg, p_m, p_v, eps, Ls, Lg, self._rng_state())
-        recon_loss = sqerr_sum(yb.float(), self.decoder(final_latent), 1.0 / self.input_dim)
+        recon_loss = sqerr_sum(y_seed32 if y_seed32 is not None else yb.float(), self.decoder(final_latent), 1.0 / self.input_dim)
         return recon_loss, SVGP_KL, GAT_KL, alignment_loss, final_latent
 
     # ---- the three parts of forward() on their own (GraphedStepper's staged mode replays them as separate graphs:
@@ -104,11 +105,13 @@ class SpaDOT(nn.Module):
         """GAT branch: (mu | logvar) of the seeds [b, 2 Lg]; taps: see GATEncoder.pre_head."""
         return self.GATEncoder.pre_head(y, edge_index, rows=batch_size, taps=taps)
 
-    def branch_svgp(self, x, y, tp, batch_size, batch_key=None):
-        """SVGP branch: posterior mean / variance at the seeds [b, Ls] (fp64) and SVGP_KL."""
+    def branch_svgp(self, x, y, tp, batch_size, batch_key=None, y_seed32=None):
+        """SVGP branch: posterior mean / variance at the seeds [b, Ls] (fp64) and SVGP_KL.  y_seed32: the seeds' rows in
+        fp32 when the batch keeps them (the encoder's first map then runs in fp32 straight from them: no weight-cast
+        launch in front of this latency-bound branch)."""
         b = batch_size
         svgp = self.svgp_dict[str(tp)]
-        z_enc = self.SVGPEncoder.pre_head(y[:b])
+        z_enc = self.SVGPEncoder.pre_head(y_seed32 if y_seed32 is not None else y[:b])
         bc = svgp.batch_constants(x[:b], key=batch_key)
         return svgp.elbo_finish(bc, svgp.elbo_start(bc, z_enc))
 

@@ -53,7 +53,7 @@ class SVGPEncoder(nn.Module):
         h = x
         for i in range(0, len(net), 3):
             lin, bn, act = net[i], net[i + 1], net[i + 2]
-            if i == 0 and self.compute_dtype != torch.float32:
+            if i == 0 and self.compute_dtype != torch.float32 and h.dtype != torch.float32:
                 h = dense_cd(h.to(self.compute_dtype), lin.weight, lin)
             else:
                 h = F.linear(h[:, :lin.in_features].float(), lin.weight)

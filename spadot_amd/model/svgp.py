@@ -19,7 +19,9 @@ import torch
 import torch.nn as nn
 
 from .._lib import model_lib
-from ..ops import _check, _p, _stream, elbo_reduce, kernel_matrix, rowdot, spd_inverse_logdet
+from ..ops import _SPLIT, _check, _p, _stream, elbo_reduce, kernel_matrix, rowdot, spd_inverse_logdet
+
+SWEEP_DIRECT_M = _SPLIT[0]      # up to here one sweep launch takes the matrices as they are (ops._spd_inverse_logdet_nograd)
 
 F64 = torch.float64
 
@@ -75,7 +77,23 @@ class _SVGPCore(torch.autograd.Function):
             m, c = rc.m, bc.c
             Kn = bc.K_nm
             mu, var, w, muw = (torch.empty((b, L), dtype=F64, device=z.device) for _ in range(4))
-            _check(model_lib().spadot_svgp_pre(_p(z), b, L, _p(mu), _p(var), _p(w), _p(muw), _stream()), "spadot_svgp_pre")
+            lib = model_lib()
+            if m <= SWEEP_DIRECT_M:
+                # one stored G_l = c K_mn diag(w_l) K_nm; the sweep adds (K + jI) -- and K^2/j for the second set of
+                # L matrices -- while it loads (no copy / add launches in front of the inverse: every short launch of
+                # this branch waits for a free slot beside the GAT branch's GEMMs)
+                A = torch.empty((L, b, m), dtype=F64, device=z.device)       # diag(w_l) K_nm, written by the pre kernel
+                _check(lib.spadot_svgp_pre2(_p(z), _p(Kn), b, L, m, _p(mu), _p(var), _p(w), _p(muw), _p(A), _stream()),
+                       "spadot_svgp_pre2")
+                G = torch.empty((L, m, m), dtype=F64, device=z.device)
+                torch.baddbmm(G, A.transpose(1, 2), Kn.unsqueeze(0).expand(L, b, m), beta=0.0, alpha=c, out=G)
+                t = muw.T @ Kn                                               # [L, m]
+                X = torch.empty((2 * L, m, m), dtype=F64, device=z.device)
+                ld = torch.empty(2 * L, dtype=F64, device=z.device)
+                _check(lib.spadot_spd_inverse_logdet2(_p(G), L, 2 * L, m, _p(rc.KjI), _p(rc.K2j), _p(X), _p(ld), _stream()),
+                       "spadot_spd_inverse_logdet2")
+                return mu, var, w, X, ld, t
+            _check(lib.spadot_svgp_pre(_p(z), b, L, _p(mu), _p(var), _p(w), _p(muw), _stream()), "spadot_svgp_pre")
             A = Kn.unsqueeze(0) * w.T.unsqueeze(2)                           # [L, b, m] = diag(w_l) K_nm
             buf = torch.empty((2 * L, m, m), dtype=F64, device=mu.device)
             torch.baddbmm(rc.KjI.expand(L, m, m), A.transpose(1, 2), Kn.unsqueeze(0).expand(L, b, m), alpha=c, out=buf[:L])
@@ -92,21 +110,28 @@ class _SVGPCore(torch.autograd.Function):
         X2 = bc.X2
         lib = model_lib()
         S = X[:L]
-        r = torch.bmm(S, t.unsqueeze(2)).squeeze(2)                          # [L, m]
-        raw = X2 @ r.T                                                       # [2b, L]
+        dev = mu.device
+        # r_l = S_l t_l, Mr_l = M r_l (M symmetric), raw = X2 r^T, sm_l = <S_l, M>: two launches for all of them
+        r = torch.empty((L, m), dtype=F64, device=dev)
+        Mr = torch.empty((L, m), dtype=F64, device=dev)
+        raw = torch.empty((2 * b, L), dtype=F64, device=dev)
+        sm = torch.empty(L, dtype=F64, device=dev)
+        nparts = (m + 3) // 4 * 4
+        smpart = torch.empty(L * nparts, dtype=F64, device=dev)
+        _check(lib.spadot_svgp_mid(_p(S), _p(t.contiguous()), _p(rc.M), _p(X2), L, m, 2 * b, _p(r), _p(Mr), _p(raw), _p(sm),
+                                   _p(smpart), L * nparts, _stream()), "spadot_svgp_mid")
         X2S = torch.matmul(X2, S)                                            # [L, 2b, m]
         rd = rowdot(X2S, X2)                                                 # [L, 2b]
-        Mr = r @ rc.M                                                        # [L, m]  (M symmetric)
-        sm = torch.mv(S.reshape(L, m * m), rc.M.reshape(m * m))              # <S_l, M>
-        p_m, mv, p_v, tr = (torch.empty((b, L), dtype=F64, device=mu.device) for _ in range(4))
-        out4 = torch.empty(4, dtype=F64, device=mu.device)
+        p_m, mv, p_v, tr = (torch.empty((b, L), dtype=F64, device=dev) for _ in range(4))
+        out4 = torch.empty(4, dtype=F64, device=dev)
+        skl32 = torch.empty(1, dtype=torch.float32, device=dev)
         _check(lib.spadot_svgp_post_forward(_p(raw), _p(rd), _p(r), _p(Mr), _p(ld), _p(sm), _p(mu), _p(var), _p(bc.ktilde),
                                             b, L, m, c, rc.logdet_K_f - rc.mlogj - m, b_over_N, _p(p_m), _p(mv), _p(p_v), _p(tr),
-                                            _p(out4), _stream()), "spadot_svgp_post_forward")
+                                            _p(out4), _p(skl32), _stream()), "spadot_svgp_post_forward")
         ctx.save_for_backward(mu, var, w, X, r, Mr, X2S, p_m, p_v, mv, tr, out4)
         ctx.bc, ctx.rc, ctx.bN = bc, rc, b_over_N
         ctx.mark_non_differentiable(out4)
-        return p_m, p_v, out4[3].float(), out4
+        return p_m, p_v, skl32[0], out4
 
     @staticmethod
     def backward(ctx, G_pm, G_pv, g_skl, _unused):

@@ -287,7 +287,8 @@ def forward_backward(model, model_config, dataloader_dict, tp_i, tp, bi, epoch, 
         x_b, y_b = loc[batch.n_id], Y[batch.n_id]
     seeds = batch.n_id[:batch.batch_size]
     recon, svgp_kl, gat_kl, align, z = model.forward(x=x_b, y=y_b, edge_index=batch.graph, tp=tp,
-                                                     batch_size=batch.batch_size, batch_key=(tp, bi), noise=noise)
+                                                     batch_size=batch.batch_size, batch_key=(tp, bi), noise=noise,
+                                                     y_seed32=batch.y_seed32 if batch.y is not None else None)
     if latent_out is not None:
         latent_out.append(z.detach())
     do_km = epoch >= 1
@@ -442,7 +443,8 @@ class GraphedStepper:
         def svgp_fwd():
             st["xs"] = batch.x[:b] if cached else loc[seeds]
             st["ys"] = batch.y[:b] if cached else Y[seeds]
-            st["pm"], st["pv"], st["skl"] = model.branch_svgp(st["xs"], st["ys"], tp, b, batch_key=(tp, bi))
+            st["pm"], st["pv"], st["skl"] = model.branch_svgp(st["xs"], st["ys"], tp, b, batch_key=(tp, bi),
+                                                              y_seed32=getattr(batch, "y_seed32", None) if cached else None)
 
         def tail():
             leaves = [st[k].detach().requires_grad_(True) for k in ("zg", "pm", "pv", "skl")]
