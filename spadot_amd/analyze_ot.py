@@ -47,3 +47,46 @@ def transition_tables(latents, labels, config=None, which="last", storage="f32",
         finally:
             solver.close()
     return out
+
+
+def write_transition_tables(output_dir, latents, labels, timepoints, prefix="", config=None, which="last", storage="f32",
+                            device="cuda:0", write_tmaps=False):
+    """The analyze stage's file outputs for the OT part (_analyze_utils.py:124-138) without anndata / wot:
+      {prefix}transition_table_{day}_{day+1}.csv / .npz   the aggregated OT matrix between the K-means domains of two
+                                                          consecutive time points (rows '<tp>_<cluster>' of the earlier one);
+                                                          days are the category codes of the sorted time points (:119)
+      OT/tmap_{day}_{day+1}.npz   (write_tmaps=True)      the spot-level transport map itself (fp32, N_t x N_{t+1}) -- what
+                                                          wot's compute_all_transport_maps(tmap_out=...) leaves under OT/
+      OT_g.txt                                            the growth vector fed to the last solve, one row per spot
+    tools/npz_to_h5ad.py turns the .npz tables into the .h5ad files the reference writes (in an environment with anndata).
+    Returns the list of tables."""
+    import os
+    os.makedirs(output_dir, exist_ok=True)
+    days = list(range(len(timepoints)))
+    tabs = []
+    growth_rows = []
+    for t in range(len(latents) - 1):
+        solver, infos = spot_transport(latents[t], latents[t + 1], config, which=which, storage=storage, device=device)
+        try:
+            la, lb = np.asarray(labels[t]), np.asarray(labels[t + 1])
+            ka, kb = int(la.max()) + 1, int(lb.max()) + 1
+            tab = solver.transition_table(la, lb, ka, kb).cpu().numpy()
+            rows = np.array([f"{timepoints[t]}_{c}" for c in range(ka)])
+            cols = np.array([f"{timepoints[t + 1]}_{c}" for c in range(kb)])
+            stem = os.path.join(output_dir, f"{prefix}transition_table_{days[t]}_{days[t + 1]}")
+            np.savez_compressed(stem + ".npz", X=tab, obs_names=rows, var_names=cols)
+            with open(stem + ".csv", "w") as fh:
+                fh.write("," + ",".join(cols.tolist()) + "\n")
+                for r, name in enumerate(rows.tolist()):
+                    fh.write(name + "," + ",".join(repr(float(v)) for v in tab[r]) + "\n")
+            growth_rows.append(solver.plan_rowsums() if which == "last" else np.ones(la.size))
+            if write_tmaps:
+                os.makedirs(os.path.join(output_dir, "OT"), exist_ok=True)
+                np.savez_compressed(os.path.join(output_dir, "OT", f"tmap_{days[t]}_{days[t + 1]}.npz"),
+                                    X=solver.plan("torch").float().cpu().numpy())
+            tabs.append(tab)
+        finally:
+            solver.close()
+    if growth_rows:
+        np.savetxt(os.path.join(output_dir, "OT_g.txt"), np.concatenate(growth_rows))
+    return tabs

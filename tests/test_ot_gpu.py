@@ -395,6 +395,34 @@ def test_transition_table_is_block_sum_of_reference_plan(OTSolver, oracle_ot):
         s.close()
 
 
+def test_analyze_stage_writers(tmp_path, oracle_ot):
+    """write_transition_tables leaves the analyze stage's OT outputs (_analyze_utils.py:124-138) as csv / npz: the tables
+    equal the block sums of the oracle's plan (last growth iteration, like wot), the row / column names are
+    '<time point>_<domain>', OT/ holds the spot-level maps, OT_g.txt one growth value per spot."""
+    from spadot_amd.analyze_ot import ANALYZE_OT_CONFIG, write_transition_tables
+    rng = np.random.default_rng(3)
+    cen = rng.normal(size=(5, 20))
+    lat = [cen[rng.integers(0, 5, n)] + 0.3 * rng.normal(size=(n, 20)) for n in (150, 130, 170)]
+    lab = [rng.integers(0, 4, 150), rng.integers(0, 5, 130), rng.integers(0, 3, 170)]
+    tabs = write_transition_tables(str(tmp_path), lat, lab, ["E10", "E11", "E12"], prefix="p_", storage="f64", write_tmaps=True)
+    assert [t.shape for t in tabs] == [(4, 5), (5, 3)]
+    for t, (a, b) in enumerate(((0, 1), (1, 2))):
+        z = np.load(tmp_path / f"p_transition_table_{a}_{b}.npz")
+        np.testing.assert_array_equal(z["X"], tabs[t])
+        assert z["obs_names"][0] == f"E1{a}_0" and z["var_names"][-1] == f"E1{b}_{tabs[t].shape[1] - 1}"
+        plan = oracle_ot.compute_transport_map(lat[a], lat[b], dict(ANALYZE_OT_CONFIG), all_growth_iters=True)
+        plan = plan[-1] if isinstance(plan, (list, tuple)) else plan
+        tm = np.load(tmp_path / "OT" / f"tmap_{a}_{b}.npz")["X"]
+        assert tm.shape == (lat[a].shape[0], lat[b].shape[0])
+        want = np.zeros(tabs[t].shape)
+        np.add.at(want, (lab[a][:, None], lab[b][None, :]), tm.astype(np.float64))
+        np.testing.assert_allclose(tabs[t], want, rtol=1e-5)
+        csv = (tmp_path / f"p_transition_table_{a}_{b}.csv").read_text().splitlines()
+        assert csv[0].split(",")[1] == f"E1{b}_0" and len(csv) == 1 + tabs[t].shape[0]
+    g = np.loadtxt(tmp_path / "OT_g.txt")
+    assert g.shape == (150 + 130,) and (g > 0).all()
+
+
 def test_spot_transport_growth_iterations_vs_oracle(oracle_ot):
     from spadot_amd import analyze_ot
     rng = np.random.default_rng(5)
