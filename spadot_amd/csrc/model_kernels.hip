@@ -1215,15 +1215,20 @@ __global__ __launch_bounds__(256) void k_adamw(float *__restrict__ p, const floa
 // Small-MLP stages: BatchNorm1d (training) + LeakyReLU, LayerNorm + LeakyReLU, each ONE launch forward and one
 // (LayerNorm: two) backward instead of the library's 4-5 and 3-4.  b rows <= a few thousand, F features <= 1024.
 // ------------------------------------------------------------------------------------------
-constexpr int BN_COLS = 16, BN_RG = 64, BN_NT = BN_COLS * BN_RG;      // 16 columns x 64 row lanes per workgroup (b = 512: 8 rows per thread)
+constexpr int BN_COLS = 16, BN_RG = 16, BN_NT = BN_COLS * BN_RG;      // 16 columns x 16 row lanes: 256-thread workgroups.  These
+// launches run on the side stream beside the GAT branch's GEMMs, whose waves fill the register files: a new workgroup
+// starts when a GEMM workgroup retires, and a 1024-thread one (64 row lanes, 30 % faster on an idle GPU) needs a whole
+// compute unit to drain first -- it sat ~100 us in the queue (rocprofv3 timeline, profiles/r02)
+constexpr int LN_RG = 64, LN_NT = BN_COLS * LN_RG;                    // the LayerNorm column pass runs alone on the main stream
 
+template <int RG = BN_RG>
 __device__ __forceinline__ float bn_col_sum(float v, float (*sh)[BN_COLS + 1], int cl, int rg) {
     __syncthreads();
     sh[rg][cl] = v;
     __syncthreads();
     float t = 0.f;
 #pragma unroll 8
-    for (int g = 0; g < BN_RG; g++) t += sh[g][cl];
+    for (int g = 0; g < RG; g++) t += sh[g][cl];
     return t;
 }
 
@@ -1350,25 +1355,25 @@ __global__ __launch_bounds__(256) void k_ln_act_bwd_rows(const float *__restrict
 }
 
 // dgamma[c] = sum_i dz x_hat, dbeta[c] = sum_i dz  (column reduction, same geometry as the BatchNorm kernels)
-__global__ __launch_bounds__(BN_NT) void k_ln_act_bwd_cols(const float *__restrict__ dy, const float *__restrict__ y,
+__global__ __launch_bounds__(LN_NT) void k_ln_act_bwd_cols(const float *__restrict__ dy, const float *__restrict__ y,
                                                          const float *__restrict__ x, const float *__restrict__ save_mean,
                                                          const float *__restrict__ save_invstd, int b, int F, float slope,
                                                          float *__restrict__ dgamma, float *__restrict__ dbeta) {
-    __shared__ float sh[BN_RG][BN_COLS + 1];
+    __shared__ float sh[LN_RG][BN_COLS + 1];
     const int cl = threadIdx.x & (BN_COLS - 1), rg = threadIdx.x / BN_COLS;
     const int c = blockIdx.x * BN_COLS + cl;
     const bool on = c < F;
     float sb = 0.f, sg = 0.f;
     if (on)
 #pragma unroll 4
-        for (int i = rg; i < b; i += BN_RG) {
+        for (int i = rg; i < b; i += LN_RG) {
             const size_t e = (size_t)i * F + c;
             const float dz = dy[e] * (y[e] > 0.f ? 1.f : slope);
             sb += dz;
             sg += dz * (x[e] - save_mean[i]) * save_invstd[i];
         }
-    sb = bn_col_sum(sb, sh, cl, rg);
-    sg = bn_col_sum(sg, sh, cl, rg);
+    sb = bn_col_sum<LN_RG>(sb, sh, cl, rg);
+    sg = bn_col_sum<LN_RG>(sg, sh, cl, rg);
     if (on && rg == 0) { dgamma[c] = sg; dbeta[c] = sb; }
 }
 
@@ -1992,7 +1997,7 @@ int spadot_ln_act_backward(const float *dy, const float *y, const float *x, cons
     hipStream_t st_ = (hipStream_t)stream;
     hipLaunchKernelGGL(k_ln_act_bwd_rows, dim3((b + 3) / 4), dim3(256), 0, st_, dy, y, x, gamma, save_mean, save_invstd, b, F,
                        (float)slope, dx);
-    hipLaunchKernelGGL(k_ln_act_bwd_cols, dim3((F + BN_COLS - 1) / BN_COLS), dim3(BN_NT), 0, st_, dy, y, x, save_mean,
+    hipLaunchKernelGGL(k_ln_act_bwd_cols, dim3((F + BN_COLS - 1) / BN_COLS), dim3(LN_NT), 0, st_, dy, y, x, save_mean,
                        save_invstd, b, F, (float)slope, dgamma, dbeta);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
