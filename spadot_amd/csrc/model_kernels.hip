@@ -317,15 +317,18 @@ __global__ __launch_bounds__(256) void k_gat_datt_part(const T *__restrict__ h, 
         }
     }
 }
-// out[c] = sum_s part[s][c]: 64 columns x 16 slab-groups per workgroup, groups combined in fixed order.
-__global__ __launch_bounds__(1024) void k_colsum_parts(const float *__restrict__ part, int nslab, int width,
-                                                       float *__restrict__ out) {
-    __shared__ float sh[16][65];
+// out[c] = sum_s part[s][c]: 64 columns x CS_GY slab-groups per workgroup, groups combined in fixed order.
+// (16 groups = 1024 threads; the 256-thread form was tried for the side stream's sake -- see BN_RG -- and lost 2 % of
+// the step on the same box: tools/ab_wgsize.sh)
+constexpr int CS_GY = 16, CS_NT = 64 * CS_GY;
+__global__ __launch_bounds__(CS_NT) void k_colsum_parts(const float *__restrict__ part, int nslab, int width,
+                                                        float *__restrict__ out) {
+    __shared__ float sh[CS_GY][65];
     const int cx = threadIdx.x & 63, gy = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cx;
     float acc = 0.f;
     if (c < width) {
-        const int per = (nslab + 15) / 16;
+        const int per = (nslab + CS_GY - 1) / CS_GY;
         const int s0 = gy * per, s1 = min(nslab, s0 + per);
         for (int sb = s0; sb < s1; sb += 8) {              // eight loads in flight, added in ascending order
             float q[8];
@@ -340,7 +343,7 @@ __global__ __launch_bounds__(1024) void k_colsum_parts(const float *__restrict__
     if (gy != 0 || c >= width) return;
     acc = 0.f;
 #pragma unroll
-    for (int g = 0; g < 16; g++) acc += sh[g][cx];
+    for (int g = 0; g < CS_GY; g++) acc += sh[g][cx];
     out[c] = acc;
 }
 
@@ -1218,7 +1221,8 @@ __global__ __launch_bounds__(256) void k_adamw(float *__restrict__ p, const floa
 constexpr int BN_COLS = 16, BN_RG = 16, BN_NT = BN_COLS * BN_RG;      // 16 columns x 16 row lanes: 256-thread workgroups.  These
 // launches run on the side stream beside the GAT branch's GEMMs, whose waves fill the register files: a new workgroup
 // starts when a GEMM workgroup retires, and a 1024-thread one (64 row lanes, 30 % faster on an idle GPU) needs a whole
-// compute unit to drain first -- it sat ~100 us in the queue (rocprofv3 timeline, profiles/r02)
+// compute unit to drain first -- it sat ~100 us in the queue (rocprofv3 timeline, profiles/r02).  Same box, same run
+// (tools/ab_wgsize.sh): 479 steps/s with 64 row lanes, 494 with 16.
 constexpr int LN_RG = 64, LN_NT = BN_COLS * LN_RG;                    // the LayerNorm column pass runs alone on the main stream
 
 template <int RG = BN_RG>
@@ -1807,7 +1811,7 @@ int spadot_gat_att_grad(const void *h, int dtype, const float *ds_src, const flo
     else
         return -22;
     // scratch rows are [slab][src H*C | dst H*C (| g_pre column sums H*C)]: one column sum writes all outputs (adjacent)
-    hipLaunchKernelGGL(k_colsum_parts, dim3((width + 63) / 64), dim3(1024), 0, st_, scratch, nslab, width, datt_src);
+    hipLaunchKernelGGL(k_colsum_parts, dim3((width + 63) / 64), dim3(CS_NT), 0, st_, scratch, nslab, width, datt_src);
     (void)datt_dst;
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
@@ -1833,7 +1837,7 @@ int spadot_cast_rows_multi(const float *const *src, void *const *dst, const int 
 
 int spadot_colsum(const float *x, int rows, int width, float *out, void *stream) {
     if (rows <= 0 || width <= 0) return -22;
-    hipLaunchKernelGGL(k_colsum_parts, dim3((width + 63) / 64), dim3(1024), 0, (hipStream_t)stream, x, rows, width, out);
+    hipLaunchKernelGGL(k_colsum_parts, dim3((width + 63) / 64), dim3(CS_NT), 0, (hipStream_t)stream, x, rows, width, out);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
