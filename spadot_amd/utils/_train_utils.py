@@ -360,7 +360,8 @@ class GraphedStepper:
         # every launch of the step is ours or a plain library GEMM (the SPD inverse has no library factorisation at
         # any number of inducing points: ops._spd_inverse_logdet_nograd), so the step is always capturable
         self.capturable = True
-        self.issue_main_first = os.environ.get("SPADOT_ISSUE_MAIN_FIRST", "1") == "1"
+        # which graph of a pair is launched first: 'm' main (GAT) / 's' side (SVGP), forward pair then backward pair
+        self.issue_order = (os.environ.get("SPADOT_ISSUE_ORDER", "mm") + "mm")[:2]
         self.version = getattr(model, "_state_version", 0)
 
     def _body(self, tp_i, tp, bi, epoch, with_update=True):
@@ -498,7 +499,7 @@ class GraphedStepper:
         # covers the work in front of the pair, not the GAT graph itself.
         if two_streams:
             side.wait_stream(main)
-        if self.issue_main_first and two_streams:
+        if self.issue_order[0] == "m" and two_streams:
             fns[0]()
             with torch.cuda.stream(side):
                 fns[1]()
@@ -511,7 +512,7 @@ class GraphedStepper:
         res = fns[2]()
         if two_streams:
             side.wait_stream(main)
-        if self.issue_main_first and two_streams:
+        if self.issue_order[1] == "m" and two_streams:
             fns[4]()
             with torch.cuda.stream(side):
                 fns[3]()
