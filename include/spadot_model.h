@@ -279,6 +279,13 @@ int spadot_gat_softmax_backward(const float *alpha, const float *s_src, const fl
                                 void *acell_s, void *stream);
 int spadot_gat_ds_src(const float *dz, const int *rowptr_t, const int *eid_t, int n, int H, float *ds_src, void *stream);
 
+/* ---- dense map of a GAT layer on the matrix cores (csrc/gemm_bf16.hip) -------------------------------------------------
+ * C [M x N] (bf16, row stride ldc) = A [M x K] (bf16, lda) . B^T with B stored [N x K] (bf16, ldb); fp32 accumulation.
+ * Replaces the library GEMM under GATConv's `lin` (/root/reference/SpaDOT/model/encoder.py:41-58 -> torch_geometric
+ * GATConv.lin) at the training shapes.  Requires N % 256 == 0, K % 32 == 0, 16-byte aligned pointers and strides that are
+ * multiples of 8 elements; returns -22 otherwise (the caller then uses the library).  One 320 x 256 tile per workgroup. */
+int spadot_gemm_tn_bf16(const void *A, int lda, const void *B, int ldb, void *C, int ldc, int M, int N, int K, void *stream);
+
 /* dst[t][r, 0:K[t]] = (bf16) src[t][r, 0:K[t]] for n <= 4 row-major matrices in one launch (fp32 weights -> their
  * compute-dtype images; dst rows have Kp[t] >= K[t] elements, the padding is not touched; K, Kp multiples of 4). */
 int spadot_cast_rows_multi(const float *const *src, void *const *dst, const int *rows, const int *K, const int *Kp, int n,

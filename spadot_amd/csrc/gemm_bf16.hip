@@ -1,0 +1,229 @@
+// gemm_bf16.hip -- C [M x N] = A [M x K] . B^T (B stored [N x K]), bf16 operands, fp32 accumulate, bf16 result (gfx950).
+//
+// The dense map of a GAT layer, h = x W^T (/root/reference/SpaDOT/model/encoder.py:41-58: GATConv's `lin`), at the shapes
+// of the training step: M = n_sub ~ 10^4 rows, N = H C = 2048, K = 3072 (genes, padded) or 2048.  Both operands are
+// K-contiguous, so every MFMA fragment is a plain 16-byte row read.
+//
+// Design (one 320 x 256 tile per compute unit: 32 x 8 = 256 tiles for M <= 10240, N = 2048 -- one wave of workgroups, where
+// the library's 832 tiles of 192 x 128 or 312 of 256 x 256 leave the last round a quarter full):
+//   * 512 threads = 8 waves as 2 (M) x 4 (N), each wave a 160 x 64 sub-tile = 5 x 2 MFMA tiles (160 accumulator VGPRs);
+//   * K-step = 64: a stage is 320 + 256 rows x 128 B = 72 KiB of WHOLE cache lines, two stages in LDS (144 KiB), filled by
+//     LDS-DMA (global_load_lds_dwordx4, 8 rows per wave instruction, scalar base + constant per-lane offset), the 16-byte
+//     chunks XOR-swizzled through the SOURCE address so that the fragment reads (ds_read_b128) are bank-conflict free
+//     without padding.  (A first version with 64-byte rows -- K-step 32, four stages -- ran 148 us instead of 110: every line
+//     was requested twice, half used each time);
+//   * software pipeline over 16-wide k-steps: fragments of the next k-step are read while the 10 MFMAs of the current one
+//     run (two named fragment sets, reads as inline asm with hand-counted lgkmcnt); ONE raw s_barrier per K-step, in front
+//     of the stage's last k-step: by then every wave has read the stage, the slot is re-requested for stage P + 2;
+//   * workgroups that share an A panel sit on one XCD (its L2 serves the 8 re-reads);
+//   * epilogue per wave through a private 4 KiB LDS patch so that global stores are whole 128-byte row pieces.
+// Measured alone (tools/gemm_bench.py, random data, same box as the library): 9980 x 2048 x 3072 in 110 us = 1.14 PFLOP/s
+// (library 119 us); built without the DMA 99 us, without the MFMAs 67 us, with neither 39 us, skeleton 19 us -- i.e. the MFMAs
+// alone run at 1.57 PFLOP/s, the rate of a bare v_mfma_f32_32x32x16_bf16 loop on random data on this chip
+// (tools/mfma_peak.hip: 1.59-1.78), and the DMA (885 MB per GEMM from L2 at ~18 TB/s) hides behind them but for ~11 us.
+// Inside the training step it does not pay (spadot_amd/ops.py: GEMM_FWD), so the step keeps the library by default.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+#include "../../include/spadot_model.h"
+
+#ifndef GEMM_ABLATE
+#define GEMM_ABLATE 0        // experiments only: 1 = no DMA after the prologue, 2 = no MFMA, 4 = no fragment reads
+#endif
+
+namespace {
+
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 320, BN = 256, BK = 64, STAGES = 2, NT = 512;
+constexpr int ROWB = BK * 2;                         // 128 bytes per staged row: one cache line
+constexpr int STAGE_ROWS = BM + BN;                  // 576
+constexpr int STAGEB = STAGE_ROWS * ROWB;            // 73728
+constexpr int PIECES = STAGE_ROWS / 8 / 8;           // 9 wave instructions (8 rows x 128 B each) per wave and stage
+constexpr int LDS_BYTES = STAGES * STAGEB;           // 147456 (the epilogue patches reuse it)
+
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+    const unsigned short a = __builtin_bit_cast(unsigned short, (__bf16)lo), b = __builtin_bit_cast(unsigned short, (__bf16)hi);
+    return (unsigned)a | ((unsigned)b << 16);
+}
+
+__global__ __launch_bounds__(NT, 1) void k_gemm_tn_bf16(const __bf16 *__restrict__ A, int lda, const __bf16 *__restrict__ B,
+                                                       int ldb, __bf16 *__restrict__ C, int ldc, int M, int N, int K,
+                                                       int mtiles, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // tile of this workgroup: the ntiles column tiles of one row panel are consecutive work items of one XCD
+    const int total = mtiles * ntiles;
+    const int per_xcd = (total + 7) >> 3;
+    const int item = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (item >= total) return;
+    const int mt = item / ntiles, nt = item - mt * ntiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;                     // wave grid 2 x 4: rows wm * 160, columns wn * 64
+    const unsigned lds0 = (unsigned)(size_t)smem;
+
+    // ---- LDS-DMA: piece q (0..71) of a stage covers staged rows 8 q .. 8 q + 7 (A rows 0..319, then B rows 0..255), whole
+    // 128-byte lines; lane i -> row 8 q + i / 8, LDS chunk i % 8, which receives GLOBAL chunk (i % 8) ^ ((row >> 1) & 7) of that
+    // row (the fragment reads apply the same XOR).  This wave's pieces: q = wave + 8 u.  Source = scalar base (advanced by
+    // 128 bytes per stage) + a 32-bit per-lane offset that never changes.
+    unsigned off[PIECES];
+#pragma unroll
+    for (int u = 0; u < PIECES; u++) {
+        const int row = 8 * (wave + 8 * u) + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        // pieces u < 5 are A rows (q < 40), the others B rows; rows past M re-read the last row (never stored)
+        off[u] = u < 5 ? (unsigned)min(m0 + row, M - 1) * (unsigned)(lda * 2) + chunk * 16
+                       : (unsigned)(n0 + row - BM) * (unsigned)(ldb * 2) + chunk * 16;
+    }
+    auto request = [&](int ks) __attribute__((always_inline)) {
+        const unsigned base = lds0 + (unsigned)(ks % STAGES) * STAGEB + (unsigned)wave * 1024u;
+        const char *ga = reinterpret_cast<const char *>(A) + (size_t)ks * ROWB;
+        const char *gb = reinterpret_cast<const char *>(B) + (size_t)ks * ROWB;
+#pragma unroll
+        for (int u = 0; u < PIECES; u++) {
+            unsigned keep;
+            const unsigned dst = __builtin_amdgcn_readfirstlane(base + (unsigned)u * 8192u);
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(off[u]), "s"(u < 5 ? ga : gb), "s"(dst) : "memory");
+        }
+    };
+
+    f16v acc[5][2];
+#pragma unroll
+    for (int i = 0; i < 5; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+
+    // fragment reads: lane (r = lane & 31, hh = lane >> 5), 16-wide k-step s4 in 0..3: global chunk 2 s4 + hh of its row, found
+    // at LDS chunk (2 s4 + hh) ^ ((row >> 1) & 7); (row >> 1) & 7 == (r >> 1) & 7 for every tile of this wave, so one base
+    // per k-step and operand, tiles at immediate offsets of 32 rows.  Inline asm: the compiler's own counter model would put an
+    // lgkmcnt(0) in front of each MFMA batch; here every wait is written by hand, with a sched_barrier behind it to keep the
+    // (register-only) MFMAs from moving across.
+    const int r = lane & 31, hh = lane >> 5;
+    unsigned a_base[4], b_base[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; s4++) {
+        const unsigned sw = (unsigned)(((2 * s4 + hh) ^ ((r >> 1) & 7)) << 4);
+        a_base[s4] = lds0 + (unsigned)(wm * 160 + r) * ROWB + sw;
+        b_base[s4] = lds0 + (unsigned)(BM + wn * 64 + r) * ROWB + sw;
+    }
+    auto read_frags = [&](unsigned stage_off, int s4, bf8 (&af)[5], bf8 (&bf)[2]) __attribute__((always_inline)) {
+        if (GEMM_ABLATE & 4) return;
+        const unsigned pb = b_base[s4] + stage_off, pa = a_base[s4] + stage_off;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(bf[0]) : "v"(pb));
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(bf[1]) : "v"(pb));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(af[0]) : "v"(pa));
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(af[1]) : "v"(pa));
+        asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(af[2]) : "v"(pa));
+        asm volatile("ds_read_b128 %0, %1 offset:12288" : "=v"(af[3]) : "v"(pa));
+        asm volatile("ds_read_b128 %0, %1 offset:16384" : "=v"(af[4]) : "v"(pa));
+    };
+    // operands swapped: the result has the output ROW on the lane and 16 columns in registers
+    auto mma = [&](const bf8 (&af)[5], const bf8 (&bf)[2]) __attribute__((always_inline)) {
+        if (GEMM_ABLATE & 2) {
+#pragma unroll
+            for (int i = 0; i < 5; i++) asm volatile("" ::"v"(af[i]));
+#pragma unroll
+            for (int j = 0; j < 2; j++) asm volatile("" ::"v"(bf[j]));
+            return;
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 5; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto frags_ready = [&]() __attribute__((always_inline)) {      // the OLDER of the two fragment sets in flight has landed
+        asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // Software pipeline over 16-wide k-steps: the fragments of the next one are read while the 10 MFMAs of the current one run.
+    // Two stages of K = 64: stage P + 1 lands while stage P is multiplied; once every wave has read the LAST fragments of stage
+    // P (the barrier in front of its fourth k-step), stage P + 2 is requested into that slot:
+    //   rd s1 | mma s0 | rd s2 | mma s1 | rd s3 | mma s2 | wait(P + 1 landed) barrier request(P + 2) | rd (P + 1) s0 | mma s3
+    const int nk = K / BK;
+    request(0);
+    if (1 < nk) {
+        request(1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    bf8 a0[5], b0[2], a1[5], b1[2];
+    read_frags(0u, 0, a0, b0);
+    for (int P = 0; P < nk; P++) {
+        const unsigned so = (unsigned)(P % STAGES) * STAGEB;
+        read_frags(so, 1, a1, b1);
+        frags_ready();
+        mma(a0, b0);
+        read_frags(so, 2, a0, b0);
+        frags_ready();
+        mma(a1, b1);
+        read_frags(so, 3, a1, b1);
+        frags_ready();
+        mma(a0, b0);
+        if (P + 1 < nk) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of stage P + 1 (nothing younger is out)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // ... and it has left stage P
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            if (P + 2 < nk && !(GEMM_ABLATE & 1)) request(P + 2);
+            read_frags((unsigned)((P + 1) % STAGES) * STAGEB, 0, a0, b0);
+            asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a1, b1);
+    }
+
+    // ---- epilogue: per wave and 32-row tile, accumulators -> bf16 [32 x 64] patch in LDS -> 128-byte row pieces
+    __syncthreads();
+    unsigned char *patch = smem + (size_t)wave * 4096;            // 32 rows x 128 B, private to the wave
+    // element (row m, column n) of acc[i][j]: lane m (+32: hh), register e -> n = (e & 3) + 8 (e >> 2) + 4 hh
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int n = j * 32 + 8 * g + 4 * hh;
+                *reinterpret_cast<uint2 *>(patch + r * 128 + n * 2) =
+                    make_uint2(pack2(acc[i][j][4 * g], acc[i][j][4 * g + 1]), pack2(acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]));
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // (same wave wrote the patch: no barrier needed)
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const int pr = p * 8 + (lane >> 3), pc = lane & 7;    // 8 rows per pass, 8 x 16 B per row
+            const int gm = m0 + wm * 160 + i * 32 + pr;
+            const uint4 v = *reinterpret_cast<const uint4 *>(patch + pr * 128 + pc * 16);
+            if (gm < M) *reinterpret_cast<uint4 *>(C + (size_t)gm * ldc + n0 + wn * 64 + pc * 8) = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
+}  // namespace
+
+extern "C" int spadot_gemm_tn_bf16(const void *A, int lda, const void *B, int ldb, void *C, int ldc, int M, int N, int K,
+                                   void *stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || N % BN != 0 || K % BK != 0 || lda < K || ldb < K || ldc < N) return -22;
+    if (((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((uintptr_t)C & 15) || lda % 8 || ldb % 8 || ldc % 8) return -22;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)k_gemm_tn_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return -5;
+        attr_set = true;
+    }
+    const int mtiles = (M + BM - 1) / BM, ntiles = N / BN;
+    const unsigned grid = 8u * (unsigned)((mtiles * ntiles + 7) / 8);
+    hipLaunchKernelGGL(k_gemm_tn_bf16, dim3(grid), dim3(NT), LDS_BYTES, (hipStream_t)stream, (const __bf16 *)A, lda,
+                       (const __bf16 *)B, ldb, (__bf16 *)C, ldc, M, N, K, mtiles, ntiles);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}

@@ -254,6 +254,33 @@ def cast_rows(pairs):
         _check(lib.spadot_cast_rows_multi(src, dst, rows, K, Kp, n, _stream()), "spadot_cast_rows_multi")
 
 
+# csrc/gemm_bf16.hip under the GAT layers' dense maps.  Measured on one box (tools/gemm_bench.py, tools/ab_multi.sh, cfg3):
+# alone it beats the library at the layer shapes (9980 x 2048 x 3072: 110 vs 119 us, x 2048: 80 vs 90 us), inside the step it
+# loses (forward maps: 476 vs 489 steps/s; dx: 485 vs 490) -- its 256 workgroups hold every compute unit's registers and LDS
+# for the whole GEMM, and the latency-bound SVGP branch on the other stream, which bounds the forward pair, waits behind them;
+# the library's ~800 short-lived workgroups let that branch's small kernels in.  So both uses are opt-in.
+GEMM_FWD = [__import__("os").environ.get("SPADOT_GEMM_FWD", "0") == "1"]
+GEMM_DGRAD = [__import__("os").environ.get("SPADOT_GEMM_DGRAD", "0") == "1"]
+GEMM_OWN = [True]                                  # [False]: gemm_tn() itself goes to the library (tests)
+
+
+def gemm_tn(x, w):
+    """x [M, K] . w[N, K]^T -> [M, N], bf16 operands, fp32 accumulation: csrc/gemm_bf16.hip (one 320 x 256 tile per compute
+    unit) where its shape conditions hold and the output fills at least half the chip's compute units with whole tiles,
+    otherwise the library."""
+    M, K = x.shape
+    N = w.shape[0]
+    if (GEMM_OWN[0] and x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.is_contiguous()
+            and w.is_contiguous() and N % 256 == 0 and K % 64 == 0 and w.shape[1] == K and M >= 2560 and N >= 1024):
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
+        rc = model_lib().spadot_gemm_tn_bf16(x.data_ptr(), K, w.data_ptr(), K, out.data_ptr(), N, M, N, K, _stream())
+        if rc == 0:
+            return out
+        if rc != -22:
+            _check(rc, "spadot_gemm_tn_bf16")
+    return torch.nn.functional.linear(x, w)
+
+
 class _DenseCD(torch.autograd.Function):
     """h = x W^T with x already in the compute dtype (bf16) and possibly zero-padded along K (so that the
     G-sized GEMM gets a K that is a multiple of 128), W the fp32 parameter [N, K].  Backward writes the weight
@@ -272,13 +299,19 @@ class _DenseCD(torch.autograd.Function):
         # directly (FlatAdamW.backward then has nothing to copy for this parameter)
         g = W.grad
         ctx.wgrad = g if (g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.shape == W.shape) else None
-        return torch.nn.functional.linear(x, wbuf)
+        return gemm_tn(x, wbuf) if GEMM_FWD[0] else torch.nn.functional.linear(x, wbuf)
 
     @staticmethod
     def backward(ctx, g):
         x, wbuf = ctx.saved_tensors
         g = g.contiguous()
-        dx = g @ wbuf if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            # dx = g W: the same kernel as the forward map on the transposed weight image (contraction index contiguous)
+            if GEMM_DGRAD[0] and GEMM_OWN[0] and g.shape[0] >= 2560 and wbuf.shape[1] % 256 == 0 and wbuf.shape[0] % 64 == 0:
+                dx = gemm_tn(g, wbuf.t().contiguous())
+            else:
+                dx = g @ wbuf
         # (x[:, :K] is a strided view: the GEMM takes its row stride, the result is a dense [N, K])
         dW = None
         if ctx.needs_input_grad[1]:
