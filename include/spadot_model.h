@@ -286,6 +286,23 @@ int spadot_gat_ds_src(const float *dz, const int *rowptr_t, const int *eid_t, in
  * multiples of 8 elements; returns -22 otherwise (the caller then uses the library).  One 320 x 256 tile per workgroup. */
 int spadot_gemm_tn_bf16(const void *A, int lda, const void *B, int ldb, void *C, int ldc, int M, int N, int K, void *stream);
 
+/* ---- hidden stages of the decoder as one launch each way (csrc/mlp_chain.hip) -------------------------------------------
+ * /root/reference/SpaDOT/model/decoder.py:3-20: [Linear, LayerNorm, LeakyReLU] x n_layers on x [b, dims[0]] (fp32);
+ * stage l maps dims[l] -> dims[l + 1].  forward keeps, per stage, a (linear output), y (stage output), mean, invstd.
+ * backward: dy = gradient at the last stage's output; writes dx [b, dims[0]] (may be NULL) and `grads`, laid out per stage
+ * as [dW (dout x din) | dbias (dout) | dgamma (dout) | dbeta (dout)] (spadot_mlp_chain_workspace gives that width and the
+ * number of workspace rows; workspace = rows x width floats of scratch).  Fixed summation order.
+ * supported: <= 4 stages, widths <= 256, input widths % 4 == 0, output widths % 8 == 0; all pointers 16-byte aligned. */
+int spadot_mlp_chain_supported(int n_layers, const int *dims);
+int spadot_mlp_chain_workspace(int b, int n_layers, const int *dims, int *n_rows, int *width);
+int spadot_mlp_chain_forward(const float *x, int b, int n_layers, const int *dims, const float *const *W,
+                             const float *const *bias, const float *const *gamma, const float *const *beta, const double *eps,
+                             const double *slope, float *const *a, float *const *y, float *const *mean, float *const *invstd,
+                             void *stream);
+int spadot_mlp_chain_backward(const float *dy, const float *x, int b, int n_layers, const int *dims, const float *const *W,
+                              const float *const *gamma, const double *slope, float *const *a, float *const *y,
+                              float *const *mean, float *const *invstd, float *dx, float *workspace, float *grads, void *stream);
+
 /* dst[t][r, 0:K[t]] = (bf16) src[t][r, 0:K[t]] for n <= 4 row-major matrices in one launch (fp32 weights -> their
  * compute-dtype images; dst rows have Kp[t] >= K[t] elements, the padding is not touched; K, Kp multiples of 4). */
 int spadot_cast_rows_multi(const float *const *src, void *const *dst, const int *rows, const int *K, const int *Kp, int n,

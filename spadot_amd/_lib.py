@@ -112,6 +112,10 @@ def model_lib():
         "spadot_gat_aggregate": [vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp, vp],
         "spadot_gat_edge_dot": [vp, vp, vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp, vp],
         "spadot_gemm_tn_bf16": [vp, ci, vp, ci, vp, ci, ci, ci, ci, vp],
+        "spadot_mlp_chain_supported": [ci, vp],
+        "spadot_mlp_chain_workspace": [ci, ci, vp, vp, vp],
+        "spadot_mlp_chain_forward": [vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+        "spadot_mlp_chain_backward": [vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
         "spadot_kernel_matrix": [vp, vp, ci, ci, ci, cd, ci, ci, vp, vp],
         "spadot_spd_inverse_logdet": [vp, ci, ci, vp, vp, vp],
         "spadot_rowdot_forward": [vp, vp, ci, ci, ci, ci, vp, vp],

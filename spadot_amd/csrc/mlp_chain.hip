@@ -1,0 +1,384 @@
+// mlp_chain.hip -- the hidden stages of the decoder as ONE launch forward and ONE (+ a column sum) backward (gfx950).
+//
+// /root/reference/SpaDOT/model/decoder.py:3-20: decoder_net = [Linear, LayerNorm, LeakyReLU] x len(decoder_layers), then the
+// output Linear.  With decoder_layers = [64, 256] and z_dim = 20 the hidden part is 1024 x 20 -> 64 -> 256: a few MFLOP, but
+// as separate launches (GEMM, LN+act per stage forward; LN rows, LN columns, bias column sum, two GEMMs per stage backward)
+// it was 4 + 10 dependent launches of ~5 us each on the one stream the loss tail of a step runs on.  Every quantity of a
+// stage is row-local except the parameter gradients, so a workgroup carries its rows through all stages:
+//   forward : 4 rows per workgroup; per stage  a = x W^T + b (thread per output column, the 4 rows share each weight load),
+//             LayerNorm by one wave per row (two-pass mean / variance like k_ln_act_fwd), LeakyReLU; a, y, mean, invstd kept;
+//   backward: 8 rows per workgroup, stages last to first:  LN + activation backward per row (32 lanes per row), the stage's
+//             weight-gradient partial da^T x over the 8 rows in 8 x 4 register tiles, its column partials (bias, gamma,
+//             beta), then dx = da W into LDS as the next stage's incoming gradient.  Partials go to a workspace
+//             [workgroup][all parameters of all stages]; ONE k_colsum_parts launch (spadot_colsum) adds them in workgroup
+//             order into a buffer laid out like one workspace row -- fixed order, no atomics.
+// Limits (the caller falls back to the per-stage launches otherwise): <= 4 stages, widths <= 256 and multiples of 4, output
+// widths multiples of 8.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+#include "../../include/spadot_model.h"
+
+namespace {
+
+constexpr int MAXL = 4, MAXD = 256, WAVE = 64;
+constexpr int RBF = 4;                  // rows per workgroup, forward
+constexpr int RBB = 8;                  // rows per workgroup, backward
+constexpr int LDW = MAXD + 4;           // LDS row stride (floats): 16-byte aligned rows, off the 256-byte bank period
+
+struct Stage {
+    const float *W, *bias, *gamma, *beta;
+    float *a, *y, *mean, *invstd;       // saved by forward, read by backward
+    int din, dout;
+    float eps, slope;
+    int ws_off;                         // backward: offset of this stage's partials inside a workspace row
+};
+struct Chain {
+    Stage s[MAXL];
+    int n;
+};
+
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, WAVE);
+    return x;
+}
+
+__global__ __launch_bounds__(256) void k_mlp_chain_fwd(const float *__restrict__ x, int b, Chain ch) {
+    __shared__ __attribute__((aligned(16))) float act[2][RBF][LDW];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int r0 = blockIdx.x * RBF;
+    int cur = 0;
+    {
+        const int d0 = ch.s[0].din;
+        for (int e = t; e < RBF * d0; e += 256) {
+            const int r = e / d0, k = e - r * d0;
+            act[0][r][k] = (r0 + r < b) ? x[(size_t)(r0 + r) * d0 + k] : 0.f;
+        }
+    }
+    __syncthreads();
+    for (int l = 0; l < ch.n; l++) {
+        const Stage &s = ch.s[l];
+        const int din = s.din, dout = s.dout;
+        // a[r][j] = bias[j] + <W[j, :], x[r, :]>: one thread per output column, the rows share each 16-byte weight load
+        for (int j = t; j < dout; j += 256) {
+            float acc[RBF];
+            const float bj = s.bias[j];
+#pragma unroll
+            for (int r = 0; r < RBF; r++) acc[r] = bj;
+            const float4 *w4 = reinterpret_cast<const float4 *>(s.W + (size_t)j * din);
+            for (int k4 = 0; k4 < din / 4; k4++) {
+                const float4 w = w4[k4];
+#pragma unroll
+                for (int r = 0; r < RBF; r++) {
+                    const float4 xv = *reinterpret_cast<const float4 *>(&act[cur][r][4 * k4]);
+                    acc[r] += w.x * xv.x + w.y * xv.y + w.z * xv.z + w.w * xv.w;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < RBF; r++) act[cur ^ 1][r][j] = acc[r];
+        }
+        __syncthreads();
+        // LayerNorm + LeakyReLU: wave r owns row r
+        {
+            const int r = wave, row = r0 + r;
+            float *ar = act[cur ^ 1][r];
+            float sm = 0.f;
+            for (int j = lane; j < dout; j += WAVE) sm += ar[j];
+            const float mean = wave_sum(sm) / (float)dout;
+            float ss = 0.f;
+            for (int j = lane; j < dout; j += WAVE) { const float d = ar[j] - mean; ss += d * d; }
+            const float invstd = rsqrtf(wave_sum(ss) / (float)dout + s.eps);
+            for (int j = lane; j < dout; j += WAVE) {
+                const float av = ar[j];
+                const float v = (av - mean) * invstd * s.gamma[j] + s.beta[j];
+                const float yv = v > 0.f ? v : s.slope * v;
+                ar[j] = yv;
+                if (row < b) { s.a[(size_t)row * dout + j] = av; s.y[(size_t)row * dout + j] = yv; }
+            }
+            if (lane == 0 && row < b) { s.mean[row] = mean; s.invstd[row] = invstd; }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
+// Backward.  LDS: gz = incoming gradient of the current stage, turned into dz = dy * act'(y) in place; xh = normalised linear
+// output; da = gradient at the stage's linear output; xs = the stage's input rows; wst = W (whole, or in chunks of whole rows).
+// Nothing in a serial loop reads global memory: tiles are loaded cooperatively (independent, coalesced loads), the loops run
+// out of LDS.  8 rows per workgroup: the fp32 FMA work of a stage (da^T x and da W) is spread over b / 8 compute units.
+constexpr int WST = 16384;                                  // floats of W staged at a time (64 KiB)
+constexpr int LPR = 256 / RBB;                              // lanes per row in the per-row phase
+constexpr int LDS_BWD_FLOATS = 4 * RBB * LDW + 2 * RBB + WST;
+__global__ __launch_bounds__(256) void k_mlp_chain_bwd(const float *__restrict__ dy_last, const float *__restrict__ x, int b,
+                                                       Chain ch, float *__restrict__ dx_out, float *__restrict__ ws,
+                                                       int ws_width) {
+    extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
+    float (*gz)[LDW] = reinterpret_cast<float (*)[LDW]>(lds_dyn);
+    float (*da)[LDW] = reinterpret_cast<float (*)[LDW]>(lds_dyn + RBB * LDW);
+    float (*xs)[LDW] = reinterpret_cast<float (*)[LDW]>(lds_dyn + 2 * RBB * LDW);
+    float (*xh)[LDW] = reinterpret_cast<float (*)[LDW]>(lds_dyn + 3 * RBB * LDW);
+    float *rmean = lds_dyn + 4 * RBB * LDW, *rinv = rmean + RBB;
+    float *wst = rinv + RBB;
+    const int t = threadIdx.x;
+    const int r0 = blockIdx.x * RBB;
+    float *wrow = ws + (size_t)blockIdx.x * ws_width;
+    {   // incoming gradient of the last stage
+        const int d = ch.s[ch.n - 1].dout;
+        float v[RBB * MAXD / 256];
+#pragma unroll
+        for (int u = 0; u < RBB * MAXD / 256; u++) {               // all loads first (fixed trip count, predicated)
+            const int e = t + u * 256, r = e / d, j = e - r * d;
+            v[u] = (e < RBB * d && r0 + r < b) ? dy_last[(size_t)(r0 + r) * d + j] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < RBB * MAXD / 256; u++) {
+            const int e = t + u * 256, r = e / d, j = e - r * d;
+            if (e < RBB * d) gz[r][j] = v[u];
+        }
+    }
+    for (int l = ch.n - 1; l >= 0; l--) {
+        const Stage &s = ch.s[l];
+        const int din = s.din, dout = s.dout;
+        const float *xin = l == 0 ? x : ch.s[l - 1].y;
+        const int tk = din / 4;
+        const int jc = min(dout, WST / din);                        // W rows per staged chunk (all of them when W fits)
+        const bool need_dx = l > 0 || dx_out != nullptr;
+        {
+            // every global load of the stage is issued before the first LDS store (fixed trip counts, predicated): one
+            // round trip instead of one per unrolled group
+            constexpr int NE = RBB * MAXD / 256, NW = WST / 4 / 256;
+            float vx[NE], vy[NE], va[NE];
+            float4 vw[NW];
+#pragma unroll
+            for (int u = 0; u < NE; u++) {
+                const int e = t + u * 256;
+                const int r = e / din, k = e - r * din;
+                vx[u] = (e < RBB * din && r0 + r < b) ? xin[(size_t)(r0 + r) * din + k] : 0.f;
+                const int r2 = e / dout, j = e - r2 * dout;
+                const bool on = e < RBB * dout && r0 + r2 < b;
+                vy[u] = on ? s.y[(size_t)(r0 + r2) * dout + j] : 0.f;
+                va[u] = on ? s.a[(size_t)(r0 + r2) * dout + j] : 0.f;
+            }
+            if (need_dx) {
+                const float4 *src = reinterpret_cast<const float4 *>(s.W);
+#pragma unroll
+                for (int u = 0; u < NW; u++) {
+                    const int e = t + u * 256;
+                    vw[u] = e < jc * tk ? src[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+            if (t < RBB) {
+                const bool live = r0 + t < b;
+                rmean[t] = live ? s.mean[r0 + t] : 0.f;
+                rinv[t] = live ? s.invstd[r0 + t] : 0.f;
+            }
+            __syncthreads();                   // (rmean / rinv; and the previous stage's C has finished writing gz)
+#pragma unroll
+            for (int u = 0; u < NE; u++) {
+                const int e = t + u * 256;
+                if (e < RBB * din) { const int r = e / din; xs[r][e - r * din] = vx[u]; }
+                if (e < RBB * dout) {
+                    // A0 (element-wise): dz = dy act'(y) -> gz, xhat = (a - mean) invstd -> xh
+                    const int r = e / dout, j = e - r * dout;
+                    const bool live = r0 + r < b;
+                    gz[r][j] = live ? gz[r][j] * (vy[u] > 0.f ? 1.f : s.slope) : 0.f;
+                    xh[r][j] = live ? (va[u] - rmean[r]) * rinv[r] : 0.f;
+                }
+            }
+            if (need_dx) {
+                float4 *dst = reinterpret_cast<float4 *>(wst);
+#pragma unroll
+                for (int u = 0; u < NW; u++) {
+                    const int e = t + u * 256;
+                    if (e < jc * tk) dst[e] = vw[u];
+                }
+            }
+        }
+        __syncthreads();
+        // ---- A1: per row (32 lanes each): da = invstd (dz gamma - mean_j(dz gamma) - xhat mean_j(dz gamma xhat))
+        {
+            const int r = t / LPR, sl = t % LPR;
+            const float inv = rinv[r];
+            float s1 = 0.f, s2 = 0.f;
+            for (int j = sl; j < dout; j += LPR) {
+                const float dg = gz[r][j] * s.gamma[j];
+                s1 += dg;
+                s2 += dg * xh[r][j];
+            }
+#pragma unroll
+            for (int off = LPR / 2; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off, WAVE); s2 += __shfl_xor(s2, off, WAVE); }
+            const float m1 = s1 / (float)dout, m2 = s2 / (float)dout;
+            for (int j = sl; j < dout; j += LPR) da[r][j] = inv * (gz[r][j] * s.gamma[j] - m1 - xh[r][j] * m2);
+        }
+        __syncthreads();
+        // ---- B: weight-gradient partial  dW[j][k] = sum_r da[r][j] xs[r][k], 8 (j) x 4 (k) register tiles
+        {
+            const int ntile = (dout / 8) * tk;
+            for (int tile = t; tile < ntile; tile += 256) {
+                const int j0 = (tile / tk) * 8, k0 = (tile - (tile / tk) * tk) * 4;
+                float acc[8][4];
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+#pragma unroll
+                    for (int v = 0; v < 4; v++) acc[u][v] = 0.f;
+#pragma unroll
+                for (int r = 0; r < RBB; r++) {
+                    const float4 d0 = *reinterpret_cast<const float4 *>(&da[r][j0]);
+                    const float4 d1 = *reinterpret_cast<const float4 *>(&da[r][j0 + 4]);
+                    const float4 xv = *reinterpret_cast<const float4 *>(&xs[r][k0]);
+                    const float dv[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+                    const float xw[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+                    for (int u = 0; u < 8; u++)
+#pragma unroll
+                        for (int v = 0; v < 4; v++) acc[u][v] += dv[u] * xw[v];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    *reinterpret_cast<float4 *>(wrow + s.ws_off + (size_t)(j0 + u) * din + k0) =
+                        make_float4(acc[u][0], acc[u][1], acc[u][2], acc[u][3]);
+            }
+        }
+        // ---- D: column partials over the rows: bias (sum da), gamma (sum dz xhat), beta (sum dz)
+        for (int j = t; j < dout; j += 256) {
+            float sb = 0.f, sg = 0.f, sbeta = 0.f;
+#pragma unroll
+            for (int r = 0; r < RBB; r++) {
+                const float dz = gz[r][j];
+                sb += da[r][j];
+                sg += dz * xh[r][j];
+                sbeta += dz;
+            }
+            float *p = wrow + s.ws_off + (size_t)dout * din;
+            p[j] = sb;
+            p[dout + j] = sg;
+            p[2 * dout + j] = sbeta;
+        }
+        __syncthreads();                       // D is done with gz and xh: C writes dx into gz, its halves meet in xh
+        // ---- C: dx[r][k] = sum_j da[r][j] W[j][k]: the next (lower) stage's incoming gradient, or the chain's result.
+        // Item = (row, 4 columns); the two halves of the workgroup take the two halves of each chunk's j range.
+        if (need_dx) {
+            const int nitem = RBB * tk;                             // <= 8 * 64 = 512: two passes of 256 at most
+            const int half = t >> 7, it0 = t & 127;
+            float4 acc[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int jb = 0; jb < dout; jb += jc) {
+                const int jn = min(jc, dout - jb);
+                if (jb > 0) {
+                    __syncthreads();
+                    const float4 *src = reinterpret_cast<const float4 *>(s.W + (size_t)jb * din);
+                    float4 *dst = reinterpret_cast<float4 *>(wst);
+#pragma unroll 4
+                    for (int e = t; e < jn * tk; e += 256) dst[e] = src[e];
+                    __syncthreads();
+                }
+                const int jh = (jn + 1) / 2, ja = half * jh, jz = min(jn, ja + jh);
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int e = it0 + u * 128;
+                    if (e < nitem) {
+                        const int r = e / tk, k0 = (e - r * tk) * 4;
+                        float4 a4 = acc[u];
+#pragma unroll 8
+                        for (int j = ja; j < jz; j++) {
+                            const float d = da[r][jb + j];
+                            const float4 w = *reinterpret_cast<const float4 *>(wst + (size_t)j * din + k0);
+                            a4.x += d * w.x; a4.y += d * w.y; a4.z += d * w.z; a4.w += d * w.w;
+                        }
+                        acc[u] = a4;
+                    }
+                }
+            }
+            // the upper half hands its sums over through xh (free after D), the lower half adds and stores
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int e = it0 + u * 128;
+                if (half == 1 && e < nitem) *reinterpret_cast<float4 *>(&xh[0][0] + 4 * e) = acc[u];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int e = it0 + u * 128;
+                if (half == 0 && e < nitem) {
+                    const int r = e / tk, k0 = (e - r * tk) * 4;
+                    const float4 o = *reinterpret_cast<const float4 *>(&xh[0][0] + 4 * e);
+                    const float4 a4 = make_float4(acc[u].x + o.x, acc[u].y + o.y, acc[u].z + o.z, acc[u].w + o.w);
+                    if (l > 0) *reinterpret_cast<float4 *>(&gz[r][k0]) = a4;
+                    else if (r0 + r < b) *reinterpret_cast<float4 *>(dx_out + (size_t)(r0 + r) * din + k0) = a4;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+bool fill_chain(Chain &ch, int n_layers, const int *dims, const float *const *W, const float *const *bias,
+                const float *const *gamma, const float *const *beta, const double *eps, const double *slope, float *const *a,
+                float *const *y, float *const *mean, float *const *invstd) {
+    if (n_layers < 1 || n_layers > MAXL) return false;
+    int off = 0;
+    for (int l = 0; l < n_layers; l++) {
+        const int din = dims[l], dout = dims[l + 1];
+        if (din <= 0 || dout <= 0 || din > MAXD || dout > MAXD || din % 4 || dout % 8) return false;
+        Stage &s = ch.s[l];
+        s.W = W[l]; s.bias = bias ? bias[l] : nullptr; s.gamma = gamma[l]; s.beta = beta ? beta[l] : nullptr;
+        s.a = a[l]; s.y = y[l]; s.mean = mean[l]; s.invstd = invstd[l];
+        s.din = din; s.dout = dout; s.eps = eps ? (float)eps[l] : 0.f; s.slope = (float)slope[l];
+        s.ws_off = off;
+        off += dout * din + 3 * dout;
+    }
+    ch.n = n_layers;
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int spadot_mlp_chain_supported(int n_layers, const int *dims) {
+    if (n_layers < 1 || n_layers > MAXL) return 0;
+    for (int l = 0; l < n_layers; l++)
+        if (dims[l] <= 0 || dims[l + 1] <= 0 || dims[l] > MAXD || dims[l + 1] > MAXD || dims[l] % 4 || dims[l + 1] % 8) return 0;
+    return 1;
+}
+
+int spadot_mlp_chain_workspace(int b, int n_layers, const int *dims, int *n_rows, int *width) {
+    if (!spadot_mlp_chain_supported(n_layers, dims) || b <= 0) return -22;
+    int w = 0;
+    for (int l = 0; l < n_layers; l++) w += dims[l + 1] * dims[l] + 3 * dims[l + 1];
+    *n_rows = (b + RBB - 1) / RBB;
+    *width = w;
+    return 0;
+}
+
+int spadot_mlp_chain_forward(const float *x, int b, int n_layers, const int *dims, const float *const *W,
+                             const float *const *bias, const float *const *gamma, const float *const *beta, const double *eps,
+                             const double *slope, float *const *a, float *const *y, float *const *mean, float *const *invstd,
+                             void *stream) {
+    Chain ch;
+    if (b <= 0 || !fill_chain(ch, n_layers, dims, W, bias, gamma, beta, eps, slope, a, y, mean, invstd)) return -22;
+    hipLaunchKernelGGL(k_mlp_chain_fwd, dim3((b + RBF - 1) / RBF), dim3(256), 0, (hipStream_t)stream, x, b, ch);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+int spadot_mlp_chain_backward(const float *dy, const float *x, int b, int n_layers, const int *dims, const float *const *W,
+                              const float *const *gamma, const double *slope, float *const *a, float *const *y,
+                              float *const *mean, float *const *invstd, float *dx, float *workspace, float *grads, void *stream) {
+    Chain ch;
+    if (b <= 0 || !fill_chain(ch, n_layers, dims, W, nullptr, gamma, nullptr, nullptr, slope, a, y, mean, invstd)) return -22;
+    int rows, width;
+    if (spadot_mlp_chain_workspace(b, n_layers, dims, &rows, &width)) return -22;
+    constexpr int LDS_BWD = LDS_BWD_FLOATS * (int)sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)k_mlp_chain_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BWD) != hipSuccess) return -5;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_mlp_chain_bwd, dim3(rows), dim3(256), LDS_BWD, (hipStream_t)stream, dy, x, b, ch, dx, workspace, width);
+    if (hipGetLastError() != hipSuccess) return -5;
+    return spadot_colsum(workspace, rows, width, grads, stream);     // grads: one workspace row = [dW | dbias | dgamma | dbeta] per stage
+}
+
+}  // extern "C"

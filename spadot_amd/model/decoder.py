@@ -9,7 +9,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..ops import linear_bias, ln_act
+from ..ops import linear_bias, ln_act, mlp_chain, mlp_chain_ok
 
 
 def _hidden_stage(fan_in, fan_out):
@@ -32,9 +32,12 @@ class Decoder(nn.Module):
     def forward(self, latent_sample):
         stages = list(self.decoder_net)
         h = latent_sample
-        for i in range(0, len(stages) - 1, 3):
-            dense, norm, act = stages[i], stages[i + 1], stages[i + 2]
-            h = ln_act(linear_bias(h, dense.weight, dense.bias), norm, act.negative_slope)     # LN + LeakyReLU: one launch
+        hidden = [(stages[i], stages[i + 1], stages[i + 2].negative_slope) for i in range(0, len(stages) - 1, 3)]
+        if hidden and mlp_chain_ok(h, hidden):
+            h = mlp_chain(h, hidden)                    # all hidden stages: one launch forward, two backward
+        else:
+            for dense, norm, slope in hidden:
+                h = ln_act(linear_bias(h, dense.weight, dense.bias), norm, slope)     # LN + LeakyReLU: one launch
         last = stages[-1]
         # hidden -> G is the only large GEMM here: compute dtype on MFMA (fp32 accumulate), fp32 result
         return linear_bias(h, last.weight, last.bias, self.compute_dtype)

@@ -472,6 +472,90 @@ def ln_act(x, ln, slope=0.01):
     return _LNAct.apply(x, ln.weight, ln.bias, ln.eps, slope)
 
 
+# ----------------------------------------------------------------------------- fused hidden stages (csrc/mlp_chain.hip)
+
+MLP_CHAIN = [__import__("os").environ.get("SPADOT_MLP_CHAIN", "1") == "1"]     # [False]: one launch per piece (A/B runs, tests)
+
+
+def _ptr_array(tensors):
+    return (ctypes.c_void_p * len(tensors))(*(t_.data_ptr() for t_ in tensors))
+
+
+class _MLPChain(torch.autograd.Function):
+    """[Linear, LayerNorm, LeakyReLU] x n on a 2-D fp32 input: one launch forward, one + a column sum backward."""
+
+    @staticmethod
+    def forward(ctx, x, eps, slope, *params):
+        n = len(params) // 4
+        Ws, bs, gs, betas = params[0::4], params[1::4], params[2::4], params[3::4]
+        b = x.shape[0]
+        dims = [x.shape[1]] + [W.shape[0] for W in Ws]
+        dev = x.device
+        a = [torch.empty((b, d), dtype=torch.float32, device=dev) for d in dims[1:]]
+        y = [torch.empty((b, d), dtype=torch.float32, device=dev) for d in dims[1:]]
+        stats = torch.empty((2 * n, b), dtype=torch.float32, device=dev)
+        mean, inv = [stats[2 * l] for l in range(n)], [stats[2 * l + 1] for l in range(n)]
+        cd = (ctypes.c_int * (n + 1))(*dims)
+        ce = (ctypes.c_double * n)(*[float(e) for e in eps])
+        cs = (ctypes.c_double * n)(*[float(v) for v in slope])
+        _check(model_lib().spadot_mlp_chain_forward(_p(x), b, n, cd, _ptr_array(Ws), _ptr_array(bs), _ptr_array(gs),
+                                                    _ptr_array(betas), ce, cs, _ptr_array(a), _ptr_array(y), _ptr_array(mean),
+                                                    _ptr_array(inv), _stream()), "spadot_mlp_chain_forward")
+        ctx.save_for_backward(x, stats, *Ws, *gs, *a, *y)
+        ctx.n, ctx.dims, ctx.slope = n, dims, [float(v) for v in slope]
+        return y[-1]
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, dims = ctx.n, ctx.dims
+        sv = ctx.saved_tensors
+        x, stats = sv[0], sv[1]
+        Ws, gs, a, y = sv[2:2 + n], sv[2 + n:2 + 2 * n], sv[2 + 2 * n:2 + 3 * n], sv[2 + 3 * n:2 + 4 * n]
+        b = x.shape[0]
+        dev = x.device
+        cd = (ctypes.c_int * (n + 1))(*dims)
+        rows, width = ctypes.c_int(0), ctypes.c_int(0)
+        lib = model_lib()
+        _check(lib.spadot_mlp_chain_workspace(b, n, cd, ctypes.byref(rows), ctypes.byref(width)), "spadot_mlp_chain_workspace")
+        ws = torch.empty((rows.value, width.value), dtype=torch.float32, device=dev)
+        grads = torch.empty(width.value, dtype=torch.float32, device=dev)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        mean, inv = [stats[2 * l] for l in range(n)], [stats[2 * l + 1] for l in range(n)]
+        cs = (ctypes.c_double * n)(*ctx.slope)
+        _check(lib.spadot_mlp_chain_backward(_p(dy.contiguous().float()), _p(x), b, n, cd, _ptr_array(Ws), _ptr_array(gs), cs,
+                                             _ptr_array(a), _ptr_array(y), _ptr_array(mean), _ptr_array(inv),
+                                             None if dx is None else _p(dx), _p(ws), _p(grads), _stream()),
+               "spadot_mlp_chain_backward")
+        out = []
+        off = 0
+        for l in range(n):
+            din, dout = dims[l], dims[l + 1]
+            out += [grads[off:off + dout * din].view(dout, din), grads[off + dout * din:off + dout * din + dout],
+                    grads[off + dout * din + dout:off + dout * din + 2 * dout],
+                    grads[off + dout * din + 2 * dout:off + dout * din + 3 * dout]]
+            off += dout * din + 3 * dout
+        return (dx, None, None, *out)
+
+
+def mlp_chain_ok(x, stages):
+    """stages: [(Linear, LayerNorm, negative_slope), ...].  True when csrc/mlp_chain.hip covers them."""
+    if not (MLP_CHAIN[0] and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and 1 <= len(stages) <= 4):
+        return False
+    dims = [x.shape[1]] + [lin.out_features for lin, _, _ in stages]
+    if any(lin.in_features != d for (lin, _, _), d in zip(stages, dims[:-1])):
+        return False
+    ts = [t_ for lin, ln, _ in stages for t_ in (lin.weight, lin.bias, ln.weight, ln.bias)]
+    if any(t_ is None or t_.dtype != torch.float32 or not t_.is_contiguous() or t_.data_ptr() % 16 for t_ in ts):
+        return False
+    return bool(model_lib().spadot_mlp_chain_supported(len(stages), (ctypes.c_int * len(dims))(*dims)))
+
+
+def mlp_chain(x, stages):
+    """leaky_relu(LayerNorm(Linear(.))) applied stage after stage (decoder.py:3-20's hidden part)."""
+    params = [t_ for lin, ln, _ in stages for t_ in (lin.weight, lin.bias, ln.weight, ln.bias)]
+    return _MLPChain.apply(x.contiguous(), [ln.eps for _, ln, _ in stages], [sl for _, _, sl in stages], *params)
+
+
 # ----------------------------------------------------------------------------- loss tail (single-workgroup kernels)
 
 _counters = {}

@@ -1,0 +1,118 @@
+"""GPU: the fused hidden stages of the decoder (csrc/mlp_chain.hip) against a torch fp64 reference of the same stages
+([Linear, LayerNorm, LeakyReLU] x n, /root/reference/SpaDOT/model/decoder.py:3-20) and against the per-stage launches they
+replace.  fp32 kernels, fp32 accumulation: values within 2e-5 relative to the fp64 reference, parameter gradients (sums over
+the batch) within 1e-4 of their norm."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _stages(dims, seed):
+    torch.manual_seed(seed)
+    out = []
+    for din, dout in zip(dims[:-1], dims[1:]):
+        lin, ln = nn.Linear(din, dout), nn.LayerNorm(dout)
+        with torch.no_grad():
+            ln.weight.uniform_(0.5, 1.5)
+            ln.bias.uniform_(-0.3, 0.3)
+        out.append((lin.to(DEV), ln.to(DEV), 0.01 if len(out) % 2 == 0 else 0.2))
+    return out
+
+
+def _reference(x, stages, w):
+    h = x.double()
+    ps = []
+    for lin, ln, slope in stages:
+        W, b, g, be = (t.detach().double().requires_grad_(True) for t in (lin.weight, lin.bias, ln.weight, ln.bias))
+        ps += [W, b, g, be]
+        h = torch.nn.functional.leaky_relu(torch.nn.functional.layer_norm(h @ W.t() + b, (W.shape[0],), g, be, ln.eps), slope)
+    (h * w.double()).sum().backward()
+    return h.detach(), [p.grad for p in ps]
+
+
+def _run(ops, x, stages, w, fused):
+    ops.MLP_CHAIN[0] = fused
+    try:
+        for lin, ln, _ in stages:
+            for p in (*lin.parameters(), *ln.parameters()):
+                p.grad = None
+        xin = x.clone().requires_grad_(True)
+        if fused:
+            assert ops.mlp_chain_ok(xin, stages)
+            h = ops.mlp_chain(xin, stages)
+        else:
+            h = xin
+            for lin, ln, slope in stages:
+                h = ops.ln_act(ops.linear_bias(h, lin.weight, lin.bias), ln, slope)
+        (h * w).sum().backward()
+        grads = [p.grad.detach().clone() for lin, ln, _ in stages for p in (lin.weight, lin.bias, ln.weight, ln.bias)]
+        return h.detach(), xin.grad.detach(), grads
+    finally:
+        ops.MLP_CHAIN[0] = True
+
+
+@pytest.mark.parametrize("b,dims", [
+    (1024, [20, 64, 256]),        # the decoder of config.yaml at cfg3's batch
+    (37, [20, 64, 256]),          # fewer rows than one backward block of 32 + a remainder
+    (1000, [8, 16]),              # a single stage
+    (513, [12, 24, 8, 256]),      # three stages, widths going down and up, one row past a block
+    (64, [256, 256]),             # the widest stage the kernel takes
+])
+def test_chain_matches_fp64_reference_and_unfused_path(b, dims):
+    from spadot_amd import ops
+    stages = _stages(dims, seed=b)
+    g = torch.Generator(device=DEV).manual_seed(b + 1)
+    x = torch.randn((b, dims[0]), device=DEV, generator=g)
+    w = torch.randn((b, dims[-1]), device=DEV, generator=g)
+    xr = x.double().requires_grad_(True)
+    ref, ref_grads = _reference(xr, stages, w)
+    out, dx, grads = _run(ops, x, stages, w, True)
+    out_u, dx_u, grads_u = _run(ops, x, stages, w, False)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.cpu().numpy(), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(out.cpu().numpy(), out_u.cpu().numpy(), rtol=2e-5, atol=2e-5)
+    rdx = xr.grad
+    assert (dx.double() - rdx).norm() <= 1e-4 * rdx.norm() + 1e-9
+    assert (dx - dx_u).norm() <= 1e-4 * dx_u.norm() + 1e-9
+    for k, (a, r, u) in enumerate(zip(grads, ref_grads, grads_u)):
+        assert a.shape == r.shape
+        assert (a.double() - r).norm() <= 1e-4 * r.norm() + 1e-7, (k, float((a.double() - r).norm() / r.norm()))
+        assert (a - u).norm() <= 2e-4 * u.norm() + 1e-7, k
+    # fixed summation order: the same bits on every launch
+    out2, dx2, grads2 = _run(ops, x, stages, w, True)
+    assert torch.equal(out, out2) and torch.equal(dx, dx2) and all(torch.equal(p, q) for p, q in zip(grads, grads2))
+
+
+def test_chain_declines_what_it_does_not_cover():
+    from spadot_amd import ops
+    x = torch.randn((16, 6), device=DEV)
+    assert not ops.mlp_chain_ok(x, _stages([6, 16], 0))            # input width not a multiple of 4
+    x = torch.randn((16, 8), device=DEV)
+    assert not ops.mlp_chain_ok(x, _stages([8, 12], 0))            # output width not a multiple of 8
+    assert not ops.mlp_chain_ok(x, _stages([8, 512], 0))           # wider than the kernel's LDS rows
+    assert ops.mlp_chain_ok(x, _stages([8, 16], 0))
+
+
+def test_decoder_uses_the_chain_and_keeps_its_gradients():
+    """Decoder.forward with and without the fused stages: same reconstruction, same parameter gradients."""
+    from spadot_amd import ops
+    from spadot_amd.model.decoder import Decoder
+    torch.manual_seed(3)
+    dec = Decoder(input_dim=300, z_dim=20, decoder_layers=[64, 256]).to(DEV)
+    z = torch.randn((512, 20), device=DEV)
+    res = []
+    for fused in (True, False):
+        ops.MLP_CHAIN[0] = fused
+        try:
+            dec.zero_grad(set_to_none=True)
+            out = dec(z)
+            out.square().mean().backward()
+            res.append((out.detach().clone(), [p.grad.detach().clone() for p in dec.parameters()]))
+        finally:
+            ops.MLP_CHAIN[0] = True
+    np.testing.assert_allclose(res[0][0].cpu().numpy(), res[1][0].cpu().numpy(), rtol=1e-4, atol=1e-5)
+    for a, u in zip(res[0][1], res[1][1]):
+        assert (a - u).norm() <= 2e-4 * u.norm() + 1e-8

@@ -16,7 +16,7 @@ def family(name):
     n = name
     if "k_gat_" in n:
         return "gat_edge"
-    if "k_gemm_bf16" in n:
+    if "k_gemm_tn_bf16" in n:
         return "gemm_bf16_own"
     if n.startswith("Cijk_") or n.startswith("Custom_Cijk") or "rocblas_gem" in n or "gemv" in n.lower():
         if "_DB_" in n or "double" in n:
@@ -59,6 +59,37 @@ def main():
         print(f"family {k:20s} {fam_c[k]/steps:6.1f}/step {v/steps/1e3:8.1f} us/step")
     for n, v in sorted(t.items(), key=lambda x: -x[1])[:top]:
         print(f"{c[n]/steps:6.1f}/step {v/c[n]/1e3:8.1f} us  {v/steps/1e3:7.1f} us/step  {n[:110]}")
+    # device idle: intervals inside the timed region in which NO kernel of any queue runs, charged to the kernel that ends them
+    idle = collections.Counter(); idle_n = collections.Counter()
+    busy_end = int(sel[0]['Start_Timestamp']); idle_total = 0
+    for r in sel:
+        s0, e0 = int(r['Start_Timestamp']), int(r['End_Timestamp'])
+        if s0 > busy_end:
+            gap = s0 - busy_end
+            idle_total += gap
+            if gap > 3000:
+                idle[r['Kernel_Name']] += gap; idle_n[r['Kernel_Name']] += 1
+        busy_end = max(busy_end, e0)
+    print(f"device idle (no kernel on any queue): {idle_total / steps / 1e3:.0f} us/step; gaps > 3 us by the kernel that follows:")
+    for n, v in sorted(idle.items(), key=lambda x: -x[1])[:14]:
+        print(f"   idle {v / steps / 1e3:6.1f} us/step  ({idle_n[n] / steps:.1f} gaps/step, {v / idle_n[n] / 1e3:5.1f} us each) before {n[:90]}")
+    if len(sys.argv) > 6:      # region report: launches between two kernel-name patterns, for a few steps (argv[6] = "patA,patB")
+        pa, pb = sys.argv[6].split(",")
+        shown = 0
+        i = first
+        while i < len(rows) and shown < 4:
+            if pa in rows[i]['Kernel_Name']:
+                j = i
+                while j < len(rows) and pb not in rows[j]['Kernel_Name']:
+                    j += 1
+                t0 = int(rows[i]['Start_Timestamp'])
+                print(f"--- region {pa} .. {pb}, occurrence {shown}")
+                for r in rows[i:j + 1]:
+                    print(f"{(int(r['Start_Timestamp']) - t0) / 1e3:9.1f} us  +{(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:7.1f} us  q{r.get('Queue_Id', '?')}  {r['Kernel_Name'][:100]}")
+                shown += 1
+                i = j + len(sel) // steps * 9        # skip ahead ~9 steps
+            else:
+                i += 1
     if len(sys.argv) > 5:      # the launches of the last timed step, in start order (stream = queue id): who sits between whom
         last = rows[idx[-2] + 1:idx[-1] + 1]
         t0 = int(last[0]['Start_Timestamp'])
