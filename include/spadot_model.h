@@ -303,6 +303,15 @@ int spadot_mlp_chain_backward(const float *dy, const float *x, int b, int n_laye
                               const float *const *gamma, const double *slope, float *const *a, float *const *y,
                               float *const *mean, float *const *invstd, float *dx, float *workspace, float *grads, void *stream);
 
+/* ---- reconstruction term on the output map's GEMM result (csrc/mlp_chain.hip) -------------------------------------------
+ * out[0] = inv_scale * sum_{r,c} (y[r,c] - (o[r,c] + bias[c]))^2   (/root/reference/SpaDOT/model/SpaDOT.py:89 on the
+ * decoder's output map, decoder.py:20), o = h W^T [b x G] fp32 without the bias: two launches (b <= 4096; scratch: >= 4096 doubles).  backward: g (bf16 [b x G]) = g1[0] * d out / d o and
+ * dbias[c] = sum_r of the same values in fp32, fixed order. */
+int spadot_bias_sqerr_forward(const float *o, const float *bias, const float *y, int b, int G, double inv_scale, double *scratch,
+                              float *out, void *stream);
+int spadot_bias_sqerr_backward(const float *g1, const float *o, const float *bias, const float *y, int b, int G,
+                               double inv_scale, void *g_bf16, float *dbias, void *stream);
+
 /* dst[t][r, 0:K[t]] = (bf16) src[t][r, 0:K[t]] for n <= 4 row-major matrices in one launch (fp32 weights -> their
  * compute-dtype images; dst rows have Kp[t] >= K[t] elements, the padding is not touched; K, Kp multiples of 4). */
 int spadot_cast_rows_multi(const float *const *src, void *const *dst, const int *rows, const int *K, const int *Kp, int n,

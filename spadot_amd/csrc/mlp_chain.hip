@@ -314,6 +314,94 @@ __global__ __launch_bounds__(256) void k_mlp_chain_bwd(const float *__restrict__
     }
 }
 
+// ---- the reconstruction term on the output map's GEMM result -------------------------------------------------------------
+// recon = inv_scale * sum (y - (o + bias))^2 with o = h W^T straight out of the GEMM (SpaDOT.py:89 on decoder.py:20's output
+// map): bias add and squared error in one launch (fp64 partials, one per row) and a one-workgroup sum in fixed order; backward: dL/d(o) in bf16 for the two GEMMs AND the bias gradient (column sums, fixed order) in one launch.
+__device__ __forceinline__ double block_sum_d(double x, double *sh) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, WAVE);
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = x;
+    __syncthreads();
+    double t = 0.0;
+    for (int k = 0; k < nw; k++) t += sh[k];
+    return t;
+}
+
+constexpr int SQ_ROWS = 1;                  // rows per workgroup: b workgroups (16 waves per compute unit at b = 1024)
+__global__ __launch_bounds__(256) void k_bias_sqerr_part(const float *__restrict__ o, const float *__restrict__ bias,
+                                                         const float *__restrict__ y, int b, int G,
+                                                         double *__restrict__ part) {
+    __shared__ double sh[16];
+    const size_t row = (size_t)blockIdx.x * G;
+    double acc = 0.0;
+    // four column steps per trip: 12 independent loads in flight per thread (the kernel is latency-bound otherwise)
+    for (int c0 = threadIdx.x; c0 < G; c0 += 4 * 256) {
+        float yo[4], oo[4], bc[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int c = c0 + u * 256;
+            const bool on = c < G;
+            yo[u] = on ? y[row + c] : 0.f;
+            oo[u] = on ? o[row + c] : 0.f;
+            bc[u] = on ? bias[c] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const double d = (double)yo[u] - (double)(oo[u] + bc[u]);
+            acc += d * d;
+        }
+    }
+    acc = block_sum_d(acc, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = acc;
+}
+// (Not a last-workgroup-finishes kernel: the device-scope release each workgroup needs for that writes the XCD's L2 back, and
+// behind a GEMM that has just left 12 MB of dirty output there the one-launch form took 19-38 us against 5 + 5 for two.)
+__global__ __launch_bounds__(1024) void k_sum_parts(const double *__restrict__ part, int nparts, double scale,
+                                                    float *__restrict__ out) {
+    __shared__ double sh[16];
+    double acc = 0.0;
+    for (int k = threadIdx.x; k < nparts; k += 1024) acc += part[k];
+    acc = block_sum_d(acc, sh);
+    if (threadIdx.x == 0) out[0] = (float)(acc * scale);
+}
+
+constexpr int SB_COLS = 32, SB_GY = 32;
+__global__ __launch_bounds__(SB_COLS * SB_GY) void k_bias_sqerr_bwd(const float *__restrict__ g1, const float *__restrict__ o,
+                                                                    const float *__restrict__ bias, const float *__restrict__ y,
+                                                                    int b, int G, double inv_scale, __bf16 *__restrict__ g,
+                                                                    float *__restrict__ dbias) {
+    __shared__ float sh[SB_GY][SB_COLS + 1];
+    const int cx = threadIdx.x & (SB_COLS - 1), gy = threadIdx.x / SB_COLS;
+    const int c = blockIdx.x * SB_COLS + cx;
+    const double coef = -2.0 * inv_scale * (double)g1[0];
+    float acc = 0.f;
+    if (c < G) {
+        const float bc = bias[c];
+        const int per = (b + SB_GY - 1) / SB_GY;
+        const int ra = gy * per, rz = min(b, ra + per);
+        for (int r = ra; r < rz; r += 8) {                           // eight rows in flight, added in ascending order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const size_t e = (size_t)(r + u) * G + c;
+                v[u] = (r + u < rz) ? (float)(coef * ((double)y[e] - (double)(o[e] + bc))) : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (r + u < rz) { g[(size_t)(r + u) * G + c] = (__bf16)v[u]; acc += v[u]; }
+        }
+    }
+    sh[gy][cx] = acc;
+    __syncthreads();
+    if (gy != 0 || c >= G) return;
+    acc = 0.f;
+#pragma unroll
+    for (int q = 0; q < SB_GY; q++) acc += sh[q][cx];
+    dbias[c] = acc;
+}
+
 bool fill_chain(Chain &ch, int n_layers, const int *dims, const float *const *W, const float *const *bias,
                 const float *const *gamma, const float *const *beta, const double *eps, const double *slope, float *const *a,
                 float *const *y, float *const *mean, float *const *invstd) {
@@ -379,6 +467,23 @@ int spadot_mlp_chain_backward(const float *dy, const float *x, int b, int n_laye
     hipLaunchKernelGGL(k_mlp_chain_bwd, dim3(rows), dim3(256), LDS_BWD, (hipStream_t)stream, dy, x, b, ch, dx, workspace, width);
     if (hipGetLastError() != hipSuccess) return -5;
     return spadot_colsum(workspace, rows, width, grads, stream);     // grads: one workspace row = [dW | dbias | dgamma | dbeta] per stage
+}
+
+int spadot_bias_sqerr_forward(const float *o, const float *bias, const float *y, int b, int G, double inv_scale, double *scratch,
+                              float *out, void *stream) {
+    const int nb = (b + SQ_ROWS - 1) / SQ_ROWS;                    // one partial per workgroup: scratch holds 4096 doubles
+    if (b <= 0 || G <= 0 || !scratch || nb > 4096) return -22;
+    hipLaunchKernelGGL(k_bias_sqerr_part, dim3(nb), dim3(256), 0, (hipStream_t)stream, o, bias, y, b, G, scratch);
+    hipLaunchKernelGGL(k_sum_parts, dim3(1), dim3(1024), 0, (hipStream_t)stream, scratch, nb, inv_scale, out);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+int spadot_bias_sqerr_backward(const float *g1, const float *o, const float *bias, const float *y, int b, int G,
+                               double inv_scale, void *g_bf16, float *dbias, void *stream) {
+    if (b <= 0 || G <= 0) return -22;
+    hipLaunchKernelGGL(k_bias_sqerr_bwd, dim3((G + SB_COLS - 1) / SB_COLS), dim3(SB_COLS * SB_GY), 0, (hipStream_t)stream, g1, o,
+                       bias, y, b, G, inv_scale, (__bf16 *)g_bf16, dbias);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
 }  // extern "C"

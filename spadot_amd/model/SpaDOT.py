@@ -96,7 +96,7 @@ class SpaDOT(nn.Module):
             t.record_stream(main)
         # both reparameterised samples (noise drawn in the kernel), GAT KL and the alignment term: one launch
         final_latent, GAT_KL, alignment_loss = latent_head(zg, p_m, p_v, eps, Ls, Lg, self._rng_state())
-        recon_loss = sqerr_sum(y_seed32 if y_seed32 is not None else yb.float(), self.decoder(final_latent), 1.0 / self.input_dim)
+        recon_loss = self.decoder.recon_loss(final_latent, y_seed32 if y_seed32 is not None else yb.float(), 1.0 / self.input_dim)
         return recon_loss, SVGP_KL, GAT_KL, alignment_loss, final_latent
 
     # ---- the three parts of forward() on their own (GraphedStepper's staged mode replays them as separate graphs:
@@ -124,7 +124,7 @@ class SpaDOT(nn.Module):
         eps = None if noise is None else torch.cat([noise[0][:b].float(), noise[1][:b].float()], dim=1)
         final_latent, GAT_KL, alignment_loss = latent_head(zg, p_m, p_v, eps, Ls, Lg, self._rng_state())
         yb32 = y_seed32 if y_seed32 is not None else y[:b, :self.input_dim].float()
-        recon_loss = sqerr_sum(yb32, self.decoder(final_latent), 1.0 / self.input_dim)
+        recon_loss = self.decoder.recon_loss(final_latent, yb32, 1.0 / self.input_dim)
         return recon_loss, GAT_KL, alignment_loss, final_latent
 
     def _rng_state(self):

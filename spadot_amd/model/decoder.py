@@ -9,7 +9,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..ops import linear_bias, ln_act, mlp_chain, mlp_chain_ok
+from ..ops import linear_bias, ln_act, mlp_chain, mlp_chain_ok, recon_sqerr, recon_sqerr_ok, sqerr_sum
 
 
 def _hidden_stage(fan_in, fan_out):
@@ -30,6 +30,19 @@ class Decoder(nn.Module):
         self.decoder_net = nn.Sequential(*stages)
 
     def forward(self, latent_sample):
+        h, last = self._hidden(latent_sample)
+        # hidden -> G is the only large GEMM here: compute dtype on MFMA (fp32 accumulate), fp32 result
+        return linear_bias(h, last.weight, last.bias, self.compute_dtype)
+
+    def recon_loss(self, latent_sample, y, inv_scale):
+        """inv_scale * sum (y - decoder(latent))^2 (SpaDOT.py:89) without materialising the reconstruction separately: in the
+        bf16 compute dtype the bias add, the squared error and its sum are one launch behind the output map's GEMM."""
+        h, last = self._hidden(latent_sample)
+        if self.compute_dtype == torch.bfloat16 and recon_sqerr_ok(h, last.weight, last.bias, y):
+            return recon_sqerr(h, last.weight, last.bias, y, inv_scale)
+        return sqerr_sum(y, linear_bias(h, last.weight, last.bias, self.compute_dtype), inv_scale)
+
+    def _hidden(self, latent_sample):
         stages = list(self.decoder_net)
         h = latent_sample
         hidden = [(stages[i], stages[i + 1], stages[i + 2].negative_slope) for i in range(0, len(stages) - 1, 3)]
@@ -38,6 +51,4 @@ class Decoder(nn.Module):
         else:
             for dense, norm, slope in hidden:
                 h = ln_act(linear_bias(h, dense.weight, dense.bias), norm, slope)     # LN + LeakyReLU: one launch
-        last = stages[-1]
-        # hidden -> G is the only large GEMM here: compute dtype on MFMA (fp32 accumulate), fp32 result
-        return linear_bias(h, last.weight, last.bias, self.compute_dtype)
+        return h, stages[-1]

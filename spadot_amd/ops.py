@@ -874,6 +874,54 @@ def sqerr_sum(y, yhat, inv_scale):
     return _SqErr.apply(y, yhat, inv_scale)
 
 
+RECON_FUSED = [__import__("os").environ.get("SPADOT_RECON_FUSED", "1") == "1"]   # [False]: linear_bias + sqerr_sum (A/B, tests)
+
+
+class _LinearSqErr(torch.autograd.Function):
+    """inv_scale * sum (y - (h W^T + bias))^2 with the output map in bf16 on the matrix cores (fp32 accumulate, fp32 result):
+    cast, GEMM, [bias + squared error], sum forward; [d/d(o) in bf16 + bias gradient], two GEMMs backward -- 4 + 3
+    launches where linear_bias + sqerr_sum take 5 + 5."""
+
+    @staticmethod
+    def forward(ctx, h, W, bias, y, inv_scale):
+        b, G = y.shape
+        hc = torch.empty(h.shape, dtype=torch.bfloat16, device=h.device)
+        Wc = torch.empty(W.shape, dtype=torch.bfloat16, device=W.device)
+        cast_rows([(h, hc), (W.detach().contiguous(), Wc)])
+        o = torch.mm(hc, Wc.t(), out_dtype=torch.float32)
+        out = torch.empty(1, dtype=torch.float32, device=h.device)
+        _check(model_lib().spadot_bias_sqerr_forward(_p(o), _p(bias), _p(y), b, G, float(inv_scale), _p(_get_scratch(h.device)),
+                                                     _p(out), _stream()), "spadot_bias_sqerr_forward")
+        ctx.save_for_backward(hc, Wc, o, bias, y)
+        ctx.inv_scale = float(inv_scale)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        hc, Wc, o, bias, y = ctx.saved_tensors
+        b, G = y.shape
+        g1 = g.reshape(1).contiguous().float()
+        gc = torch.empty((b, G), dtype=torch.bfloat16, device=y.device)
+        db = torch.empty(G, dtype=torch.float32, device=y.device)
+        _check(model_lib().spadot_bias_sqerr_backward(_p(g1), _p(o), _p(bias), _p(y), b, G, ctx.inv_scale, _p(gc), _p(db),
+                                                      _stream()), "spadot_bias_sqerr_backward")
+        dh = torch.mm(gc, Wc, out_dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        dW = torch.mm(gc.t(), hc, out_dtype=torch.float32)
+        return dh, dW, db, None, None
+
+
+def recon_sqerr_ok(h, W, bias, y):
+    return bool(RECON_FUSED[0] and h.is_cuda and h.dtype == torch.float32 and y.dtype == torch.float32 and h.dim() == 2
+                and y.dim() == 2 and h.shape[1] % 4 == 0 and W.shape[1] % 4 == 0 and y.shape == (h.shape[0], W.shape[0])
+                and h.shape[0] <= 4096
+                and bias is not None)
+
+
+def recon_sqerr(h, W, bias, y, inv_scale):
+    """inv_scale * sum (y - linear(h, W, bias))^2, the output map computed in bf16 (see _LinearSqErr)."""
+    return _LinearSqErr.apply(h.contiguous(), W, bias, y.contiguous(), inv_scale)
+
+
 def kmeans_assign(x, centers):
     """int32 labels = nearest centre (fp64 distance accumulation, first minimum wins)."""
     _need_cuda(x, centers)
@@ -977,6 +1025,12 @@ class FlatAdamW:
         `outputs` (weighted by grad_outputs; None for a scalar loss) w.r.t. `params` go to their views of the flat
         buffer (written, not accumulated; zeros where unreachable), those w.r.t. `extra_inputs` are returned."""
         ins = list(params) + list(extra_inputs)
+        if grad_outputs is None and torch.is_tensor(outputs) and outputs.dim() == 0 and outputs.dtype == torch.float32:
+            # the seed of a scalar loss from a constant instead of a ones_like fill launch per step
+            one = getattr(self, "_one", None)
+            if one is None or one.device != outputs.device:
+                one = self._one = torch.ones((), dtype=torch.float32, device=outputs.device)
+            grad_outputs = one
         _DIRECT_GRAD[0] = True
         try:
             grads = torch.autograd.grad(outputs, ins, grad_outputs=grad_outputs, allow_unused=True)

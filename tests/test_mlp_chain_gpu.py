@@ -116,3 +116,37 @@ def test_decoder_uses_the_chain_and_keeps_its_gradients():
     np.testing.assert_allclose(res[0][0].cpu().numpy(), res[1][0].cpu().numpy(), rtol=1e-4, atol=1e-5)
     for a, u in zip(res[0][1], res[1][1]):
         assert (a - u).norm() <= 2e-4 * u.norm() + 1e-8
+
+
+@pytest.mark.parametrize("b,G,K", [(1024, 3000, 256), (37, 100, 64), (512, 33, 8)])
+def test_fused_reconstruction_term_matches_the_separate_launches(b, G, K):
+    """Decoder.recon_loss in the bf16 compute dtype: [cast, GEMM, bias + squared error + sum] against linear_bias + sqerr_sum
+    (the same bf16 GEMM, so the values agree to summation order), and against an fp64 evaluation of the same bf16 operands."""
+    from spadot_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(G)
+    h = torch.randn((b, K), device=DEV, generator=g)
+    W = (torch.randn((G, K), device=DEV, generator=g) * 0.1)
+    bias = torch.randn(G, device=DEV, generator=g) * 0.1
+    y = torch.randn((b, G), device=DEV, generator=g)
+    inv = 1.0 / G
+    res = []
+    for fused in (True, False):
+        hh, WW, bb = (t.clone().requires_grad_(True) for t in (h, W, bias))
+        if fused:
+            assert ops.recon_sqerr_ok(hh, WW, bb, y)
+            loss = ops.recon_sqerr(hh, WW, bb, y, inv)
+        else:
+            loss = ops.sqerr_sum(y, ops.linear_bias(hh, WW, bb, torch.bfloat16), inv)
+        (loss * 0.37).backward()
+        res.append((loss.detach().double().item(), hh.grad, WW.grad, bb.grad))
+    ref = inv * ((y.double() - (h.bfloat16().double() @ W.bfloat16().double().t() + bias.double())) ** 2).sum().item()
+    assert abs(res[0][0] - ref) <= 2e-6 * abs(ref)
+    assert abs(res[0][0] - res[1][0]) <= 2e-6 * abs(ref)
+    for a, u in zip(res[0][1:], res[1][1:]):
+        assert (a - u).norm() <= 1e-5 * u.norm() + 1e-9
+    # same bits on every launch
+    hh, WW, bb = (t.clone().requires_grad_(True) for t in (h, W, bias))
+    loss = ops.recon_sqerr(hh, WW, bb, y, inv)
+    (loss * 0.37).backward()
+    assert loss.item() == res[0][0] or abs(loss.double().item() - res[0][0]) == 0.0
+    assert torch.equal(bb.grad, res[0][3])
