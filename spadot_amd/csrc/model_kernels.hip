@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 
 #include "../../include/spadot_model.h"
 
@@ -1187,6 +1188,39 @@ __global__ __launch_bounds__(256) void k_sumsq_last(const float *__restrict__ g,
 
 __global__ void k_step_inc(int *step) { step[0] += 1; }
 
+// The same sum as two launches: per-workgroup partials (no cross-workgroup hand-over, so any number of workgroups), then one
+// workgroup adds them in order and advances the step count.  k_sumsq_last's hand-over needs a device-scope release per
+// workgroup, which writes the XCD's L2 back -- right behind the backward pass that has just filled it with dirty gradient lines.
+template <int U>
+__global__ __launch_bounds__(256) void k_sumsq_part_u(const float *__restrict__ g, long long count, double *__restrict__ part) {
+    __shared__ double sh[16];
+    double acc = 0.0;
+    const long long n4 = count / 4;
+    const float4 *g4 = reinterpret_cast<const float4 *>(g);
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < n4; k += U * stride) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            v[u] = (k + u * stride < n4) ? g4[k + u * stride] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            acc += ((double)v[u].x * v[u].x + (double)v[u].y * v[u].y) + ((double)v[u].z * v[u].z + (double)v[u].w * v[u].w);
+    }
+    if (blockIdx.x == 0)
+        for (long long k = n4 * 4 + threadIdx.x; k < count; k += 256) acc += (double)g[k] * g[k];
+    acc = block_sum_d(acc, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = acc;
+}
+__global__ __launch_bounds__(1024) void k_final_sum_step(const double *__restrict__ part, int nparts, float *__restrict__ out,
+                                                         int *__restrict__ step_dev) {
+    __shared__ double sh[16];
+    double acc = 0.0;
+    for (int k = threadIdx.x; k < nparts; k += 1024) acc += part[k];
+    acc = block_sum_d(acc, sh);
+    if (threadIdx.x == 0) { out[0] = (float)acc; if (step_dev) step_dev[0] += 1; }
+}
+
 __global__ __launch_bounds__(256) void k_adamw(float *__restrict__ p, const float *__restrict__ g,
                                                float *__restrict__ m, float *__restrict__ v,
                                                const float *__restrict__ sumsq, long long count, float lr,
@@ -2218,7 +2252,13 @@ int spadot_clip_adamw_dev(float *param, const float *grad, float *exp_avg, float
     // 512 workgroups: every workgroup ends with an agent-scope release (L2 write-back) before its counter add, so
     // the launch got SLOWER with more of them (2048: 56 us, 512: 31 us for 64 MB; tools/adamw_bench.py)
     const int nbs = (int)(want4 < 1 ? 1 : (want4 < 512 ? want4 : 512));
-    hipLaunchKernelGGL(k_sumsq_last<4>, dim3(nbs), dim3(256), 0, st_, grad, count, scratch, sumsq, step_dev, counter);
+    static const int split = [] { const char *e = getenv("SPADOT_SUMSQ_SPLIT"); return e ? atoi(e) : 2048; }();   // 0: the one-launch form (same-box A/B: 1.972 -> 1.941 ms per step with 2048)
+    if (split > 0) {
+        const int nb2 = (int)(want4 < 1 ? 1 : (want4 < split ? want4 : split));
+        hipLaunchKernelGGL(k_sumsq_part_u<4>, dim3(nb2), dim3(256), 0, st_, grad, count, scratch);
+        hipLaunchKernelGGL(k_final_sum_step, dim3(1), dim3(1024), 0, st_, (const double *)scratch, nb2, sumsq, step_dev);
+    } else
+        hipLaunchKernelGGL(k_sumsq_last<4>, dim3(nbs), dim3(256), 0, st_, grad, count, scratch, sumsq, step_dev, counter);
     const long long want = (count + 255) / 256;
     const int nb = (int)(want < 4096 ? want : 4096);
     hipLaunchKernelGGL(k_adamw, dim3(nb), dim3(256), 0, st_, param, grad, exp_avg, exp_avg_sq, (const float *)sumsq, count,

@@ -481,6 +481,20 @@ def _ptr_array(tensors):
     return (ctypes.c_void_p * len(tensors))(*(t_.data_ptr() for t_ in tensors))
 
 
+def _contiguous_grad_block(params):
+    """One fp32 tensor over the .grad views of `params` when those are consecutive pieces of one storage, else None."""
+    gs_ = [p.grad for p in params]
+    if any(g is None or g.dtype != torch.float32 or not g.is_contiguous() for g in gs_):
+        return None
+    st0, off = gs_[0].untyped_storage(), gs_[0].storage_offset()
+    pos = off
+    for g in gs_:
+        if g.untyped_storage().data_ptr() != st0.data_ptr() or g.storage_offset() != pos:
+            return None
+        pos += g.numel()
+    return torch.empty(0, dtype=torch.float32, device=gs_[0].device).set_(st0, off, (pos - off,))
+
+
 class _MLPChain(torch.autograd.Function):
     """[Linear, LayerNorm, LeakyReLU] x n on a 2-D fp32 input: one launch forward, one + a column sum backward."""
 
@@ -503,6 +517,9 @@ class _MLPChain(torch.autograd.Function):
                                                     _ptr_array(inv), _stream()), "spadot_mlp_chain_forward")
         ctx.save_for_backward(x, stats, *Ws, *gs, *a, *y)
         ctx.n, ctx.dims, ctx.slope = n, dims, [float(v) for v in slope]
+        # FlatAdamW keeps every .grad as a view of its flat buffer; when this chain's parameters sit there back to back in
+        # (W, bias, gamma, beta) order -- the module order -- the backward pass writes its result row straight into it
+        ctx.flat_out = _contiguous_grad_block(params)
         return y[-1]
 
     @staticmethod
@@ -518,7 +535,8 @@ class _MLPChain(torch.autograd.Function):
         lib = model_lib()
         _check(lib.spadot_mlp_chain_workspace(b, n, cd, ctypes.byref(rows), ctypes.byref(width)), "spadot_mlp_chain_workspace")
         ws = torch.empty((rows.value, width.value), dtype=torch.float32, device=dev)
-        grads = torch.empty(width.value, dtype=torch.float32, device=dev)
+        direct = ctx.flat_out is not None and _DIRECT_GRAD[0] and ctx.flat_out.numel() == width.value
+        grads = ctx.flat_out if direct else torch.empty(width.value, dtype=torch.float32, device=dev)
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         mean, inv = [stats[2 * l] for l in range(n)], [stats[2 * l + 1] for l in range(n)]
         cs = (ctypes.c_double * n)(*ctx.slope)
@@ -672,11 +690,14 @@ class _MixLosses(torch.autograd.Function):
         ctx.save_for_backward(w6)
         log7 = out8[:7]
         ctx.mark_non_differentiable(log7)
+        ctx.set_materialize_grads(False)          # (no zero-filled gradient for the logging vector: one launch less per step)
         return out8[7], log7
 
     @staticmethod
     def backward(ctx, g, _):
         (w6,) = ctx.saved_tensors
+        if g is None:
+            return (None,) * 7
         g6 = torch.empty(6, dtype=torch.float32, device=w6.device)
         _check(model_lib().spadot_mix_losses_backward(_p(g.contiguous().float()), _p(w6), _p(g6), _stream()),
                "spadot_mix_losses_backward")
@@ -894,6 +915,8 @@ class _LinearSqErr(torch.autograd.Function):
                                                      _p(out), _stream()), "spadot_bias_sqerr_forward")
         ctx.save_for_backward(hc, Wc, o, bias, y)
         ctx.inv_scale = float(inv_scale)
+        ok = lambda g_, p_: g_ if (g_ is not None and g_.dtype == torch.float32 and g_.is_contiguous() and g_.shape == p_.shape) else None
+        ctx.wgrad, ctx.bgrad = ok(W.grad, W), ok(bias.grad, bias)      # views of the flat gradient buffer (FlatAdamW): written in place
         return out[0]
 
     @staticmethod
@@ -902,11 +925,15 @@ class _LinearSqErr(torch.autograd.Function):
         b, G = y.shape
         g1 = g.reshape(1).contiguous().float()
         gc = torch.empty((b, G), dtype=torch.bfloat16, device=y.device)
-        db = torch.empty(G, dtype=torch.float32, device=y.device)
+        direct = _DIRECT_GRAD[0]
+        db = ctx.bgrad if (direct and ctx.bgrad is not None) else torch.empty(G, dtype=torch.float32, device=y.device)
         _check(model_lib().spadot_bias_sqerr_backward(_p(g1), _p(o), _p(bias), _p(y), b, G, ctx.inv_scale, _p(gc), _p(db),
                                                       _stream()), "spadot_bias_sqerr_backward")
         dh = torch.mm(gc, Wc, out_dtype=torch.float32) if ctx.needs_input_grad[0] else None
-        dW = torch.mm(gc.t(), hc, out_dtype=torch.float32)
+        if direct and ctx.wgrad is not None:
+            dW = torch.mm(gc.t(), hc, out_dtype=torch.float32, out=ctx.wgrad)
+        else:
+            dW = torch.mm(gc.t(), hc, out_dtype=torch.float32)
         return dh, dW, db, None, None
 
 

@@ -492,6 +492,10 @@ class GraphedStepper:
         beside it, and the all-reduce of the rest."""
         main = torch.cuda.current_stream()
         side = self.model._side_stream() if two_streams else main
+        skip = os.environ.get("SPADOT_SKIP_STAGE")          # timing experiments only (wrong results): leave one stage out
+        if skip is not None and two_streams:
+            fns = list(fns)
+            fns[int(skip)] = lambda: None
         # Issue order inside a pair: the GAT graph (main stream, the longer one) FIRST.  A graph launch costs the host
         # ~2.5 us per node, and the graph launched second only starts once the first has been handed over: with the
         # ~45-node SVGP graph in front, the main stream sat idle for 120 us (forward) and 190 us (backward) per step
