@@ -261,6 +261,7 @@ def cast_rows(pairs):
 # the library's ~800 short-lived workgroups let that branch's small kernels in.  So both uses are opt-in.
 GEMM_FWD = [__import__("os").environ.get("SPADOT_GEMM_FWD", "0") == "1"]
 GEMM_DGRAD = [__import__("os").environ.get("SPADOT_GEMM_DGRAD", "0") == "1"]
+GEMM_MAX_WGS = [int(__import__("os").environ.get("SPADOT_GEMM_MAXWG", "256"))]   # own GEMM only up to this many tiles (CUs left free)
 GEMM_OWN = [True]                                  # [False]: gemm_tn() itself goes to the library (tests)
 
 
@@ -271,7 +272,8 @@ def gemm_tn(x, w):
     M, K = x.shape
     N = w.shape[0]
     if (GEMM_OWN[0] and x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.is_contiguous()
-            and w.is_contiguous() and N % 256 == 0 and K % 64 == 0 and w.shape[1] == K and M >= 2560 and N >= 1024):
+            and w.is_contiguous() and N % 256 == 0 and K % 64 == 0 and w.shape[1] == K and M >= 2560 and N >= 1024
+            and ((M + 319) // 320) * (N // 256) <= GEMM_MAX_WGS[0]):
         out = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
         rc = model_lib().spadot_gemm_tn_bf16(x.data_ptr(), K, w.data_ptr(), K, out.data_ptr(), N, M, N, K, _stream())
         if rc == 0:
