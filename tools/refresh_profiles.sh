@@ -32,6 +32,15 @@ cp $O/gat_bench.txt $P/gat_cfg3_bf16_microbench.txt
 tail -1 $O/sink.json > $P/sinkhorn_cfg3_f32_bench_under_rocprof.json
 tail -1 $O/train.json > $P/train_cfg3_bf16_bench_under_rocprof.json
 python3 tools/prof_summary.py $O/train 40 40 $P/train_cfg3_bf16_families.json > $P/train_cfg3_bf16_per_step_breakdown.txt
+# GEMM evidence: the box's bare-MFMA rate, the library on the step's shapes, csrc/gemm_bf16.hip against the library
+{
+  echo "== tools/mfma_peak.hip (bare v_mfma loops, this box)"
+  /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/mfma_peak.hip -o /tmp/mfma_peak 2>/dev/null && timeout -k 10 120 /tmp/mfma_peak
+  echo "== tools/gemm_shapes.py (library bf16 GEMM on the step's shapes, alone)"
+  PYTHONPATH=$R timeout -k 10 200 python3 tools/gemm_shapes.py 2>/dev/null
+  echo "== tools/gemm_bench.py (csrc/gemm_bf16.hip vs the library, interleaved rounds, random data)"
+  PYTHONPATH=$R timeout -k 10 200 python3 tools/gemm_bench.py 2>/dev/null
+} > $P/gemm_probes.txt || true
 # the plain line (reads the summaries just written for roofline.traffic and roofline_train)
 timeout -k 10 900 python3 bench.py > $O/bench.json 2> $O/bench.log
 tail -1 $O/bench.json > $P/bench_cfg3_1gpu.json
