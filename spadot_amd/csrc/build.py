@@ -46,7 +46,8 @@ def build_all(force=False, verbose=True):
             for s, name in zip(paths, srcs):          # one object per translation unit, then one link
                 obj = s[:-4] + ".o"
                 if force or _stale(s, obj, headers):
-                    cmd = [HIPCC] + [f for f in FLAGS if f != "-shared"] + EXTRA.get(name, []) + ["-c", "-o", obj, s]
+                    defs = os.environ.get("SPADOT_BUILD_DEFS", "").split()      # e.g. "-DAGG_RING=4" (A/B builds on the GPU box)
+                    cmd = [HIPCC] + [f for f in FLAGS if f != "-shared"] + EXTRA.get(name, []) + defs + ["-c", "-o", obj, s]
                     if verbose:
                         print(" ".join(cmd), flush=True)
                     subprocess.check_call(cmd)

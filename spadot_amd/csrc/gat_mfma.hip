@@ -229,8 +229,11 @@ constexpr int ROWB = 2 * C + 64;                    // staged row stride (bytes)
 constexpr int CHUNKB = KSTEP * ROWB;                // 17408
 constexpr int OUTB = 2 * C + 16;                    // epilogue image row stride (bytes)
 constexpr int ATILEB = 2048;                        // hi (1 KiB) | lo (1 KiB)
-constexpr int RING = 3;
-constexpr int MAXC = 1024;                          // longest column list of a block
+#ifndef AGG_RING
+#define AGG_RING 3
+#endif
+constexpr int RING = AGG_RING;                      // chunks of LDS ring: RING - 1 in flight while one is multiplied
+constexpr int MAXC = 1024 - ROWS;                   // longest column list of a block (ids + row ids = 4 KiB)
 constexpr int LDS_RING = RING * CHUNKB;             // 52224 >= 32 * OUTB
 constexpr int LDS_BYTES = LDS_RING + RING * ATILEB + MAXC * 4 + ROWS * 4;
 }  // namespace agg
@@ -320,14 +323,18 @@ __global__ __launch_bounds__(NT, 2) void k_gat_agg(
         }
     };
 
-    if (0 < nch) request(0);
-    if (1 < nch) request(1);
+#pragma unroll
+    for (int c = 0; c < RING - 1; c++)
+        if (c < nch) request(c);
     for (int it = 0; it < nch; it++) {
-        if (it + 1 < nch) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        // chunk `it` has landed when at most the 5-operation groups of the younger chunks in flight are outstanding
+        const int younger = min(nch - 1 - it, RING - 2);
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (it + 2 < nch) request(it + 2);
+        if (it + RING - 1 < nch) request(it + RING - 1);
         multiply(it);
     }
 

@@ -461,7 +461,8 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_fused_pass(
     const T *__restrict__ K, const double *__restrict__ w, double *__restrict__ a,
     double *__restrict__ old_a, double *__restrict__ adx, const double *__restrict__ p,
     const double *__restrict__ dx, const double *__restrict__ u, double alpha1, double inv_l1e,
-    double tau, T *__restrict__ part, int I, int ld, int rows_per_block, int *flag) {
+    double tau, T *__restrict__ part, int I, int ld, int rows_per_block, int *flag, const int *__restrict__ stop) {
+    if (stop != nullptr && *stop != 0) return;       // a speculatively enqueued batch behind the converged one: nothing to do
     constexpr int V = Vec<T>::N;
     extern __shared__ double smem[];
     constexpr int WPAD = VPT * FUSED_THREADS * V;    // w image padded with zeros to the register tile
@@ -542,7 +543,8 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_fused_pass(
 template <typename T, int VPT, int R, typename WT = double>
 __global__ __launch_bounds__(FUSED_THREADS) void k_fused_rowdot(const T *__restrict__ K, const double *__restrict__ w,
                                                                 double *__restrict__ sdot, int I, int ld,
-                                                                int rows_per_block) {
+                                                                int rows_per_block, const int *__restrict__ stop) {
+    if (stop != nullptr && *stop != 0) return;
     constexpr int V = Vec<T>::N;
     constexpr int NW = FUSED_THREADS / 64;
     extern __shared__ double smem[];
@@ -625,7 +627,8 @@ __global__ __launch_bounds__(1024) void k_col_fin2(const PT *__restrict__ part, 
                                                    const double *__restrict__ dy,
                                                    const double *__restrict__ v, double alpha2,
                                                    double inv_l2e, double tau, int J, int ld,
-                                                   int *flag, double *t_out, int mode) {
+                                                   int *flag, double *t_out, int mode, const int *__restrict__ stop) {
+    if (stop != nullptr && *stop != 0) return;
     __shared__ double sh[16][65];
     const int cx = threadIdx.x & 63, gy = threadIdx.x >> 6;
     const int j = blockIdx.x * 64 + cx;
@@ -853,6 +856,15 @@ __global__ __launch_bounds__(256) void k_row_dot(const T *__restrict__ K, const 
     if (lane == 0) sdot[row] = sm;
 }
 
+// Device-side stop decision of a speculatively enqueued batch (ctl = {stop, converged batch + 1, tau batch + 1}): the batch
+// whose measure is no longer above the threshold -- or that raised the tau flag, which sends the host back to that batch's
+// snapshot -- sets ctl[0]; every kernel of the batches enqueued behind it sees it and returns at once.
+__device__ __forceinline__ void decide_stop(double measure, double threshold, int batch, int *ctl, const int *tauflag) {
+    if (ctl == nullptr) return;
+    if (tauflag != nullptr && *tauflag != 0) { ctl[2] = batch + 1; ctl[0] = 1; }
+    else if (!(measure > threshold)) { ctl[1] = batch + 1; ctl[0] = 1; }
+}
+
 // Duality gap from vectors only (uniform dx = 1/I, dy = 1/J as the solver always has, ot_solvers.py:221).
 // With R_ij = a_i K_ij b_j and K_ij = exp((u_i + v_j - C_ij)/eps) the matrix part of the primal collapses:
 //   eps sum R ln R + sum R C = sum_ij R_ij (eps ln a_i + u_i + eps ln b_j + v_j)
@@ -869,7 +881,9 @@ __global__ __launch_bounds__(256) void k_gap2_part(const double *__restrict__ sd
                                                    const double *__restrict__ v,
                                                    const double *__restrict__ p,
                                                    const double *__restrict__ q, double eps, double l1,
-                                                   double l2, int I, int J, double *__restrict__ red) {
+                                                   double l2, int I, int J, double *__restrict__ red,
+                                                   const int *__restrict__ stop) {
+    if (stop != nullptr && *stop != 0) return;
     __shared__ double sh[16];
     const int e = blockIdx.x * 256 + threadIdx.x;
     const double dx = 1.0 / I, dy = 1.0 / J;
@@ -899,7 +913,9 @@ __global__ __launch_bounds__(256) void k_gap2_part(const double *__restrict__ sd
     }
 }
 __global__ __launch_bounds__(256) void k_gap2_final(const double *__restrict__ red, int nblk, double eps,
-                                                    double l1, double l2, int I, int J, double *scal) {
+                                                    double l1, double l2, int I, int J, double *scal, double threshold,
+                                                    int batch, int *ctl, const int *tauflag) {
+    if (ctl != nullptr && ctl[0] != 0) return;
     __shared__ double sh[16];
     double acc[6] = {0, 0, 0, 0, 0, 0};
     for (int k = threadIdx.x; k < nblk; k += 256)
@@ -912,7 +928,10 @@ __global__ __launch_bounds__(256) void k_gap2_final(const double *__restrict__ r
         const double pri = l1 * acc[0] + l2 * acc[1] + (acc[2] - eps * acc[3] + eps * skb) / mn;
         const double dua = -(l1 * acc[4]) - (l2 * acc[5]) - eps * (acc[3] - skb) / mn;
         scal[1] = pri; scal[2] = dua;
-        scal[0] = (pri - dua) / fabs(pri);
+        const double m = (pri - dua) / fabs(pri);
+        scal[0] = m;
+        decide_stop(m, threshold, batch, ctl, tauflag);
+        return;
     }
 }
 
@@ -923,7 +942,8 @@ __global__ __launch_bounds__(256) void k_drift_part(const double *__restrict__ a
                                                     const double *__restrict__ b,
                                                     const double *__restrict__ old_b,
                                                     const double *__restrict__ v, double eps, int I, int J,
-                                                    double *__restrict__ red) {
+                                                    double *__restrict__ red, const int *__restrict__ stop) {
+    if (stop != nullptr && *stop != 0) return;
     __shared__ double sh[16];
     const int e = blockIdx.x * 256 + threadIdx.x;
     double d1 = 0, n1 = 0, d2 = 0, n2 = 0;
@@ -941,7 +961,9 @@ __global__ __launch_bounds__(256) void k_drift_part(const double *__restrict__ a
         o[0] = d1; o[1] = n1; o[2] = d2; o[3] = n2;
     }
 }
-__global__ __launch_bounds__(256) void k_drift_final(const double *__restrict__ red, int nblk, double *scal) {
+__global__ __launch_bounds__(256) void k_drift_final(const double *__restrict__ red, int nblk, double *scal, double threshold,
+                                                     int batch, int *ctl, const int *tauflag) {
+    if (ctl != nullptr && ctl[0] != 0) return;
     __shared__ double sh[16];
     double acc[4] = {0, 0, 0, 0};
     for (int k = threadIdx.x; k < nblk; k += 256)
@@ -952,7 +974,9 @@ __global__ __launch_bounds__(256) void k_drift_final(const double *__restrict__ 
     if (threadIdx.x == 0) {
         const double g1 = sqrt(acc[0]) / (1.0 + sqrt(acc[1]));
         const double g2 = sqrt(acc[2]) / (1.0 + sqrt(acc[3]));
-        scal[0] = (g1 < g2) ? g2 : g1;   // std::max(g1, g2): a NaN g1 wins (ot_func.cpp:922)
+        const double m = (g1 < g2) ? g2 : g1;   // std::max(g1, g2): a NaN g1 wins (ot_func.cpp:922)
+        scal[0] = m;
+        decide_stop(m, threshold, batch, ctl, tauflag);
     }
 }
 
@@ -1102,6 +1126,9 @@ struct spadot_ot_solver {
     double *rt = nullptr;      // 4 x I
     double *scal = nullptr;    // 8 device scalars: gap, primal, dual, sumKbar, ...
     int *flags = nullptr;      // MAX_BATCH + 1 ints (last = absorb counter)
+    int *ctl = nullptr;        // {stop, converged batch + 1, tau batch + 1, -}: device-side stop decision of speculated batches
+    int *h_ctl = nullptr;      // pinned mirror
+    int *stop_arg = nullptr;   // what the hot kernels receive as `stop`: ctl while batches are speculated, else null
     double *h_scal = nullptr;  // pinned
     int *h_flags = nullptr;    // pinned
     int nchunk = 1, rows_per_chunk = 1;
@@ -1178,7 +1205,8 @@ void launch_fused(spadot_ot_solver *s, const IterParams &P, int *flag) {
     }
     hipLaunchKernelGGL(kern, dim3(s->fused_blocks), dim3(FUSED_THREADS), s->fused_lds, s->stream,
                        (const T *)s->K, s->w, s->a, s->old_a, s->adx, s->p, s->dx, s->u, P.al1,
-                       1.0 / (P.l1 + P.eps), P.tau, (T *)s->part, s->I, s->ld, s->fused_rows_per_block, flag);
+                       1.0 / (P.l1 + P.eps), P.tau, (T *)s->part, s->I, s->ld, s->fused_rows_per_block, flag,
+                       (const int *)s->stop_arg);
 }
 
 template <typename T> void fused_pass_T(spadot_ot_solver *s, const IterParams &P, int *flag);
@@ -1212,7 +1240,7 @@ void launch_fused_rowdot(spadot_ot_solver *s) {
         attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3(s->fused_blocks), dim3(FUSED_THREADS), s->fused_lds, s->stream, (const T *)s->K,
-                       s->w, s->rt, s->I, s->ld, s->fused_rows_per_block);
+                       s->w, s->rt, s->I, s->ld, s->fused_rows_per_block, (const int *)s->stop_arg);
 }
 template <typename T> void fused_rowdot_T(spadot_ot_solver *s);
 #define FUSED_CASE(T, VPT, R) case VPT: launch_fused_rowdot<T, VPT, R>(s); break;
@@ -1249,7 +1277,7 @@ template <typename T> void one_iteration_T(spadot_ot_solver *s, const IterParams
         fused_pass_T<T>(s, P, flag);
         hipLaunchKernelGGL(k_col_fin2<T>, dim3((ld + 63) / 64), dim3(1024), 0, s->stream, (const T *)s->part,
                            s->fused_blocks, s->b, s->old_b, s->w, s->q, s->dy, s->v, P.al2,
-                           1.0 / (P.l2 + P.eps), P.tau, J, ld, flag, s->tcol, 0);
+                           1.0 / (P.l2 + P.eps), P.tau, J, ld, flag, s->tcol, 0, (const int *)s->stop_arg);
     } else {
         hipLaunchKernelGGL(k_row_pass<T>, dim3((I + ROW_WAVES - 1) / ROW_WAVES), dim3(256), 0, s->stream,
                            (const T *)s->K, s->w, s->a, s->old_a, s->adx, s->p, s->dx, s->u, P.al1,
@@ -1287,7 +1315,18 @@ void run_iterations(spadot_ot_solver *s, const IterParams &P, int iters, bool ab
     }
 }
 
+__global__ __launch_bounds__(256) void k_copy_unless(double *__restrict__ dst, const double *__restrict__ src, size_t n,
+                                                     const int *__restrict__ stop) {
+    if (*stop != 0) return;
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (size_t)gridDim.x * 256) dst[k] = src[k];
+}
 void snapshot(spadot_ot_solver *s) {
+    if (s->stop_arg != nullptr) {      // speculated batch: the snapshot of a batch behind the stopping one must not be taken
+        const size_t n = s->mut_count;
+        hipLaunchKernelGGL(k_copy_unless, dim3((unsigned)std::min<size_t>((n + 255) / 256, 1024)), dim3(256), 0, s->stream,
+                           s->backup, (const double *)s->a, n, (const int *)s->stop_arg);
+        return;
+    }
     HIP_CHECK(hipMemcpyAsync(s->backup, s->a, sizeof(double) * s->mut_count, hipMemcpyDeviceToDevice, s->stream));
 }
 void restore(spadot_ot_solver *s) {
@@ -1302,15 +1341,17 @@ double read_gap(spadot_ot_solver *s) {
     return s->h_scal[0];
 }
 
-void drift_measure(spadot_ot_solver *s, double eps) {
+// (threshold, batch: only read when batches are being speculated, i.e. s->stop_arg is set)
+void drift_measure(spadot_ot_solver *s, double eps, double threshold = 0.0, int batch = 0) {
     const int nblk = (std::max(s->I, s->J) + 255) / 256;
     hipLaunchKernelGGL(k_drift_part, dim3(nblk), dim3(256), 0, s->stream, s->a, s->old_a, s->u, s->b, s->old_b,
-                       s->v, eps, s->I, s->J, s->red);
-    hipLaunchKernelGGL(k_drift_final, dim3(1), dim3(256), 0, s->stream, s->red, nblk, s->scal);
+                       s->v, eps, s->I, s->J, s->red, (const int *)s->stop_arg);
+    hipLaunchKernelGGL(k_drift_final, dim3(1), dim3(256), 0, s->stream, s->red, nblk, s->scal, threshold, batch,
+                       s->stop_arg, (const int *)s->flags);
 }
 
 // Solver-only gap (uniform dx, dy): ONE sweep of K for sdot, everything else from vectors (k_gap2_part).
-void gap_measure_fast(spadot_ot_solver *s, const IterParams &P) {
+void gap_measure_fast(spadot_ot_solver *s, const IterParams &P, double threshold = 0.0, int batch = 0) {
     const int I = s->I, J = s->J, ld = s->ld;
     dim3 g((I + ROW_WAVES - 1) / ROW_WAVES);
     if (s->fused_vpt > 0) {
@@ -1322,8 +1363,9 @@ void gap_measure_fast(spadot_ot_solver *s, const IterParams &P) {
         hipLaunchKernelGGL(k_row_dot<double>, g, dim3(256), 0, s->stream, (const double *)s->K, s->w, s->rt, I, ld);
     const int nblk = (std::max(I, J) + 255) / 256;
     hipLaunchKernelGGL(k_gap2_part, dim3(nblk), dim3(256), 0, s->stream, s->rt, s->tcol, s->a, s->b, s->u, s->v,
-                       s->p, s->q, P.eps, P.l1, P.l2, I, J, s->red);
-    hipLaunchKernelGGL(k_gap2_final, dim3(1), dim3(256), 0, s->stream, s->red, nblk, P.eps, P.l1, P.l2, I, J, s->scal);
+                       s->p, s->q, P.eps, P.l1, P.l2, I, J, s->red, (const int *)s->stop_arg);
+    hipLaunchKernelGGL(k_gap2_final, dim3(1), dim3(256), 0, s->stream, s->red, nblk, P.eps, P.l1, P.l2, I, J, s->scal,
+                       threshold, batch, s->stop_arg, (const int *)s->flags);
 }
 
 // True primal-dual gap of the current (a, b, K) with R = a K b formed on the fly; scal[3] must
@@ -1360,6 +1402,41 @@ double process_stage(spadot_ot_solver *s, const IterParams &P, bool last_stage, 
         else if (fast) gap_measure_fast(s, P);
         else gap_measure(s, P, Rout);
     };
+    // Fast mode on a fused geometry: SPEC batches are enqueued at a time and the DEVICE decides after each whether the stage is
+    // over (k_drift_final / k_gap2_final -> ctl); the batches behind the deciding one return at once, and the host reads one
+    // 16-byte record per group instead of stalling the queue after every batch.  Same batches, same order, same counts.
+    static const int SPEC = [] { const char *e = getenv("SPADOT_OT_SPEC_BATCHES"); return e ? atoi(e) : 3; }();
+    while (fast && SPEC > 1 && s->fused_vpt > 0 && gap > threshold) {
+        const int iters = last_stage ? batch_size : 5;
+        if (cur_iter + SPEC * iters >= max_iter) break;          // near max_iter: the batch-by-batch loop below keeps the quirks
+        HIP_CHECK(hipMemsetAsync(s->ctl, 0, sizeof(int) * 4, s->stream));
+        s->stop_arg = s->ctl;
+        for (int j = 0; j < SPEC; j++) {
+            snapshot(s);
+            run_iterations(s, P, iters, /*absorb=*/false);
+            if (!last_stage) drift_measure(s, P.eps, threshold, j);
+            else gap_measure_fast(s, P, threshold, j);
+        }
+        s->stop_arg = nullptr;
+        HIP_CHECK(hipMemcpyAsync(s->h_ctl, s->ctl, sizeof(int) * 4, hipMemcpyDeviceToHost, s->stream));
+        gap = read_gap(s);                                       // (synchronises; scal[0] is the deciding batch's measure)
+        const int conv = s->h_ctl[1], taub = s->h_ctl[2];
+        if (taub != 0) {
+            // batch taub - 1 raised the tau flag: the state is that batch's (approximate) result, the backup its start; the
+            // batches before it count, this one is redone exactly
+            const int before = taub - 1;
+            done += before * iters; cur_iter += before * iters; nchecks += before;
+            restore(s);
+            run_iterations(s, P, iters, /*absorb=*/true);
+            measure();
+            gap = read_gap(s);
+            s->redo_batches++;
+            done += iters; cur_iter += iters; nchecks++;
+        } else {
+            const int ran = conv != 0 ? conv : SPEC;
+            done += ran * iters; cur_iter += ran * iters; nchecks += ran;
+        }
+    }
     while (gap > threshold) {
         const int iters = last_stage ? batch_size : 5;
         // step1_process: stops early (returning -1) once the counter reaches max_iter
@@ -1496,6 +1573,9 @@ int spadot_ot_create(spadot_ot_solver **out, int I, int J, int storage, void *st
     s->rt = (double *)dmalloc(sizeof(double) * 4 * (size_t)I);
     s->scal = (double *)dmalloc(sizeof(double) * 8);
     s->flags = (int *)dmalloc(sizeof(int) * (MAX_BATCH + 1));
+    s->ctl = (int *)dmalloc(sizeof(int) * 4);
+    HIP_CHECK(hipMemsetAsync(s->ctl, 0, sizeof(int) * 4, s->stream));
+    HIP_CHECK(hipHostMalloc((void **)&s->h_ctl, sizeof(int) * 4, hipHostMallocDefault));
     HIP_CHECK(hipMemsetAsync(s->scal, 0, sizeof(double) * 8, s->stream));
     HIP_CHECK(hipMemsetAsync(s->flags, 0, sizeof(int) * (MAX_BATCH + 1), s->stream));
     HIP_CHECK(hipHostMalloc((void **)&s->h_scal, sizeof(double) * 8, hipHostMallocDefault));
@@ -1511,7 +1591,8 @@ void spadot_ot_destroy(spadot_ot_solver *s) {
     SPADOT_ENTER
     if (!s) return;
     (void)hipStreamSynchronize(s->stream);
-    void *dev[] = {s->C, s->K, s->a, s->backup, s->red, s->part, s->rt, s->scal, s->flags, s->cost_ws};
+    void *dev[] = {s->C, s->K, s->a, s->backup, s->red, s->part, s->rt, s->scal, s->flags, s->cost_ws, s->ctl};
+    (void)hipHostFree(s->h_ctl);
     for (void *p : dev) (void)hipFree(p);
     (void)hipHostFree(s->h_scal); (void)hipHostFree(s->h_flags);
     (void)hipEventDestroy(s->ev0); (void)hipEventDestroy(s->ev1);
@@ -1925,9 +2006,9 @@ int spadot_ot_time_kernels(spadot_ot_solver *s, const spadot_ot_config *cfg, dou
             else fused_pass_T<double>(s, P, flag);
             HIP_CHECK(hipEventRecord(ev[3 * r + 1], s->stream));
             if (s->storage == SPADOT_F32)
-                hipLaunchKernelGGL(k_col_fin2<float>, dim3((ld + 63) / 64), dim3(1024), 0, s->stream, (const float *)s->part, s->fused_blocks, s->b, s->old_b, s->w, s->q, s->dy, s->v, P.al2, 1.0 / (P.l2 + P.eps), P.tau, J, ld, flag, s->tcol, 0);
+                hipLaunchKernelGGL(k_col_fin2<float>, dim3((ld + 63) / 64), dim3(1024), 0, s->stream, (const float *)s->part, s->fused_blocks, s->b, s->old_b, s->w, s->q, s->dy, s->v, P.al2, 1.0 / (P.l2 + P.eps), P.tau, J, ld, flag, s->tcol, 0, (const int *)nullptr);
             else
-                hipLaunchKernelGGL(k_col_fin2<double>, dim3((ld + 63) / 64), dim3(1024), 0, s->stream, (const double *)s->part, s->fused_blocks, s->b, s->old_b, s->w, s->q, s->dy, s->v, P.al2, 1.0 / (P.l2 + P.eps), P.tau, J, ld, flag, s->tcol, 0);
+                hipLaunchKernelGGL(k_col_fin2<double>, dim3((ld + 63) / 64), dim3(1024), 0, s->stream, (const double *)s->part, s->fused_blocks, s->b, s->old_b, s->w, s->q, s->dy, s->v, P.al2, 1.0 / (P.l2 + P.eps), P.tau, J, ld, flag, s->tcol, 0, (const int *)nullptr);
             HIP_CHECK(hipEventRecord(ev[3 * r + 2], s->stream));
         }
         HIP_CHECK(hipStreamSynchronize(s->stream));

@@ -29,3 +29,8 @@ with torch.no_grad():
         torch.cuda.synchronize(); t0 = time.perf_counter()
         lat = model.all_latent_samples(loc, Y, dd["graphs"][0], 0, as_numpy=False); torch.cuda.synchronize()
         print(f"all_latent_samples (one time point, 10k spots): {(time.perf_counter()-t0)*1e3:.1f} ms")
+    from spadot_amd.kmeans import KMeansDevice
+    for _ in range(2):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        km = KMeansDevice(cfg["n_clusters"], random_state=cfg["seed"], n_init=10).fit(lat); torch.cuda.synchronize()
+        print(f"KMeansDevice.fit (10 restarts, 10k x 20): {(time.perf_counter()-t0)*1e3:.1f} ms, n_iter {getattr(km, 'n_iter_', None)}")
