@@ -1397,6 +1397,7 @@ double process_stage(spadot_ot_solver *s, const IterParams &P, bool last_stage, 
                      int *checks, bool fast = false, int *cur_iter_out = nullptr) {
     double gap = 1e100;
     int done = 0, nchecks = 0;
+    s->stop_arg = nullptr;             // (a failed call may have left a speculation group open)
     auto measure = [&]() {
         if (!last_stage) drift_measure(s, P.eps);
         else if (fast) gap_measure_fast(s, P);
