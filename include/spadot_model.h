@@ -312,6 +312,15 @@ int spadot_bias_sqerr_forward(const float *o, const float *bias, const float *y,
 int spadot_bias_sqerr_backward(const float *g1, const float *o, const float *bias, const float *y, int b, int G,
                                double inv_scale, void *g_bf16, float *dbias, void *stream);
 
+/* ---- GAT_fc on the bf16 rows of the last GAT layer (csrc/mlp_chain.hip) -------------------------------------------------
+ * out [b x N] (fp32) = h [b x K] (bf16) . W^T [N x K] (fp32) + bias, N <= 32, K % 8 == 0: the (mu | logvar) head of
+ * /root/reference/SpaDOT/model/encoder.py:59-61 without an fp32 copy of h.  backward (fixed order): dh (bf16) and per-8-row partials of dW, db in
+ * one launch, summed by a second. */
+int spadot_headfc_forward(const void *h_bf16, const float *W, const float *bias, int b, int K, int N, float *out, void *stream);
+int spadot_headfc_backward(const float *g, const void *h_bf16, const float *W, int b, int K, int N, void *dh_bf16,
+                           float *workspace /* ceil(b / 8) x (N K + N) floats */, float *grads /* [dW (N x K) | db (N)] */,
+                           void *stream);
+
 /* dst[t][r, 0:K[t]] = (bf16) src[t][r, 0:K[t]] for n <= 4 row-major matrices in one launch (fp32 weights -> their
  * compute-dtype images; dst rows have Kp[t] >= K[t] elements, the padding is not touched; K, Kp multiples of 4). */
 int spadot_cast_rows_multi(const float *const *src, void *const *dst, const int *rows, const int *K, const int *Kp, int n,

@@ -11,7 +11,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..graph import build_batch_graph
-from ..ops import BatchGraph, bn_act, cast_rows, dense_cd, gat_edge, linear_bias, weight_image
+from ..ops import BatchGraph, bn_act, cast_rows, dense_cd, gat_edge, head_fc, head_fc_ok, linear_bias, weight_image
 
 
 class SVGPEncoder(nn.Module):
@@ -162,4 +162,6 @@ class GATEncoder(nn.Module):
             h = self.gat3(h, edge_index, act=False, fresh=fresh)
             if rows is not None:
                 h = h[:rows]
+        if head_fc_ok(h, self.GAT_fc.weight, self.GAT_fc.bias):
+            return head_fc(h, self.GAT_fc.weight, self.GAT_fc.bias)              # bf16 rows in, fp32 out: no cast launches
         return linear_bias(h.float(), self.GAT_fc.weight, self.GAT_fc.bias)

@@ -576,6 +576,56 @@ def mlp_chain(x, stages):
     return _MLPChain.apply(x.contiguous(), [ln.eps for _, ln, _ in stages], [sl for _, _, sl in stages], *params)
 
 
+HEAD_FC_FWD = [__import__("os").environ.get("SPADOT_HEAD_FC_FWD", "0") == "1"]
+HEAD_FC = [__import__("os").environ.get("SPADOT_HEAD_FC", "1") == "1"]          # [False]: h.float() + linear_bias (A/B, tests)
+
+
+class _HeadFC(torch.autograd.Function):
+    """(mu | logvar) = h W^T + b on the bf16 rows of the last GAT layer with a two-launch backward: dh comes out in bf16 (what
+    that layer's backward reads), dW and db as per-8-row partials + one column sum -- in place of a bias column sum, two
+    library GEMMs and a bf16 cast."""
+
+    @staticmethod
+    def forward(ctx, h, W, bias):
+        b, K = h.shape
+        N = W.shape[0]
+        if HEAD_FC_FWD[0]:
+            out = torch.empty((b, N), dtype=torch.float32, device=h.device)
+            _check(model_lib().spadot_headfc_forward(_p(h), _p(W), _p(bias), b, K, N, _p(out), _stream()), "spadot_headfc_forward")
+        else:
+            # (the one-launch forward exists and is tested, but measured 18-35 us at the end of the forward pair against
+            # 5 + 7 us for the cast + library GEMM: the step keeps those)
+            out = torch.addmm(bias, h.float(), W.t())
+        ctx.save_for_backward(h, W)
+        ctx.flat_out = _contiguous_grad_block((W, bias))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        h, W = ctx.saved_tensors
+        b, K = h.shape
+        N = W.shape[0]
+        dev = h.device
+        dh = torch.empty_like(h)
+        ws = torch.empty(((b + 7) // 8, N * K + N), dtype=torch.float32, device=dev)
+        direct = ctx.flat_out is not None and _DIRECT_GRAD[0] and ctx.flat_out.numel() == N * K + N
+        grads = ctx.flat_out if direct else torch.empty(N * K + N, dtype=torch.float32, device=dev)
+        _check(model_lib().spadot_headfc_backward(_p(g.contiguous().float()), _p(h), _p(W), b, K, N, _p(dh), _p(ws), _p(grads),
+                                                  _stream()), "spadot_headfc_backward")
+        return dh, grads[:N * K].view(N, K), grads[N * K:]
+
+
+def head_fc_ok(h, W, bias):
+    return bool(HEAD_FC[0] and h.is_cuda and h.dtype == torch.bfloat16 and h.dim() == 2 and h.is_contiguous()
+                and W.dtype == torch.float32 and W.is_contiguous() and bias is not None and W.shape[0] <= 32
+                and h.shape[1] % 8 == 0 and W.shape[1] == h.shape[1] and W.data_ptr() % 16 == 0 and h.data_ptr() % 16 == 0
+                and W.numel() * 4 <= 65536)
+
+
+def head_fc(h, W, bias):
+    return _HeadFC.apply(h, W, bias)
+
+
 # ----------------------------------------------------------------------------- loss tail (single-workgroup kernels)
 
 _counters = {}

@@ -150,3 +150,44 @@ def test_fused_reconstruction_term_matches_the_separate_launches(b, G, K):
     (loss * 0.37).backward()
     assert loss.item() == res[0][0] or abs(loss.double().item() - res[0][0]) == 0.0
     assert torch.equal(bb.grad, res[0][3])
+
+
+@pytest.mark.parametrize("b,K,N", [(512, 512, 20), (37, 64, 20), (1000, 512, 32), (8, 8, 1)])
+def test_head_fc_from_bf16_rows_matches_float_linear(b, K, N):
+    """ops.head_fc (GAT_fc on the bf16 rows of the last GAT layer) against linear_bias on h.float(): the same fp32 products of
+    the same bf16-rounded inputs, other summation order; dh is rounded to bf16 once."""
+    from spadot_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(K + N)
+    h = torch.randn((b, K), device=DEV, generator=g).bfloat16()
+    W = torch.randn((N, K), device=DEV, generator=g) * 0.05
+    bias = torch.randn(N, device=DEV, generator=g) * 0.1
+    w = torch.randn((b, N), device=DEV, generator=g)
+    res = []
+    ops.HEAD_FC_FWD[0] = True                   # the one-launch forward too (the step uses the library for that half)
+    for fused in (True, False):
+        hh = h.clone().requires_grad_(True)
+        WW, bb = W.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+        if fused:
+            assert ops.head_fc_ok(hh, WW, bb)
+            out = ops.head_fc(hh, WW, bb)
+        else:
+            out = ops.linear_bias(hh.float(), WW, bb)
+        (out * w).sum().backward()
+        res.append((out.detach(), hh.grad, WW.grad, bb.grad))
+    ref = h.double() @ W.double().t() + bias.double()
+    np.testing.assert_allclose(res[0][0].cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(res[0][0].cpu().numpy(), res[1][0].cpu().numpy(), rtol=1e-5, atol=1e-5)
+    assert res[0][1].dtype == torch.bfloat16
+    dh_ref = (w.double() @ W.double())
+    assert (res[0][1].double() - dh_ref).norm() <= 3e-3 * dh_ref.norm() + 1e-9          # one bf16 rounding per element
+    for a, u in zip(res[0][2:], res[1][2:]):
+        assert (a - u).norm() <= 1e-5 * u.norm() + 1e-7
+    hh = h.clone().requires_grad_(True)
+    WW, bb = W.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    out = ops.head_fc(hh, WW, bb)
+    (out * w).sum().backward()
+    assert torch.equal(out.detach(), res[0][0]) and torch.equal(WW.grad, res[0][2]) and torch.equal(hh.grad, res[0][1])
+    ops.HEAD_FC_FWD[0] = False
+    hh = h.clone().requires_grad_(True)
+    out2 = ops.head_fc(hh, WW.detach().requires_grad_(True), bb.detach().requires_grad_(True))
+    np.testing.assert_allclose(out2.detach().cpu().numpy(), res[0][0].cpu().numpy(), rtol=1e-5, atol=1e-5)
