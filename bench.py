@@ -347,6 +347,8 @@ def _main(real_stdout):
         stepper = (tu.GraphedStepper(model, opt, cfg, dd, grad_sync=grad_sync, grad_sync_async=grad_sync_async)
                    if use_graphs else None)
 
+        if stepper is not None:
+            stepper.clone_output = os.environ.get("SPADOT_STEP_CLONE") == "1"      # like train_SpaDOT: losses consumed in-stream
         state = {"stepper": stepper}
 
         def step(i):

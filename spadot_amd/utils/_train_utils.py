@@ -362,6 +362,10 @@ class GraphedStepper:
         self.capturable = True
         # which graph of a pair is launched first: 'm' main (GAT) / 's' side (SVGP), forward pair then backward pair
         self.issue_order = (os.environ.get("SPADOT_ISSUE_ORDER", "mm") + "mm")[:2]
+        self._beta1 = None
+        # step() returns a copy of the graph's loss vector by default; a caller that consumes it on the same stream before its
+        # next step (the training loop's `tot += ...`) may take the graph's own buffer and save the copy launch
+        self.clone_output = os.environ.get("SPADOT_STEP_NOCLONE") != "1"
         self.version = getattr(model, "_state_version", 0)
 
     def _body(self, tp_i, tp, bi, epoch, with_update=True):
@@ -399,7 +403,9 @@ class GraphedStepper:
         if getattr(self.model, "_state_version", 0) != self.version:      # a state tensor was re-allocated
             self.graphs.clear()
             self.version = getattr(self.model, "_state_version", 0)
-        self.beta1_t[1].fill_(-float(beta1))
+        if self._beta1 != float(beta1):               # (constant within an epoch: one fill launch per epoch, not per step)
+            self.beta1_t[1].fill_(-float(beta1))
+            self._beta1 = float(beta1)
         if not self.capturable:
             return self._body(tp_i, tp, bi, epoch, with_update=with_update)
         if self.staged:
@@ -408,14 +414,14 @@ class GraphedStepper:
         if key in self.graphs:
             g, out = self.graphs[key]
             g.replay()
-            return out.clone()
+            return out.clone() if self.clone_output else out
         if key not in self.seen:                                            # warm-up visit: plain eager step
             self.seen.add(key)
             return self._body(tp_i, tp, bi, epoch, with_update=with_update)
         g, out = self._capture(lambda: self._body(tp_i, tp, bi, epoch, with_update=with_update))
         self.graphs[key] = (g, out)
         g.replay()
-        return out.clone()
+        return out.clone() if self.clone_output else out
 
     # ---- staged mode: the step as SIX graphs instead of one.  A replayed hipGraph runs its two branches mostly
     # one after the other (tools/graph_probe.py); two graphs replayed on two streams do overlap.  So: GAT forward
@@ -548,7 +554,7 @@ class GraphedStepper:
         if key in self.graphs:
             graphs, out = self.graphs[key]
             self._issue_staged([g.replay for g in graphs])
-            res = out.clone()
+            res = out.clone() if self.clone_output else out
         elif key not in self.seen:                                          # warm-up visit: eager, same stages
             self.seen.add(key)
             res = self._issue_staged(list(self._stages(tp_i, tp, bi, epoch)), two_streams=False)
@@ -569,7 +575,7 @@ class GraphedStepper:
                 graphs.append(g)
             self.graphs[key] = (graphs, out)
             self._issue_staged([g.replay for g in graphs])
-            res = out.clone()
+            res = out.clone() if self.clone_output else out
         if with_update:
             self.update()
         return res
@@ -608,6 +614,8 @@ def train_SpaDOT(dataloader_dict, model_config, verbose=True):
     model = SpaDOT.SpaDOT(model_config, dataloader_dict).to(device)
     optimizer = FlatAdamW(model.parameters(), lr=model_config["lr"])
     stepper = GraphedStepper(model, optimizer, model_config, dataloader_dict) if model_config.get("use_hip_graphs", True) else None
+    if stepper is not None:
+        stepper.clone_output = False          # the loop below adds every step's losses to `tot` right away
     beta1s = _beta_cycle_linear(model_config["maxiter"], stop=model_config["beta1"])
     tp_indexed_list = list(enumerate(model_config["timepoints"]))
     loss_dict = OrderedDict((e, OrderedDict((n, 0.0) for n in LOSS_NAMES)) for e in range(model_config["maxiter"]))
