@@ -46,6 +46,7 @@ __device__ __forceinline__ float wave_sum(float x) {
 
 __global__ __launch_bounds__(256) void k_mlp_chain_fwd(const float *__restrict__ x, int b, Chain ch) {
     __shared__ __attribute__((aligned(16))) float act[2][RBF][LDW];
+    __shared__ float par[3][MAXD];                       // bias, gamma, beta of the current stage
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int r0 = blockIdx.x * RBF;
     int cur = 0;
@@ -61,18 +62,26 @@ __global__ __launch_bounds__(256) void k_mlp_chain_fwd(const float *__restrict__
         const Stage &s = ch.s[l];
         const int din = s.din, dout = s.dout;
         // a[r][j] = bias[j] + <W[j, :], x[r, :]>: one thread per output column, the rows share each 16-byte weight load
+        if (t < dout) { par[0][t] = s.bias[t]; par[1][t] = s.gamma[t]; par[2][t] = s.beta[t]; }      // (dout <= 256 = threads)
         for (int j = t; j < dout; j += 256) {
             float acc[RBF];
             const float bj = s.bias[j];
 #pragma unroll
             for (int r = 0; r < RBF; r++) acc[r] = bj;
             const float4 *w4 = reinterpret_cast<const float4 *>(s.W + (size_t)j * din);
-            for (int k4 = 0; k4 < din / 4; k4++) {
-                const float4 w = w4[k4];
+            for (int kb = 0; kb < din / 4; kb += 16) {                 // 16 weight loads in flight, then their products
+                float4 w[16];
 #pragma unroll
-                for (int r = 0; r < RBF; r++) {
-                    const float4 xv = *reinterpret_cast<const float4 *>(&act[cur][r][4 * k4]);
-                    acc[r] += w.x * xv.x + w.y * xv.y + w.z * xv.z + w.w * xv.w;
+                for (int u = 0; u < 16; u++) w[u] = kb + u < din / 4 ? w4[kb + u] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int u = 0; u < 16; u++) {
+                    if (kb + u < din / 4) {
+#pragma unroll
+                        for (int r = 0; r < RBF; r++) {
+                            const float4 xv = *reinterpret_cast<const float4 *>(&act[cur][r][4 * (kb + u)]);
+                            acc[r] += w[u].x * xv.x + w[u].y * xv.y + w[u].z * xv.z + w[u].w * xv.w;
+                        }
+                    }
                 }
             }
 #pragma unroll
@@ -91,7 +100,7 @@ __global__ __launch_bounds__(256) void k_mlp_chain_fwd(const float *__restrict__
             const float invstd = rsqrtf(wave_sum(ss) / (float)dout + s.eps);
             for (int j = lane; j < dout; j += WAVE) {
                 const float av = ar[j];
-                const float v = (av - mean) * invstd * s.gamma[j] + s.beta[j];
+                const float v = (av - mean) * invstd * par[1][j] + par[2][j];
                 const float yv = v > 0.f ? v : s.slope * v;
                 ar[j] = yv;
                 if (row < b) { s.a[(size_t)row * dout + j] = av; s.y[(size_t)row * dout + j] = yv; }
@@ -109,7 +118,7 @@ __global__ __launch_bounds__(256) void k_mlp_chain_fwd(const float *__restrict__
 // out of LDS.  8 rows per workgroup: the fp32 FMA work of a stage (da^T x and da W) is spread over b / 8 compute units.
 constexpr int WST = 16384;                                  // floats of W staged at a time (64 KiB)
 constexpr int LPR = 256 / RBB;                              // lanes per row in the per-row phase
-constexpr int LDS_BWD_FLOATS = 4 * RBB * LDW + 2 * RBB + WST;
+constexpr int LDS_BWD_FLOATS = 4 * RBB * LDW + 2 * RBB + MAXD + WST;
 __global__ __launch_bounds__(256) void k_mlp_chain_bwd(const float *__restrict__ dy_last, const float *__restrict__ x, int b,
                                                        Chain ch, float *__restrict__ dx_out, float *__restrict__ ws,
                                                        int ws_width) {
@@ -119,7 +128,8 @@ __global__ __launch_bounds__(256) void k_mlp_chain_bwd(const float *__restrict__
     float (*xs)[LDW] = reinterpret_cast<float (*)[LDW]>(lds_dyn + 2 * RBB * LDW);
     float (*xh)[LDW] = reinterpret_cast<float (*)[LDW]>(lds_dyn + 3 * RBB * LDW);
     float *rmean = lds_dyn + 4 * RBB * LDW, *rinv = rmean + RBB;
-    float *wst = rinv + RBB;
+    float *gam = rinv + RBB;                                    // gamma of the current stage (MAXD floats)
+    float *wst = gam + MAXD;
     const int t = threadIdx.x;
     const int r0 = blockIdx.x * RBB;
     float *wrow = ws + (size_t)blockIdx.x * ws_width;
@@ -173,7 +183,8 @@ __global__ __launch_bounds__(256) void k_mlp_chain_bwd(const float *__restrict__
                 rmean[t] = live ? s.mean[r0 + t] : 0.f;
                 rinv[t] = live ? s.invstd[r0 + t] : 0.f;
             }
-            __syncthreads();                   // (rmean / rinv; and the previous stage's C has finished writing gz)
+            if (t < dout) gam[t] = s.gamma[t];
+            __syncthreads();                   // (rmean / rinv / gam; and the previous stage's C has finished writing gz)
 #pragma unroll
             for (int u = 0; u < NE; u++) {
                 const int e = t + u * 256;
@@ -202,14 +213,14 @@ __global__ __launch_bounds__(256) void k_mlp_chain_bwd(const float *__restrict__
             const float inv = rinv[r];
             float s1 = 0.f, s2 = 0.f;
             for (int j = sl; j < dout; j += LPR) {
-                const float dg = gz[r][j] * s.gamma[j];
+                const float dg = gz[r][j] * gam[j];
                 s1 += dg;
                 s2 += dg * xh[r][j];
             }
 #pragma unroll
             for (int off = LPR / 2; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off, WAVE); s2 += __shfl_xor(s2, off, WAVE); }
             const float m1 = s1 / (float)dout, m2 = s2 / (float)dout;
-            for (int j = sl; j < dout; j += LPR) da[r][j] = inv * (gz[r][j] * s.gamma[j] - m1 - xh[r][j] * m2);
+            for (int j = sl; j < dout; j += LPR) da[r][j] = inv * (gz[r][j] * gam[j] - m1 - xh[r][j] * m2);
         }
         __syncthreads();
         // ---- B: weight-gradient partial  dW[j][k] = sum_r da[r][j] xs[r][k], 8 (j) x 4 (k) register tiles
