@@ -286,6 +286,16 @@ int spadot_gat_ds_src(const float *dz, const int *rowptr_t, const int *eid_t, in
  * multiples of 8 elements; returns -22 otherwise (the caller then uses the library).  One 320 x 256 tile per workgroup. */
 int spadot_gemm_tn_bf16(const void *A, int lda, const void *B, int ldb, void *C, int ldc, int M, int N, int K, void *stream);
 
+/* ---- weight gradient of a GAT layer's dense map on the matrix cores (csrc/gemm_wgrad_bf16.hip) ---------------------------
+ * dW [N x K] (fp32, row stride ldw) = G^T X with G [M x N] (bf16, ldg) and X [M x >= K] (bf16, ldx; columns K .. the next
+ * multiple of 256 must be readable -- the padded gene axis of the batch cache is).  256 x 256 output tiles x `slices`
+ * slices of the M rows (0: one), partial tiles added in slice order by the last workgroup of a tile: bit-reproducible.
+ * Requires N % 256 == 0, 16-byte aligned operands, strides % 8 == 0; -22 otherwise.  Scratch (partials, counters) is kept by
+ * the library per device: the first call of a shape allocates (issue it once outside graph capture), and calls must not run
+ * concurrently on different streams. */
+int spadot_gemm_wgrad_bf16(const void *G, int ldg, const void *X, int ldx, float *dW, int ldw, int M, int N, int K,
+                           int slices, void *stream);
+
 /* ---- hidden stages of the decoder as one launch each way (csrc/mlp_chain.hip) -------------------------------------------
  * /root/reference/SpaDOT/model/decoder.py:3-20: [Linear, LayerNorm, LeakyReLU] x n_layers on x [b, dims[0]] (fp32);
  * stage l maps dims[l] -> dims[l + 1].  forward keeps, per stage, a (linear output), y (stage output), mean, invstd.

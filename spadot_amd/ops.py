@@ -283,6 +283,32 @@ def gemm_tn(x, w):
     return torch.nn.functional.linear(x, w)
 
 
+WGRAD_OWN = [__import__("os").environ.get("SPADOT_WGRAD_OWN", "1") == "1"]       # [False]: library GEMM for the weight gradients
+
+
+def wgrad_bf16(g, x, K, out=None):
+    """g^T x[:, :K] -> fp32 [N, K] for g [M, N], x [M, Kp >= K] (bf16): csrc/gemm_wgrad_bf16.hip where its conditions hold
+    (N % 256 == 0, the X rows readable up to the next multiple of 256 columns), else the library."""
+    M, N = g.shape
+    Kp = x.shape[1]
+    kt = (K + 255) // 256
+    if (WGRAD_OWN[0] and g.is_cuda and g.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and g.is_contiguous()
+            and x.is_contiguous() and N % 256 == 0 and Kp >= kt * 256 and Kp % 8 == 0 and M >= 1024 and N >= 1024 and K >= 1024):
+        if out is None:
+            out = torch.empty((N, K), dtype=torch.float32, device=g.device)
+        if out.is_contiguous() and out.dtype == torch.float32 and out.shape == (N, K):
+            tiles = (N // 256) * kt
+            rc = model_lib().spadot_gemm_wgrad_bf16(g.data_ptr(), N, x.data_ptr(), Kp, out.data_ptr(), K, M, N, K,
+                                                    max(1, 256 // tiles), _stream())
+            if rc == 0:
+                return out
+            if rc != -22:
+                _check(rc, "spadot_gemm_wgrad_bf16")
+    if out is not None:
+        return torch.mm(g.t(), x[:, :K], out_dtype=torch.float32, out=out)
+    return torch.mm(g.t(), x[:, :K], out_dtype=torch.float32)
+
+
 class _DenseCD(torch.autograd.Function):
     """h = x W^T with x already in the compute dtype (bf16) and possibly zero-padded along K (so that the
     G-sized GEMM gets a K that is a multiple of 128), W the fp32 parameter [N, K].  Backward writes the weight
@@ -317,10 +343,7 @@ class _DenseCD(torch.autograd.Function):
         # (x[:, :K] is a strided view: the GEMM takes its row stride, the result is a dense [N, K])
         dW = None
         if ctx.needs_input_grad[1]:
-            if ctx.wgrad is not None and _DIRECT_GRAD[0]:
-                dW = torch.mm(g.t(), x[:, :ctx.K], out_dtype=torch.float32, out=ctx.wgrad)
-            else:
-                dW = torch.mm(g.t(), x[:, :ctx.K], out_dtype=torch.float32)
+            dW = wgrad_bf16(g, x, ctx.K, ctx.wgrad if (ctx.wgrad is not None and _DIRECT_GRAD[0]) else None)
         return dx, dW, None, None
 
 

@@ -82,3 +82,49 @@ def test_dense_map_uses_own_gemm_and_matches_library():
     finally:
         ops.GEMM_OWN[0] = True
     np.testing.assert_allclose(a.float().cpu().numpy(), b.float().cpu().numpy(), rtol=2 ** -7, atol=2e-3)
+
+
+@pytest.mark.parametrize("M,N,K,Kp,slices", [
+    (64, 256, 256, 256, 1),            # one chunk, one tile, no slicing
+    (100, 256, 256, 256, 2),           # rows past M in the second chunk come from the zero row
+    (1000, 512, 300, 512, 3),          # partial last column tile, three slices (one chunk short of even)
+    (9980, 2048, 2048, 2048, 4),       # layer-2 shape: 64 tiles x 4 slices
+    (9980, 2048, 3000, 3072, 2),       # layer-1 shape: 96 tiles x 2 slices, output row stride 3000
+])
+def test_wgrad_matches_fp32_reference(M, N, K, Kp, slices):
+    """csrc/gemm_wgrad_bf16.hip: dW = G^T X in fp32 from bf16 operands.  fp32 accumulation over M products in the kernel's own
+    order: within 2e-6 * sum |g x| (+ 1e-6 relative) of the fp64 value; the same bits on every launch (slice order is fixed)."""
+    from spadot_amd import _lib
+    lib = _lib.model_lib()
+    g = torch.Generator(device=DEV).manual_seed(M + K)
+    G = (torch.randn((M, N), device=DEV, generator=g) * 0.3).bfloat16()
+    X = torch.zeros((M, Kp), device=DEV, dtype=torch.bfloat16)
+    X[:, :K] = (torch.randn((M, K), device=DEV, generator=g) * 0.5).bfloat16()
+    outs = []
+    for _ in range(2):
+        dW = torch.full((N, K), float("nan"), device=DEV)
+        rc = lib.spadot_gemm_wgrad_bf16(G.data_ptr(), N, X.data_ptr(), Kp, dW.data_ptr(), K, M, N, K, slices,
+                                        torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert rc == 0
+        outs.append(dW)
+    ref = G.double().t() @ X[:, :K].double()
+    mag = G.double().abs().t() @ X[:, :K].double().abs()
+    err = (outs[0].double() - ref).abs()
+    assert torch.isfinite(outs[0]).all()
+    assert bool((err <= 2e-6 * mag + 1e-6 * ref.abs() + 1e-12).all()), float((err / (2e-6 * mag + 1e-12)).max())
+    assert torch.equal(outs[0], outs[1])
+
+
+def test_wgrad_refuses_what_it_does_not_cover():
+    from spadot_amd import _lib
+    lib = _lib.model_lib()
+    G = torch.zeros((64, 128), device=DEV, dtype=torch.bfloat16)
+    X = torch.zeros((64, 256), device=DEV, dtype=torch.bfloat16)
+    dW = torch.zeros((128, 256), device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.spadot_gemm_wgrad_bf16(G.data_ptr(), 128, X.data_ptr(), 256, dW.data_ptr(), 256, 64, 128, 256, 1, st) == -22   # N % 256
+    G = torch.zeros((64, 256), device=DEV, dtype=torch.bfloat16)
+    X = torch.zeros((64, 200), device=DEV, dtype=torch.bfloat16)
+    dW = torch.zeros((256, 200), device=DEV)
+    assert lib.spadot_gemm_wgrad_bf16(G.data_ptr(), 256, X.data_ptr(), 200, dW.data_ptr(), 200, 64, 256, 200, 1, st) == -22   # X rows too short

@@ -60,7 +60,7 @@ def run(M, N, K, reps=30):
                 tflops_library=round(fl / t_lib / 1e6, 1), max_err=err, max_err_library=err_lib, scale=scale)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "wgrad" not in sys.argv:
     import os
     shapes = [(10240, 2048, 3072), (9980, 2048, 3072), (9980, 2048, 2048), (8500, 2048, 2048), (321, 256, 128), (9980, 2048, 3072)]
     for s in shapes:
@@ -68,3 +68,43 @@ if __name__ == "__main__":
         print(json.dumps(r), flush=True)
         if not os.environ.get("GEMM_LIB"):
             assert r["max_err"] <= 2 ** -7 * r["scale"] + 1e-3, r
+
+
+def run_wgrad(M, N, K, Kp, slices, reps=30):
+    """csrc/gemm_wgrad_bf16.hip against the library's g^T x (fp32 out), interleaved rounds."""
+    lib = _lib.model_lib()
+    g = torch.Generator(device="cuda").manual_seed(M + K)
+    G = (torch.randn((M, N), device="cuda", generator=g) * 0.3).bfloat16()
+    X = torch.zeros((M, Kp), device="cuda", dtype=torch.bfloat16)
+    X[:, :K] = (torch.randn((M, K), device="cuda", generator=g) * 0.5).bfloat16()
+    dW = torch.empty((N, K), device="cuda")
+    ref = torch.empty((N, K), device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+
+    def timed(fn, n):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n * 1e3
+
+    mine = lambda: lib.spadot_gemm_wgrad_bf16(G.data_ptr(), N, X.data_ptr(), Kp, dW.data_ptr(), K, M, N, K, slices, st)
+    libf = lambda: torch.mm(G.t(), X[:, :K], out_dtype=torch.float32, out=ref)
+    assert mine() == 0
+    timed(mine, 10), timed(libf, 10)
+    tm, tl = [], []
+    for _ in range(7):
+        tm.append(timed(mine, reps))
+        tl.append(timed(libf, reps))
+    t_mine, t_lib = sorted(tm)[3], sorted(tl)[3]
+    fl = 2.0 * M * N * K
+    err = (dW - ref).abs().max().item() / (ref.abs().max().item() + 1e-30)
+    return dict(kind="wgrad", M=M, N=N, K=K, slices=slices, us=round(t_mine, 1), us_library=round(t_lib, 1),
+                tflops=round(fl / t_mine / 1e6, 1), tflops_library=round(fl / t_lib / 1e6, 1), max_rel_diff_vs_library=err)
+
+
+if __name__ == "__main__" and "wgrad" in sys.argv:
+    for shp in [(9980, 2048, 2048, 2048, 4), (9980, 2048, 2048, 2048, 1), (9980, 2048, 3000, 3072, 2), (9980, 2048, 2048, 2048, 2)]:
+        print(json.dumps(run_wgrad(*shp)), flush=True)
