@@ -283,6 +283,7 @@ def gemm_tn(x, w):
     return torch.nn.functional.linear(x, w)
 
 
+WGRAD_MIN_WGS = [int(__import__("os").environ.get("SPADOT_WGRAD_MIN_WGS", "200"))]   # same-box A/B: 2048 x 3000 (192 workgroups) is 0.4 % better on the library
 WGRAD_OWN = [__import__("os").environ.get("SPADOT_WGRAD_OWN", "1") == "1"]       # [False]: library GEMM for the weight gradients
 
 
@@ -296,8 +297,12 @@ def wgrad_bf16(g, x, K, out=None):
             and x.is_contiguous() and N % 256 == 0 and Kp >= kt * 256 and Kp % 8 == 0 and M >= 1024 and N >= 1024 and K >= 1024):
         if out is None:
             out = torch.empty((N, K), dtype=torch.float32, device=g.device)
+        tiles = 0
         if out.is_contiguous() and out.dtype == torch.float32 and out.shape == (N, K):
             tiles = (N // 256) * kt
+            if tiles * max(1, 256 // tiles) < WGRAD_MIN_WGS[0]:
+                tiles = 0                      # too few workgroups for the chip (2048 x 3000: 96 tiles x 2): library
+        if tiles:
             rc = model_lib().spadot_gemm_wgrad_bf16(g.data_ptr(), N, x.data_ptr(), Kp, out.data_ptr(), K, M, N, K,
                                                     max(1, 256 // tiles), _stream())
             if rc == 0:
