@@ -285,6 +285,9 @@ int spadot_gat_ds_src(const float *dz, const int *rowptr_t, const int *eid_t, in
  * GATConv.lin) at the training shapes.  Requires N % 256 == 0, K % 32 == 0, 16-byte aligned pointers and strides that are
  * multiples of 8 elements; returns -22 otherwise (the caller then uses the library).  One 320 x 256 tile per workgroup. */
 int spadot_gemm_tn_bf16(const void *A, int lda, const void *B, int ldb, void *C, int ldc, int M, int N, int K, void *stream);
+/* The same kernel with B stored [K x N] (contraction index = row; transposed LDS reads for that operand): C = A . B, the
+ * input gradient of a dense map (dx = g W with W the [N_out x K_in] weight image).  Same shape conditions. */
+int spadot_gemm_nn_bf16(const void *A, int lda, const void *B, int ldb, void *C, int ldc, int M, int N, int K, void *stream);
 
 /* ---- weight gradient of a GAT layer's dense map on the matrix cores (csrc/gemm_wgrad_bf16.hip) ---------------------------
  * dW [N x K] (fp32, row stride ldw) = G^T X with G [M x N] (bf16, ldg) and X [M x >= K] (bf16, ldx; columns K .. the next

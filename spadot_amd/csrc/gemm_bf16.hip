@@ -48,9 +48,16 @@ __device__ __forceinline__ unsigned pack2(float lo, float hi) {
     return (unsigned)a | ((unsigned)b << 16);
 }
 
-__global__ __launch_bounds__(NT, 1) void k_gemm_tn_bf16(const __bf16 *__restrict__ A, int lda, const __bf16 *__restrict__ B,
-                                                       int ldb, __bf16 *__restrict__ C, int ldc, int M, int N, int K,
-                                                       int mtiles, int ntiles) {
+typedef short s4v __attribute__((ext_vector_type(4)));
+
+// BT = false: B stored [N x K] (contraction contiguous: the forward map, h = x W^T).
+// BT = true : B stored [K x N] (contraction index = ROW: the input gradient, dx = g W): its stage is 64 contraction rows x 256
+//             columns (512-byte rows, 64-byte granules XORed with row & 3, two rows per LDS-DMA piece) and its fragments are
+//             transposed reads (ds_read_b64_tr_b16, two per fragment) -- the B side of csrc/gemm_wgrad_bf16.hip.
+template <bool BT>
+__global__ __launch_bounds__(NT, 1) void k_gemm_bf16(const __bf16 *__restrict__ A, int lda, const __bf16 *__restrict__ B,
+                                                    int ldb, __bf16 *__restrict__ C, int ldc, int M, int N, int K,
+                                                    int mtiles, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // tile of this workgroup: the ntiles column tiles of one row panel are consecutive work items of one XCD
     const int total = mtiles * ntiles;
@@ -74,13 +81,19 @@ __global__ __launch_bounds__(NT, 1) void k_gemm_tn_bf16(const __bf16 *__restrict
         const int row = 8 * (wave + 8 * u) + (lane >> 3);
         const int chunk = (lane & 7) ^ ((row >> 1) & 7);
         // pieces u < 5 are A rows (q < 40), the others B rows; rows past M re-read the last row (never stored)
-        off[u] = u < 5 ? (unsigned)min(m0 + row, M - 1) * (unsigned)(lda * 2) + chunk * 16
-                       : (unsigned)(n0 + row - BM) * (unsigned)(ldb * 2) + chunk * 16;
+        if (u < 5) {
+            off[u] = (unsigned)min(m0 + row, M - 1) * (unsigned)(lda * 2) + chunk * 16;
+        } else if (!BT) {
+            off[u] = (unsigned)(n0 + row - BM) * (unsigned)(ldb * 2) + chunk * 16;
+        } else {
+            const int brow = 2 * (wave + 8 * (u - 5)) + (lane >> 5);                 // contraction row inside the stage
+            off[u] = (unsigned)brow * (unsigned)(ldb * 2) + (unsigned)n0 * 2 + (((lane & 31) ^ ((brow & 3) << 2)) << 4);
+        }
     }
     auto request = [&](int ks) __attribute__((always_inline)) {
         const unsigned base = lds0 + (unsigned)(ks % STAGES) * STAGEB + (unsigned)wave * 1024u;
         const char *ga = reinterpret_cast<const char *>(A) + (size_t)ks * ROWB;
-        const char *gb = reinterpret_cast<const char *>(B) + (size_t)ks * ROWB;
+        const char *gb = reinterpret_cast<const char *>(B) + (BT ? (size_t)ks * BK * ldb * 2 : (size_t)ks * ROWB);
 #pragma unroll
         for (int u = 0; u < PIECES; u++) {
             unsigned keep;
@@ -111,11 +124,33 @@ __global__ __launch_bounds__(NT, 1) void k_gemm_tn_bf16(const __bf16 *__restrict
         a_base[s4] = lds0 + (unsigned)(wm * 160 + r) * ROWB + sw;
         b_base[s4] = lds0 + (unsigned)(BM + wn * 64 + r) * ROWB + sw;
     }
+    // BT: transposed reads of the [64 x 256] B image: lane (hh, g16, qq, pp) -> contraction row 8 hh + qq (+ 4), columns
+    // 64 wn + 32 j + 16 g16 + 4 pp .. + 3, the 64-byte granule index XORed with qq
+    unsigned bt_base[2];
+    {
+        const int g16 = (lane >> 4) & 1, qq = (lane & 15) >> 2, pp = lane & 3;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int g = wn * 2 + j;
+            bt_base[j] = lds0 + (unsigned)(BM * ROWB) + (unsigned)((8 * hh + qq) * 512 + (g & ~3) * 64 + ((g ^ qq) & 3) * 64 + 32 * g16 + 8 * pp);
+        }
+    }
     auto read_frags = [&](unsigned stage_off, int s4, bf8 (&af)[5], bf8 (&bf)[2]) __attribute__((always_inline)) {
         if (GEMM_ABLATE & 4) return;
         const unsigned pb = b_base[s4] + stage_off, pa = a_base[s4] + stage_off;
-        asm volatile("ds_read_b128 %0, %1" : "=v"(bf[0]) : "v"(pb));
-        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(bf[1]) : "v"(pb));
+        if (BT) {
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                s4v lo, hi;
+                const unsigned p = bt_base[j] + stage_off + (unsigned)s4 * 8192u;
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(p));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(hi) : "v"(p));
+                bf[j] = __builtin_bit_cast(bf8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+        } else {
+            asm volatile("ds_read_b128 %0, %1" : "=v"(bf[0]) : "v"(pb));
+            asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(bf[1]) : "v"(pb));
+        }
         asm volatile("ds_read_b128 %0, %1" : "=v"(af[0]) : "v"(pa));
         asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(af[1]) : "v"(pa));
         asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(af[2]) : "v"(pa));
@@ -139,7 +174,8 @@ __global__ __launch_bounds__(NT, 1) void k_gemm_tn_bf16(const __bf16 *__restrict
         __builtin_amdgcn_s_setprio(0);
     };
     auto frags_ready = [&]() __attribute__((always_inline)) {      // the OLDER of the two fragment sets in flight has landed
-        asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
+        if (BT) asm volatile("s_waitcnt lgkmcnt(9)" ::: "memory");       // 5 + 4 reads per fragment set
+        else asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
     };
 
@@ -176,7 +212,8 @@ __global__ __launch_bounds__(NT, 1) void k_gemm_tn_bf16(const __bf16 *__restrict
             __builtin_amdgcn_s_barrier();
             if (P + 2 < nk && !(GEMM_ABLATE & 1)) request(P + 2);
             read_frags((unsigned)((P + 1) % STAGES) * STAGEB, 0, a0, b0);
-            asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
+            if (BT) asm volatile("s_waitcnt lgkmcnt(9)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
         } else {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
@@ -212,18 +249,29 @@ __global__ __launch_bounds__(NT, 1) void k_gemm_tn_bf16(const __bf16 *__restrict
 
 }  // namespace
 
-extern "C" int spadot_gemm_tn_bf16(const void *A, int lda, const void *B, int ldb, void *C, int ldc, int M, int N, int K,
-                                   void *stream) {
-    if (M <= 0 || N <= 0 || K <= 0 || N % BN != 0 || K % BK != 0 || lda < K || ldb < K || ldc < N) return -22;
+template <bool BT>
+static int launch_gemm(const void *A, int lda, const void *B, int ldb, void *C, int ldc, int M, int N, int K, void *stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || N % BN != 0 || K % BK != 0 || lda < K || ldb < (BT ? N : K) || ldc < N) return -22;
     if (((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((uintptr_t)C & 15) || lda % 8 || ldb % 8 || ldc % 8) return -22;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)k_gemm_tn_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return -5;
+        if (hipFuncSetAttribute((const void *)k_gemm_bf16<BT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return -5;
         attr_set = true;
     }
     const int mtiles = (M + BM - 1) / BM, ntiles = N / BN;
     const unsigned grid = 8u * (unsigned)((mtiles * ntiles + 7) / 8);
-    hipLaunchKernelGGL(k_gemm_tn_bf16, dim3(grid), dim3(NT), LDS_BYTES, (hipStream_t)stream, (const __bf16 *)A, lda,
+    hipLaunchKernelGGL(k_gemm_bf16<BT>, dim3(grid), dim3(NT), LDS_BYTES, (hipStream_t)stream, (const __bf16 *)A, lda,
                        (const __bf16 *)B, ldb, (__bf16 *)C, ldc, M, N, K, mtiles, ntiles);
     return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+extern "C" int spadot_gemm_tn_bf16(const void *A, int lda, const void *B, int ldb, void *C, int ldc, int M, int N, int K,
+                                   void *stream) {
+    return launch_gemm<false>(A, lda, B, ldb, C, ldc, M, N, K, stream);
+}
+
+// C [M x N] = A [M x K] . B with B stored [K x N] (the input gradient of a dense map: dx = g W, W the [N_out x K_in] weight image)
+extern "C" int spadot_gemm_nn_bf16(const void *A, int lda, const void *B, int ldb, void *C, int ldc, int M, int N, int K,
+                                   void *stream) {
+    return launch_gemm<true>(A, lda, B, ldb, C, ldc, M, N, K, stream);
 }

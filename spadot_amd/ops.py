@@ -260,7 +260,8 @@ def cast_rows(pairs):
 # for the whole GEMM, and the latency-bound SVGP branch on the other stream, which bounds the forward pair, waits behind them;
 # the library's ~800 short-lived workgroups let that branch's small kernels in.  So both uses are opt-in.
 GEMM_FWD = [__import__("os").environ.get("SPADOT_GEMM_FWD", "0") == "1"]
-GEMM_DGRAD = [__import__("os").environ.get("SPADOT_GEMM_DGRAD", "0") == "1"]
+GEMM_DGRAD = [__import__("os").environ.get("SPADOT_GEMM_DGRAD", "1") == "1"]
+GEMM_DGRAD_MIN_WGS = [int(__import__("os").environ.get("SPADOT_GEMM_DGRAD_MIN_WGS", "240"))]
 GEMM_MAX_WGS = [int(__import__("os").environ.get("SPADOT_GEMM_MAXWG", "256"))]   # own GEMM only up to this many tiles (CUs left free)
 GEMM_OWN = [True]                                  # [False]: gemm_tn() itself goes to the library (tests)
 
@@ -341,9 +342,18 @@ class _DenseCD(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             # dx = g W: the same kernel as the forward map on the transposed weight image (contraction index contiguous)
-            if GEMM_DGRAD[0] and GEMM_OWN[0] and g.shape[0] >= 2560 and wbuf.shape[1] % 256 == 0 and wbuf.shape[0] % 64 == 0:
-                dx = gemm_tn(g, wbuf.t().contiguous())
-            else:
+            dx = None
+            M_, Kp_ = g.shape[0], wbuf.shape[1]
+            if (GEMM_DGRAD[0] and GEMM_OWN[0] and g.is_cuda and g.dtype == torch.bfloat16 and M_ >= 2560 and Kp_ % 256 == 0
+                    and wbuf.shape[0] % 64 == 0 and wbuf.is_contiguous() and ((M_ + 319) // 320) * (Kp_ // 256) >= GEMM_DGRAD_MIN_WGS[0]):
+                dx = torch.empty((M_, Kp_), dtype=torch.bfloat16, device=g.device)
+                rc = model_lib().spadot_gemm_nn_bf16(g.data_ptr(), g.shape[1], wbuf.data_ptr(), Kp_, dx.data_ptr(), Kp_, M_, Kp_,
+                                                     g.shape[1], _stream())
+                if rc == -22:
+                    dx = None
+                elif rc != 0:
+                    _check(rc, "spadot_gemm_nn_bf16")
+            if dx is None:
                 dx = g @ wbuf
         # (x[:, :K] is a strided view: the GEMM takes its row stride, the result is a dense [N, K])
         dW = None

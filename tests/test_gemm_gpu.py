@@ -128,3 +128,25 @@ def test_wgrad_refuses_what_it_does_not_cover():
     X = torch.zeros((64, 200), device=DEV, dtype=torch.bfloat16)
     dW = torch.zeros((256, 200), device=DEV)
     assert lib.spadot_gemm_wgrad_bf16(G.data_ptr(), 256, X.data_ptr(), 200, dW.data_ptr(), 200, 64, 256, 200, 1, st) == -22   # X rows too short
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 256, 64), (321, 512, 192), (2000, 2048, 2048), (9980, 2048, 2048)])
+def test_gemm_nn_matches_fp32_reference(M, N, K):
+    """The B-stored-[K x N] form of csrc/gemm_bf16.hip (input gradient of a dense map): transposed LDS reads for B."""
+    from spadot_amd import _lib
+    lib = _lib.model_lib()
+    g = torch.Generator(device=DEV).manual_seed(M * 3 + K)
+    A = (torch.randn((M, K), device=DEV, generator=g) * 0.7).bfloat16()
+    B = (torch.randn((K, N), device=DEV, generator=g) * 0.1).bfloat16()
+    outs = []
+    for _ in range(2):
+        C = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)
+        rc = lib.spadot_gemm_nn_bf16(A.data_ptr(), K, B.data_ptr(), N, C.data_ptr(), N, M, N, K, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert rc == 0
+        outs.append(C)
+    ref = A.float() @ B.float()
+    mag = A.float().abs() @ B.float().abs()
+    err = (outs[0].float() - ref).abs()
+    assert bool((err <= 2.0 ** -8 * ref.abs() + 1e-5 * mag + 1e-30).all()), float(err.max())
+    assert torch.equal(outs[0], outs[1])
