@@ -16,8 +16,8 @@ def family(name):
     n = name
     if "k_gat_" in n:
         return "gat_edge"
-    if "k_gemm_tn_bf16" in n:
-        return "gemm_bf16_own"
+    if "k_gemm_bf16" in n or "k_gemm_wgrad_bf16" in n or "k_wgrad_reduce" in n or "k_gemm_tn_bf16" in n:
+        return "gemm_bf16_own"          # csrc/gemm_bf16.hip, csrc/gemm_wgrad_bf16.hip (with its partial-sum launch)
     if n.startswith("Cijk_") or n.startswith("Custom_Cijk") or "rocblas_gem" in n or "gemv" in n.lower():
         if "_DB_" in n or "double" in n:
             return "gemm_f64_library"
