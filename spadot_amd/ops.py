@@ -198,7 +198,15 @@ class _GATEdge(torch.autograd.Function):
         g_pre = torch.empty((nt, H * C), dtype=h.dtype, device=h.device)
         dz = torch.empty((graph.E, H), dtype=torch.float32, device=h.device)
         # rows >= nt are not targets: their destination-logit gradient is zero
-        ds_dst = (torch.empty if nt == n else torch.zeros)((n, H), dtype=torch.float32, device=h.device)
+        if nt == n:
+            ds_dst = torch.empty((n, H), dtype=torch.float32, device=h.device)
+        else:
+            # kept with the graph: the kernel rewrites rows < nt every step, rows >= nt stay zero -- no fill launch per step
+            key = ("ds_dst", H)
+            bufs = graph.__dict__.setdefault("_bwd_bufs", {})
+            ds_dst = bufs.get(key)
+            if ds_dst is None or ds_dst.device != h.device:
+                ds_dst = bufs[key] = torch.zeros((n, H), dtype=torch.float32, device=h.device)
         _check(lib.spadot_gat_backward_target(_p(g_out), _p(out), _p(h), _DT[h.dtype], _p(s_src), _p(s_dst), _p(alpha),
                                               _p(graph.rowptr), _p(graph.col), nt, H, C, int(ctx.concat), int(ctx.act),
                                               _p(g_pre), _p(dz), _p(ds_dst), _stream()), "spadot_gat_backward_target")
