@@ -106,5 +106,6 @@ def run_wgrad(M, N, K, Kp, slices, reps=30):
 
 
 if __name__ == "__main__" and "wgrad" in sys.argv:
-    for shp in [(9980, 2048, 2048, 2048, 4), (9980, 2048, 2048, 2048, 1), (9980, 2048, 3000, 3072, 2), (9980, 2048, 2048, 2048, 2)]:
+    for shp in [(9980, 2048, 2048, 2048, 4), (8031, 2048, 2048, 2048, 4), (9980, 2048, 3000, 3072, 2), (9980, 2048, 2048, 2048, 2),
+                (9980, 2048, 2048, 2048, 1)]:
         print(json.dumps(run_wgrad(*shp)), flush=True)

@@ -40,6 +40,8 @@ python3 tools/prof_summary.py $O/train 40 40 $P/train_cfg3_bf16_families.json > 
   PYTHONPATH=$R timeout -k 10 200 python3 tools/gemm_shapes.py 2>/dev/null
   echo "== tools/gemm_bench.py (csrc/gemm_bf16.hip vs the library, interleaved rounds, random data)"
   PYTHONPATH=$R timeout -k 10 200 python3 tools/gemm_bench.py 2>/dev/null
+  echo "== tools/gemm_bench.py wgrad (csrc/gemm_wgrad_bf16.hip vs the library's g^T x, fp32 out)"
+  PYTHONPATH=$R timeout -k 10 200 python3 tools/gemm_bench.py wgrad 2>/dev/null
 } > $P/gemm_probes.txt || true
 # the plain line (reads the summaries just written for roofline.traffic and roofline_train)
 timeout -k 10 900 python3 bench.py > $O/bench.json 2> $O/bench.log
