@@ -120,3 +120,29 @@ def test_config_yaml_is_the_reference_schema_plus_three_documented_keys():
     import pytest
     with pytest.raises(ValueError):
         _utils.resolve_compute_dtype("float16")
+
+
+def test_decoder_hidden_gradients_form_one_block_of_a_flat_buffer():
+    """ops._contiguous_grad_block: when the hidden stages' (W, bias, gamma, beta) gradient views sit back to back in one flat
+    buffer in module order (what FlatAdamW lays out on the device), they are returned as ONE tensor over that storage -- what
+    lets the fused decoder backward (csrc/mlp_chain.hip) write its result row straight into it.  Host logic only."""
+    import torch
+    from spadot_amd import ops
+    from spadot_amd.model.decoder import Decoder
+    dec = Decoder(input_dim=40, z_dim=20, decoder_layers=[64, 256])
+    plist = list(dec.parameters())
+    flat = torch.zeros(sum(p.numel() for p in plist))
+    off = 0
+    for p in plist:                                   # FlatAdamW's layout: module order, sizes here are multiples of 4
+        p.grad = flat[off:off + p.numel()].view_as(p)
+        off += p.numel()
+    stages = list(dec.decoder_net)
+    params = [t for i in range(0, len(stages) - 1, 3) for t in (stages[i].weight, stages[i].bias, stages[i + 1].weight, stages[i + 1].bias)]
+    blk = ops._contiguous_grad_block(params)
+    assert blk is not None and blk.numel() == sum(p.numel() for p in params)
+    blk.fill_(3.0)
+    assert all(float(p.grad.min()) == 3.0 and float(p.grad.max()) == 3.0 for p in params)
+    assert float(stages[-1].weight.grad.abs().max()) == 0.0            # the output map's slot is not part of the block
+    assert ops._contiguous_grad_block(params[::-1]) is None            # another order is not one block
+    stages[0].bias.grad = torch.zeros(64)                              # a gradient outside the buffer breaks the block
+    assert ops._contiguous_grad_block(params) is None
