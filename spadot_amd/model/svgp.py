@@ -131,6 +131,7 @@ class _SVGPCore(torch.autograd.Function):
         ctx.save_for_backward(mu, var, w, X, r, Mr, X2S, p_m, p_v, mv, tr, out4)
         ctx.bc, ctx.rc, ctx.bN = bc, rc, b_over_N
         ctx.mark_non_differentiable(out4)
+        ctx.set_materialize_grads(False)          # no zero-filled gradient tensors for outputs the loss does not use
         return p_m, p_v, skl32[0], out4
 
     @staticmethod
@@ -157,7 +158,7 @@ class _SVGPCore(torch.autograd.Function):
                                              _p(p_m), _p(p_v), _p(bc.ktilde), _p(Mr), _p(rc.M), b, L, m, c, ctx.bN, _p(g_mu),
                                              _p(g_var), _p(G1), _p(G2T), _p(g_kl), _p(gMr), _p(gM), _stream()),
                "spadot_svgp_post_backward")
-        dr = torch.addmm(gMr, G1.T, X2, alpha=c)                             # [L, m]
+        dr = gMr.addmm_(G1.T, X2, alpha=c)                                   # [L, m] (in place: no copy of gMr in front of the GEMM)
         dt = torch.bmm(S, dr.unsqueeze(2)).squeeze(2)                        # [L, m]
         A2 = X2.unsqueeze(0) * G2T.unsqueeze(2)                              # [L, 2b, m]
         D = torch.baddbmm(gM.expand(L, m, m), A2.transpose(1, 2), X2.unsqueeze(0).expand(L, 2 * b, m))

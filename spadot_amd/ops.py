@@ -447,6 +447,19 @@ def dense_cd(x, W, holder, tag="_wpad", fresh=False):
 
 # ----------------------------------------------------------------------------- small-MLP stages
 
+_ZEROS = {}
+
+
+def _const_zeros(like):
+    """A read-only all-zero tensor shaped like `like`, kept per (shape, dtype, device): gradients that are identically zero
+    are handed to autograd from here (consumers copy or add them, nobody writes them)."""
+    key = (tuple(like.shape), like.dtype, str(like.device))
+    z = _ZEROS.get(key)
+    if z is None:
+        z = _ZEROS[key] = torch.zeros_like(like)
+    return z
+
+
 class _BNAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, lin_bias, gamma, beta, bn, slope):
@@ -476,7 +489,7 @@ class _BNAct(torch.autograd.Function):
                                                   None if lin_bias is None else _p(lin_bias), _p(gamma), _p(sm), _p(si), b, F_,
                                                   ctx.slope, _p(dx), _p(dg), _p(db), _stream()), "spadot_bn_act_backward")
         # the batch mean removes a per-feature shift: the preceding Linear's bias has a zero gradient
-        dlb = None if lin_bias is None else torch.zeros_like(lin_bias)
+        dlb = None if lin_bias is None else _const_zeros(lin_bias)       # (a kept all-zero tensor: no fill launch per step)
         return dx, dlb, dg, db, None, None
 
 
