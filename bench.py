@@ -67,6 +67,20 @@ def cpu_sinkhorn(I, J, budget_s=10.0):
             "sample": f"{n} update_a_b iterations of one {I}x{J} fp64 problem (oracle/ot_oracle.c, 1 thread), {el:.1f} s"}
 
 
+def cpu_sinkhorn_parity(x, y, plan_dev, stage_iters_dev):
+    """ONE whole optimal_transport_duality_gap of the C oracle (fp64, 1 thread) on the benchmarked pair problem, and the
+    device plan of that same problem against it (oracle/ot_parity.py; tests/test_ot_gpu.py holds the asserting version:
+    per-stage iteration counts within one convergence check, marginals rtol 1e-4, entries > 1e-9 max rtol 1e-3)."""
+    from oracle import ot_parity
+    ref, rinfo, secs = ot_parity.oracle_solve_from_latents(x, y, OT_CFG)
+    rep = ot_parity.compare_plans(plan_dev, stage_iters_dev, ref, rinfo["stage_iters"])
+    rep["oracle_solve_s"] = secs
+    rep["oracle_iters_per_s_whole_solve"] = float(sum(rep["stage_iters_ref"])) / secs
+    rep["what"] = ("device plan (fp32 storage, fp64 scalings) of the benchmarked problem vs one whole six-stage solve of "
+                   "oracle/ot_oracle.c (fp64, 1 thread) on the same latents")
+    return rep
+
+
 def cpu_train_steps(model, opt, dd, cfg, tu, tp, bi, tp_prev, epoch, beta1, n_steps=3):
     """`n_steps` training steps of the same batch on the host: oracle/model_oracle.training_step (fp64, torch CPU with
     all cores), the reference's arithmetic including its (b, m, m) ELBO tensor (SURVEY 8d asks for >= 3 steps).
@@ -246,6 +260,8 @@ def _main(real_stdout):
     ap.add_argument("--cpu-steps", type=int, default=3, help="oracle training steps timed for cpu_baseline")
     ap.add_argument("--no-epoch", action="store_true", help="skip the whole-epoch block (100 steps + K-means + OT update)")
     ap.add_argument("--leg", default="both", choices=["both", "train", "sinkhorn"])
+    ap.add_argument("--no-sinkhorn-parity", action="store_true",
+                    help="skip the whole-solve oracle check of the Sinkhorn leg (about a minute of one host thread)")
     args = ap.parse_args()
 
     import torch
@@ -410,11 +426,14 @@ def _main(real_stdout):
         from spadot_amd.ot import OTSolver
         I = J = N
         solver = OTSolver(I, J, storage=args.ot_storage, device=dev)
-        solver.set_cost_from_latents(synthetic_latents(I, 100 + rank), synthetic_latents(J, 200 + rank))
+        lat_x, lat_y = synthetic_latents(I, 100 + rank), synthetic_latents(J, 200 + rank)
+        solver.set_cost_from_latents(lat_x, lat_y)
         t0 = time.perf_counter()
         info = solver.solve(OT_CFG)                 # whole 6-stage solve; leaves a converged state
         torch.cuda.synchronize()
         solve_s = time.perf_counter() - t0
+        want_parity = rank == 0 and world == 1 and not args.no_cpu_baseline and not args.no_sinkhorn_parity
+        plan_first = solver.plan("numpy") if want_parity else None     # (before the timed iterations move a, b on)
         for _ in range(args.warmup):
             solver.run_iterations(OT_CFG, OT_CFG["epsilon"], ITERS_PER_STEP, timed=False)
         barrier()
@@ -454,9 +473,12 @@ def _main(real_stdout):
                     roof["traffic"] = (2.0 * float(row[1]) + float(row[3])) * 1024.0
                     roof["traffic_source"] = (f"replayed from {os.path.relpath(pmc, ROOT)} (separate rocprofv3 --pmc passes of this "
                                               "command: 2*FETCH_SIZE + WRITE_SIZE, bytes per launch) -- not measured in this run")
-        if rank == 0 and world == 1 and not args.no_cpu_baseline:
-            sk_res["cpu_baseline"] = cpu_sinkhorn(I, J)
         solver.close()
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            sk_res["cpu_baseline"] = cpu_sinkhorn(I, J, budget_s=6.0 if want_parity else 10.0)
+            if want_parity:
+                sk_res["parity_check"] = cpu_sinkhorn_parity(lat_x, lat_y, plan_first, info.stage_iters)
+                del plan_first
 
     if rank == 0:
         if train_res is not None:
@@ -484,7 +506,9 @@ def _main(real_stdout):
             if train_res is not None and k in train_res:
                 out[k] = train_res[k]
         if sk_res is not None:
-            out["sinkhorn"] = {k: v for k, v in sk_res.items() if k != "cpu_baseline"}
+            out["sinkhorn"] = {k: v for k, v in sk_res.items() if k not in ("cpu_baseline", "parity_check")}
+            if "parity_check" in sk_res:
+                out["parity_check_sinkhorn"] = sk_res["parity_check"]
             out["roofline"] = roof
         cb = (train_res or {}).get("cpu_baseline") or (sk_res or {}).get("cpu_baseline")
         if cb:

@@ -7,8 +7,11 @@
  * which the reference binds with ctypes at ot_func.py:10-315.  All pointers in part A are
  * HOST pointers to caller-owned, C-contiguous, row-major (m, n) arrays; the library uploads
  * them, runs the HIP kernels on the current device's null stream, and writes every array the
- * reference mutates back in place.  Nothing is kept between calls.  There is no CPU path: if
- * no HIP device is usable the call prints a message on stderr and aborts.
+ * reference mutates back in place.  Nothing is kept between calls.  There is no CPU path and no abort():
+ * if no HIP device is usable, or a HIP call fails, the call prints a message on stderr and returns an error value --
+ * NaN from the double / float valued entries (the reference's driver turns a NaN gap into a RuntimeError,
+ * ot_solvers.py:446-447), -5 (SPADOT_EHIP) from step1_process_double and from every int-valued entry of part B,
+ * NULL from the pointer-valued ones; bad arguments are -22.
  *
  * PART B is the device-resident solver the hot path actually uses: cost, kernel and scalings
  * stay in HBM across all six epsilon stages; only 8-byte convergence scalars cross PCIe.
@@ -166,6 +169,45 @@ int spadot_ot_run_checked(spadot_ot_solver *s, const spadot_ot_config *cfg, doub
  * column finalise}; the last two are 0 when the shape does not admit the fused path. */
 int spadot_ot_time_kernels(spadot_ot_solver *s, const spadot_ot_config *cfg, double eps_stage, int reps,
                            float *ms_out);
+
+/* ------------------------------------------------------------------------------------------
+ * PART C -- whole solves of SMALL problems (I, J <= spadot_ot_small_max() = 64), batched: one launch, one
+ * wavefront per problem, everything in LDS, NO host synchronisation.  This is the solve the training loop runs:
+ * _update_OT_matrix (_train_utils.py:309-321) couples the 10 x 10 K-means centres of consecutive time points through
+ * compute_transport_map (ot_solvers.py:95-121: cost = sqeuclidean / median, first growth solve returned) and
+ * optimal_transport_duality_gap (:164-449); all T - 1 pairs go into one call.  fp64 throughout.
+ * ---------------------------------------------------------------------------------------- */
+
+typedef struct spadot_ot_small_problem {
+    const double *x_dev;       /* I x d latents, row-major fp64 (device); NULL => the cost comes from C_dev */
+    const double *y_dev;       /* J x d */
+    const double *C_dev;       /* I x J cost, row-major fp64 (device); read only when x_dev == NULL */
+    const double *G_dev;       /* growth p (I doubles, device) or NULL for ones; q = mean(G) (ot_solvers.py:223-224) */
+    double *plan_dev;          /* out (may be NULL): I x J plan R / J (ot_solvers.py:449) */
+    float *gamma_rownorm_dev;  /* out (may be NULL): I x J fp32, rows of the plan normalised to sum 1, NaN / inf -> 0:
+                                  what _compute_OT_loss makes of it every step (_train_utils.py:299-300) */
+    int I, J;
+} spadot_ot_small_problem;
+
+typedef struct spadot_ot_small_info {
+    double gap;                /* final convergence measure; NaN => the reference raises (ot_solvers.py:446-447) */
+    int stage_iters[6];        /* scaling iterations run in each epsilon stage */
+    int absorbs;               /* tau-stabilisations */
+    int gap_checks;            /* convergence checks */
+    int status;                /* bit 0: a stage reached max_iter (the reference prints and goes on, ot_func.cpp:821-824);
+                                  bit 1: a stage passed 2^20 iterations and the kernel gave up (plan not converged) */
+    int reserved;
+} spadot_ot_small_info;
+
+int spadot_ot_small_max(void);
+
+/* Enqueues the solves of `nprob` problems on `stream` (a hipStream_t) and returns at once: nothing is allocated, nothing
+ * is synchronised.  `probs` is a HOST array (the descriptors travel as kernel arguments; the pointers inside are device
+ * pointers), d the latent dimension (<= 32), divide_by_median as in spadot_ot_set_cost_from_latents_dev, info_dev a
+ * DEVICE array of nprob records or NULL.  Returns 0, -22 for a bad argument (a size outside 1..64 included), -5 when no HIP
+ * device is usable or the launch fails. */
+int spadot_ot_small_solve(int nprob, const spadot_ot_small_problem *probs, int d, int divide_by_median,
+                          const spadot_ot_config *cfg, spadot_ot_small_info *info_dev, void *stream);
 
 /* Library/version probe. */
 const char *spadot_ot_version(void);

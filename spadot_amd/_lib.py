@@ -44,6 +44,19 @@ class OTInfo(ctypes.Structure):
                 ("gap_checks", ctypes.c_int)]
 
 
+class OTSmallProblem(ctypes.Structure):
+    """struct spadot_ot_small_problem (include/spadot_ot.h part C)."""
+    _fields_ = [("x_dev", ctypes.c_void_p), ("y_dev", ctypes.c_void_p), ("C_dev", ctypes.c_void_p),
+                ("G_dev", ctypes.c_void_p), ("plan_dev", ctypes.c_void_p), ("gamma_rownorm_dev", ctypes.c_void_p),
+                ("I", ctypes.c_int), ("J", ctypes.c_int)]
+
+
+class OTSmallInfo(ctypes.Structure):
+    """struct spadot_ot_small_info (include/spadot_ot.h part C)."""
+    _fields_ = [("gap", ctypes.c_double), ("stage_iters", ctypes.c_int * 6), ("absorbs", ctypes.c_int),
+                ("gap_checks", ctypes.c_int), ("status", ctypes.c_int), ("reserved", ctypes.c_int)]
+
+
 def ot_lib():
     """libspadot_ot.so with argtypes/restypes of include/spadot_ot.h part B set."""
     lib = _load("libspadot_ot.so")
@@ -89,6 +102,10 @@ def ot_lib():
     lib.spadot_ot_run_checked.restype = ci
     lib.spadot_ot_time_kernels.argtypes = [vp, ctypes.POINTER(OTConfig), cd, ci, ctypes.POINTER(ctypes.c_float)]
     lib.spadot_ot_time_kernels.restype = ci
+    lib.spadot_ot_small_max.argtypes = []
+    lib.spadot_ot_small_max.restype = ci
+    lib.spadot_ot_small_solve.argtypes = [ci, ctypes.POINTER(OTSmallProblem), ci, ci, ctypes.POINTER(OTConfig), vp, vp]
+    lib.spadot_ot_small_solve.restype = ci
     lib._spadot_ready = True
     return lib
 

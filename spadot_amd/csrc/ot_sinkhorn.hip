@@ -30,7 +30,8 @@
 
 // Error handling: no HIP failure ends the host process.  Every HIP call is checked; a failure unwinds to the C entry
 // point, which reports it on stderr and returns SPADOT_EHIP (part B: int results), NaN (part A: double / float results,
-// which the reference's driver turns into a RuntimeError, ot_solvers.py:446-447) or -2 (step1_process_double).
+// which the reference's driver turns into a RuntimeError, ot_solvers.py:446-447) or SPADOT_EHIP again (step1_process_double).
+// Temporaries are owned by DevBuf guards, so an unwinding call frees them.
 struct hip_failure { hipError_t err; const char *file; int line; const char *expr; };
 #define HIP_CHECK(expr)                                                        \
     do {                                                                       \
@@ -1151,6 +1152,16 @@ void *dmalloc(size_t bytes) {
     return p;
 }
 
+// Owner of a temporary device allocation: freed when the scope is left, also by an unwinding HIP_CHECK.
+struct DevBuf {
+    void *p = nullptr;
+    explicit DevBuf(size_t bytes) : p(dmalloc(bytes)) {}
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    template <typename T> T *as() const { return (T *)p; }
+};
+
 dim3 grid_cols(const spadot_ot_solver *s, int V) {
     // rows are strided over gridDim.y: ~2k blocks fill the chip, and a launch that exits on a clear
     // tau flag stays cheap
@@ -1547,7 +1558,11 @@ int spadot_ot_create(spadot_ot_solver **out, int I, int J, int storage, void *st
     *out = nullptr;
     if (I <= 0 || J <= 0 || (storage != SPADOT_F64 && storage != SPADOT_F32)) return -22;
     require_device();
-    auto *s = new spadot_ot_solver();
+    struct Guard {                        // a failing allocation below unwinds: give back what was taken so far
+        spadot_ot_solver *s;
+        ~Guard() { if (s) spadot_ot_destroy(s); }
+    } guard{new spadot_ot_solver()};
+    spadot_ot_solver *s = guard.s;
     s->I = I; s->J = J; s->storage = storage; s->stream = (hipStream_t)stream;
     s->ld = round_up(J, 64);
     choose_chunks(s);
@@ -1562,8 +1577,8 @@ int spadot_ot_create(spadot_ot_solver **out, int I, int J, int storage, void *st
     s->mut_count = 3 * (size_t)I + 3 * L;
     const size_t vec_count = 6 * (size_t)I + 7 * L;
     double *vb = (double *)dmalloc(sizeof(double) * vec_count);
-    HIP_CHECK(hipMemsetAsync(vb, 0, sizeof(double) * vec_count, s->stream));
-    s->a = vb; s->old_a = vb + I; s->adx = vb + 2 * (size_t)I;
+    s->a = vb;                                            // (owned by the solver from here on)
+    HIP_CHECK(hipMemsetAsync(vb, 0, sizeof(double) * vec_count, s->stream)); s->old_a = vb + I; s->adx = vb + 2 * (size_t)I;
     s->b = vb + 3 * (size_t)I; s->old_b = s->b + L; s->w = s->b + 2 * L;
     double *cb = vb + s->mut_count;
     s->u = cb; s->p = cb + I; s->dx = cb + 2 * (size_t)I;
@@ -1583,6 +1598,7 @@ int spadot_ot_create(spadot_ot_solver **out, int I, int J, int storage, void *st
     HIP_CHECK(hipHostMalloc((void **)&s->h_flags, sizeof(int) * (MAX_BATCH + 1), hipHostMallocDefault));
     HIP_CHECK(hipEventCreate(&s->ev0));
     HIP_CHECK(hipEventCreate(&s->ev1));
+    guard.s = nullptr;
     *out = s;
     return 0;
     SPADOT_LEAVE(SPADOT_EHIP)
@@ -1593,10 +1609,12 @@ void spadot_ot_destroy(spadot_ot_solver *s) {
     if (!s) return;
     (void)hipStreamSynchronize(s->stream);
     void *dev[] = {s->C, s->K, s->a, s->backup, s->red, s->part, s->rt, s->scal, s->flags, s->cost_ws, s->ctl};
-    (void)hipHostFree(s->h_ctl);
-    for (void *p : dev) (void)hipFree(p);
-    (void)hipHostFree(s->h_scal); (void)hipHostFree(s->h_flags);
-    (void)hipEventDestroy(s->ev0); (void)hipEventDestroy(s->ev1);
+    for (void *p : dev) if (p) (void)hipFree(p);
+    if (s->h_ctl) (void)hipHostFree(s->h_ctl);
+    if (s->h_scal) (void)hipHostFree(s->h_scal);
+    if (s->h_flags) (void)hipHostFree(s->h_flags);
+    if (s->ev0) (void)hipEventDestroy(s->ev0);
+    if (s->ev1) (void)hipEventDestroy(s->ev1);
     delete s;
     SPADOT_LEAVE()
 }
@@ -1643,7 +1661,8 @@ int spadot_ot_matrix_host(spadot_ot_solver *s, int which, double *out) {
     void *src = spadot_ot_matrix_dev(s, which);
     if (!src || !out) return -22;
     const size_t n = (size_t)s->I * s->J;
-    double *tmp = (double *)dmalloc(sizeof(double) * n);
+    DevBuf buf(sizeof(double) * n);
+    double *tmp = buf.as<double>();
     dim3 g((s->J + 255) / 256, (unsigned)std::min(s->I, 8192));
     if (s->storage == SPADOT_F32)
         hipLaunchKernelGGL((k_convert<float, double>), g, dim3(256), 0, s->stream, (const float *)src, s->ld, tmp, s->J, s->I, s->J);
@@ -1651,7 +1670,6 @@ int spadot_ot_matrix_host(spadot_ot_solver *s, int which, double *out) {
         hipLaunchKernelGGL((k_convert<double, double>), g, dim3(256), 0, s->stream, (const double *)src, s->ld, tmp, s->J, s->I, s->J);
     HIP_CHECK(hipMemcpyAsync(out, tmp, sizeof(double) * n, hipMemcpyDeviceToHost, s->stream));
     HIP_CHECK(hipStreamSynchronize(s->stream));
-    HIP_CHECK(hipFree(tmp));
     return 0;
     SPADOT_LEAVE(SPADOT_EHIP)
 }
@@ -1678,11 +1696,11 @@ int spadot_ot_set_cost_dev(spadot_ot_solver *s, const void *C_dev, int dtype, in
 int spadot_ot_set_cost_host(spadot_ot_solver *s, const double *C_host) {
     SPADOT_ENTER
     if (!s || !C_host) return -22;
-    double *tmp = (double *)dmalloc(sizeof(double) * (size_t)s->I * s->J);
+    DevBuf buf(sizeof(double) * (size_t)s->I * s->J);
+    double *tmp = buf.as<double>();
     HIP_CHECK(hipMemcpyAsync(tmp, C_host, sizeof(double) * (size_t)s->I * s->J, hipMemcpyHostToDevice, s->stream));
     int rc = spadot_ot_set_cost_dev(s, tmp, SPADOT_F64, s->J);
     HIP_CHECK(hipStreamSynchronize(s->stream));
-    HIP_CHECK(hipFree(tmp));
     return rc;
     SPADOT_LEAVE(SPADOT_EHIP)
 }
@@ -1692,7 +1710,8 @@ int spadot_ot_set_cost_host(spadot_ot_solver *s, const double *C_host) {
 namespace {
 // k-th smallest (0-based) of n non-negative doubles on the device, exact, by 12-bit radix select.
 double select_kth(spadot_ot_solver *s, const double *D, size_t n, size_t k) {
-    unsigned long long *hist = (unsigned long long *)dmalloc(sizeof(unsigned long long) * 4096);
+    DevBuf hbuf(sizeof(unsigned long long) * 4096);
+    unsigned long long *hist = hbuf.as<unsigned long long>();
     std::vector<unsigned long long> h(4096);
     unsigned long long prefix = 0;
     const int shifts[6] = {52, 40, 28, 16, 4, 0};
@@ -1712,7 +1731,6 @@ double select_kth(spadot_ot_solver *s, const double *D, size_t n, size_t k) {
         }
         prefix = (prefix << nbits[pass]) | (unsigned long long)bin;
     }
-    HIP_CHECK(hipFree(hist));
     double out;
     memcpy(&out, &prefix, sizeof(double));
     return out;
@@ -1740,7 +1758,8 @@ extern "C" int spadot_ot_set_cost_from_latents_dev(spadot_ot_solver *s, const do
     }
     const int I = s->I, J = s->J;
     const size_t n = (size_t)I * J;
-    double *D = (double *)dmalloc(sizeof(double) * n);
+    DevBuf dbuf(sizeof(double) * n);
+    double *D = dbuf.as<double>();
     const int rpb = 32;
     hipLaunchKernelGGL(k_sqeuclid, dim3((J + 255) / 256, (I + rpb - 1) / rpb), dim3(256), 0, s->stream, x_dev,
                        y_dev, d, I, J, D, rpb);
@@ -1756,7 +1775,6 @@ extern "C" int spadot_ot_set_cost_from_latents_dev(spadot_ot_solver *s, const do
     else
         hipLaunchKernelGGL(k_scale_to_cost<double>, g, dim3(256), 0, s->stream, D, denom, (double *)s->C, I, J, s->ld);
     HIP_CHECK(hipStreamSynchronize(s->stream));
-    HIP_CHECK(hipFree(D));
     s->sum_kbar_eps = -1.0;
     return 0;
     SPADOT_LEAVE(SPADOT_EHIP)
@@ -1858,12 +1876,12 @@ int spadot_ot_plan_group_sums_dev(spadot_ot_solver *s, const int *col_labels_dev
 int spadot_ot_plan_host(spadot_ot_solver *s, double *plan_host) {
     SPADOT_ENTER
     if (!s || !plan_host) return -22;
-    double *tmp = (double *)dmalloc(sizeof(double) * (size_t)s->I * s->J);
+    DevBuf buf(sizeof(double) * (size_t)s->I * s->J);
+    double *tmp = buf.as<double>();
     int rc = spadot_ot_plan_dev(s, tmp, SPADOT_F64, s->J);
     if (rc == 0)
         HIP_CHECK(hipMemcpyAsync(plan_host, tmp, sizeof(double) * (size_t)s->I * s->J, hipMemcpyDeviceToHost, s->stream));
     HIP_CHECK(hipStreamSynchronize(s->stream));
-    HIP_CHECK(hipFree(tmp));
     return rc;
     SPADOT_LEAVE(SPADOT_EHIP)
 }
@@ -2058,7 +2076,8 @@ void compat_update_k(T *K, T *K_, T *C, const double *u, const double *v, double
     upload_mat<T>(s, s->C, C);
     upload_vec(s, s->u, u, m);
     upload_vec(s, s->v, v, n);
-    void *kb = dmalloc((size_t)m * s->ld * sizeof(T));
+    DevBuf kbuf((size_t)m * s->ld * sizeof(T));
+    void *kb = kbuf.p;
     constexpr int V = Vec<T>::N;
     hipLaunchKernelGGL(k_build_Kbar<T>, grid_cols(s, V), dim3(256), 0, s->stream, (T *)kb, (const T *)s->C,
                        eps, m, n, s->ld);
@@ -2066,7 +2085,6 @@ void compat_update_k(T *K, T *K_, T *C, const double *u, const double *v, double
     download_mat<T>(s, K_, kb);
     download_mat<T>(s, K, s->K);
     HIP_CHECK(hipStreamSynchronize(s->stream));
-    HIP_CHECK(hipFree(kb));
 }
 
 template <typename T>
@@ -2240,12 +2258,13 @@ double update_process_double(double *R, double *a, double *b, double *old_a, dou
     Tmp t(m, n, SPADOT_F64);
     spadot_ot_solver *s = t.s;
     const bool last = (cur_epsilon_scaling == epsilon_scalings);
+    DevBuf rbuf(last ? (size_t)m * s->ld * sizeof(double) : 8);
     void *Rdev = nullptr;
     if (last) {
         // sum(_K) from the caller's matrix: the K slot is free until the state is loaded
         upload_mat<double>(s, s->K, _K);
         sum_kbar(s, s->K, epsilon, false);
-        Rdev = dmalloc((size_t)m * s->ld * sizeof(double));
+        Rdev = rbuf.p;
     }
     compat_load_state(s, a, b, old_a, old_b, K, C, dx, dy, p, q, u, v);
     IterParams P{epsilon, tau, lambda1, lambda2, alpha1, alpha2};
@@ -2253,7 +2272,6 @@ double update_process_double(double *R, double *a, double *b, double *old_a, dou
     compat_store_state(s, a, b, old_a, old_b, K, u, v);
     if (last) download_mat<double>(s, R, Rdev);
     HIP_CHECK(hipStreamSynchronize(s->stream));
-    if (Rdev) HIP_CHECK(hipFree(Rdev));
     return gap;
     SPADOT_LEAVE(NAN)
 }

@@ -10,7 +10,7 @@ import ctypes
 import numpy as np
 import torch
 
-from ._lib import OTConfig, OTInfo, ot_lib
+from ._lib import OTConfig, OTInfo, OTSmallInfo, OTSmallProblem, ot_lib
 
 F64, F32 = 0, 1
 _TORCH_DT = {F64: torch.float64, F32: torch.float32}
@@ -209,3 +209,120 @@ class OTSolver:
         g = (ctypes.c_int * 4)()
         self.lib.spadot_ot_fused_geometry(self.h, g)
         return {"vpt": g[0], "rows_per_group": g[1], "workgroups": g[2], "rows_per_workgroup": g[3]}
+
+
+# ------------------------------------------------------------------------------ small problems (include/spadot_ot.h part C)
+
+SMALL_MAX = 64          # spadot_ot_small_max(): largest I, J of the one-wavefront solver
+SMALL_MAX_D = 32
+
+
+def small_problem_ok(I, J, d=None):
+    """True when an I x J problem (latent dimension d) can take the single-launch small solver."""
+    return 1 <= int(I) <= SMALL_MAX and 1 <= int(J) <= SMALL_MAX and (d is None or 1 <= int(d) <= SMALL_MAX_D)
+
+
+class SmallSolveResult:
+    """plans: list of numpy fp64 (I, J) arrays (R / J, ot_solvers.py:449); infos: list of OTSmallInfo."""
+
+    def __init__(self, plans, infos):
+        self.plans, self.infos = plans, infos
+
+
+def solve_small(cfg, pairs=None, costs=None, growth=None, divide_by_median=True, gamma_out=None, device="cuda:0",
+                fetch=True):
+    """Whole solves of a batch of small problems in ONE launch (csrc/ot_small.hip): what _update_OT_matrix needs for
+    its T - 1 pairs of 10 x 10 K-means centres (_train_utils.py:309-321).
+
+    pairs: list of (x [I, d], y [J, d]) latents (numpy or torch, any device) -> cost = sqeuclidean [/ median]
+           (ot_solvers.py:101-103), or
+    costs: list of (I, J) cost matrices (numpy or torch) used as they are;
+    growth: optional list of length-I vectors (None entries = ones);
+    gamma_out: optional list of contiguous fp32 device tensors (I, J) (None entries allowed) that receive the
+           row-normalised plan with NaN / inf -> 0 (_train_utils.py:299-300), written in place by the kernel;
+    fetch=False enqueues the launch and returns None without any host synchronisation (the results are then only the
+           gamma_out tensors)."""
+    lib = ot_lib()
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError("solve_small needs a HIP device (torch device type 'cuda'); there is no CPU path")
+    items = pairs if pairs is not None else costs
+    n = len(items)
+    if n == 0:
+        return SmallSolveResult([], [])
+    c = make_config(cfg)
+
+    # everything that is still on the host goes up in ONE copy
+    host_parts, slots = [], []
+
+    def stage(arr, k, field):
+        if isinstance(arr, torch.Tensor) and arr.is_cuda:
+            t = arr.to(device=device, dtype=torch.float64).contiguous()
+            slots.append((k, field, t, None))
+        else:
+            a = np.ascontiguousarray(arr.detach().cpu().numpy() if isinstance(arr, torch.Tensor) else arr, dtype=np.float64)
+            slots.append((k, field, None, (sum(p.size for p in host_parts), a.size)))
+            host_parts.append(a.reshape(-1))
+
+    shapes, d = [], 0
+    for k, it in enumerate(items):
+        if pairs is not None:
+            x, y = it
+            I, J, dk = int(x.shape[0]), int(y.shape[0]), int(x.shape[1])
+            if int(y.shape[1]) != dk or (d and dk != d):
+                raise ValueError("all latents of a batch must share their dimension")
+            d = dk
+            stage(x, k, "x_dev"); stage(y, k, "y_dev")
+        else:
+            I, J = int(it.shape[0]), int(it.shape[1])
+            stage(it, k, "C_dev")
+        if not small_problem_ok(I, J, d or None):
+            raise ValueError(f"problem {k} ({I} x {J}, d = {d}) is outside the small solver's range")
+        shapes.append((I, J))
+        if growth is not None and growth[k] is not None:
+            g = growth[k]
+            if int(np.prod(g.shape)) != I:
+                raise ValueError("growth vector of the wrong length")
+            stage(g, k, "G_dev")
+    up = torch.as_tensor(np.concatenate(host_parts)).to(device) if host_parts else None
+    keep = [up]
+    total = sum(I * J for I, J in shapes)
+    plan_buf = torch.empty(total, dtype=torch.float64, device=device) if fetch else None
+    info_buf = torch.zeros(n * ctypes.sizeof(OTSmallInfo), dtype=torch.uint8, device=device) if fetch else None
+    probs = (OTSmallProblem * n)()
+    off = 0
+    for k, (I, J) in enumerate(shapes):
+        probs[k].I, probs[k].J = I, J
+        if plan_buf is not None:
+            probs[k].plan_dev = plan_buf.data_ptr() + 8 * off
+        off += I * J
+        if gamma_out is not None and gamma_out[k] is not None:
+            g = gamma_out[k]
+            if not (g.is_cuda and g.dtype == torch.float32 and g.is_contiguous() and tuple(g.shape) == (I, J)):
+                raise ValueError("gamma_out entries must be contiguous fp32 device tensors of the plan's shape")
+            probs[k].gamma_rownorm_dev = g.data_ptr()
+    for k, field, t, span in slots:
+        if t is not None:
+            keep.append(t)
+            setattr(probs[k], field, t.data_ptr())
+        else:
+            setattr(probs[k], field, up.data_ptr() + 8 * span[0])
+    stream = torch.cuda.current_stream(device)
+    rc = lib.spadot_ot_small_solve(n, probs, d, 1 if divide_by_median else 0, ctypes.byref(c),
+                                   ctypes.c_void_p(info_buf.data_ptr()) if info_buf is not None else None,
+                                   ctypes.c_void_p(stream.cuda_stream))
+    if rc != 0:
+        raise RuntimeError(f"spadot_ot_small_solve failed with {rc}")
+    for t in keep:                       # inputs stay alive until the kernel has read them
+        if t is not None:
+            t.record_stream(stream)
+    if not fetch:
+        return None
+    flat = plan_buf.cpu().numpy()        # (synchronises)
+    raw = info_buf.cpu().numpy().tobytes()
+    plans, infos, off = [], [], 0
+    for k, (I, J) in enumerate(shapes):
+        plans.append(flat[off:off + I * J].reshape(I, J).copy())
+        off += I * J
+        infos.append(OTSmallInfo.from_buffer_copy(raw, k * ctypes.sizeof(OTSmallInfo)))
+    return SmallSolveResult(plans, infos)

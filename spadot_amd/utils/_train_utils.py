@@ -22,7 +22,7 @@ import torch
 from ..graph import build_batch_graph, knn_graph, precompute_batches
 from ..model import SpaDOT
 from ..ops import FlatAdamW, cluster_losses, mix_losses
-from .OT_loss.ot_solvers import compute_transport_map
+from .OT_loss.ot_solvers import compute_transport_map, compute_transport_maps
 
 LOSS_NAMES = ["elbo", "Recon", "SVGP_KL", "GAT_KL", "alignment", "KMeans", "OT"]
 
@@ -230,17 +230,40 @@ def _set_gamma(model, key, gamma, device):
 
 
 def _update_OT_matrix(model, model_config):
-    """_train_utils.py:309-321: transport plan between the K-means centres of consecutive time points."""
+    """_train_utils.py:309-321: transport plan between the K-means centres of consecutive time points.  All pairs are
+    solved by ONE launch (ot_solvers.compute_transport_maps -> csrc/ot_small.hip: one wavefront per pair, cost, median,
+    six epsilon stages and the row-normalised plan of _compute_OT_loss on the device); the plans come back in one copy
+    for the reference's `model.gammas`.  Centre sets beyond 64 clusters take the streaming solver pair by pair."""
     model.eval()
     device = torch.device(model_config["device"])
     timepoints = model_config["timepoints"]
+    keys, pairs = [], []
     for tp_i, tp in enumerate(timepoints[:-1]):
         nxt = timepoints[tp_i + 1]
         if tp not in model.kmeans_center_dict or nxt not in model.kmeans_center_dict:
             continue
-        gamma = compute_transport_map(model.kmeans_center_dict[tp], model.kmeans_center_dict[nxt],
-                                      model_config["ot_config"], G=None)
-        _set_gamma(model, f"{tp}_{nxt}", gamma, device)
+        keys.append(f"{tp}_{nxt}")
+        pairs.append((np.asarray(model.kmeans_center_dict[tp]), np.asarray(model.kmeans_center_dict[nxt])))
+    if not pairs:
+        return
+    if not hasattr(model, "_gamma_dev"):
+        model._kmeans_dev, model._gamma_dev = getattr(model, "_kmeans_dev", {}), {}
+    outs = []
+    for key, (a, b) in zip(keys, pairs):               # stable addresses: captured graphs read these tensors
+        cur = model._gamma_dev.get(key)
+        if cur is None or tuple(cur.shape) != (a.shape[0], b.shape[0]):
+            if cur is not None:
+                model._state_version = getattr(model, "_state_version", 0) + 1
+            cur = model._gamma_dev[key] = torch.zeros((a.shape[0], b.shape[0]), dtype=torch.float32, device=device)
+        outs.append(cur)
+    plans = compute_transport_maps(pairs, model_config["ot_config"], gamma_out=outs, device=device)
+    if plans is not None:
+        for key, gamma in zip(keys, plans):
+            model.gammas[key] = gamma
+        return
+    for key, (a, b) in zip(keys, pairs):
+        gamma = compute_transport_map(a, b, model_config["ot_config"], G=None, device=device)
+        _set_gamma(model, key, gamma, device)
 
 
 # ------------------------------------------------------------------------------ the step
