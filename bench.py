@@ -13,10 +13,11 @@ The metric has two halves and both are measured, inputs resident in HBM:
     clip_grad_norm + AdamW (_train_utils.py:187-217), all loss terms active (epoch >= ot_epoch);
   * Sinkhorn iters/s  -- `sinkhorn.value`: one iteration = one update_a_b (ot_func.cpp:586-687) of the
     N_t x N_t coupling between consecutive time points (fp32 kernel matrix, fp64 scalings).
-Multi-GPU ("weak"): rank r owns time point r mod 5 (its data, graph, SVGP constants) and the pair
+Multi-GPU ("weak": one batch per rank per step): the job's (time point, batch) units are dealt to the ranks for the
+whole run (spadot_amd.parallel, granularity 'batch'), every rank holds all time points' rows; rank r also solves the pair
 problem (r mod 4, r mod 4 + 1); every step all-reduces the flat gradient buffer over RCCL (two buckets, the first
-beside the end of the backward pass); pair
-solves need no collective.  `value` = steps of all ranks / max-over-ranks wall time.
+beside the end of the backward pass); pair solves need no collective.  `value` = steps of all ranks / max-over-ranks
+wall time.
 
 Prints ONE JSON line on rank 0.
 """
@@ -124,7 +125,7 @@ def newest_profile(name):
     return None
 
 
-def roofline_train(dd, tp, cfg, G, compute_dtype, n_params, live_ms_per_step):
+def roofline_train(dd, unit, cfg, G, compute_dtype, n_params, live_ms_per_step):
     """Where the training step stands against the machine, per kernel family.
 
     ALGORITHMIC work per step comes from the shapes of the batch actually run (computed here, live); the MICROSECONDS
@@ -138,7 +139,7 @@ def roofline_train(dd, tp, cfg, G, compute_dtype, n_params, live_ms_per_step):
           side and source side each read and write one n x H C image) -- against the 8 TB/s HBM peak;
       optimizer: 8 fp32 streams over the flat buffers (p, g, m, v read; p, m, v written; g read once more for the norm);
       everything else is latency (20 workgroups of fp64 sweep, ~90 launches of a few microseconds)."""
-    b0 = dd["dataloaders"][tp][0]
+    b0 = dd["dataloaders"][unit[0]][unit[1]]
     g1 = b0.graph
     lg = g1.layer_graphs
     H, C = cfg["gat_attention_heads"], cfg["gat_encoder_hidden"]
@@ -320,16 +321,21 @@ def _main(real_stdout):
         from spadot_amd.model import SpaDOT
         from spadot_amd.ops import FlatAdamW
         cfg = _utils.load_model_config(types.SimpleNamespace(config=None))
-        # N == 1: the whole 5-time-point job on one GPU.  N > 1: rank r owns time point r mod T and its
-        # predecessor (needed for the OT term); the model is replicated, gradients are all-reduced.
+        # N == 1: the whole 5-time-point job on one GPU.  N > 1: the same job dealt to the ranks batch by batch
+        # (spadot_amd.parallel, granularity 'batch': batch bi of time point t runs on rank (20 t + bi) mod N for the whole
+        # run); every rank holds every time point's rows (0.3 GB) and K-means state, builds and caches only ITS batches;
+        # the model is replicated, gradients are all-reduced.
+        data = make_dataset(T, N, G, seed=1993)
+        cfg.update(input_dim=G, timepoints=list(range(T)), device=torch.device(dev), compute_dtype=cdt)
+        plan = None
         if world == 1:
             own = list(range(T))
+            cfg["owned_timepoints"] = own
         else:
-            t_own = 1 + (rank % (T - 1))
-            own = [t_own - 1, t_own]
-        data = make_dataset(T, N, G, seed=1993)
-        cfg.update(input_dim=G, timepoints=list(range(T)), device=torch.device(dev), compute_dtype=cdt,
-                   owned_timepoints=own)
+            from spadot_amd.parallel import configure_shard
+            cfg["shard_granularity"] = "batch"
+            plan = configure_shard(data, cfg, world, rank)
+            own = list(cfg["owned_timepoints"])
         owned_all = [own]
         if world > 1:
             owned_all = [None] * world
@@ -351,7 +357,9 @@ def _main(real_stdout):
             opt.grad_scale.fill_(1.0 / world)       # every rank has a batch in every step: update on the MEAN gradient
         # schedule: (tp_i, batch) round robin over the time points that have a predecessor on this rank
         train_tps = [t for t in own if t >= 1 and (t - 1) in own]
-        sched = [(t, bi) for bi in range(len(dd["dataloaders"][train_tps[0]])) for t in train_tps]
+        sched = [(t, bi) for bi in range(len(dd["dataloaders"][train_tps[0]])) for t in train_tps
+                 if plan is None or plan.unit_owner(t, bi) == rank]
+        assert sched, f"rank {rank} has no batch of a time point with a predecessor"
         epoch = cfg["ot_epoch"]                     # every loss term active
         beta1 = 0.5
 
@@ -398,18 +406,19 @@ def _main(real_stdout):
             barrier()
             regions.append(max_over_ranks(time.perf_counter() - t0))
         el = float(np.median(regions))
-        b0 = dd["dataloaders"][train_tps[0]][0]
+        b0 = dd["dataloaders"][sched[0][0]][sched[0][1]]
         train_res = {"value": world * args.steps / el, "ms_per_step": 1e3 * el / args.steps,
                      "repeats": {"n": len(regions), "ms_per_step": [1e3 * r / args.steps for r in regions],
                                  "min": 1e3 * min(regions) / args.steps, "max": 1e3 * max(regions) / args.steps,
                                  "spread_pct": 100.0 * (max(regions) - min(regions)) / el},
                      "setup_s": setup_s, "n_sub": b0.graph.n, "E_sub": b0.graph.E,
-                     "m_inducing": int(dd["inducing_points"][train_tps[0]].shape[0]),
+                     "m_inducing": int(dd["inducing_points"][sched[0][0]].shape[0]),
                      "params": int(opt.count), "last_losses": [float(v) for v in last.cpu().tolist()],
                      "hip_graphs": state["stepper"] is not None,
                      "staged_graphs": bool(state["stepper"] is not None and state["stepper"].staged),
                      "bucketed_grad_exchange": bool(state["stepper"] is not None and state["stepper"].overlap)}
-        train_res["roofline_train"] = roofline_train(dd, train_tps[0], cfg, G, args.compute_dtype, int(opt.count),
+        train_res["units_in_schedule"] = len(sched)
+        train_res["roofline_train"] = roofline_train(dd, sched[0], cfg, G, args.compute_dtype, int(opt.count),
                                                      train_res["ms_per_step"])
         if world == 1 and not args.no_epoch:
             train_res["epoch"] = epoch_block(tu, model, opt, cfg, dd, state["stepper"], T, beta1, torch)
@@ -493,11 +502,13 @@ def _main(real_stdout):
                          "train": {k: v for k, v in (train_res or {}).items()
                                    if k not in ("cpu_baseline", "parity_check", "roofline_train", "epoch")},
                          "parallelism": "1 GPU" if world == 1 else (
-                             f"{world} ranks (one per GPU, backend {backend}, all-reduce of ones = {rccl_ranks}): rank r trains time "
-                             f"point 1 + r mod {T - 1} (holding it and its predecessor) and solves pair problem (r mod {T - 1}, "
-                             f"r mod {T - 1} + 1)" + (f"; ranks >= {T - 1} repeat the data of rank r - {T - 1} (weak scaling: "
-                             "fixed work per rank)" if world > T - 1 else "") + "; flat-gradient all-reduce (sum, update on the mean) in two "
-                             "buckets, the first overlapped with the backward pass; no collective in the pair solves")}
+                             f"{world} ranks (one per GPU, backend {backend}, all-reduce of ones = {rccl_ranks}): the job's "
+                             f"(time point, batch) units dealt to the ranks for the whole run -- batch bi of time point t on rank "
+                             f"({N // 512 + (1 if N % 512 else 0)} t + bi) mod {world} -- every rank holds all {T} time points' rows "
+                             "and K-means state and builds, caches and captures only its own batches; one step = one batch per "
+                             "rank, flat-gradient all-reduce (sum, update on the mean) in two buckets, the first overlapped with "
+                             "the backward pass; the timed steps draw from time points 1.. (all loss terms active); pair solves: "
+                             "rank r solves pair (r mod " + str(T - 1) + ", r mod " + str(T - 1) + " + 1), no collective")}
         out["rccl_ranks"] = rccl_ranks
         if train_res is not None:
             out["rank_timepoints"] = owned_all

@@ -155,14 +155,18 @@ class Batch:
         self.y_seed32 = None        # optional cache: the seeds' expression rows in fp32 (reconstruction target)
 
 
-def precompute_batches(edge_index, n_nodes, batch_size, device, hops=2, coords=None, plans=False):
-    """All batches of one time point in loader order (consecutive seed blocks, last one partial).
+def precompute_batches(edge_index, n_nodes, batch_size, device, hops=2, coords=None, plans=False, only=None):
+    """All batches of one time point in loader order (consecutive seed blocks, last one partial); with `only` (a set of
+    batch indices) the other entries of the list are None (a data-parallel rank builds its own batches only).
     With `coords`, the nodes of each hop of every batch are stored in Z-order of their coordinates: the
     neighbours a GAT workgroup gathers are then close in memory and in launch order (L2 reuse per XCD).
     Each batch graph carries the per-layer graphs of build_batch_graph(tiers=...)."""
     key = morton_key(coords) if coords is not None else None
     out = []
     for s in range(0, n_nodes, batch_size):
+        if only is not None and s // batch_size not in only:
+            out.append(None)
+            continue
         seeds = np.arange(s, min(n_nodes, s + batch_size))
         n_id, sub, tiers = induced_batch(edge_index, n_nodes, seeds, hops, order_key=key, return_tiers=True)
         g = build_batch_graph(sub, n_id.size, device, seeds=seeds.size, tiers=tiers if hops == 2 else None,

@@ -4,8 +4,23 @@ process / single device); the design follows SURVEY 8(e):
 
   * Sinkhorn: the T-1 consecutive-pair solves are independent units -> pairs are dealt round-robin to
     ranks, NO data-path collective (only the small 10 x 10 training plans are gathered).
-  * Training: time points are dealt round-robin to ranks (data, graph, SVGP constants and K-means state
-    of a time point live on its owner); the model is replicated; each global step every rank computes
+  * Training: the model is replicated and the epoch's work units are dealt to the ranks at one of two
+    granularities (model_config['shard_granularity']):
+      'batch' (default)  -- the unit is one (time point, batch): batch bi of time point tp belongs to rank
+          (its index in the canonical, unshuffled list of all batches) mod P, for the whole run, so a rank captures
+          the hipGraphs of its own batches only and caches only their inputs.  Every rank draws batches from every
+          time point, so it holds every time point's rows (cfg3: 0.3 GB in bf16, cfg5: 2 GB -- of 288 GB) and
+          K-means state; the per-epoch inference + K-means refit of a time point still runs on ONE rank
+          (time points round-robin) and its centres AND labels are gathered.  All P ranks have work in every global
+          step whatever T is (cfg3's T = 5 keeps 8 ranks busy; cfg5's T = 10 balances), and a global step averages P
+          batches that mostly belong to the SAME time point -- the ranks walk the epoch's shuffled time-point order
+          together -- which is the closest synchronous analogue of the reference's time point after time point loop
+          (_train_utils.py:181-217).
+      'timepoint'        -- the unit is a whole time point (data, graph, SVGP constants and K-means state live on
+          its owner only); a global step then averages batches of P DIFFERENT time points, ranks beyond T idle, and
+          T not divisible by P leaves up to 2:1 imbalance.  Kept for data sets whose time points do not fit one GPU
+          next to each other.
+    Each global step every rank computes
     the gradient of ITS next batch into the flat gradient buffer, ONE all-reduce (sum) of that buffer
     crosses xGMI, and every replica applies the same clip + AdamW update to the MEAN over the replicas that
     had a batch in that step (the 1/n sits in the update kernel's `grad_scale`).  Ranks that have run out of
@@ -26,16 +41,42 @@ def world():
 
 
 class ShardPlan:
-    """Who owns what.  timepoints: ordered list; pairs are (timepoints[i], timepoints[i+1])."""
+    """Who owns what.  timepoints: ordered list; pairs are (timepoints[i], timepoints[i+1]).
+    granularity 'timepoint': a time point's batches all run on its owner.  granularity 'batch' (needs
+    batches_per_tp = {tp: number of batches}): batch bi of time point tp runs on rank (index of (tp, bi) in the
+    canonical list of all batches) mod P; `owner` then only says who refits a time point's K-means / solves a pair."""
 
-    def __init__(self, timepoints, world_size, rank):
+    def __init__(self, timepoints, world_size, rank, granularity="timepoint", batches_per_tp=None):
         self.timepoints = list(timepoints)
         self.world_size, self.rank = int(world_size), int(rank)
+        if granularity not in ("timepoint", "batch"):
+            raise ValueError("shard granularity must be 'timepoint' or 'batch'")
+        if granularity == "batch" and batches_per_tp is None:
+            raise ValueError("granularity 'batch' needs the number of batches of every time point")
+        self.granularity = granularity
         T = len(self.timepoints)
         self.owner = {tp: i % self.world_size for i, tp in enumerate(self.timepoints)}
         self.pair_owner = {(self.timepoints[i], self.timepoints[i + 1]): i % self.world_size for i in range(T - 1)}
+        self.batches_per_tp = None if batches_per_tp is None else {tp: int(batches_per_tp[tp]) for tp in self.timepoints}
+        self._base, acc = {}, 0
+        for tp in self.timepoints:                # canonical index of a time point's first batch
+            self._base[tp] = acc
+            acc += self.batches_per_tp[tp] if self.batches_per_tp is not None else 0
+
+    def unit_owner(self, tp, bi):
+        """Rank that runs batch `bi` of time point `tp` (fixed for the whole run)."""
+        if self.granularity == "timepoint":
+            return self.owner[tp]
+        return (self._base[tp] + int(bi)) % self.world_size
+
+    def owned_batches(self, tp, rank=None):
+        r = self.rank if rank is None else rank
+        if self.batches_per_tp is None:
+            raise ValueError("this plan was built without batch counts")
+        return [bi for bi in range(self.batches_per_tp[tp]) if self.unit_owner(tp, bi) == r]
 
     def owned_timepoints(self, rank=None):
+        """Time points whose per-epoch inference + K-means refit this rank runs."""
         r = self.rank if rank is None else rank
         return [tp for tp in self.timepoints if self.owner[tp] == r]
 
@@ -44,9 +85,36 @@ class ShardPlan:
         return [p for p, o in self.pair_owner.items() if o == r]
 
     def data_timepoints(self, rank=None):
-        """Time points whose DATA a rank must hold: the ones it trains on (their K-means state is
-        computed locally); centres of predecessors arrive through the all-gather."""
-        return self.owned_timepoints(rank)
+        """Time points whose DATA a rank must hold: the ones it draws batches from and the ones whose K-means it
+        refits.  Per-time-point plans: the owned ones (centres of predecessors arrive through the all-gather);
+        per-batch plans: every time point that has a batch on this rank."""
+        own = self.owned_timepoints(rank)
+        if self.granularity == "timepoint":
+            return own
+        return [tp for tp in self.timepoints if tp in own or self.owned_batches(tp, rank)]
+
+
+def plan_from_counts(timepoints, n_per_tp, batch_size, world_size, rank, granularity="batch"):
+    """ShardPlan from the spot count of every time point: the loader cuts a time point into ceil(N_t / batch_size)
+    consecutive seed blocks (_train_utils.py:80-85)."""
+    nb = {tp: -(-int(n_per_tp[tp]) // int(batch_size)) for tp in timepoints}
+    return ShardPlan(timepoints, world_size, rank, granularity=granularity, batches_per_tp=nb)
+
+
+def configure_shard(adata, model_config, world_size, rank):
+    """Call before prepare_dataloader on every rank: builds the plan from the data's time-point column and tells
+    prepare_dataloader which time points (model_config['owned_timepoints']) and which of their batches
+    (model_config['owned_batches']) this rank needs.  Returns the plan."""
+    tps = np.asarray(adata.obs["timepoint"])
+    counts = {tp: int(np.sum(tps == tp)) for tp in model_config["timepoints"]}
+    plan = plan_from_counts(model_config["timepoints"], counts, model_config["batch_size"], world_size, rank,
+                            model_config.get("shard_granularity", "batch"))
+    model_config["owned_timepoints"] = plan.data_timepoints()
+    if plan.granularity == "batch":
+        model_config["owned_batches"] = {tp: plan.owned_batches(tp) for tp in plan.data_timepoints()}
+    else:
+        model_config.pop("owned_batches", None)
+    return plan
 
 
 def epoch_schedule(plan, batches_per_tp, order):
@@ -55,8 +123,8 @@ def epoch_schedule(plan, batches_per_tp, order):
     comes from Python's `random` seeded identically, _train_utils.py:181)."""
     per_rank = [[] for _ in range(plan.world_size)]
     for tp_i, tp in order:
-        r = plan.owner[tp]
-        per_rank[r].extend((tp_i, tp, bi) for bi in range(batches_per_tp[tp]))
+        for bi in range(batches_per_tp[tp]):
+            per_rank[plan.unit_owner(tp, bi)].append((tp_i, tp, bi))
     return per_rank, max(len(x) for x in per_rank)
 
 
@@ -128,6 +196,23 @@ def gather_centres(local_centres, plan, n_clusters, z_dim, device):
     return {tp: out[i] for i, tp in enumerate(plan.timepoints)}
 
 
+def gather_labels(local_labels, plan, n_per_tp, device):
+    """local_labels: {tp: int array [N_tp]} for the time points whose K-means this rank refitted -> the same dict for
+    ALL time points on every rank (one all-reduce of a T x max N zero-padded int32 tensor).  Per-batch plans need it:
+    every rank trains on batches of every time point, and the K-means / OT loss terms read the seeds' labels."""
+    T = len(plan.timepoints)
+    nmax = max(int(n_per_tp[tp]) for tp in plan.timepoints)
+    buf = torch.zeros((T, nmax), dtype=torch.int32, device=device)
+    for i, tp in enumerate(plan.timepoints):
+        if tp in local_labels:
+            lab = torch.as_tensor(np.asarray(local_labels[tp]), dtype=torch.int32)
+            buf[i, :lab.numel()] = lab.to(device)
+    if plan.world_size > 1:
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    out = buf.cpu().numpy()
+    return {tp: out[i, :int(n_per_tp[tp])].copy() for i, tp in enumerate(plan.timepoints)}
+
+
 def gather_small_plans(local_plans, plan, shape, device):
     """{(tp, next): ndarray shape} from the pair owners -> every rank (training-size plans only)."""
     pairs = list(plan.pair_owner)
@@ -188,7 +273,14 @@ def train_SpaDOT_parallel(dataloader_dict, model_config, verbose=False):
     from .utils import _train_utils as tu
     rank, P = world()
     device = torch.device(model_config["device"])
-    plan = ShardPlan(model_config["timepoints"], P, rank)
+    plan = plan_from_counts(model_config["timepoints"], dataloader_dict["N_train"], model_config["batch_size"], P, rank,
+                            model_config.get("shard_granularity", "batch"))
+    for tp in model_config["timepoints"]:          # the loader this rank was given must cover its share of the plan
+        mine = plan.owned_batches(tp)
+        have = dataloader_dict["dataloaders"].get(tp, [])
+        if mine and (len(have) != plan.batches_per_tp[tp] or any(have[bi] is None for bi in mine)):
+            raise ValueError(f"rank {rank}: the dataloader lacks batches of time point {tp} that the shard plan gives it "
+                             "(call parallel.configure_shard before prepare_dataloader)")
     model = SpaDOT.SpaDOT(model_config, dataloader_dict).to(device)
     # identical replicas: broadcast rank 0's initial parameters and buffers
     if P > 1:
@@ -198,13 +290,8 @@ def train_SpaDOT_parallel(dataloader_dict, model_config, verbose=False):
     sync, sync_async = make_grad_sync(opt)
     beta1s = tu._beta_cycle_linear(model_config["maxiter"], stop=model_config["beta1"])
     order = list(enumerate(model_config["timepoints"]))
-    batches_per_tp = {tp: 0 for tp in model_config["timepoints"]}
-    for tp, bl in dataloader_dict["dataloaders"].items():
-        batches_per_tp[tp] = len(bl)
-    if P > 1:   # every rank needs every time point's batch count to agree on the schedule
-        cnt = torch.tensor([batches_per_tp[tp] for tp in model_config["timepoints"]], device=device)
-        dist.all_reduce(cnt, op=dist.ReduceOp.MAX)
-        batches_per_tp = dict(zip(model_config["timepoints"], cnt.cpu().tolist()))
+    batches_per_tp = plan.batches_per_tp           # (from the spot counts: the same on every rank, no collective)
+    refit = [tp for tp in plan.owned_timepoints() if tp in dataloader_dict["datasets"]]
     losses = {}
     # replayed hipGraphs, as in the single-replica trainer: one forward+backward graph per (time point, batch),
     # the all-reduce of the flat gradient between replays (not captured), one clip + AdamW graph
@@ -237,18 +324,29 @@ def train_SpaDOT_parallel(dataloader_dict, model_config, verbose=False):
                               set_grad_scale=lambda x: opt.grad_scale.fill_(x))
         losses[epoch] = torch.stack(acc).mean(0).cpu().tolist() if acc else None
         average_buffers(model, weight=n_mine)
-        tu._update_Kmeans(model, model_config, dataloader_dict)
-        centres = gather_centres({tp: model.kmeans_center_dict[tp] for tp in dataloader_dict["datasets"]},
+        # inference + K-means refit of a time point on ONE rank; centres (and, where other ranks train on that time
+        # point's batches, labels) to everyone
+        tu._update_Kmeans(model, model_config, dataloader_dict, timepoints=refit)
+        centres = gather_centres({tp: model.kmeans_center_dict[tp] for tp in refit},
                                  plan, model_config["n_clusters"], model_config["z_dim"], device)
+        labels = None
+        if plan.granularity == "batch" and P > 1:
+            labels = gather_labels({tp: model.kmeans_cluster_dict[tp] for tp in refit}, plan,
+                                   dataloader_dict["N_train"], device)
         for tp, c in centres.items():
-            if tp not in dataloader_dict["datasets"]:
+            if tp in refit:
+                continue
+            if tp in dataloader_dict["datasets"] and labels is not None:
+                tu._set_kmeans_state(model, tp, c, labels[tp], dataloader_dict["datasets"][tp][2], device)
+            else:
                 tu._set_kmeans_state(model, tp, c, np.arange(c.shape[0]), np.arange(c.shape[0]), device)
         if (epoch + 1) % model_config["ot_config"]["ot_epochs"] == 0:
             # pair solves are sharded; every rank ends up with every (tiny) plan
             local = {}
             for (a, b) in plan.owned_pairs():
                 from .utils.OT_loss.ot_solvers import compute_transport_map
-                local[(a, b)] = compute_transport_map(centres[a], centres[b], model_config["ot_config"], G=None)
+                local[(a, b)] = compute_transport_map(centres[a], centres[b], model_config["ot_config"], G=None,
+                                                      device=device)
             K = model_config["n_clusters"]
             for (a, b), g in gather_small_plans(local, plan, (K, K), device).items():
                 tu._set_gamma(model, f"{a}_{b}", g, device)

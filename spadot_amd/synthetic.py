@@ -40,11 +40,16 @@ def make_timepoint(n_spots, n_genes, seed, n_domains=10, shuffle=True, dtype=np.
 
 
 def make_dataset(n_timepoints, spots_per_tp, n_genes, seed=1993, shuffle=True):
+    """spots_per_tp: one count for every time point, or a list of n_timepoints counts (ragged time points, like the
+    747 / 1966 / 1916 / 1967 spots of the reference's ChickenHeart tutorial, examples/ChickenHeart.ipynb:221-230)."""
+    counts = [int(spots_per_tp)] * n_timepoints if np.isscalar(spots_per_tp) else [int(c) for c in spots_per_tp]
+    if len(counts) != n_timepoints:
+        raise ValueError("spots_per_tp must be a count or one count per time point")
     Xs, tps, locs, doms = [], [], [], []
     for t in range(n_timepoints):
-        xy, Y, lab = make_timepoint(spots_per_tp, n_genes, seed + 17 * t, shuffle=shuffle)
+        xy, Y, lab = make_timepoint(counts[t], n_genes, seed + 17 * t, shuffle=shuffle)
         Xs.append(Y); locs.append(xy); doms.append(lab)
-        tps.append(np.full(spots_per_tp, t))
+        tps.append(np.full(counts[t], t))
     data = SpatialData(np.concatenate(Xs), np.concatenate(tps), np.concatenate(locs))
     data.obs["domain"] = np.concatenate(doms)
     return data

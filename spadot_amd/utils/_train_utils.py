@@ -82,7 +82,11 @@ def prepare_dataloader(adata, model_config):
         datasets[tp] = (torch.as_tensor(loc[ix, :2]).to(device), Y, ix)
         # block plans for the matrix-core GAT edge kernels: bf16 rows only (fp32 compute keeps the per-edge kernels)
         plans = store == torch.bfloat16 and model_config.get("gat_block_plans", True)
-        dataloaders[tp] = precompute_batches(ei, n, model_config["batch_size"], device, coords=spatial[ix], plans=plans)
+        # data-parallel runs at batch granularity (spadot_amd.parallel.configure_shard): only this rank's batches are
+        # built; the others stay None in the list (its length is still the time point's batch count)
+        only = model_config.get("owned_batches")
+        dataloaders[tp] = precompute_batches(ei, n, model_config["batch_size"], device, coords=spatial[ix], plans=plans,
+                                             only=None if only is None else set(only.get(tp, ())))
         from ..graph import morton_key
         graphs[tp] = build_batch_graph(ei, n, device, order_key=morton_key(spatial[ix]), plans=plans)
     _cache_batch_inputs(dataloaders, datasets, model_config)
@@ -101,7 +105,7 @@ def _cache_batch_inputs(dataloaders, datasets, model_config):
         Y = datasets[tp][1]
         G = Y.shape[1]
         Gp = (G + 127) // 128 * 128 if Y.element_size() == 2 else G
-        need += sum(b.n_id.numel() for b in batches) * Gp * Y.element_size()
+        need += sum(b.n_id.numel() for b in batches if b is not None) * Gp * Y.element_size()
     if need > budget:
         return False
     for tp, batches in dataloaders.items():
@@ -109,6 +113,8 @@ def _cache_batch_inputs(dataloaders, datasets, model_config):
         G = Y.shape[1]
         Gp = (G + 127) // 128 * 128 if Y.element_size() == 2 else G
         for b in batches:
+            if b is None:
+                continue
             b.x = loc[b.n_id]
             if Gp == G:
                 b.y = Y[b.n_id]
@@ -197,17 +203,20 @@ def _set_kmeans_state(model, tp, centers, labels, global_idx, device):
         model._state_version = getattr(model, "_state_version", 0) + 1
 
 
-def _update_Kmeans(model, model_config, dataloader_dict):
+def _update_Kmeans(model, model_config, dataloader_dict, timepoints=None):
     """_train_utils.py:255-269: full-time-point inference + KMeans(n_clusters, random_state=seed, n_init=10)
     per time point.  model_config['kmeans_backend']: 'device' (default: spadot_amd.kmeans.KMeansDevice, the same
     algorithm with the latents left in HBM -- at cfg3 the refit of all time points takes ~0.03 s per epoch against
     ~0.28 s, i.e. more than the epoch's 100 training steps, on the host) or 'sklearn' (the reference's host fit, kept
-    as the parity option: labels for given centres are bit-identical either way, the fit itself is third-party RNG)."""
+    as the parity option: labels for given centres are bit-identical either way, the fit itself is third-party RNG).
+    timepoints (extension, data-parallel runs): refit only these (default: every time point this process holds)."""
     model.eval()
     device = torch.device(model_config["device"])
     backend = model_config.get("kmeans_backend", "device")
     with torch.no_grad():
         for tp in dataloader_dict["datasets"]:
+            if timepoints is not None and tp not in timepoints:
+                continue
             loc, Y, ix = dataloader_dict["datasets"][tp]
             if backend == "device":
                 from ..kmeans import KMeansDevice
@@ -390,6 +399,9 @@ class GraphedStepper:
         # next step (the training loop's `tot += ...`) may take the graph's own buffer and save the copy launch
         self.clone_output = os.environ.get("SPADOT_STEP_NOCLONE") != "1"
         self.version = getattr(model, "_state_version", 0)
+        # parity checks only: with keep_latents set before a key is captured, latents[(tp, batch)] is the final_latent
+        # tensor of that key's tail graph (rewritten by every replay)
+        self.keep_latents, self.latents = False, {}
 
     def _body(self, tp_i, tp, bi, epoch, with_update=True):
         losses = forward_backward(self.model, self.cfg, self.dd, tp_i, tp, bi, epoch, self.beta1_t,
@@ -483,6 +495,8 @@ class GraphedStepper:
             km, ot = _cluster_terms(model, cfg, tp, tp_i, seeds, z, do_km, do_ot)
             elbo, losses = mix_losses(self.beta1_t, (recon, leaves[3], gkl, align, km, ot))
             st["g"] = opt.backward_partial(elbo, None, P["tail"], extra_inputs=leaves)
+            if self.keep_latents:
+                self.latents[(tp, bi)] = z.detach()
             return losses
 
         def svgp_bwd():

@@ -657,9 +657,11 @@ def test_full_size_10k_pair_problem_vs_the_oracle(OTSolver):
         json.dump(rep, open(os.path.join(out, "sinkhorn_parity_10k_f32.json"), "w"), indent=1)
     except OSError:
         pass
-    assert rep["stage_iters_max_diff"] <= 5, (rep["stage_iters_dev"], rep["stage_iters_ref"])
-    assert rep["marginal_rel_err"] <= 1e-4
-    assert rep["plan_rel_err_top"] <= 1e-3
+    # asserted well inside the stated tolerances (measured on the MI355X, round 3: iteration counts equal, marginals
+    # 7.6e-9, worst compared entry 1.25e-6 over 5.2e7 entries)
+    assert rep["stage_iters_equal"], (rep["stage_iters_dev"], rep["stage_iters_ref"])
+    assert rep["marginal_rel_err"] <= 1e-6
+    assert rep["plan_rel_err_top"] <= 1e-4
     assert info.gap <= OT_CFG["tolerance"] and rinfo["gap"] <= OT_CFG["tolerance"]
 
 

@@ -11,14 +11,21 @@
   * cfg5 shape (20 000 spots x 5 000 genes per time point, 256 inducing points over 10 time points -> m ~ 26, k = 30):
     the step runs, staged replay == eager, everything finite.
 
-Stated tolerances (the reference is fp64 on the CPU):
-  fp32 compute: loss terms rtol 1e-4, latent rtol 1e-4 / atol 1e-5 x scale, per-parameter gradient cosine >= 0.9999 and
-                relative L2 error <= 2e-3;
-  bf16 compute (GAT branch and the two G-sized linears in bf16, fp32 accumulate): loss terms rtol 2e-2, latent
-                relative L2 <= 2e-2, per-parameter gradient cosine >= 0.99 and relative L2 error <= 0.1, gradient as
-                a whole (the direction AdamW follows) cosine >= 0.995.  (Measured on the MI355X, round 2: loss terms
-                <= 3e-4, latent 1.6e-3, worst parameter cosine 0.998 / relative L2 0.063, whole gradient 0.9989;
-                fp32: loss terms <= 1e-7, worst parameter relative L2 4e-5.)
+  * cfg1 shape (ChickenHeart-like ragged pair: 747 + 1 966 spots, k = 6 / 12, G = 500, last batches of 235 and 430
+    seeds): one oracle-checked fp32 step per time point on its PARTIAL last batch (N_train / b with the partial b,
+    svgp.py:63,74; per-time-point k, _train_utils.py:69-70).
+
+Stated tolerances (the reference is fp64 on the CPU), asserted at about 3x what the MI355X measures:
+  fp32 compute: loss terms rtol 1e-5, latent rtol 1e-5 / atol 1e-5 x scale, per-parameter gradient cosine >= 0.999999 and
+                relative L2 error <= 2e-4 (measured: loss terms 1.1e-7, latent 3e-7, worst parameter relative L2 4.1e-5);
+  bf16 compute (GAT branch and the two G-sized linears in bf16, fp32 accumulate): loss terms rtol 3e-4, latent relative
+                L2 <= 3e-3, gradient as a whole (the direction AdamW follows) cosine >= 0.99999; per parameter: the
+                attention vectors att_src / att_dst (2 048 numbers each, sums of bf16 products over ~10^4 nodes) cosine
+                >= 0.998 and relative L2 <= 0.1, every other parameter cosine >= 0.9998 and relative L2 <= 0.03.
+                (Measured, round 2 final tree: loss terms 2.1e-5, latent 8.5e-4, whole gradient 0.999998; attention
+                vectors: worst cosine 0.99941 / relative L2 0.049 (gat3.att_dst); every other parameter: cosine >= 0.99996,
+                relative L2 <= 0.0087.)
+  The same thresholds hold for the step as bench.py runs it -- the REPLAYED staged hipGraphs, fed the same noise.
 """
 import json
 import os
@@ -88,17 +95,41 @@ def test_cfg3_training_step_matches_the_fp64_oracle(dtype):
     print(json.dumps({k: v for k, v in rep.items() if k != "per_param"}))
     assert np.isfinite(dl).all() and all(np.isfinite(v).all() for v in dg.values())
     assert (np.asarray(rep["loss_ref"])[4:] > 0).all()         # alignment, K-means and OT terms are live
+    _assert_step_parity(rep, dtype, ref)
+
+    # the step as bench.py runs it: the same batch through the REPLAYED staged graphs (eager visit, capture + replay,
+    # replay), the same noise at a fixed address -- compared with the same oracle step, no eager hop in between
+    model.fixed_noise = (noise[0].to(DEV), noise[1].float().to(DEV))
+    stepper = tu.GraphedStepper(model, opt, dict(cfg, staged_graphs=True), dd)
+    stepper.keep_latents = True
+    for k in range(3):
+        opt.flat_grad.fill_(7.0)
+        lr = stepper.fb(1, tp, bi, epoch, beta1)
+    torch.cuda.synchronize()
+    assert stepper.staged and len(stepper.graphs) == 1
+    gr = {n: p.grad.detach().float().cpu().numpy().copy() for n, p in model.named_parameters()}
+    rep2 = sp.compare(lr.detach().float().cpu().numpy().astype(np.float64), stepper.latents[(tp, bi)].float().cpu().numpy(), gr, ref)
+    rep2["dtype"] = dtype
+    _report(f"cfg3_{dtype}_replayed", rep2)
+    print(json.dumps({k: v for k, v in rep2.items() if k != "per_param"}))
+    _assert_step_parity(rep2, dtype, ref)
+
+
+def _assert_step_parity(rep, dtype, ref):
     if dtype == "f32":
-        assert rep["max_rel_loss_err"] <= 1e-4, rep["loss_rel_err"]
-        assert rep["latent_max_abs_err"] <= 1e-4 * max(1.0, float(np.abs(ref["latent"]).max())) + 1e-5
-        assert rep["grad_cos_min"] >= 0.9999, (rep["grad_cos_min_param"], rep["grad_cos_min"])
-        assert rep["grad_rel_l2_max"] <= 2e-3, (rep["grad_rel_l2_max_param"], rep["grad_rel_l2_max"])
+        assert rep["max_rel_loss_err"] <= 1e-5, rep["loss_rel_err"]
+        assert rep["latent_max_abs_err"] <= 1e-5 * max(1.0, float(np.abs(ref["latent"]).max())) + 1e-5
+        assert rep["grad_cos_min"] >= 0.999999, (rep["grad_cos_min_param"], rep["grad_cos_min"])
+        assert rep["grad_rel_l2_max"] <= 2e-4, (rep["grad_rel_l2_max_param"], rep["grad_rel_l2_max"])
     else:
-        assert rep["max_rel_loss_err"] <= 2e-2, rep["loss_rel_err"]
-        assert rep["latent_rel_l2_err"] <= 2e-2
-        assert rep["grad_cos_min"] >= 0.99, (rep["grad_cos_min_param"], rep["grad_cos_min"])
-        assert rep["grad_rel_l2_max"] <= 0.1, (rep["grad_rel_l2_max_param"], rep["grad_rel_l2_max"])
-        assert rep["grad_cos_global"] >= 0.995
+        assert rep["max_rel_loss_err"] <= 3e-4, rep["loss_rel_err"]
+        assert rep["latent_rel_l2_err"] <= 3e-3
+        assert rep["grad_cos_global"] >= 0.99999
+        for name, (l2, cos) in rep["per_param"].items():
+            if ".att_" in name:
+                assert cos >= 0.998 and l2 <= 0.1, (name, l2, cos)
+            else:
+                assert cos >= 0.9998 and l2 <= 0.03, (name, l2, cos)
     # a Linear bias in front of BatchNorm has a zero gradient in exact arithmetic: zero on the device as well
     assert len(rep["zero_grad_params"]) >= 2 and rep["zero_grad_dev_rel_norm_max"] <= 1e-6
 
@@ -184,3 +215,60 @@ def test_cfg5_shape_step_runs_staged_equals_eager():
         out = staged.step(1, tp, 0, epoch, beta1)
     torch.cuda.synchronize()
     assert torch.isfinite(out).all() and torch.isfinite(opt.flat_param).all()
+
+
+def test_cfg1_ragged_timepoints_partial_last_batches_match_the_oracle():
+    """BASELINE.json configs[0] shape (the reference's CPU-runnable plumbing case, ChickenHeart's first two time points):
+    747 + 1 966 spots -> k = 6 and 12, batches of 512 with PARTIAL last batches of 235 and 430 seeds, 500 genes, fp32
+    compute.  One whole step (7 loss terms, latent, every gradient) per time point on its partial last batch against the
+    fp64 oracle: N_train / b uses the partial b (svgp.py:63,74), the OT term is live for the second time point only."""
+    from oracle import step_parity as sp
+    from spadot_amd.model import SpaDOT
+    from spadot_amd.ops import FlatAdamW
+    from spadot_amd.synthetic import make_dataset
+    from spadot_amd.utils import _train_utils as tu, _utils
+    data = make_dataset(2, [747, 1966], 500, seed=7)
+    cfg = _utils.load_model_config(types.SimpleNamespace(config=None))
+    cfg.update(input_dim=500, timepoints=[0, 1], device=torch.device(DEV), compute_dtype=torch.float32,
+               inducing_point_nums=480, kmeans_backend="sklearn")
+    _utils.set_seed(cfg["seed"])
+    dd = tu.prepare_dataloader(data, cfg)
+    assert [len(dd["dataloaders"][t]) for t in (0, 1)] == [2, 4]
+    assert [dd["dataloaders"][t][-1].batch_size for t in (0, 1)] == [235, 430]
+    deg = [int(dd["graphs"][t].E) // dd["graphs"][t].n - 1 for t in (0, 1)]
+    assert deg == [6, 12], deg                                   # k = min(30, 6 * round(N_t / 1000)) per time point
+    assert sum(int(dd["inducing_points"][t].shape[0]) for t in (0, 1)) == 480
+    model = SpaDOT.SpaDOT(cfg, dd).to(DEV)
+    opt = FlatAdamW(model.parameters(), lr=cfg["lr"])
+    tu._update_Kmeans(model, cfg, dd)
+    tu._update_OT_matrix(model, cfg)
+    model.train()
+    epoch, beta1 = cfg["ot_epoch"], 0.5
+    for tp_i, tp in enumerate((0, 1)):
+        bi = len(dd["dataloaders"][tp]) - 1
+        b = dd["dataloaders"][tp][bi].batch_size
+        noise = sp.make_noise(b, seed=tp)
+        inp = sp.oracle_inputs(model, dd, cfg, tp, bi, tp - 1, do_km=True, do_ot=tp_i != 0)
+        assert inp["b"] == b
+        ref = sp.oracle_step(inp, cfg, beta1, noise)
+        dl, dz, dg = sp.device_step(model, opt, cfg, dd, tu, tp_i, tp, bi, epoch, beta1, noise)
+        rep = sp.compare(dl, dz, dg, ref)
+        _report(f"cfg1_tp{tp}_f32", rep)
+        print(json.dumps({k: v for k, v in rep.items() if k != "per_param"}))
+        assert (rep["loss_ref"][6] > 0) == (tp_i != 0)           # OT term: only with a predecessor
+        assert rep["loss_ref"][5] > 0
+        assert rep["max_rel_loss_err"] <= 1e-4, rep["loss_rel_err"]
+        assert rep["latent_max_abs_err"] <= 1e-4 * max(1.0, float(np.abs(ref["latent"]).max())) + 1e-5
+        assert rep["grad_cos_min"] >= 0.9999, (rep["grad_cos_min_param"], rep["grad_cos_min"])
+        assert rep["grad_rel_l2_max"] <= 2e-3, (rep["grad_rel_l2_max_param"], rep["grad_rel_l2_max"])
+    # and the staged replay of the partial batch gives what its eager step gives
+    model.fixed_noise = (torch.zeros((512, 10), device=DEV), torch.zeros((512, 10), device=DEV))
+    staged = tu.GraphedStepper(model, opt, dict(cfg, staged_graphs=True), dd)
+    for rep_i in range(3):
+        staged.beta1_t[1].fill_(-beta1)
+        la = tu.forward_backward(model, cfg, dd, 1, 1, 3, epoch, staged.beta1_t, optimizer=opt)
+        ga = opt.flat_grad.clone()
+        opt.flat_grad.fill_(7.0)
+        lb = staged.fb(1, 1, 3, epoch, beta1)
+        np.testing.assert_allclose(lb.cpu().numpy(), la.cpu().numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(opt.flat_grad.cpu().numpy(), ga.cpu().numpy(), rtol=2e-3, atol=2e-4 * float(ga.abs().max()))

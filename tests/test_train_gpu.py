@@ -321,7 +321,7 @@ def test_bucketed_exchange_splits_the_backward_without_changing_the_gradient():
             np.testing.assert_array_equal(seen[0][2].cpu().numpy(), ga[:cut].cpu().numpy())    # final when handed over
 
 
-def _dp_worker(rank, world, port, q, staged=None):
+def _dp_worker(rank, world, port, q, staged=None, granularity="batch"):
     """One data-parallel rank on cuda:0 (both ranks share the one GPU of the test box; gloo carries the
     collectives, on a real node the backend is nccl = RCCL)."""
     import os
@@ -333,14 +333,20 @@ def _dp_worker(rank, world, port, q, staged=None):
         from spadot_amd.synthetic import make_dataset
         from spadot_amd.utils import _train_utils as tu, _utils
         cfg = _small_config()
-        cfg.update(maxiter=2, input_dim=40, timepoints=[0, 1, 2], device=torch.device(DEV))
+        cfg.update(maxiter=2, input_dim=40, timepoints=[0, 1, 2], device=torch.device(DEV), shard_granularity=granularity)
         if staged is not None:
             cfg["staged_graphs"] = staged
-        plan = par.ShardPlan(cfg["timepoints"], world, rank)
-        cfg["owned_timepoints"] = plan.data_timepoints()
         data = make_dataset(3, 1200, 40, seed=11)
+        plan = par.configure_shard(data, cfg, world, rank)
+        if granularity == "batch":      # 5 batches per time point, 15 units: rank 0 owns the even canonical indices
+            assert cfg["owned_timepoints"] == [0, 1, 2]
+            assert cfg["owned_batches"][1] == ([1, 3] if rank == 0 else [0, 2, 4])
+        else:
+            assert cfg["owned_timepoints"] == ([0, 2] if rank == 0 else [1]) and "owned_batches" not in cfg
         _utils.set_seed(cfg["seed"])
         dd = tu.prepare_dataloader(data, cfg)
+        if granularity == "batch":
+            assert [b is not None for b in dd["dataloaders"][1]] == [bi in cfg["owned_batches"][1] for bi in range(5)]
         model, losses = par.train_SpaDOT_parallel(dd, cfg)
         flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu().numpy()
         q.put((rank, flat, sorted(model.gammas), sorted(model.kmeans_center_dict), losses[1]))
@@ -348,8 +354,8 @@ def _dp_worker(rank, world, port, q, staged=None):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("staged", [None, True])
-def test_data_parallel_training_two_ranks_one_gpu(staged):
+@pytest.mark.parametrize("staged,granularity", [(None, "batch"), (True, "batch"), (None, "timepoint")])
+def test_data_parallel_training_two_ranks_one_gpu(staged, granularity):
     """staged=None: what two ranks sharing a device get by default (two graphs per step, one exchange in two
     buckets); staged=True: what ranks on their own devices get -- staged graphs with the bucketed exchange issued
     beside the first GAT layer's backward (here forced onto the shared GPU, gloo carrying the async collectives)."""
@@ -358,7 +364,7 @@ def test_data_parallel_training_two_ranks_one_gpu(staged):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q, staged)) for r in range(2)]
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q, staged, granularity)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda r: r[0])
@@ -430,3 +436,40 @@ def test_training_with_device_kmeans_and_knn_backends(tmp_path):
     model, loss = spadot_amd.train(args)
     assert np.isfinite(loss.values).all() and set(model.kmeans_center_dict) == {0, 1}
     assert len(model.kmeans_cluster_dict[0]) == 1200
+
+
+def test_cfg4_shape_eight_ragged_timepoints_train_end_to_end(tmp_path, capsys):
+    """BASELINE.json configs[3] shape on one GPU (MouseOrganogenesis-like: 8 time points, here with ragged small spot
+    counts): whole epochs through spadot_amd.train -- every (time point, batch) step as replayed graphs, all 8 K-means
+    refits and all 7 consecutive-pair OT solves (one launch of the small solver) per epoch
+    (_train_utils.py:174-231, 309-321)."""
+    import spadot_amd
+    import yaml
+    from spadot_amd.synthetic import make_dataset
+    counts = [500, 700, 650, 900, 800, 550, 600, 750]
+    data = make_dataset(8, counts, 40, seed=3)
+    cfg = _small_config()
+    cfg.update(maxiter=4, inducing_point_nums=160, kmeans_backend="device")
+    cfg_path = tmp_path / "cfg.yaml"
+    yaml.safe_dump(cfg, open(cfg_path, "w"))
+    args = types.SimpleNamespace(data=data, output_dir=str(tmp_path / "out"), prefix="m_", config=str(cfg_path),
+                                 save_model=False, device=DEV)
+    model, loss_df = spadot_amd.train(args)
+    out = capsys.readouterr().out
+    assert out.count("OT iter 0") == 7 * 4                       # 7 pair solves after each of the 4 epochs (ot_epochs = 1)
+    loss = loss_df.T
+    assert loss.shape == (4, 7) and np.isfinite(loss.values).all()
+    assert (loss["KMeans"].iloc[1:] > 0).all() and (loss["OT"].iloc[1:] > 0).all()
+    assert set(model.kmeans_center_dict) == set(range(8))
+    assert sorted(model.gammas) == sorted(f"{t}_{t + 1}" for t in range(7))
+    for t in range(8):
+        assert np.asarray(model.kmeans_center_dict[t]).shape == (4, 20)
+        assert len(model.kmeans_cluster_dict[t]) == counts[t]
+    for key, g in model.gammas.items():
+        assert g.shape == (4, 4) and np.isfinite(g).all() and g.sum() > 0
+        dev = model._gamma_dev[key].cpu().numpy()               # what the OT loss kernel reads: rows normalised
+        np.testing.assert_allclose(dev, g / g.sum(axis=1, keepdims=True), rtol=2e-6)
+    z = np.load(tmp_path / "out" / "m_latent.npz")
+    assert z["X"].shape == (sum(counts), 20) and np.isfinite(z["X"]).all()
+    steps = sum(-(-c // 256) for c in counts)
+    assert steps == 27
