@@ -115,6 +115,25 @@ def cpu_train_steps(model, opt, dd, cfg, tu, tp, bi, tp_prev, epoch, beta1, n_st
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak (spec; the guide measures ~1.25-1.5 PF on random data)
 
 
+def source_fingerprint():
+    """sha256 (first 16 hex digits) over the sources the measured kernels come from: spadot_amd/**/*.{py,hip,yaml},
+    include/*.h and this file.  tools/prof_summary.py stores it in the committed profile summaries; `stale_profile` in the
+    bench line says whether the tree that runs is the tree that was profiled (a commit that only adds the profile files
+    does not change it, unlike `git rev-parse HEAD`)."""
+    import hashlib
+    h = hashlib.sha256()
+    files = [os.path.join(ROOT, "bench.py")]
+    for base, exts in ((os.path.join(ROOT, "spadot_amd"), (".py", ".hip", ".yaml")), (os.path.join(ROOT, "include"), (".h",))):
+        for d, _, names in os.walk(base):
+            if "__pycache__" in d:
+                continue
+            files += [os.path.join(d, n) for n in names if n.endswith(exts)]
+    for f in sorted(files):
+        h.update(os.path.relpath(f, ROOT).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def newest_profile(name):
     """Path of profiles/rNN/<name> of the highest round that has it, or None."""
     base = os.path.join(ROOT, "profiles")
@@ -172,6 +191,11 @@ def roofline_train(dd, unit, cfg, G, compute_dtype, n_params, live_ms_per_step):
     out["source"] = (f"kernel microseconds REPLAYED from {os.path.relpath(fam_path, ROOT)} (rocprofv3 --kernel-trace of "
                      f"`bench.py --leg train`, {prof['steps']} steps, {prof['wall_us_per_step']:.0f} us/step under the profiler); "
                      "algorithmic flops / bytes computed live from this run's batch")
+    out["profile_head"] = prof.get("head")
+    out["profile_source_sha16"] = prof.get("source_sha16")
+    out["stale_profile"] = prof.get("source_sha16") != source_fingerprint()      # True: the tree changed since it was profiled
+    if "mfma" in prof:
+        out["mfma_counters"] = prof["mfma"]
     out["families"] = {
         "gemm_" + compute_dtype: {"bound": "mfma", "us_per_step": gemm_us, "achieved": gemm_flops / max(gemm_us, 1e-9) / 1e6,
                                   "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -479,9 +503,21 @@ def _main(real_stdout):
             import csv
             for row in csv.reader(open(pmc)):
                 if row and "k_fused_pass<float, 5, 2" in row[0]:
-                    roof["traffic"] = (2.0 * float(row[1]) + float(row[3])) * 1024.0
-                    roof["traffic_source"] = (f"replayed from {os.path.relpath(pmc, ROOT)} (separate rocprofv3 --pmc passes of this "
-                                              "command: 2*FETCH_SIZE + WRITE_SIZE, bytes per launch) -- not measured in this run")
+                    traffic = (2.0 * float(row[1]) + float(row[3])) * 1024.0
+                    src = (f"replayed from {os.path.relpath(pmc, ROOT)} (separate rocprofv3 --pmc passes of this command with "
+                           "SPADOT_OT_SPEC_BATCHES=1, i.e. no launch that returns on the stop word: 2*FETCH_SIZE + WRITE_SIZE, "
+                           "bytes per launch) -- not measured in this run")
+                    if traffic >= alg:
+                        roof["traffic"], roof["traffic_source"] = traffic, src
+                    else:       # a kernel cannot move less than it must read: such a mean is polluted, not a result
+                        roof["traffic_source"] = (f"REJECTED: {src}; its mean of {traffic:.0f} bytes per launch is below the "
+                                                  f"{alg:.0f} algorithmic bytes (launches that did not sweep are in it)")
+            meta = newest_profile("sinkhorn_cfg3_f32_profile_meta.json")
+            if meta:
+                m = json.load(open(meta))
+                roof["profile_kernel_us"] = m.get("fused_pass_avg_us")
+                roof["profile_source_sha16"] = m.get("source_sha16")
+                roof["stale_profile"] = m.get("source_sha16") != source_fingerprint()
         solver.close()
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             sk_res["cpu_baseline"] = cpu_sinkhorn(I, J, budget_s=6.0 if want_parity else 10.0)

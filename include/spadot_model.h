@@ -292,12 +292,14 @@ int spadot_gemm_nn_bf16(const void *A, int lda, const void *B, int ldb, void *C,
 /* ---- weight gradient of a GAT layer's dense map on the matrix cores (csrc/gemm_wgrad_bf16.hip) ---------------------------
  * dW [N x K] (fp32, row stride ldw) = G^T X with G [M x N] (bf16, ldg) and X [M x >= K] (bf16, ldx; columns K .. the next
  * multiple of 256 must be readable -- the padded gene axis of the batch cache is).  256 x 256 output tiles x `slices`
- * slices of the M rows (0: one), partial tiles added in slice order by the last workgroup of a tile: bit-reproducible.
- * Requires N % 256 == 0, 16-byte aligned operands, strides % 8 == 0; -22 otherwise.  Scratch (partials, counters) is kept by
- * the library per device: the first call of a shape allocates (issue it once outside graph capture), and calls must not run
- * concurrently on different streams. */
+ * slices of the M rows (0: one), partial tiles added in slice order by a second launch: bit-reproducible.
+ * Requires N % 256 == 0, 16-byte aligned operands, strides % 8 == 0, operand images below 4 GiB; -22 otherwise.
+ * The library keeps NO state: `workspace` (fp32, spadot_gemm_wgrad_bf16_workspace(M, N, K, slices) floats, 16-byte aligned;
+ * may be NULL when that is 0) and `zero_row` (512 bytes of zeros, 16-byte aligned: the source of rows past M) belong to the
+ * caller, so that calls on different streams, or captured into different graphs, never share scratch. */
+long long spadot_gemm_wgrad_bf16_workspace(int M, int N, int K, int slices);
 int spadot_gemm_wgrad_bf16(const void *G, int ldg, const void *X, int ldx, float *dW, int ldw, int M, int N, int K,
-                           int slices, void *stream);
+                           int slices, float *workspace, const void *zero_row, void *stream);
 
 /* ---- hidden stages of the decoder as one launch each way (csrc/mlp_chain.hip) -------------------------------------------
  * /root/reference/SpaDOT/model/decoder.py:3-20: [Linear, LayerNorm, LeakyReLU] x n_layers on x [b, dims[0]] (fp32);

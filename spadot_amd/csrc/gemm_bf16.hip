@@ -253,6 +253,9 @@ template <bool BT>
 static int launch_gemm(const void *A, int lda, const void *B, int ldb, void *C, int ldc, int M, int N, int K, void *stream) {
     if (M <= 0 || N <= 0 || K <= 0 || N % BN != 0 || K % BK != 0 || lda < K || ldb < (BT ? N : K) || ldc < N) return -22;
     if (((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((uintptr_t)C & 15) || lda % 8 || ldb % 8 || ldc % 8) return -22;
+    // the per-lane LDS-DMA source offsets are 32-bit (row * row stride in bytes): an operand image of 4 GiB or more would
+    // wrap and read the wrong rows -- refused, the callers then use the library
+    if ((size_t)M * lda * 2 >= ((size_t)1 << 32) || (size_t)(BT ? K : N) * ldb * 2 >= ((size_t)1 << 32)) return -22;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void *)k_gemm_bf16<BT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return -5;

@@ -229,59 +229,52 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ 
     }
 }
 
-struct Scratch {
-    __bf16 *zrow = nullptr;
-    float *part = nullptr;
-    size_t part_floats = 0;
-    int device = -1;
-};
-Scratch g_scratch;
-
-}  // namespace
-
-extern "C" int spadot_gemm_wgrad_bf16(const void *G, int ldg, const void *X, int ldx, float *dW, int ldw, int M, int N, int K,
-                                      int slices, void *stream) {
-    if (M <= 0 || N <= 0 || K <= 0 || N % TN != 0 || ldg < N || ldx < K || ldw < K || ldg % 8 || ldx % 8) return -22;
-    if (((uintptr_t)G & 15) || ((uintptr_t)X & 15) || ((uintptr_t)dW & 15) || (ldw % 4)) return -22;
-    // the X image reads whole 256-column tiles: the row stride must cover the last (partial) tile
-    const int ktiles = (K + TK - 1) / TK, ntiles = N / TN;
-    if (ldx < ktiles * TK) return -22;
+// slices actually used for an (M, slices) request: at most one slice per 64-row chunk, at most 8, none empty
+static int effective_slices(int M, int slices, int *cps_out) {
     const int nchunk = (M + CH - 1) / CH;
     int S = slices > 0 ? slices : 1;
     if (S > nchunk) S = nchunk;
     if (S > 8) S = 8;
     const int cps = (nchunk + S - 1) / S;
-    S = (nchunk + cps - 1) / cps;                                   // no empty slices
+    S = (nchunk + cps - 1) / cps;
+    if (cps_out) *cps_out = cps;
+    return S;
+}
+
+}  // namespace
+
+// floats of caller-owned workspace a call with these arguments needs (0: a single slice writes dW directly)
+extern "C" long long spadot_gemm_wgrad_bf16_workspace(int M, int N, int K, int slices) {
+    if (M <= 0 || N <= 0 || K <= 0 || N % TN != 0) return -22;
+    const int S = effective_slices(M, slices, nullptr);
+    const long long tiles = (long long)(N / TN) * ((K + TK - 1) / TK);
+    return S > 1 ? (long long)S * tiles * TN * TK : 0;
+}
+
+extern "C" int spadot_gemm_wgrad_bf16(const void *G, int ldg, const void *X, int ldx, float *dW, int ldw, int M, int N, int K,
+                                      int slices, float *workspace, const void *zero_row, void *stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || N % TN != 0 || ldg < N || ldx < K || ldw < K || ldg % 8 || ldx % 8) return -22;
+    if (((uintptr_t)G & 15) || ((uintptr_t)X & 15) || ((uintptr_t)dW & 15) || (ldw % 4)) return -22;
+    if (!zero_row || ((uintptr_t)zero_row & 15)) return -22;
+    // the X image reads whole 256-column tiles: the row stride must cover the last (partial) tile
+    const int ktiles = (K + TK - 1) / TK, ntiles = N / TN;
+    if (ldx < ktiles * TK) return -22;
+    // the LDS-DMA source offsets are 32-bit: an operand image must stay below 4 GiB
+    if ((size_t)M * ldg * 2 >= ((size_t)1 << 32) || (size_t)M * ldx * 2 >= ((size_t)1 << 32)) return -22;
+    int cps = 0;
+    const int S = effective_slices(M, slices, &cps);
     const int tiles = ntiles * ktiles;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return -5;
-    Scratch &sc = g_scratch;
-    const size_t need = S > 1 ? (size_t)S * tiles * TN * TK : 0;
-    if (sc.device != dev || sc.zrow == nullptr || sc.part_floats < need) {
-        // (first call, or a larger problem: allocate -- not capturable, so callers warm up eagerly once per shape)
-        if (sc.device != dev) { sc = Scratch(); sc.device = dev; }
-        if (!sc.zrow) {
-            if (hipMalloc((void **)&sc.zrow, 512) != hipSuccess || hipMemset(sc.zrow, 0, 512) != hipSuccess) return -5;
-        }
-        if (sc.part_floats < need) {
-            if (sc.part) (void)hipFree(sc.part);
-            sc.part = nullptr; sc.part_floats = 0;
-            if (hipMalloc((void **)&sc.part, need * sizeof(float)) != hipSuccess) return -5;
-            sc.part_floats = need;
-        }
-    }
     if (tiles > 4096) return -22;
+    if (S > 1 && (!workspace || ((uintptr_t)workspace & 15))) return -22;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void *)k_gemm_wgrad_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return -5;
         attr_set = true;
     }
     hipLaunchKernelGGL(k_gemm_wgrad_bf16, dim3((unsigned)(tiles * S)), dim3(NT), LDS_BYTES, (hipStream_t)stream, (const __bf16 *)G, ldg,
-                       (const __bf16 *)X, ldx, dW, ldw, M, N, K, ktiles, S, cps, (const __bf16 *)sc.zrow, sc.part);
-    if (S > 1) {
-        if (((uintptr_t)dW & 15) || (ldw % 4)) return -22;          // (checked before anything was launched: see above)
-        hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)tiles * 64u), dim3(256), 0, (hipStream_t)stream, (const float *)sc.part, S,
+                       (const __bf16 *)X, ldx, dW, ldw, M, N, K, ktiles, S, cps, (const __bf16 *)zero_row, workspace);
+    if (S > 1)
+        hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)tiles * 64u), dim3(256), 0, (hipStream_t)stream, (const float *)workspace, S,
                            tiles, ktiles, dW, ldw, N, K);
-    }
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }

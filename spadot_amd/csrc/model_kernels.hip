@@ -2252,7 +2252,9 @@ int spadot_clip_adamw_dev(float *param, const float *grad, float *exp_avg, float
     // 512 workgroups: every workgroup ends with an agent-scope release (L2 write-back) before its counter add, so
     // the launch got SLOWER with more of them (2048: 56 us, 512: 31 us for 64 MB; tools/adamw_bench.py)
     const int nbs = (int)(want4 < 1 ? 1 : (want4 < 512 ? want4 : 512));
-    static const int split = [] { const char *e = getenv("SPADOT_SUMSQ_SPLIT"); return e ? atoi(e) : 2048; }();   // 0: the one-launch form (same-box A/B: 1.972 -> 1.941 ms per step with 2048)
+    // 0: the one-launch form (same-box A/B: 1.972 -> 1.941 ms per step with 2048); clamped to the scratch buffer's
+    // capacity (FlatAdamW.scratch: 4096 doubles, one partial per workgroup)
+    static const int split = [] { const char *e = getenv("SPADOT_SUMSQ_SPLIT"); const int v = e ? atoi(e) : 2048; return v > 4096 ? 4096 : v; }();
     if (split > 0) {
         const int nb2 = (int)(want4 < 1 ? 1 : (want4 < split ? want4 : split));
         hipLaunchKernelGGL(k_sumsq_part_u<4>, dim3(nb2), dim3(256), 0, st_, grad, count, scratch);

@@ -244,8 +244,10 @@ _DIRECT_GRAD = [False]     # True only inside FlatAdamW.backward (a plain .backw
 def cast_rows(pairs):
     """[(src fp32 [R, K] contiguous, dst bf16 [R, Kp >= K] contiguous), ...] -> dst[:, :K] = src, ONE launch for up to
     four matrices (csrc: k_cast_rows_multi) instead of one library cast launch each."""
+    # (the kernel reads 16-byte and writes 8-byte vectors: a view at an odd storage offset takes the library copy below)
     ok = all(s_.dtype == torch.float32 and d_.dtype == torch.bfloat16 and s_.is_contiguous() and d_.is_contiguous()
-             and s_.dim() == 2 and s_.shape[1] % 4 == 0 and d_.shape[1] % 4 == 0 and s_.is_cuda for s_, d_ in pairs)
+             and s_.dim() == 2 and s_.shape[1] % 4 == 0 and d_.shape[1] % 4 == 0 and s_.is_cuda
+             and s_.data_ptr() % 16 == 0 and d_.data_ptr() % 8 == 0 for s_, d_ in pairs)
     if not ok:
         for s_, d_ in pairs:
             d_[:, :s_.shape[1]].copy_(s_)
@@ -296,6 +298,21 @@ WGRAD_MIN_WGS = [int(__import__("os").environ.get("SPADOT_WGRAD_MIN_WGS", "200")
 WGRAD_OWN = [__import__("os").environ.get("SPADOT_WGRAD_OWN", "1") == "1"]       # [False]: library GEMM for the weight gradients
 
 
+_ZERO_ROWS = {}
+
+
+def _zero_row(device):
+    """512 bytes of zeros on `device` (what the weight-gradient kernel reads for rows past M): one per device, created on
+    the first eager call; a first call under graph capture gets a row of its own that the capturing graph keeps."""
+    key = (device.type, device.index)
+    z = _ZERO_ROWS.get(key)
+    if z is None:
+        z = torch.zeros(256, dtype=torch.bfloat16, device=device)
+        if not torch.cuda.is_current_stream_capturing():
+            _ZERO_ROWS[key] = z
+    return z
+
+
 def wgrad_bf16(g, x, K, out=None):
     """g^T x[:, :K] -> fp32 [N, K] for g [M, N], x [M, Kp >= K] (bf16): csrc/gemm_wgrad_bf16.hip where its conditions hold
     (N % 256 == 0, the X rows readable up to the next multiple of 256 columns), else the library."""
@@ -312,8 +329,14 @@ def wgrad_bf16(g, x, K, out=None):
             if tiles * max(1, 256 // tiles) < WGRAD_MIN_WGS[0]:
                 tiles = 0                      # too few workgroups for the chip (2048 x 3000: 96 tiles x 2): library
         if tiles:
-            rc = model_lib().spadot_gemm_wgrad_bf16(g.data_ptr(), N, x.data_ptr(), Kp, out.data_ptr(), K, M, N, K,
-                                                    max(1, 256 // tiles), _stream())
+            lib = model_lib()
+            slices = max(1, 256 // tiles)
+            need = int(lib.spadot_gemm_wgrad_bf16_workspace(M, N, K, slices))
+            # the split-contraction partials belong to THIS call: under capture they come out of the capturing graph's
+            # pool, so graphs replayed on different streams never share them and nothing a graph points at is ever freed
+            ws = torch.empty(max(need, 4), dtype=torch.float32, device=g.device) if need >= 0 else None
+            rc = -22 if ws is None else lib.spadot_gemm_wgrad_bf16(g.data_ptr(), N, x.data_ptr(), Kp, out.data_ptr(), K, M, N, K,
+                                                                  slices, ws.data_ptr(), _zero_row(g.device).data_ptr(), _stream())
             if rc == 0:
                 return out
             if rc != -22:

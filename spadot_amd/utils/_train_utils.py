@@ -658,6 +658,9 @@ def train_SpaDOT(dataloader_dict, model_config, verbose=True):
     loss_dict = OrderedDict((e, OrderedDict((n, 0.0) for n in LOSS_NAMES)) for e in range(model_config["maxiter"]))
     if verbose:
         print("Training SpaDOT model...")
+        # (the per-epoch K-means fit: 'device' = spadot_amd.kmeans on the GPU, its own k-means++ stream; 'sklearn' = the
+        # reference's host fit.  Labels for given centres are bit-identical either way, the fitted centres are not.)
+        print("K-means backend: %s" % model_config.get("kmeans_backend", "device"))
     t_start = time()
     for epoch in range(model_config["maxiter"]):
         beta1 = float(beta1s[epoch])

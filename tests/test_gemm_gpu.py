@@ -101,10 +101,14 @@ def test_wgrad_matches_fp32_reference(M, N, K, Kp, slices):
     X = torch.zeros((M, Kp), device=DEV, dtype=torch.bfloat16)
     X[:, :K] = (torch.randn((M, K), device=DEV, generator=g) * 0.5).bfloat16()
     outs = []
+    need = int(lib.spadot_gemm_wgrad_bf16_workspace(M, N, K, slices))
+    assert need >= 0 and (need == 0) == (slices <= 1 or M <= 64)
+    zrow = torch.zeros(256, device=DEV, dtype=torch.bfloat16)
     for _ in range(2):
         dW = torch.full((N, K), float("nan"), device=DEV)
+        ws = torch.full((max(need, 4),), float("nan"), device=DEV)          # caller-owned partials: the library keeps no state
         rc = lib.spadot_gemm_wgrad_bf16(G.data_ptr(), N, X.data_ptr(), Kp, dW.data_ptr(), K, M, N, K, slices,
-                                        torch.cuda.current_stream().cuda_stream)
+                                        ws.data_ptr(), zrow.data_ptr(), torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         assert rc == 0
         outs.append(dW)
@@ -123,11 +127,19 @@ def test_wgrad_refuses_what_it_does_not_cover():
     X = torch.zeros((64, 256), device=DEV, dtype=torch.bfloat16)
     dW = torch.zeros((128, 256), device=DEV)
     st = torch.cuda.current_stream().cuda_stream
-    assert lib.spadot_gemm_wgrad_bf16(G.data_ptr(), 128, X.data_ptr(), 256, dW.data_ptr(), 256, 64, 128, 256, 1, st) == -22   # N % 256
+    z = torch.zeros(256, device=DEV, dtype=torch.bfloat16)
+    assert lib.spadot_gemm_wgrad_bf16(G.data_ptr(), 128, X.data_ptr(), 256, dW.data_ptr(), 256, 64, 128, 256, 1, None, z.data_ptr(), st) == -22   # N % 256
     G = torch.zeros((64, 256), device=DEV, dtype=torch.bfloat16)
     X = torch.zeros((64, 200), device=DEV, dtype=torch.bfloat16)
     dW = torch.zeros((256, 200), device=DEV)
-    assert lib.spadot_gemm_wgrad_bf16(G.data_ptr(), 256, X.data_ptr(), 200, dW.data_ptr(), 200, 64, 256, 200, 1, st) == -22   # X rows too short
+    assert lib.spadot_gemm_wgrad_bf16(G.data_ptr(), 256, X.data_ptr(), 200, dW.data_ptr(), 200, 64, 256, 200, 1, None, z.data_ptr(), st) == -22   # X rows too short
+    # several slices without a workspace, or without the zero row: refused before anything is launched
+    G = torch.zeros((512, 256), device=DEV, dtype=torch.bfloat16)
+    X = torch.zeros((512, 256), device=DEV, dtype=torch.bfloat16)
+    dW = torch.zeros((256, 256), device=DEV)
+    assert lib.spadot_gemm_wgrad_bf16_workspace(512, 256, 256, 4) == 4 * 65536
+    assert lib.spadot_gemm_wgrad_bf16(G.data_ptr(), 256, X.data_ptr(), 256, dW.data_ptr(), 256, 512, 256, 256, 4, None, z.data_ptr(), st) == -22
+    assert lib.spadot_gemm_wgrad_bf16(G.data_ptr(), 256, X.data_ptr(), 256, dW.data_ptr(), 256, 512, 256, 256, 1, None, None, st) == -22
 
 
 @pytest.mark.parametrize("M,N,K", [(1, 256, 64), (321, 512, 192), (2000, 2048, 2048), (9980, 2048, 2048)])

@@ -90,7 +90,10 @@ def run_wgrad(M, N, K, Kp, slices, reps=30):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / n * 1e3
 
-    mine = lambda: lib.spadot_gemm_wgrad_bf16(G.data_ptr(), N, X.data_ptr(), Kp, dW.data_ptr(), K, M, N, K, slices, st)
+    ws = torch.empty(max(4, int(lib.spadot_gemm_wgrad_bf16_workspace(M, N, K, slices))), device="cuda:0")
+    zrow = torch.zeros(256, device="cuda:0", dtype=torch.bfloat16)
+    mine = lambda: lib.spadot_gemm_wgrad_bf16(G.data_ptr(), N, X.data_ptr(), Kp, dW.data_ptr(), K, M, N, K, slices,
+                                              ws.data_ptr(), zrow.data_ptr(), st)
     libf = lambda: torch.mm(G.t(), X[:, :K], out_dtype=torch.float32, out=ref)
     assert mine() == 0
     timed(mine, 10), timed(libf, 10)

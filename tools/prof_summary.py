@@ -33,6 +33,20 @@ def family(name):
     return "own_small"
 
 
+def tree_stamp():
+    """{head, source_sha16} of the tree the profile was taken on: .git_head is written next to the sources before the
+    snapshot goes to the GPU box (it has no .git); the fingerprint is bench.source_fingerprint()."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from bench import source_fingerprint
+    head = None
+    try:
+        head = open(os.path.join(root, ".git_head")).read().strip() or None
+    except OSError:
+        pass
+    return {"head": head, "source_sha16": source_fingerprint()}
+
+
 def main():
     d = sys.argv[1]
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 40
@@ -98,11 +112,14 @@ def main():
                 fh.write(f"{(int(r['Start_Timestamp']) - t0) / 1e3:9.1f} us  +{(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:7.1f} us  "
                          f"q{r.get('Queue_Id', '?')}  {r['Kernel_Name'][:150]}\n")
     if len(sys.argv) > 4:
-        out = {"steps": steps, "wall_us_per_step": wall, "kernel_sum_us_per_step": tot, "launches_per_step": len(sel) / steps,
+        out = {**tree_stamp(), "steps": steps, "wall_us_per_step": wall, "kernel_sum_us_per_step": tot, "launches_per_step": len(sel) / steps,
                "under_12us": {"launches_per_step": small_n, "us_per_step": small},
                "families": {k: {"us_per_step": fam_t[k] / steps / 1e3, "launches_per_step": fam_c[k] / steps} for k in fam_t},
                "top_kernels": [{"name": n[:160], "per_step": c[n] / steps, "avg_us": v / c[n] / 1e3, "us_per_step": v / steps / 1e3}
                                for n, v in sorted(t.items(), key=lambda x: -x[1])[:12]]}
+        mf = os.environ.get("SPADOT_MFMA_SUMMARY")          # tools/mfma_summary.py output of the same tree: carried along
+        if mf and os.path.exists(mf):
+            out["mfma"] = json.load(open(mf))
         json.dump(out, open(sys.argv[4], "w"), indent=1)
 
 
