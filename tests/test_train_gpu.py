@@ -472,4 +472,4 @@ def test_cfg4_shape_eight_ragged_timepoints_train_end_to_end(tmp_path, capsys):
     z = np.load(tmp_path / "out" / "m_latent.npz")
     assert z["X"].shape == (sum(counts), 20) and np.isfinite(z["X"]).all()
     steps = sum(-(-c // 256) for c in counts)
-    assert steps == 27
+    assert steps == 25
