@@ -258,8 +258,13 @@ int spadot_knn(const double *x, int n, int d, int kk, int *out, void *stream);
  *   spadot_gat_aggregate         mode 0: out[row] = act?(sum_cols w x[col] + vec_a (bias));              plan by target
  *                                mode 1: out[row] = sum_cols w x[col] + ds_src[row] vec_a + ds_dst[row] vec_b  (att_src,
  *                                att_dst: the logits' own gradient path);                                plan by source
+ *                                with att_part (mode 1; h_rows = the layer's input h): block b also leaves the partial sums
+ *                                sum_rows ds_src[row] h[row] at att_part[b * part_width + 0 ..] and the ds_dst ones at
+ *                                [.. + H C ..] -- the attention-vector gradients up to a column sum over the blocks
  *   spadot_gat_edge_dot          g_pre = g_out * (act ? LeakyReLU'(out) : 1) (written), dz[e] = <g_pre[row], h[col]> through
- *                                plan_cell [chunk][32 rows][16] -> edge position or -1
+ *                                plan_cell [chunk][32 rows][16] -> edge position or -1; with bias_part block b leaves the
+ *                                column sums of its 32 rows of g_pre at bias_part[b * part_width + part_col ..] (the bias
+ *                                gradient up to a column sum over the blocks: spadot_colsum, fixed order)
  *   spadot_gat_softmax_backward  dz (raw d alpha) -> d logits in place, ds_dst[i] = sum over incoming edges; alpha also
  *                                written into the by-SOURCE plan's image (cellq_s indexed by by-target edge position)
  *   spadot_gat_ds_src            ds_src[j] = sum of dz over the outgoing edges of j (transposed CSR)
@@ -269,10 +274,11 @@ int spadot_gat_alpha(const float *s_src, const float *s_dst, const int *rowptr, 
                      int H, float *alpha, void *acell, void *stream);
 int spadot_gat_aggregate(const void *x, int dtype, const void *acell, const int *plan_rows, const int *plan_sptr,
                          const int *plan_cols, int nb, int max_cols, int H, int C, int mode, const float *vec_a,
-                         const float *vec_b, int act, const float *ds_src, const float *ds_dst, void *out, void *stream);
+                         const float *vec_b, int act, const float *ds_src, const float *ds_dst, void *out,
+                         const void *h_rows, float *att_part, int part_width, void *stream);
 int spadot_gat_edge_dot(const void *g_out, const void *out, const void *h, int dtype, const int *plan_rows,
                         const int *plan_sptr, const int *plan_cols, const int *plan_cell, int nb, int max_cols, int H,
-                        int C, int act, void *g_pre, float *dz, void *stream);
+                        int C, int act, void *g_pre, float *dz, float *bias_part, int part_width, int part_col, void *stream);
 /* (ds_dst has n_all >= n_tgt rows: the rows of nodes that are sources only are written as zeros) */
 int spadot_gat_softmax_backward(const float *alpha, const float *s_src, const float *s_dst, const int *rowptr,
                                 const int *col, const int *cellq_s, int n_tgt, int n_all, int H, float *dz, float *ds_dst,
@@ -357,6 +363,24 @@ int spadot_clip_adamw_dev(float *param, const float *grad, float *exp_avg, float
 /* grad_scale_dev (device scalar, may be NULL = 1): `grad` stands for grad_scale * grad -- the data-parallel step
  * all-reduces a SUM over replicas and passes 1 / (number of replicas that had a batch in this step), so that the clip
  * threshold and the update see the MEAN gradient, as a single replica would (spadot_amd/parallel.py). */
+/* The same two-stage clip + AdamW, with the update ALSO keeping bf16 images of registered weight matrices current: image w
+ * is the row-major [rows x Kp] bf16 copy (columns K .. Kp-1 are padding the kernel never writes) of the fp32 weight that
+ * occupies flat elements [offset, offset + rows * K).  The GAT layers' dense maps read such images; casting them took a
+ * launch at the head of every step.  Requires count % 4 == 0, 16-byte aligned buffers, K, Kp, offset % 4 == 0,
+ * rows * K < 2^31, at most 8 images; -22 otherwise. */
+typedef struct spadot_weight_image {
+    long long offset;
+    int rows, K, Kp, reserved;
+    void *image;
+} spadot_weight_image;
+typedef struct spadot_weight_images {
+    int n, reserved;
+    spadot_weight_image w[8];
+} spadot_weight_images;
+int spadot_clip_adamw_images_dev(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long long count, double lr,
+                                 double beta1, double beta2, double eps, double weight_decay, double max_norm, double *scratch,
+                                 float *sumsq, int *step_dev, const float *grad_scale_dev, const spadot_weight_images *images,
+                                 void *stream);
 int spadot_adamw_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
                       const float *sumsq, long long count, double lr, double beta1, double beta2,
                       double eps, double weight_decay, double max_norm, int step, void *stream);

@@ -57,6 +57,17 @@ class OTSmallInfo(ctypes.Structure):
                 ("gap_checks", ctypes.c_int), ("status", ctypes.c_int), ("reserved", ctypes.c_int)]
 
 
+class WeightImage(ctypes.Structure):
+    """struct spadot_weight_image (include/spadot_model.h)."""
+    _fields_ = [("offset", ctypes.c_longlong), ("rows", ctypes.c_int), ("K", ctypes.c_int), ("Kp", ctypes.c_int),
+                ("reserved", ctypes.c_int), ("image", ctypes.c_void_p)]
+
+
+class WeightImages(ctypes.Structure):
+    """struct spadot_weight_images (include/spadot_model.h)."""
+    _fields_ = [("n", ctypes.c_int), ("reserved", ctypes.c_int), ("w", WeightImage * 8)]
+
+
 def ot_lib():
     """libspadot_ot.so with argtypes/restypes of include/spadot_ot.h part B set."""
     lib = _load("libspadot_ot.so")
@@ -126,8 +137,8 @@ def model_lib():
         "spadot_gat_softmax_backward": [vp, vp, vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp],
         "spadot_gat_ds_src": [vp, vp, vp, ci, ci, vp, vp],
         "spadot_gat_mfma_supported": [ci, ci, ci, ci],
-        "spadot_gat_aggregate": [vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp, vp],
-        "spadot_gat_edge_dot": [vp, vp, vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp, vp],
+        "spadot_gat_aggregate": [vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp, vp, vp, ci, vp],
+        "spadot_gat_edge_dot": [vp, vp, vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, ci, ci, vp],
         "spadot_gemm_tn_bf16": [vp, ci, vp, ci, vp, ci, ci, ci, ci, vp],
         "spadot_gemm_nn_bf16": [vp, ci, vp, ci, vp, ci, ci, ci, ci, vp],
         "spadot_gemm_wgrad_bf16": [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, vp, vp, vp],
@@ -171,6 +182,7 @@ def model_lib():
         "spadot_knn": [vp, ci, ci, ci, vp, vp],
         "spadot_grad_sumsq": [vp, ll, vp, vp, vp],
         "spadot_clip_adamw_dev": [vp, vp, vp, vp, ll, cd, cd, cd, cd, cd, cd, vp, vp, vp, vp, vp, vp],
+        "spadot_clip_adamw_images_dev": [vp, vp, vp, vp, ll, cd, cd, cd, cd, cd, cd, vp, vp, vp, vp, ctypes.POINTER(WeightImages), vp],
         "spadot_adamw_step": [vp, vp, vp, vp, vp, ll, cd, cd, cd, cd, cd, cd, ci, vp],
         "spadot_adamw_step_dev": [vp, vp, vp, vp, vp, ll, cd, cd, cd, cd, cd, cd, vp, vp],
     }

@@ -246,7 +246,9 @@ __global__ __launch_bounds__(NT, 2) void k_gat_agg(
     const int *__restrict__ sptr, const int *__restrict__ pcol, int nb, int H,
     const float *__restrict__ vec_a,      // MODE 0: bias [H*C]; MODE 1: att_src [H*C]
     const float *__restrict__ vec_b,      // MODE 1: att_dst [H*C]
-    int act, const float *__restrict__ ds_src, const float *__restrict__ ds_dst, __bf16 *__restrict__ out) {
+    int act, const float *__restrict__ ds_src, const float *__restrict__ ds_dst, __bf16 *__restrict__ out,
+    const __bf16 *__restrict__ hrows,     // MODE 1, optional: h (the layer's input rows), for the attention-vector gradients
+    float *__restrict__ att_part, int part_width) {   // MODE 1: [nb][part_width] partials: src at column 0, dst at column H*C
     using namespace agg;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *ring = smem;
@@ -338,6 +340,19 @@ __global__ __launch_bounds__(NT, 2) void k_gat_agg(
         multiply(it);
     }
 
+    // MODE 1 with att_part: the attention-vector gradients d att_src[c] = sum_j ds_src[j] h[j, c], d att_dst likewise with
+    // ds_dst (k_gat_datt_part took a pass of its own over h and g for them: 25 us per layer).  This block's 32 rows of h
+    // are requested here, 16 bytes per thread and row, and consumed behind the epilogue.
+    u32x4 hv[8];
+    if (MODE == 1 && att_part != nullptr) {
+        const int pc = tid & 63, rg = tid >> 6;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int node = rid[8 * rg + u];
+            hv[u] = node >= 0 ? *reinterpret_cast<const u32x4 *>(hrows + (size_t)node * HC + hoff + (size_t)pc * 8) : u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+
     // ---- epilogue: accumulators -> bf16 image in LDS (the ring is free) -> whole 16-byte pieces to global memory
     __syncthreads();
     {
@@ -380,6 +395,47 @@ __global__ __launch_bounds__(NT, 2) void k_gat_agg(
             *reinterpret_cast<uint4 *>(out + (size_t)node * HC + hoff + (size_t)pc * 8) =
                 *reinterpret_cast<const uint4 *>(ring + (size_t)r * OUTB + (size_t)pc * 16);
     }
+    if (MODE == 1 && att_part != nullptr) {
+        // per-thread sums over its 8 rows, then the four row groups added in order through LDS (fixed order: reproducible)
+        __syncthreads();                                                  // the ring image has been read
+        float *dsl = reinterpret_cast<float *>(sids);                     // (the column ids are no longer needed)
+        if (tid < ROWS) {
+            const int node = rid[tid];
+            dsl[tid] = node >= 0 ? ds_src[(size_t)node * H + hd] : 0.f;
+            dsl[ROWS + tid] = node >= 0 ? ds_dst[(size_t)node * H + hd] : 0.f;
+        }
+        __syncthreads();
+        const int pc = tid & 63, rg = tid >> 6;
+        float as_[8], ad_[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) { as_[e] = 0.f; ad_[e] = 0.f; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const float ws = dsl[8 * rg + u], wd = dsl[ROWS + 8 * rg + u];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float lo = __uint_as_float(hv[u][q] << 16), hi = __uint_as_float(hv[u][q] & 0xffff0000u);
+                as_[2 * q] = fmaf(ws, lo, as_[2 * q]); as_[2 * q + 1] = fmaf(ws, hi, as_[2 * q + 1]);
+                ad_[2 * q] = fmaf(wd, lo, ad_[2 * q]); ad_[2 * q + 1] = fmaf(wd, hi, ad_[2 * q + 1]);
+            }
+        }
+        float *red = reinterpret_cast<float *>(ring);                     // [4 row groups][2][512]
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            red[(rg * 2 + 0) * C + pc * 8 + e] = as_[e];
+            red[(rg * 2 + 1) * C + pc * 8 + e] = ad_[e];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int idx = k * NT + tid, which = idx / C, ch = idx - which * C;
+            float t_ = red[(0 * 2 + which) * C + ch];
+            t_ += red[(1 * 2 + which) * C + ch];
+            t_ += red[(2 * 2 + which) * C + ch];
+            t_ += red[(3 * 2 + which) * C + ch];
+            att_part[(size_t)b * part_width + (size_t)which * HC + hoff + ch] = t_;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -395,7 +451,8 @@ __global__ __launch_bounds__(NT, 4) void k_gat_edot(const __bf16 *__restrict__ g
                                                     const __bf16 *__restrict__ Xh, const int *__restrict__ prow,
                                                     const int *__restrict__ sptr, const int *__restrict__ pcol,
                                                     const int *__restrict__ cell, int nb, int H, int act,
-                                                    __bf16 *__restrict__ g_pre, float *__restrict__ dz) {
+                                                    __bf16 *__restrict__ g_pre, float *__restrict__ dz,
+                                                    float *__restrict__ bias_part, int part_width, int part_col) {
     constexpr int C = 128 * NTW, PPR = C / 8, GS = 2 * C + 16;
     __shared__ __attribute__((aligned(16))) unsigned char gt[ROWS * GS];
     __shared__ int rid[ROWS];
@@ -432,6 +489,18 @@ __global__ __launch_bounds__(NT, 4) void k_gat_edot(const __bf16 *__restrict__ g
         *reinterpret_cast<uint4 *>(gt + (size_t)r * GS + (size_t)pc * 16) = g;
     }
     __syncthreads();
+    if (bias_part != nullptr && C == 2 * NT) {
+        // the bias gradient = column sums of g_pre: this block's 32 rows are in LDS, two channels per thread
+        // (per-block partials; spadot_colsum adds the blocks in order)
+        float b0 = 0.f, b1 = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < ROWS; r++) {
+            const unsigned w2 = *reinterpret_cast<const unsigned *>(gt + (size_t)r * GS + (size_t)tid * 4);
+            b0 += __uint_as_float(w2 << 16);
+            b1 += __uint_as_float(w2 & 0xffff0000u);
+        }
+        *reinterpret_cast<float2 *>(bias_part + (size_t)b * part_width + part_col + hoff + 2 * tid) = make_float2(b0, b1);
+    }
 
     const int s0 = sptr[b], ntile = (sptr[b + 1] - s0) / 32;
     const int sl = lane & 31, hh = lane >> 5;
@@ -511,15 +580,18 @@ int spadot_gat_ds_src(const float *dz, const int *rowptr_t, const int *eid_t, in
             attr_set = true;                                                                                       \
         }                                                                                                          \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), agg::LDS_BYTES, st_, (const __bf16 *)x, (const __bf16 *)acell, plan_rows, \
-                           plan_sptr, plan_cols, nb, H, vec_a, vec_b, act, ds_src, ds_dst, (__bf16 *)out);         \
+                           plan_sptr, plan_cols, nb, H, vec_a, vec_b, act, ds_src, ds_dst, (__bf16 *)out,          \
+                           (const __bf16 *)h_rows, att_part, part_width);                                          \
     } while (0)
 
 int spadot_gat_aggregate(const void *x, int dtype, const void *acell, const int *plan_rows, const int *plan_sptr,
                          const int *plan_cols, int nb, int max_cols, int H, int C, int mode, const float *vec_a,
-                         const float *vec_b, int act, const float *ds_src, const float *ds_dst, void *out, void *stream) {
+                         const float *vec_b, int act, const float *ds_src, const float *ds_dst, void *out,
+                         const void *h_rows, float *att_part, int part_width, void *stream) {
     if (!spadot_gat_mfma_supported(dtype, H, C, max_cols) || nb <= 0 || (mode != 0 && mode != 1)) return -22;
     if (!x || !acell || !plan_rows || !plan_sptr || !plan_cols || !vec_a || !out) return -22;
     if (mode == 1 && (!vec_b || !ds_src || !ds_dst)) return -22;
+    if (att_part && (mode != 1 || !h_rows || part_width < 2 * H * C || ((uintptr_t)h_rows & 15))) return -22;
     hipStream_t st_ = (hipStream_t)stream;
     const unsigned grid = 8u * (unsigned)((nb * H + 7) / 8);
     if (mode == 0) AGG_LAUNCH(0); else AGG_LAUNCH(1);
@@ -528,13 +600,15 @@ int spadot_gat_aggregate(const void *x, int dtype, const void *acell, const int 
 
 int spadot_gat_edge_dot(const void *g_out, const void *out, const void *h, int dtype, const int *plan_rows,
                         const int *plan_sptr, const int *plan_cols, const int *plan_cell, int nb, int max_cols, int H,
-                        int C, int act, void *g_pre, float *dz, void *stream) {
+                        int C, int act, void *g_pre, float *dz, float *bias_part, int part_width, int part_col, void *stream) {
     if (!spadot_gat_mfma_supported(dtype, H, C, max_cols) || nb <= 0) return -22;
     if (!g_out || !h || !plan_rows || !plan_sptr || !plan_cols || !plan_cell || !g_pre || !dz || (act && !out)) return -22;
+    if (bias_part && (part_col < 0 || part_col % 2 || part_width % 2 || part_width < part_col + H * C || ((uintptr_t)bias_part & 7))) return -22;
     hipStream_t st_ = (hipStream_t)stream;
     const unsigned grid = 8u * (unsigned)((nb * H + 7) / 8);
     hipLaunchKernelGGL(k_gat_edot<4>, dim3(grid), dim3(NT), 0, st_, (const __bf16 *)g_out, (const __bf16 *)out,
-                       (const __bf16 *)h, plan_rows, plan_sptr, plan_cols, plan_cell, nb, H, act, (__bf16 *)g_pre, dz);
+                       (const __bf16 *)h, plan_rows, plan_sptr, plan_cols, plan_cell, nb, H, act, (__bf16 *)g_pre, dz,
+                       bias_part, part_width, part_col);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 

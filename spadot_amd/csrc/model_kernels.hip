@@ -1221,6 +1221,28 @@ __global__ __launch_bounds__(1024) void k_final_sum_step(const double *__restric
     if (threadIdx.x == 0) { out[0] = (float)acc; if (step_dev) step_dev[0] += 1; }
 }
 
+// One element of clip + AdamW.  Contraction into fused multiply-adds is switched OFF here so that every kernel that
+// inlines this function (the scalar and the four-wide, image-writing form) performs the same roundings whatever the
+// compiler makes of the code around it: their parameters stay bit-identical.
+__device__ __forceinline__ void adamw_element(float g_, float &pp, float &mm, float &vv, float coef, float lr, float wd,
+                                              float b1, float b2, float eps, float bc1, float bc2_sqrt) {
+#pragma clang fp contract(off)
+    const float gg = g_ * coef;
+    float pn = pp * (1.f - lr * wd);
+    const float mn = mm + (gg - mm) * (1.f - b1);          // lerp_(grad, 1 - beta1)
+    const float vn = vv * b2 + gg * gg * (1.f - b2);
+    const float denom = sqrtf(vn) / bc2_sqrt + eps;
+    pn -= (lr / bc1) * (mn / denom);
+    pp = pn; mm = mn; vv = vn;
+}
+
+// clip coefficient (times grad_scale), same care: identical in every kernel that calls it
+__device__ __forceinline__ float adamw_clip_coef(float sumsq, float gs, float max_norm) {
+#pragma clang fp contract(off)
+    const float total = sqrtf(sumsq) * gs;
+    return fminf(1.f, max_norm / (total + 1e-6f)) * gs;
+}
+
 __global__ __launch_bounds__(256) void k_adamw(float *__restrict__ p, const float *__restrict__ g,
                                                float *__restrict__ m, float *__restrict__ v,
                                                const float *__restrict__ sumsq, long long count, float lr,
@@ -1235,16 +1257,66 @@ __global__ __launch_bounds__(256) void k_adamw(float *__restrict__ p, const floa
     // grad_scale (device scalar, optional): the buffer holds a SUM over replicas and stands for scale * g
     // (data-parallel steps: 1 / number of replicas that had a batch); the norm is clipped on the scaled gradient
     const float gs = grad_scale ? grad_scale[0] : 1.f;
-    const float total = sqrtf(sumsq[0]) * gs;
-    const float coef = fminf(1.f, max_norm / (total + 1e-6f)) * gs;
+    const float coef = adamw_clip_coef(sumsq[0], gs, max_norm);
     for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < count; k += (long long)gridDim.x * 256) {
-        const float gg = g[k] * coef;
-        float pp = p[k] * (1.f - lr * wd);
-        const float mm = m[k] + (gg - m[k]) * (1.f - b1);      // lerp_(grad, 1 - beta1)
-        const float vv = v[k] * b2 + gg * gg * (1.f - b2);
-        const float denom = sqrtf(vv) / bc2_sqrt + eps;
-        pp -= (lr / bc1) * (mm / denom);
+        float pp = p[k], mm = m[k], vv = v[k];
+        adamw_element(g[k], pp, mm, vv, coef, lr, wd, b1, b2, eps, bc1, bc2_sqrt);
         p[k] = pp; m[k] = mm; v[k] = vv;
+    }
+}
+
+// The same update, four elements per thread (16-byte streams), which also keeps the bf16 IMAGES of registered weight
+// matrices current: the dense maps of the GAT layers read W as a bf16 [rows x Kp] image (K zero-padded to Kp); casting
+// the three of them took a 15-24 us launch at the head of every step's critical path.  The update already holds the new
+// fp32 value in a register, so it stores the rounded copy too (2 more bytes per parameter on a ~450 MB pass).
+// Segments start at multiples of 4 elements and K % 4 == 0, so the four elements of a thread lie in one row of one image.
+// The arithmetic per element is k_adamw's, operation for operation.
+__global__ __launch_bounds__(256) void k_adamw_img(float *__restrict__ p, const float *__restrict__ g,
+                                                   float *__restrict__ m, float *__restrict__ v,
+                                                   const float *__restrict__ sumsq, long long count, float lr,
+                                                   float b1, float b2, float eps, float wd, float max_norm,
+                                                   const int *__restrict__ step_dev, const float *__restrict__ grad_scale,
+                                                   spadot_weight_images imgs) {
+    const double t = (double)step_dev[0];
+    const float bc1 = (float)(1.0 - pow((double)b1, t));
+    const float bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, t));
+    const float gs = grad_scale ? grad_scale[0] : 1.f;
+    const float coef = adamw_clip_coef(sumsq[0], gs, max_norm);
+    const long long n4 = count >> 2;
+    for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < n4; q += (long long)gridDim.x * 256) {
+        const long long k = q << 2;
+        const float4 g4 = *reinterpret_cast<const float4 *>(g + k);
+        const float4 p4 = *reinterpret_cast<const float4 *>(p + k);
+        const float4 m4 = *reinterpret_cast<const float4 *>(m + k);
+        const float4 v4 = *reinterpret_cast<const float4 *>(v + k);
+        const float gi[4] = {g4.x, g4.y, g4.z, g4.w}, pi[4] = {p4.x, p4.y, p4.z, p4.w};
+        const float mi[4] = {m4.x, m4.y, m4.z, m4.w}, vi[4] = {v4.x, v4.y, v4.z, v4.w};
+        float po[4], mo[4], vo[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            po[e] = pi[e]; mo[e] = mi[e]; vo[e] = vi[e];
+            adamw_element(gi[e], po[e], mo[e], vo[e], coef, lr, wd, b1, b2, eps, bc1, bc2_sqrt);
+        }
+        *reinterpret_cast<float4 *>(p + k) = make_float4(po[0], po[1], po[2], po[3]);
+        *reinterpret_cast<float4 *>(m + k) = make_float4(mo[0], mo[1], mo[2], mo[3]);
+        *reinterpret_cast<float4 *>(v + k) = make_float4(vo[0], vo[1], vo[2], vo[3]);
+#pragma unroll
+        for (int s_ = 0; s_ < 8; s_++) {
+            if (s_ >= imgs.n) break;
+            const spadot_weight_image W = imgs.w[s_];
+            const unsigned long long d = (unsigned long long)(k - W.offset);
+            if (d < (unsigned long long)W.rows * (unsigned long long)W.K) {
+                const unsigned row = (unsigned)d / (unsigned)W.K;                    // (d < 2^31: checked on the host)
+                const unsigned col = (unsigned)d - row * (unsigned)W.K;
+                __bf16 *dst = reinterpret_cast<__bf16 *>(W.image) + (size_t)row * W.Kp + col;
+                const unsigned lo = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)po[0]) |
+                                    ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)po[1]) << 16);
+                const unsigned hi = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)po[2]) |
+                                    ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)po[3]) << 16);
+                *reinterpret_cast<uint2 *>(dst) = make_uint2(lo, hi);
+                break;
+            }
+        }
     }
 }
 
@@ -2266,6 +2338,31 @@ int spadot_clip_adamw_dev(float *param, const float *grad, float *exp_avg, float
     hipLaunchKernelGGL(k_adamw, dim3(nb), dim3(256), 0, st_, param, grad, exp_avg, exp_avg_sq, (const float *)sumsq, count,
                        (float)lr, (float)beta1, (float)beta2, (float)eps, (float)weight_decay, (float)max_norm,
                        1.f, 1.f, (const int *)step_dev, grad_scale_dev);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+int spadot_clip_adamw_images_dev(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long long count, double lr,
+                                 double beta1, double beta2, double eps, double weight_decay, double max_norm, double *scratch,
+                                 float *sumsq, int *step_dev, const float *grad_scale_dev, const spadot_weight_images *images,
+                                 void *stream) {
+    if (count <= 0 || (count & 3) || !step_dev || !scratch || !sumsq || !images) return -22;
+    if (((uintptr_t)grad & 15) || ((uintptr_t)param & 15) || ((uintptr_t)exp_avg & 15) || ((uintptr_t)exp_avg_sq & 15)) return -22;
+    if (images->n < 0 || images->n > 8) return -22;
+    for (int s_ = 0; s_ < images->n; s_++) {
+        const spadot_weight_image &W = images->w[s_];
+        if (!W.image || ((uintptr_t)W.image & 7) || W.rows <= 0 || W.K <= 0 || (W.K & 3) || W.Kp < W.K || (W.Kp & 3) || (W.offset & 3) ||
+            W.offset < 0 || W.offset + (long long)W.rows * W.K > count || (long long)W.rows * W.K >= (1ll << 31))
+            return -22;
+    }
+    hipStream_t st_ = (hipStream_t)stream;
+    const long long want4 = (count / 4 + 255) / 256;
+    const int nb2 = (int)(want4 < 1 ? 1 : (want4 < 2048 ? want4 : 2048));
+    hipLaunchKernelGGL(k_sumsq_part_u<4>, dim3(nb2), dim3(256), 0, st_, grad, count, scratch);
+    hipLaunchKernelGGL(k_final_sum_step, dim3(1), dim3(1024), 0, st_, (const double *)scratch, nb2, sumsq, step_dev);
+    const int nb = (int)(want4 < 4096 ? want4 : 4096);
+    hipLaunchKernelGGL(k_adamw_img, dim3(nb), dim3(256), 0, st_, param, grad, exp_avg, exp_avg_sq, (const float *)sumsq, count,
+                       (float)lr, (float)beta1, (float)beta2, (float)eps, (float)weight_decay, (float)max_norm,
+                       (const int *)step_dev, grad_scale_dev, *images);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 

@@ -74,7 +74,8 @@ class SpaDOT(nn.Module):
 
         def svgp_first_half():
             with torch.cuda.stream(s_svgp):
-                z_enc = self.SVGPEncoder.pre_head(y_seed32 if y_seed32 is not None else y[:b])   # (mu | logvar); pad columns, if any, meet zero weights
+                z_enc = self.SVGPEncoder.pre_head(y_seed32 if y_seed32 is not None else y[:b],    # (mu | logvar); pad columns, if any, meet zero weights
+                                                  x_bf16=y[:b] if (y_seed32 is not None and y.dtype == torch.bfloat16) else None)
                 state["bc"] = svgp.batch_constants(x[:b], key=batch_key)
                 state["started"] = svgp.elbo_start(state["bc"], z_enc)
 
@@ -111,7 +112,8 @@ class SpaDOT(nn.Module):
         launch in front of this latency-bound branch)."""
         b = batch_size
         svgp = self.svgp_dict[str(tp)]
-        z_enc = self.SVGPEncoder.pre_head(y_seed32 if y_seed32 is not None else y[:b])
+        z_enc = self.SVGPEncoder.pre_head(y_seed32 if y_seed32 is not None else y[:b],
+                                          x_bf16=y[:b] if (y_seed32 is not None and y.dtype == torch.bfloat16) else None)
         bc = svgp.batch_constants(x[:b], key=batch_key)
         return svgp.elbo_finish(bc, svgp.elbo_start(bc, z_enc))
 

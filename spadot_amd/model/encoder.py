@@ -11,7 +11,11 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..graph import build_batch_graph
-from ..ops import BatchGraph, bn_act, cast_rows, dense_cd, gat_edge, head_fc, head_fc_ok, linear_bias, weight_image
+from ..ops import (BatchGraph, bn_act, cast_rows, dense_cd, first_map_seeds, first_map_seeds_ok, gat_edge, head_fc, head_fc_ok,
+                   linear_bias, weight_image)
+
+
+FIRST_MAP_OWN_WGRAD = [__import__("os").environ.get("SPADOT_FIRST_MAP_WGRAD", "1") == "1"]    # [False]: library (A/B runs)
 
 
 class SVGPEncoder(nn.Module):
@@ -34,8 +38,10 @@ class SVGPEncoder(nn.Module):
         mu, logvar = torch.chunk(self.pre_head(x), 2, dim=1)
         return mu, torch.exp(logvar)
 
-    def pre_head(self, x):
-        """SVGP_fc output (mu | logvar) [b, 2 z]."""
+    def pre_head(self, x, x_bf16=None):
+        """SVGP_fc output (mu | logvar) [b, 2 z].  x_bf16 (optional, training in the bf16 compute dtype): the bf16 image
+        [b, G padded] of the same rows -- the first map's weight gradient is then taken from it on the matrix cores
+        (ops.first_map_seeds), the forward stays the fp32 product of x."""
         net = list(self.SVGP_encoder_net)
         fused = self.training                          # eval mode (running statistics) takes the library modules
         if not fused:
@@ -55,6 +61,9 @@ class SVGPEncoder(nn.Module):
             lin, bn, act = net[i], net[i + 1], net[i + 2]
             if i == 0 and self.compute_dtype != torch.float32 and h.dtype != torch.float32:
                 h = dense_cd(h.to(self.compute_dtype), lin.weight, lin)
+            elif (i == 0 and self.compute_dtype == torch.bfloat16 and FIRST_MAP_OWN_WGRAD[0]
+                  and first_map_seeds_ok(h, lin.weight, x_bf16)):
+                h = first_map_seeds(h, lin.weight, x_bf16)
             else:
                 h = F.linear(h[:, :lin.in_features].float(), lin.weight)
             h = bn_act(h, lin.bias, bn, act.negative_slope)
@@ -117,6 +126,10 @@ class GATEncoder(nn.Module):
         self.GAT_fc = nn.Linear(hidden_dim, GAT_z_dim * 2)
         nn.init.xavier_uniform_(self.GAT_fc.weight)
 
+    def top_parameters(self):
+        """The parameters above the second layer's output: layer 3 and the head (what a backward pass reaches first)."""
+        return list(self.gat3.parameters()) + list(self.GAT_fc.parameters())
+
     def first_layer_parameters(self):
         """The parameters whose gradients a backward pass produces last (ops.FlatAdamW `last`)."""
         return list(self.gat1.parameters())
@@ -130,8 +143,8 @@ class GATEncoder(nn.Module):
         """GAT_fc output (mu | logvar) [rows or n, 2 z]: what ops.latent_head consumes.
         after_first_dense: optional callable run right after the first (largest) GEMM has been issued -- the
         composite model issues the start of its SVGP branch there, on another stream.
-        taps: optional dict; receives 'h1', the first layer's output (where a backward pass issued in pieces cuts:
-        everything above it is differentiated first, the first layer's own gradients last)."""
+        taps: optional dict; receives 'h1' and 'h2', the first and second layer's outputs (where a backward pass issued in
+        pieces cuts: everything above a tap is differentiated first, what is below it afterwards)."""
         lg = getattr(edge_index, "layer_graphs", None) if rows is not None else None
         g3 = getattr(edge_index, "seed_graph", None) if rows is not None else None
         if not isinstance(edge_index, BatchGraph):
@@ -140,9 +153,14 @@ class GATEncoder(nn.Module):
         fresh = False
         if self.gat1.compute_dtype == torch.bfloat16 and x.is_cuda:
             HC = self.gat2.in_channels
-            cast_rows([(self.gat1.lin.weight.detach(), weight_image(self.gat1.lin.weight, x.shape[1], torch.bfloat16, self.gat1)),
-                       (self.gat2.lin.weight.detach(), weight_image(self.gat2.lin.weight, HC, torch.bfloat16, self.gat2)),
-                       (self.gat3.lin.weight.detach(), weight_image(self.gat3.lin.weight, HC, torch.bfloat16, self.gat3))])
+            pairs = [(self.gat1.lin.weight, weight_image(self.gat1.lin.weight, x.shape[1], torch.bfloat16, self.gat1)),
+                     (self.gat2.lin.weight, weight_image(self.gat2.lin.weight, HC, torch.bfloat16, self.gat2)),
+                     (self.gat3.lin.weight, weight_image(self.gat3.lin.weight, HC, torch.bfloat16, self.gat3))]
+            # training under an optimizer that keeps the images current (ops.FlatAdamW.maintain_image: the update kernel
+            # stores the bf16 copy of every new weight): no cast launch at the head of the step
+            opt = getattr(self, "_image_optimizer", None) if self.training else None
+            if opt is None or not all(opt.maintain_image(W, im) for W, im in pairs):
+                cast_rows([(W.detach(), im) for W, im in pairs])
             fresh = True
         h = self.gat1.dense(x, fresh)
         if after_first_dense is not None:
@@ -153,12 +171,18 @@ class GATEncoder(nn.Module):
         if lg is not None and lg[1].n_tgt == rows:
             # only what the seeds' rows of layer 3 depend on: layer 2 for seeds + hop 1, layer 3 for the seeds
             h = self.gat2(h, lg[0], act=True, fresh=fresh)
+            if taps is not None:
+                taps["h2"] = h
             h = self.gat3(h, lg[1], act=False, fresh=fresh)
         elif g3 is not None and g3.n_tgt == rows:
             h = self.gat2(h, edge_index, act=True, fresh=fresh)
+            if taps is not None:
+                taps["h2"] = h
             h = self.gat3(h, g3, act=False, fresh=fresh)          # edge phase for the seeds only: same rows, ~n/rows less work
         else:
             h = self.gat2(h, edge_index, act=True, fresh=fresh)
+            if taps is not None:
+                taps["h2"] = h
             h = self.gat3(h, edge_index, act=False, fresh=fresh)
             if rows is not None:
                 h = h[:rows]

@@ -78,6 +78,7 @@ def _gat_att_scratch(device, floats):
 
 
 GAT_MFMA = [__import__("os").environ.get("SPADOT_GAT_MFMA", "1") == "1"]      # [False]: per-edge kernels everywhere (A/B runs)
+GAT_FOLD_ATT = [__import__("os").environ.get("SPADOT_GAT_FOLD_ATT", "1") == "1"]  # [False]: k_gat_datt_part for the att / bias gradients
 
 
 def _mfma_plans(h, graph, H, C, concat):
@@ -121,7 +122,8 @@ class _GATEdgeMFMA(torch.autograd.Function):
                                     _stream()), "spadot_gat_alpha")
         out = torch.empty((nt, H * C), dtype=h.dtype, device=dev)
         _check(lib.spadot_gat_aggregate(_p(h), DT_BF16, _p(img), _p(pt.rows), _p(pt.sptr), _p(pt.cols), pt.nb, pt.max_cols, H, C, 0,
-                                        _p(bias_f), None, int(act), None, None, _p(out), _stream()), "spadot_gat_aggregate")
+                                        _p(bias_f), None, int(act), None, None, _p(out), None, None, 0, _stream()),
+               "spadot_gat_aggregate")
         ctx.save_for_backward(h, s_src, s_dst, out, alpha, a_s, a_d)
         ctx.graph, ctx.H, ctx.C, ctx.act, ctx.plans = graph, H, C, act, plans
         ctx.bias_dtype, ctx.att_shape, ctx.att_dtype = bias.dtype, att_src.shape, att_src.dtype
@@ -139,8 +141,23 @@ class _GATEdgeMFMA(torch.autograd.Function):
         g_pre = torch.empty((nt, H * C), dtype=h.dtype, device=dev)
         dz = torch.empty((graph.E, H), dtype=torch.float32, device=dev)
         ds_dst = torch.empty((n, H), dtype=torch.float32, device=dev)      # (rows >= nt zeroed by the softmax kernel)
+        # attention-vector and bias gradients: per-block partial sums left by the two matrix-core kernels (the bias columns by
+        # k_gat_edot, which holds the block's g_pre rows in LDS; the att_src / att_dst columns by k_gat_agg<1>, which reads
+        # the block's 32 rows of h for it), then ONE fixed-order column sum over the blocks -- instead of k_gat_datt_part's
+        # pass of its own over h and g_pre (25 us per layer).  The partial matrix belongs to the batch graph: rows a plan
+        # does not have stay zero.
+        fold = GAT_FOLD_ATT[0]
+        W3 = 3 * H * C
+        part = None
+        if fold:
+            R = max(pt.nb, ps.nb)
+            bufs = graph.__dict__.setdefault("_bwd_bufs", {})
+            part = bufs.get(("attpart", H, C))
+            if part is None or part.device != dev or part.shape != (R, W3):
+                part = bufs[("attpart", H, C)] = torch.zeros((R, W3), dtype=torch.float32, device=dev)
         _check(lib.spadot_gat_edge_dot(_p(g_out), _p(out), _p(h), DT_BF16, _p(pt.rows), _p(pt.sptr), _p(pt.cols), _p(pt.cell),
-                                       pt.nb, pt.max_cols, H, C, int(ctx.act), _p(g_pre), _p(dz), _stream()), "spadot_gat_edge_dot")
+                                       pt.nb, pt.max_cols, H, C, int(ctx.act), _p(g_pre), _p(dz), _p(part) if fold else None, W3,
+                                       2 * H * C, _stream()), "spadot_gat_edge_dot")
         img = ps.weight_image(H)
         _check(lib.spadot_gat_softmax_backward(_p(alpha), _p(s_src), _p(s_dst), _p(graph.rowptr), _p(graph.col), _p(ps.cellq), nt, n,
                                                H, _p(dz), _p(ds_dst), _p(img), _stream()), "spadot_gat_softmax_backward")
@@ -148,13 +165,17 @@ class _GATEdgeMFMA(torch.autograd.Function):
         _check(lib.spadot_gat_ds_src(_p(dz), _p(graph.rowptr_t), _p(graph.eid_t), n, H, _p(ds_src), _stream()), "spadot_gat_ds_src")
         dh = torch.empty_like(h)
         _check(lib.spadot_gat_aggregate(_p(g_pre), DT_BF16, _p(img), _p(ps.rows), _p(ps.sptr), _p(ps.cols), ps.nb, ps.max_cols, H, C, 1,
-                                        _p(a_s), _p(a_d), 0, _p(ds_src), _p(ds_dst), _p(dh), _stream()), "spadot_gat_aggregate")
+                                        _p(a_s), _p(a_d), 0, _p(ds_src), _p(ds_dst), _p(dh), _p(h) if fold else None,
+                                        _p(part) if fold else None, W3, _stream()), "spadot_gat_aggregate")
         datt = torch.empty((3, H * C), dtype=torch.float32, device=dev)
-        floats = 3 * H * C * max(1, min((n + 15) // 16, 1024))
-        scratch = _gat_att_scratch(dev, floats)
-        _check(lib.spadot_gat_att_grad(_p(h), DT_BF16, _p(ds_src), _p(ds_dst), n, H, C, _p(scratch), floats,
-                                       _p(datt), ctypes.c_void_p(datt.data_ptr() + 4 * H * C), _p(g_pre), nt, _stream()),
-               "spadot_gat_att_grad")
+        if fold:
+            _check(lib.spadot_colsum(_p(part), part.shape[0], W3, _p(datt), _stream()), "spadot_colsum")
+        else:
+            floats = 3 * H * C * max(1, min((n + 15) // 16, 1024))
+            scratch = _gat_att_scratch(dev, floats)
+            _check(lib.spadot_gat_att_grad(_p(h), DT_BF16, _p(ds_src), _p(ds_dst), n, H, C, _p(scratch), floats,
+                                           _p(datt), ctypes.c_void_p(datt.data_ptr() + 4 * H * C), _p(g_pre), nt, _stream()),
+                   "spadot_gat_att_grad")
         return (dh, datt[0].view(ctx.att_shape).to(ctx.att_dtype), datt[1].view(ctx.att_shape).to(ctx.att_dtype),
                 datt[2].to(ctx.bias_dtype), None, None, None, None, None)
 
@@ -391,6 +412,56 @@ class _DenseCD(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dW = wgrad_bf16(g, x, ctx.K, ctx.wgrad if (ctx.wgrad is not None and _DIRECT_GRAD[0]) else None)
         return dx, dW, None, None
+
+
+class _FirstMapSeeds(torch.autograd.Function):
+    """h = x32 W^T for the SVGP encoder's G-sized first map on the b seeds (encoder.py:7-34), forward in fp32 from the cached
+    fp32 seed rows as before; the WEIGHT GRADIENT g^T x [N x G] is taken on the matrix cores (csrc/gemm_wgrad_bf16.hip:
+    N / 256 x G / 256 tiles x 8 slices of the b rows) from the bf16 image of the same rows that the GAT branch reads.
+    The library ran this fp32 product on 12-47 workgroups: 41 us alone, 130-160 us at the end of the SVGP backward beside
+    the first GAT layer's weight-gradient GEMM -- the optimizer waited for it.  Only in the bf16 compute dtype (the
+    operands are rounded to bf16 like every other large product of that mode; fp32 compute keeps the library GEMM)."""
+
+    @staticmethod
+    def forward(ctx, x32, W, xbf):
+        K = W.shape[1]
+        ctx.save_for_backward(x32, xbf)
+        ctx.K = K
+        g = W.grad
+        ctx.wgrad = g if (g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.shape == W.shape) else None
+        return torch.nn.functional.linear(x32[:, :K], W)
+
+    @staticmethod
+    def backward(ctx, g):
+        x32, xbf = ctx.saved_tensors
+        K = ctx.K
+        M, N = g.shape
+        lib = model_lib()
+        gb = g.contiguous().to(torch.bfloat16)
+        out = ctx.wgrad if (ctx.wgrad is not None and _DIRECT_GRAD[0]) else torch.empty((N, K), dtype=torch.float32, device=g.device)
+        need = int(lib.spadot_gemm_wgrad_bf16_workspace(M, N, K, 8))
+        rc = -22
+        if need >= 0:
+            ws = torch.empty(max(need, 4), dtype=torch.float32, device=g.device)
+            rc = lib.spadot_gemm_wgrad_bf16(gb.data_ptr(), N, xbf.data_ptr(), xbf.shape[1], out.data_ptr(), K, M, N, K, 8,
+                                            ws.data_ptr(), _zero_row(g.device).data_ptr(), _stream())
+        if rc == -22:                                   # (a shape the kernel refuses: the library's fp32 product)
+            return None, torch.mm(g.t(), x32[:, :K]), None
+        _check(rc, "spadot_gemm_wgrad_bf16")
+        return None, out, None
+
+
+def first_map_seeds_ok(x32, W, xbf):
+    """Whether _FirstMapSeeds takes (x32 [b, >= G] fp32, W [N, G] fp32, xbf [b, Gp] bf16 image of the same rows)."""
+    if xbf is None or not (x32.is_cuda and x32.dtype == torch.float32 and xbf.dtype == torch.bfloat16 and xbf.is_contiguous()):
+        return False
+    N, K = W.shape
+    return (N % 256 == 0 and K % 4 == 0 and xbf.shape[0] == x32.shape[0] and xbf.shape[1] >= (K + 255) // 256 * 256
+            and xbf.shape[1] % 8 == 0 and xbf.data_ptr() % 16 == 0 and x32.shape[0] >= 64 and not x32.requires_grad)
+
+
+def first_map_seeds(x32, W, xbf):
+    return _FirstMapSeeds.apply(x32, W, xbf)
 
 
 def _small_weight_grad(g, x):
@@ -1161,6 +1232,52 @@ class FlatAdamW:
         # data-parallel steps sum over replicas and set 1 / number of replicas that had a batch: parallel.run_epoch)
         self.grad_scale = torch.ones(1, dtype=torch.float32, device=dev)
         self._counter = torch.zeros(1, dtype=torch.int32, device=dev)   # last-workgroup-finishes counter of k_sumsq_last
+        # bf16 images of weight matrices that step() keeps current (maintain_image); images_version changes whenever the
+        # set does, so that a captured optimizer graph (whose launch carries the table by value) can be dropped
+        self._images, self._image_table, self.images_version = [], None, 0
+
+    # ---- bf16 weight images kept current by the update itself ------------------------------------------------------
+    def maintain_image(self, param, image):
+        """From now on every step() also writes bf16(param) into `image` [rows, Kp >= K] (a persistent tensor, e.g.
+        ops.weight_image): the dense maps that read the image need no cast launch per step.  The image is brought up to
+        date here.  Returns False (nothing registered) when the pair does not fit the kernel's conditions."""
+        if any(im.data_ptr() == image.data_ptr() for _, im in self._images):
+            return True
+        idx = next((i for i, p in enumerate(self.params) if p is param), None)
+        rows, K = (int(param.shape[0]), int(param.shape[1])) if param.dim() == 2 else (0, 0)
+        ok = (idx is not None and param.dim() == 2 and image.dtype == torch.bfloat16 and image.is_contiguous()
+              and image.dim() == 2 and image.shape[0] == rows and image.shape[1] >= K and K % 4 == 0 and image.shape[1] % 4 == 0
+              and rows * K < 2 ** 31 and image.data_ptr() % 8 == 0 and len(self._images) < 8 and self.count % 4 == 0)
+        if not ok:
+            return False
+        self._images.append((param, image))
+        self._image_table = None
+        self.images_version += 1
+        self.refresh_images([image])
+        return True
+
+    def maintains(self, image):
+        return any(im.data_ptr() == image.data_ptr() for _, im in self._images)
+
+    def refresh_images(self, only=None):
+        """Re-cast the registered images from the fp32 parameters (after anything but step() changed them: a loaded
+        state_dict, a broadcast)."""
+        pairs = [(p.detach(), im) for p, im in self._images if only is None or any(im is o for o in only)]
+        if pairs:
+            with torch.no_grad():
+                cast_rows(pairs)
+
+    def _images_struct(self):
+        if self._image_table is None:
+            from ._lib import WeightImages
+            tab = WeightImages()
+            tab.n = len(self._images)
+            for k, (p, im) in enumerate(self._images):
+                off = (p.data_ptr() - self.flat_param.data_ptr()) // 4
+                tab.w[k].offset, tab.w[k].rows, tab.w[k].K, tab.w[k].Kp = off, p.shape[0], p.shape[1], im.shape[1]
+                tab.w[k].image = im.data_ptr()
+            self._image_table = tab
+        return self._image_table
 
     def zero_grad(self):
         self.flat_grad.zero_()
@@ -1220,6 +1337,14 @@ class FlatAdamW:
         """clip + AdamW in two launches; the step count lives on the device, so the same launches can be captured in
         a hipGraph and replayed."""
         self.t += 1
+        if self._images:
+            _check(model_lib().spadot_clip_adamw_images_dev(_p(self.flat_param), _p(self.flat_grad), _p(self.exp_avg),
+                                                            _p(self.exp_avg_sq), self.count, self.lr, self.betas[0], self.betas[1],
+                                                            self.eps, self.weight_decay, self.max_norm, _p(self.scratch),
+                                                            _p(self.sumsq), _p(self.step_dev), _p(self.grad_scale),
+                                                            ctypes.byref(self._images_struct()), _stream()),
+                   "spadot_clip_adamw_images_dev")
+            return
         _check(model_lib().spadot_clip_adamw_dev(_p(self.flat_param), _p(self.flat_grad), _p(self.exp_avg),
                                                  _p(self.exp_avg_sq), self.count, self.lr, self.betas[0], self.betas[1],
                                                  self.eps, self.weight_decay, self.max_norm, _p(self.scratch), _p(self.sumsq),

@@ -394,6 +394,13 @@ class GraphedStepper:
         self.capturable = True
         # which graph of a pair is launched first: 'm' main (GAT) / 's' side (SVGP), forward pair then backward pair
         self.issue_order = (os.environ.get("SPADOT_ISSUE_ORDER", "mm") + "mm")[:2]
+        # option (off): the GAT backward as TWO graphs cut at the second layer's output, with the SVGP backward graph
+        # launched between them, so that it starts behind the ~12 nodes of the head + layer 3 instead of behind all ~40
+        # nodes of the GAT backward (under rocprofv3 it starts ~350 us late and ends ~90 us after the GAT backward).
+        # Measured without the profiler (round 3, same box, interleaved): 528.0 steps/s without against 524.2 with the
+        # split -- the SVGP backward then runs beside layer 2's GEMMs instead of layer 1's, no shorter overall.
+        self.split_bwd = bool(self.staged and not self.overlap
+                              and model_config.get("split_gat_backward", os.environ.get("SPADOT_SPLIT_BWD", "0") == "1"))
         self._beta1 = None
         # step() returns a copy of the graph's loss vector by default; a caller that consumes it on the same stream before its
         # next step (the training loop's `tot += ...`) may take the graph's own buffer and save the copy launch
@@ -402,6 +409,15 @@ class GraphedStepper:
         # parity checks only: with keep_latents set before a key is captured, latents[(tp, batch)] is the final_latent
         # tensor of that key's tail graph (rewritten by every replay)
         self.keep_latents, self.latents = False, {}
+        # the optimizer keeps the bf16 images of the GAT layers' weights current (its update kernel writes them), so the
+        # steps need no weight-cast launch; anything else that rewrites parameters must refresh them
+        if model_config.get("optimizer_weight_images", os.environ.get("SPADOT_OPT_IMAGES", "1") == "1") \
+                and hasattr(optimizer, "maintain_image"):
+            object.__setattr__(model.GATEncoder, "_image_optimizer", optimizer)
+            if not getattr(model, "_image_refresh_hook", False):
+                model.register_load_state_dict_post_hook(lambda mod, incompatible: optimizer.refresh_images())
+                object.__setattr__(model, "_image_refresh_hook", True)
+        self._images_version = getattr(optimizer, "images_version", 0)
 
     def _body(self, tp_i, tp, bi, epoch, with_update=True):
         losses = forward_backward(self.model, self.cfg, self.dd, tp_i, tp, bi, epoch, self.beta1_t,
@@ -423,6 +439,9 @@ class GraphedStepper:
     def update(self):
         """clip + AdamW as its own graph (data-parallel path: after the gradient exchange): eager once, then one
         replayed graph shared by all keys."""
+        if getattr(self.opt, "images_version", 0) != self._images_version:     # the update's image table changed:
+            self._images_version = self.opt.images_version                      # a captured launch carries the old one
+            self.opt_graph = None if self.opt_graph in (None, False) else False
         if not self.capturable:
             self.opt.step()
         elif self.opt_graph is None:
@@ -480,7 +499,7 @@ class GraphedStepper:
         # its own stream: the GAT branch all n_sub rows, the SVGP branch (and the tail after it) the seeds' rows.
         def gat_fwd():
             y_all = batch.y if cached else Y[batch.n_id]
-            st["zg"] = model.branch_gat(y_all, batch.graph, b, taps=st if self.overlap else None)
+            st["zg"] = model.branch_gat(y_all, batch.graph, b, taps=st if (self.overlap or self.split_bwd) else None)
 
         def svgp_fwd():
             st["xs"] = batch.x[:b] if cached else loc[seeds]
@@ -512,8 +531,16 @@ class GraphedStepper:
         def gat_bwd_lo():           # the first layer: its edge backward and the largest weight gradient
             opt.backward_partial([st["h1"]], [st["gh1"]], P["gat_lo"])
 
+        def gat_bwd_top():          # the head and layer 3; stops at the second layer's output
+            st["gh2"] = opt.backward_partial([st["zg"]], [st["g"][0]], P["gat_top"], extra_inputs=[st["h2"]])[0]
+
+        def gat_bwd_rest():         # layers 2 and 1
+            opt.backward_partial([st["h2"]], [st["gh2"]], P["gat_rest"])
+
         if self.overlap:
             return gat_fwd, svgp_fwd, tail, svgp_bwd, gat_bwd_hi, gat_bwd_lo
+        if self.split_bwd:
+            return gat_fwd, svgp_fwd, tail, svgp_bwd, gat_bwd_top, gat_bwd_rest
         return gat_fwd, svgp_fwd, tail, svgp_bwd, gat_bwd
 
     def _param_groups(self):
@@ -523,8 +550,10 @@ class GraphedStepper:
             svgp = [p for p in self.model.SVGPEncoder.parameters() if id(p) in own]
             taken = {id(p) for p in gat + svgp}
             lo = {id(p) for p in self.model.GATEncoder.first_layer_parameters()}
+            top = {id(p) for p in self.model.GATEncoder.top_parameters()}
             self._groups = {"gat": gat, "svgp": svgp, "tail": [p for p in self.opt.params if id(p) not in taken],
-                            "gat_lo": [p for p in gat if id(p) in lo], "gat_hi": [p for p in gat if id(p) not in lo]}
+                            "gat_lo": [p for p in gat if id(p) in lo], "gat_hi": [p for p in gat if id(p) not in lo],
+                            "gat_top": [p for p in gat if id(p) in top], "gat_rest": [p for p in gat if id(p) not in top]}
         return self._groups
 
     def _issue_staged(self, fns, two_streams=True):
@@ -559,6 +588,18 @@ class GraphedStepper:
         res = fns[2]()
         if two_streams:
             side.wait_stream(main)
+        if len(fns) == 6 and self.split_bwd:
+            # head + layer 3 (main), then the SVGP backward (side: it waits for the tail only), then layers 2 and 1 (main)
+            fns[4]()
+            if two_streams:
+                with torch.cuda.stream(side):
+                    fns[3]()
+            else:
+                fns[3]()
+            fns[5]()
+            if two_streams:
+                main.wait_stream(side)
+            return res
         if self.issue_order[1] == "m" and two_streams:
             fns[4]()
             with torch.cuda.stream(side):

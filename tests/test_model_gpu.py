@@ -394,6 +394,39 @@ def test_flat_adamw_matches_torch_clip_and_adamw(ops):
             np.testing.assert_allclose(q.detach().cpu().numpy(), p.detach().cpu().numpy(), rtol=2e-6, atol=1e-7)
 
 
+def test_flat_adamw_keeps_bf16_weight_images_current(ops):
+    """FlatAdamW.maintain_image: the update kernel that also stores bf16(new weight) into a padded [rows, Kp] image gives
+    the SAME parameters, bit for bit, as the plain update, the image equals a cast of the parameter after every step,
+    pad columns stay untouched, parameters without an image are updated as before; unsuitable pairs are refused."""
+    torch.manual_seed(3)
+    shapes = [(64, 20), (20,), (48, 24), (7, 12), (5,)]
+    base = [torch.randn(s, device=DEV) for s in shapes]
+    pa = [p.clone().requires_grad_(True) for p in base]
+    pb = [p.clone().requires_grad_(True) for p in base]
+    oa, ob = ops.FlatAdamW(pa, lr=1e-2, max_norm=0.3), ops.FlatAdamW(pb, lr=1e-2, max_norm=0.3)
+    img0 = torch.full((64, 32), 5.0, dtype=torch.bfloat16, device=DEV)      # Kp = 32 > K = 20: columns 20.. are padding
+    img2 = torch.zeros((48, 24), dtype=torch.bfloat16, device=DEV)
+    assert ob.maintain_image(pb[0], img0) and ob.maintain_image(pb[2], img2) and ob.maintain_image(pb[0], img0)
+    assert ob.maintains(img0) and ob.images_version == 2
+    assert not ob.maintain_image(pb[1], torch.zeros((20, 4), dtype=torch.bfloat16, device=DEV))     # not a matrix
+    assert not ob.maintain_image(pb[3], torch.zeros((7, 12), dtype=torch.float32, device=DEV))      # not a bf16 image
+    assert not ob.maintain_image(base[0], torch.zeros((64, 20), dtype=torch.bfloat16, device=DEV))  # not its parameter
+    np.testing.assert_array_equal(img0[:, :20].float().cpu().numpy(), pb[0].detach().bfloat16().float().cpu().numpy())
+    for step in range(4):
+        grads = [torch.randn(s, device=DEV) * (3.0 if step % 2 else 0.01) for s in shapes]
+        for q, r, gr in zip(pa, pb, grads):
+            q.grad.copy_(gr); r.grad.copy_(gr)
+        oa.step(); ob.step()
+        torch.cuda.synchronize()
+        assert torch.equal(oa.flat_param, ob.flat_param) and torch.equal(oa.exp_avg_sq, ob.exp_avg_sq)
+        assert torch.equal(img0[:, :20], pb[0].detach().bfloat16()) and torch.equal(img2, pb[2].detach().bfloat16())
+        assert bool((img0[:, 20:] == 5.0).all())
+    with torch.no_grad():
+        pb[2].mul_(2.0)
+    ob.refresh_images()
+    assert torch.equal(img2, pb[2].detach().bfloat16())
+
+
 # ------------------------------------------------------------------ fused small-MLP stages
 
 @pytest.mark.parametrize("b,F_,dt", [(512, 256, torch.float32), (37, 70, torch.float32), (512, 256, torch.bfloat16), (300, 64, torch.float32)])
