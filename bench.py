@@ -462,9 +462,14 @@ def _main(real_stdout):
         lat_x, lat_y = synthetic_latents(I, 100 + rank), synthetic_latents(J, 200 + rank)
         solver.set_cost_from_latents(lat_x, lat_y)
         t0 = time.perf_counter()
-        info = solver.solve(OT_CFG)                 # whole 6-stage solve; leaves a converged state
+        info = solver.solve(OT_CFG)                 # whole 6-stage solve (first call: code objects load, attributes are set)
+        torch.cuda.synchronize()
+        solve_cold_s = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        info2 = solver.solve(OT_CFG)                # the same solve again from scratch; leaves a converged state
         torch.cuda.synchronize()
         solve_s = time.perf_counter() - t0
+        assert list(info2.stage_iters) == list(info.stage_iters)
         want_parity = rank == 0 and world == 1 and not args.no_cpu_baseline and not args.no_sinkhorn_parity
         plan_first = solver.plan("numpy") if want_parity else None     # (before the timed iterations move a, b on)
         for _ in range(args.warmup):
@@ -490,7 +495,7 @@ def _main(real_stdout):
         ach = alg / (kt[dom] * 1e-3) / 1e9
         sk_res = {"value": world * iters / el, "unit": "Sinkhorn iters/s", "ms_per_iter": 1e3 * el / iters,
                   "event_ms_per_iter": ev_ms / iters, "problem": f"{I}x{J}", "storage": args.ot_storage,
-                  "full_solve_s": solve_s, "full_solve_iters": int(sum(info.stage_iters)),
+                  "full_solve_s": solve_s, "full_solve_first_call_s": solve_cold_s, "full_solve_iters": int(sum(info.stage_iters)),
                   "iters_per_s_with_convergence_checks": ck_it / (ck_ms * 1e-3)}
         roof = {"bound": "hbm", "kernel": "k_" + dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS, "traffic": None, "alg_bytes_per_launch": alg,

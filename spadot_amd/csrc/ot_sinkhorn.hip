@@ -59,6 +59,10 @@ namespace {
 constexpr int WAVE = 64;
 constexpr int ROW_WAVES = 4;           // waves (= rows) per 256-thread block in row-oriented kernels
 constexpr int MAX_BATCH = 64;          // max scaling iterations per convergence check
+#ifndef SPADOT_OT_FAST_EXP
+#define SPADOT_OT_FAST_EXP 1
+#endif
+constexpr bool FAST_EXP_F32 = SPADOT_OT_FAST_EXP != 0;   // fp32-stored K built with exp_to_f32 (0: fp64 exp(), A/B builds)
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
@@ -144,6 +148,20 @@ __device__ __forceinline__ double clamp_inf(double x) {
 // K = exp((u_i + v_j - C_ij)/eps) (ot_func.cpp:563-567, :802-806); pad columns written as 0.
 // `flag` (may be null): skip the whole launch unless *flag != 0 (device-side tau decision).
 // ------------------------------------------------------------------------------------------
+// exp(x) for a value that is about to be ROUNDED TO FP32 anyway (fp32 storage of K): the argument is reduced in fp64
+// (x log2 e = n + f, |f| <= 1/2, so the 6e-8 relative precision of an fp32 argument never meets a magnitude of hundreds),
+// 2^f comes from the hardware's fp32 exponential (v_exp_f32, ~1 ulp) and 2^n is an exponent-field add: ~10 instructions
+// against ~40 fp64 ones for exp() -- k_build_K was bound by those, not by HBM (3.7 TB/s).  Relative error ~1.5e-7, the
+// same order as the rounding to fp32 that follows.  Underflows to 0 like exp (x < -87.3 gives 0 in fp32 either way).
+__device__ __forceinline__ float exp_to_f32(double x) {
+    const double y = x * 1.4426950408889634;                   // log2(e)
+    if (!(y > -150.0)) return (y != y) ? __builtin_nanf("") : 0.f;     // (also -inf: cost +inf, and NaN)
+    if (y > 128.0) return __builtin_inff();
+    const double n = rint(y);
+    const float f = (float)(y - n);
+    return ldexpf(__builtin_amdgcn_exp2f(f), (int)n);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_build_K(T *__restrict__ K, const T *__restrict__ C,
                                                  const double *__restrict__ u,
@@ -160,10 +178,16 @@ __global__ __launch_bounds__(256) void k_build_K(T *__restrict__ K, const T *__r
     for (int i = blockIdx.y; i < I; i += gridDim.y) {
         const double ui = u[i];
         double c[V], o[V];
-        unpack<T>(*reinterpret_cast<const VT *>(C + (size_t)i * ld + j), c);
+        // C is read once and K written once per launch, both larger than every cache: non-temporal
+        unpack<T>(__builtin_nontemporal_load(reinterpret_cast<const VT *>(C + (size_t)i * ld + j)), c);
+        if (std::is_same<T, float>::value && FAST_EXP_F32) {
 #pragma unroll
-        for (int k = 0; k < V; k++) o[k] = (j + k < J) ? exp((ui + vv[k] - c[k]) / eps) : 0.0;
-        *reinterpret_cast<VT *>(K + (size_t)i * ld + j) = pack<T>(o);
+            for (int k = 0; k < V; k++) o[k] = (j + k < J) ? (double)exp_to_f32((ui + vv[k] - c[k]) / eps) : 0.0;
+        } else {
+#pragma unroll
+            for (int k = 0; k < V; k++) o[k] = (j + k < J) ? exp((ui + vv[k] - c[k]) / eps) : 0.0;
+        }
+        __builtin_nontemporal_store(pack<T>(o), reinterpret_cast<VT *>(K + (size_t)i * ld + j));
     }
 }
 
@@ -380,13 +404,13 @@ __device__ __forceinline__ void fused_load(FusedRows<T, VPT, R> &buf, const T *_
     }
 }
 
-template <typename T, int VPT, int R, typename WT, int PAR>
+template <typename T, int VPT, int R, typename WT, int PAR, bool WRS = false>
 __device__ __forceinline__ void fused_group(FusedRows<T, VPT, R> &buf, int row0, int row_end,
                                             const WT *wl, double *red,
                                             double *colacc, double *__restrict__ a,
                                             double *__restrict__ old_a, double *__restrict__ adx,
                                             const double *rowc, int band0, int band_rows, double alpha1,
-                                            double inv_l1e, double tau, int ld, int *flag) {
+                                            double inv_l1e, double tau, int ld, int *flag, double *__restrict__ rs_out = nullptr) {
     constexpr int V = Vec<T>::N;
     constexpr int NW = FUSED_THREADS / 64;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -441,6 +465,7 @@ __device__ __forceinline__ void fused_group(FusedRows<T, VPT, R> &buf, int row0,
             a[row] = an;
             adx[row] = x;
             if (an > tau) *flag = 1;
+            if (WRS) rs_out[row] = t;          // sum_j K_ij w_j with the w this pass started from: the gap measure's row sums
         }
     }
 #pragma unroll
@@ -457,12 +482,16 @@ __device__ __forceinline__ void fused_group(FusedRows<T, VPT, R> &buf, int row0,
     }
 }
 
-template <typename T, int VPT, int R, typename WT = double>
+// WRS = true (the first pass of a batch in the pipelined last-stage loop): the row sums s_i = sum_j K_ij w_j the pass
+// computes anyway are also stored to rs_out -- they are exactly what the duality-gap measure of the state the pass
+// STARTED from needs, so that measure costs no sweep of its own (process_stage).
+template <typename T, int VPT, int R, typename WT = double, bool WRS = false>
 __global__ __launch_bounds__(FUSED_THREADS) void k_fused_pass(
     const T *__restrict__ K, const double *__restrict__ w, double *__restrict__ a,
     double *__restrict__ old_a, double *__restrict__ adx, const double *__restrict__ p,
     const double *__restrict__ dx, const double *__restrict__ u, double alpha1, double inv_l1e,
-    double tau, T *__restrict__ part, int I, int ld, int rows_per_block, int *flag, const int *__restrict__ stop) {
+    double tau, T *__restrict__ part, int I, int ld, int rows_per_block, int *flag, const int *__restrict__ stop,
+    double *__restrict__ rs_out) {
     if (stop != nullptr && *stop != 0) return;       // a speculatively enqueued batch behind the converged one: nothing to do
     constexpr int V = Vec<T>::N;
     extern __shared__ double smem[];
@@ -507,8 +536,8 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_fused_pass(
 #pragma unroll
     for (int k = 0; k < VPT * V; k++) colacc[k] = 0.0;
     __syncthreads();
-#define FUSED_GROUP(PAR, BUF, G) fused_group<T, VPT, R, WT, PAR>(BUF, G, r1, wl, red, colacc, a, old_a, adx, rowc, r0, \
-                                                               rows_per_block, alpha1, inv_l1e, tau, ld, flag)
+#define FUSED_GROUP(PAR, BUF, G) fused_group<T, VPT, R, WT, PAR, WRS>(BUF, G, r1, wl, red, colacc, a, old_a, adx, rowc, r0, \
+                                                                    rows_per_block, alpha1, inv_l1e, tau, ld, flag, rs_out)
     int g = r0;
     // steady state: both loads unconditional (a conditional load would make the compiler wait for ALL outstanding
     // loads at the join, i.e. undo the double buffering); the loop ends while both buffers still hold valid rows
@@ -1119,7 +1148,9 @@ struct spadot_ot_solver {
     // length-ld vectors
     double *b = nullptr, *old_b = nullptr, *v = nullptr, *q = nullptr, *dy = nullptr, *w = nullptr,
            *tcol = nullptr;
-    double *backup = nullptr;  // snapshot of the six mutable vectors (a, old_a, adx, b, old_b, w)
+    double *backup = nullptr;  // two snapshots of the six mutable vectors (a, old_a, adx, b, old_b, w): backup + which * mut_count
+    int backup_sel = 0;        // which of the two snapshot()/restore() use
+    bool want_rowsums = false; // next fused pass also stores its row sums to rt (pipelined gap measure)
     size_t mut_count = 0;
     double *red = nullptr;     // block partials of the vector reductions
     int redo_batches = 0;
@@ -1206,10 +1237,10 @@ void sum_kbar(spadot_ot_solver *s, const void *M, double eps, bool from_cost) {
 
 struct IterParams { double eps, tau, l1, l2, al1, al2; };
 
-template <typename T, int VPT, int R, typename WT = double>
-void launch_fused(spadot_ot_solver *s, const IterParams &P, int *flag) {
+template <typename T, int VPT, int R, typename WT, bool WRS>
+void launch_fused_k(spadot_ot_solver *s, const IterParams &P, int *flag) {
     static bool attr_set = false;
-    auto kern = k_fused_pass<T, VPT, R, WT>;
+    auto kern = k_fused_pass<T, VPT, R, WT, WRS>;
     if (!attr_set) {
         HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
@@ -1217,7 +1248,13 @@ void launch_fused(spadot_ot_solver *s, const IterParams &P, int *flag) {
     hipLaunchKernelGGL(kern, dim3(s->fused_blocks), dim3(FUSED_THREADS), s->fused_lds, s->stream,
                        (const T *)s->K, s->w, s->a, s->old_a, s->adx, s->p, s->dx, s->u, P.al1,
                        1.0 / (P.l1 + P.eps), P.tau, (T *)s->part, s->I, s->ld, s->fused_rows_per_block, flag,
-                       (const int *)s->stop_arg);
+                       (const int *)s->stop_arg, WRS ? s->rt : (double *)nullptr);
+}
+// (s->want_rowsums: set around the first pass of a pipelined batch)
+template <typename T, int VPT, int R, typename WT = double>
+void launch_fused(spadot_ot_solver *s, const IterParams &P, int *flag) {
+    if (s->want_rowsums) launch_fused_k<T, VPT, R, WT, true>(s, P, flag);
+    else launch_fused_k<T, VPT, R, WT, false>(s, P, flag);
 }
 
 template <typename T> void fused_pass_T(spadot_ot_solver *s, const IterParams &P, int *flag);
@@ -1302,6 +1339,19 @@ template <typename T> void one_iteration_T(spadot_ot_solver *s, const IterParams
     if (absorb) absorb_if_flagged(s, P, flag);
 }
 
+// The two launches of a fused iteration on their own (the pipelined last-stage loop puts the gap measure between them).
+template <typename T> void fused_colfin_T(spadot_ot_solver *s, const IterParams &P, int *flag) {
+    hipLaunchKernelGGL(k_col_fin2<T>, dim3((s->ld + 63) / 64), dim3(1024), 0, s->stream, (const T *)s->part,
+                       s->fused_blocks, s->b, s->old_b, s->w, s->q, s->dy, s->v, P.al2,
+                       1.0 / (P.l2 + P.eps), P.tau, s->J, s->ld, flag, s->tcol, 0, (const int *)s->stop_arg);
+}
+void fused_pass_any(spadot_ot_solver *s, const IterParams &P, int *flag) {
+    if (s->storage == SPADOT_F32) fused_pass_T<float>(s, P, flag); else fused_pass_T<double>(s, P, flag);
+}
+void fused_colfin_any(spadot_ot_solver *s, const IterParams &P, int *flag) {
+    if (s->storage == SPADOT_F32) fused_colfin_T<float>(s, P, flag); else fused_colfin_T<double>(s, P, flag);
+}
+
 // `iters` scaling iterations, no host sync.
 //   safe mode (absorb = true): after every iteration the tau-absorb pair runs and acts if that
 //     iteration's flag is set (ot_func.cpp:778-819) -- exact reference semantics at any tau.
@@ -1332,16 +1382,18 @@ __global__ __launch_bounds__(256) void k_copy_unless(double *__restrict__ dst, c
     for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (size_t)gridDim.x * 256) dst[k] = src[k];
 }
 void snapshot(spadot_ot_solver *s) {
+    double *dst = s->backup + (size_t)s->backup_sel * s->mut_count;
     if (s->stop_arg != nullptr) {      // speculated batch: the snapshot of a batch behind the stopping one must not be taken
         const size_t n = s->mut_count;
         hipLaunchKernelGGL(k_copy_unless, dim3((unsigned)std::min<size_t>((n + 255) / 256, 1024)), dim3(256), 0, s->stream,
-                           s->backup, (const double *)s->a, n, (const int *)s->stop_arg);
+                           dst, (const double *)s->a, n, (const int *)s->stop_arg);
         return;
     }
-    HIP_CHECK(hipMemcpyAsync(s->backup, s->a, sizeof(double) * s->mut_count, hipMemcpyDeviceToDevice, s->stream));
+    HIP_CHECK(hipMemcpyAsync(dst, s->a, sizeof(double) * s->mut_count, hipMemcpyDeviceToDevice, s->stream));
 }
 void restore(spadot_ot_solver *s) {
-    HIP_CHECK(hipMemcpyAsync(s->a, s->backup, sizeof(double) * s->mut_count, hipMemcpyDeviceToDevice, s->stream));
+    HIP_CHECK(hipMemcpyAsync(s->a, s->backup + (size_t)s->backup_sel * s->mut_count, sizeof(double) * s->mut_count,
+                             hipMemcpyDeviceToDevice, s->stream));
 }
 
 double read_gap(spadot_ot_solver *s) {
@@ -1401,6 +1453,83 @@ void gap_measure(spadot_ot_solver *s, const IterParams &P, void *Rout) {
     else gap_measure_T<double>(s, P, Rout);
 }
 
+int spec_batches() { static const int v = [] { const char *e = getenv("SPADOT_OT_SPEC_BATCHES"); return e ? atoi(e) : 3; }(); return v; }
+bool pipe_gap() { static const bool v = [] { const char *e = getenv("SPADOT_OT_PIPE_GAP"); return !(e && e[0] == '0'); }(); return v; }
+
+// The pipelined last-stage loop (see process_stage): groups of SPEC batches until the gap is at or below `threshold`
+// (or max_groups groups have run; < 0: no limit).  Updates gap, cur_iter, done (iterations) and nchecks.
+void pipelined_gap_loop(spadot_ot_solver *s, const IterParams &P, int batch_size, double threshold, int SPEC, int max_iter,
+                    int max_groups, double &gap, int &cur_iter, int &done, int &nchecks) {
+    const int iters = batch_size;
+    const int nblk = (std::max(s->I, s->J) + 255) / 256;
+    bool carry = false;                 // the head of batch `par` has been enqueued (and the batch before it did not stop)
+    int par = 0;                        // snapshot / flag slot of the next batch to start (or of the carried one)
+    auto head = [&](int slot, int measure_batch, int measure_slot) {
+        s->backup_sel = slot;
+        snapshot(s);
+        HIP_CHECK(hipMemsetAsync(s->flags + slot, 0, sizeof(int), s->stream));
+        s->want_rowsums = true;
+        fused_pass_any(s, P, s->flags + slot);
+        s->want_rowsums = false;
+        if (measure_batch >= 0) {       // the batch before: a = old_a (the pass has moved a on), b and tcol still its own
+            hipLaunchKernelGGL(k_gap2_part, dim3(nblk), dim3(256), 0, s->stream, s->rt, s->tcol, s->old_a, s->b, s->u, s->v,
+                               s->p, s->q, P.eps, P.l1, P.l2, s->I, s->J, s->red, (const int *)s->stop_arg);
+            hipLaunchKernelGGL(k_gap2_final, dim3(1), dim3(256), 0, s->stream, s->red, nblk, P.eps, P.l1, P.l2, s->I, s->J,
+                               s->scal, threshold, measure_batch, s->stop_arg, (const int *)(s->flags + measure_slot));
+        }
+    };
+    auto body = [&](int slot) {
+        fused_colfin_any(s, P, s->flags + slot);
+        for (int t = 1; t < iters; t++) { fused_pass_any(s, P, s->flags + slot); fused_colfin_any(s, P, s->flags + slot); }
+    };
+    int groups = 0;
+    while (gap > threshold && (max_groups < 0 || groups < max_groups)) {
+        groups++;
+        if ((long long)cur_iter + (long long)(SPEC + 1) * iters >= max_iter) break;
+        HIP_CHECK(hipMemsetAsync(s->ctl, 0, sizeof(int) * 4, s->stream));
+        s->stop_arg = s->ctl;
+        const int par0 = par;           // slot of this group's batch 0
+        for (int j = 0; j < SPEC; j++) {
+            if (!(carry && j == 0)) head(par, j - 1, par ^ 1);
+            body(par);
+            par ^= 1;
+        }
+        head(par, SPEC - 1, par ^ 1);   // the next batch's head measures this group's last batch
+        s->stop_arg = nullptr;
+        HIP_CHECK(hipMemcpyAsync(s->h_ctl, s->ctl, sizeof(int) * 4, hipMemcpyDeviceToHost, s->stream));
+        gap = read_gap(s);
+        const int conv = s->h_ctl[1], taub = s->h_ctl[2];
+        if (taub != 0) {
+            // batch taub - 1 of this group exceeded tau: back to ITS snapshot, redo it exactly, measure it the plain way
+            const int before = taub - 1;
+            done += before * iters; cur_iter += before * iters; nchecks += before;
+            s->backup_sel = (par0 + before) & 1;
+            restore(s);
+            run_iterations(s, P, iters, /*absorb=*/true);
+            gap_measure_fast(s, P);
+            gap = read_gap(s);
+            s->redo_batches++;
+            done += iters; cur_iter += iters; nchecks++;
+            carry = false;
+            par = 0;
+        } else if (conv != 0) {
+            // batch conv - 1 converged: the snapshot taken at the head of the batch after it is the state it left
+            done += conv * iters; cur_iter += conv * iters; nchecks += conv;
+            s->backup_sel = (par0 + conv) & 1;
+            restore(s);
+            carry = false;
+        } else {
+            done += SPEC * iters; cur_iter += SPEC * iters; nchecks += SPEC;
+            carry = true;               // the head of batch `par` is in place; its body opens the next group
+        }
+    }
+    if (carry) {                        // leaving with a head enqueued (max_iter is near): undo its pass
+        s->backup_sel = par;
+        restore(s);
+    }
+    s->backup_sel = 0;
+}
+
 // ot_func.cpp:830-930 on device state.  Returns the measure; *iters_done counts scaling iterations.
 // The reference's cur_iter bookkeeping (including its -1 quirk, :821-824 + :869) is kept on the host.
 double process_stage(spadot_ot_solver *s, const IterParams &P, bool last_stage, int batch_size,
@@ -1417,7 +1546,19 @@ double process_stage(spadot_ot_solver *s, const IterParams &P, bool last_stage, 
     // Fast mode on a fused geometry: SPEC batches are enqueued at a time and the DEVICE decides after each whether the stage is
     // over (k_drift_final / k_gap2_final -> ctl); the batches behind the deciding one return at once, and the host reads one
     // 16-byte record per group instead of stalling the queue after every batch.  Same batches, same order, same counts.
-    static const int SPEC = [] { const char *e = getenv("SPADOT_OT_SPEC_BATCHES"); return e ? atoi(e) : 3; }();
+    const int SPEC = spec_batches();
+    const bool PIPE = pipe_gap();
+    // Last stage: the duality-gap measure of the state a batch leaves needs the row sums sum_j K_ij (b.dy)_j -- a sweep of K
+    // of its own (k_fused_rowdot, 60 us per 5 iterations at 10k x 10k).  They are also the first thing the NEXT iteration's
+    // fused pass computes.  So the loop is pipelined by one pass: the head of batch j + 1 = {snapshot, first fused pass
+    // (storing its row sums), MEASURE of batch j} and the measure reads old_a (= a of batch j's end, the pass has just
+    // moved a on), b and the column sums of batch j's last finalise, which the head leaves untouched.  A converged batch
+    // j sets the stop word there; the rest of batch j + 1 returns at once and the host restores batch j + 1's snapshot
+    // (= the state batch j left).  Two snapshots and two tau flags alternate, so that a tau flag raised by batch j
+    // still finds batch j's own snapshot.  Same batches, same iteration counts; what is spent per batch is one vector
+    // measure, what is wasted is ONE pass at the end.
+    if (fast && last_stage && SPEC > 1 && PIPE && s->fused_vpt > 0 && batch_size <= MAX_BATCH)
+        pipelined_gap_loop(s, P, batch_size, threshold, SPEC, max_iter, -1, gap, cur_iter, done, nchecks);
     while (fast && SPEC > 1 && s->fused_vpt > 0 && gap > threshold) {
         const int iters = last_stage ? batch_size : 5;
         if (cur_iter + SPEC * iters >= max_iter) break;          // near max_iter: the batch-by-batch loop below keeps the quirks
@@ -1583,7 +1724,7 @@ int spadot_ot_create(spadot_ot_solver **out, int I, int J, int storage, void *st
     double *cb = vb + s->mut_count;
     s->u = cb; s->p = cb + I; s->dx = cb + 2 * (size_t)I;
     s->v = cb + 3 * (size_t)I; s->q = s->v + L; s->dy = s->v + 2 * L; s->tcol = s->v + 3 * L;
-    s->backup = (double *)dmalloc(sizeof(double) * s->mut_count);
+    s->backup = (double *)dmalloc(sizeof(double) * 2 * s->mut_count);
     s->red = (double *)dmalloc(sizeof(double) * 8 * ((size_t)std::max<size_t>(I, L) / 256 + 2));
     s->part = (double *)dmalloc(sizeof(double) * (size_t)std::max(s->nchunk, s->fused_blocks) * L);
     s->rt = (double *)dmalloc(sizeof(double) * 4 * (size_t)I);
@@ -1946,23 +2087,34 @@ int spadot_ot_run_checked(spadot_ot_solver *s, const spadot_ot_config *cfg, doub
     if (last_stage) sum_kbar(s, s->C, eps_stage, true);
     HIP_CHECK(hipStreamSynchronize(s->stream));
     const int iters = last_stage ? cfg->batch_size : 5;
+    int ran = nbatches * iters;
     HIP_CHECK(hipEventRecord(s->ev0, s->stream));
-    for (int k = 0; k < nbatches; k++) {
-        snapshot(s);
-        run_iterations(s, P, iters, false);
-        if (last_stage) gap_measure_fast(s, P); else drift_measure(s, P.eps);
-        read_gap(s);
-        if (s->h_flags[0] != 0) {
-            restore(s);
-            run_iterations(s, P, iters, true);
+    if (last_stage && spec_batches() > 1 && pipe_gap() && s->fused_vpt > 0 && iters <= MAX_BATCH) {
+        // what spadot_ot_solve's last stage runs: groups of speculated batches, the gap measure taken from the next
+        // batch's first pass, one 16-byte read-back per group; a threshold below every measure keeps it going
+        double gap = 1e100;
+        int cur = 0, done = 0, checks = 0;
+        const int SPEC = spec_batches();
+        pipelined_gap_loop(s, P, iters, -INFINITY, SPEC, 1 << 30, (nbatches + SPEC - 1) / SPEC, gap, cur, done, checks);
+        ran = done;
+    } else {
+        for (int k = 0; k < nbatches; k++) {
+            snapshot(s);
+            run_iterations(s, P, iters, false);
             if (last_stage) gap_measure_fast(s, P); else drift_measure(s, P.eps);
             read_gap(s);
+            if (s->h_flags[0] != 0) {
+                restore(s);
+                run_iterations(s, P, iters, true);
+                if (last_stage) gap_measure_fast(s, P); else drift_measure(s, P.eps);
+                read_gap(s);
+            }
         }
     }
     HIP_CHECK(hipEventRecord(s->ev1, s->stream));
     HIP_CHECK(hipEventSynchronize(s->ev1));
     if (ms_out) HIP_CHECK(hipEventElapsedTime(ms_out, s->ev0, s->ev1));
-    if (iters_out) *iters_out = nbatches * iters;
+    if (iters_out) *iters_out = ran;
     return 0;
     SPADOT_LEAVE(SPADOT_EHIP)
 }
