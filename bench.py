@@ -251,11 +251,16 @@ def epoch_block(tu, model, opt, cfg, dd, stepper, T, beta1, torch):
     torch.cuda.synchronize()
     t3 = time.perf_counter()
     model.train()
+    ot_every = int(cfg["ot_config"].get("ot_epochs", 10))
     return {"steps": nsteps, "steps_s": t1 - t0, "update_kmeans_s": t2 - t1, "update_ot_matrix_s": t3 - t2, "total_s": t3 - t0,
-            "steps_per_s_whole_epoch": nsteps / (t3 - t0), "kmeans_backend": cfg.get("kmeans_backend", "device"),
-            "graph_warmup_s": warm_s,
+            "steps_per_s_whole_epoch": nsteps / (t3 - t0),
+            "steps_per_s_reference_cadence": nsteps / ((t2 - t0) + (t3 - t2) / max(1, ot_every)),
+            "kmeans_backend": cfg.get("kmeans_backend", "device"), "graph_warmup_s": warm_s,
             "note": "replayed-graph epoch (epoch >= 2 of a run): every (time point, batch) step, then the per-epoch K-means "
-                    "refit of all time points and the 10x10 OT plans (the reference refits the plans every 10th epoch)"}
+                    "refit of all time points (kmeans_backend 'device': its own k-means++ stream -- the fitted centres are not "
+                    "sklearn's, the labels for given centres are) and the 10x10 OT plans.  steps_per_s_whole_epoch refreshes the "
+                    f"plans EVERY epoch; steps_per_s_reference_cadence every {ot_every}th, as the reference does "
+                    "(_train_utils.py:230-231)"}
 
 
 # ------------------------------------------------------------------------------ main

@@ -237,6 +237,15 @@ int spadot_kmeans_assign(const void *x, const void *centers, int n, int k, int d
  * sums and labels only.  K <= 32, D <= 32.  (KMeans of _train_utils.py:255-269.) */
 int spadot_lloyd_step(const double *X, double *C, int n, int D, int K, int R, double tol, double *part, int *done,
                       double *inertia, int *labels, int update, void *stream);
+/* The same iteration for SEVERAL data sets in one launch pair (the per-epoch K-means of all time points,
+ * _train_utils.py:255-269): group g owns rows xoff[g] .. xoff[g] + npts[g] - 1 of X [sum npts, D] and the restarts
+ * g * rpg .. (g + 1) * rpg - 1 of C [groups * rpg, K, D]; tol[g] is its stopping threshold (device arrays); n_max = the largest
+ * npts (grid size); part needs groups * rpg * ceil(n_max / 256) * (K (D + 1) + 1) doubles.  skip_done != 0: restarts whose
+ * done flag is set are left alone entirely (their centres are final; inertia[r] then still belongs to the centres of the
+ * iteration that froze them -- measure the final one with a call that has skip_done = 0 and every done flag set). */
+int spadot_lloyd_step_groups(const double *X, double *C, const int *xoff, const int *npts, int n_max, int groups, int rpg, int D,
+                             int K, const double *tol, double *part, int *done, double *inertia, int update, int skip_done,
+                             void *stream);
 
 /* Exact kk nearest neighbours of every point among all n points (self included), brute force in fp64, ordered by
  * (squared distance, index): out [n, kk] int32.  x [n, d] fp64, d <= 4, kk <= min(n, 128).  Replaces the host

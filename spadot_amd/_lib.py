@@ -177,6 +177,7 @@ def model_lib():
         "spadot_sqerr_backward": [vp, vp, vp, ll, cd, ci, vp, vp],
         "spadot_kmeans_assign": [vp, vp, ci, ci, ci, ci, vp, vp],
         "spadot_lloyd_step": [vp, vp, ci, ci, ci, ci, cd, vp, vp, vp, vp, ci, vp],
+        "spadot_lloyd_step_groups": [vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, ci, ci, vp],
         "spadot_colsum": [vp, ci, ci, vp, vp],
         "spadot_cast_rows_multi": [vp, vp, vp, vp, vp, ci, vp],
         "spadot_knn": [vp, ci, ci, ci, vp, vp],

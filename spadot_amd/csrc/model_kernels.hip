@@ -1049,9 +1049,14 @@ __global__ __launch_bounds__(KNN_T) void k_knn(const double *__restrict__ x, int
 //                   shift compared with tol, `done` restarts frozen.
 // ------------------------------------------------------------------------------------------
 constexpr int LL_PTS = 256, LL_MAXK = 32, LL_MAXD = 32;
+// Groups (several data sets in one launch: the per-epoch K-means of ALL time points, _train_utils.py:255-269): restart r
+// belongs to group r / rpg, whose points are rows xoff[g] .. xoff[g] + npts[g] - 1 of X; n is then the LARGEST group (grid
+// and label stride); chunks past a group's end return at once.  xoff == nullptr: one data set of n rows, as before.
 __global__ __launch_bounds__(LL_PTS) void k_lloyd_assign(const double *__restrict__ X, const double *__restrict__ C,
                                                          int n, int D, int K, double *__restrict__ part,
-                                                         int *__restrict__ labels /* [R, n] or null */) {
+                                                         int *__restrict__ labels /* [R, n] or null */,
+                                                         const int *__restrict__ xoff, const int *__restrict__ npts, int rpg,
+                                                         const int *__restrict__ skip_done) {
     extern __shared__ double ll_dyn[];           // K*D centres, then 256*D point coordinates
     double *s_c = ll_dyn, *s_x = ll_dyn + (size_t)K * D;
     __shared__ int s_lab[LL_PTS];
@@ -1059,6 +1064,14 @@ __global__ __launch_bounds__(LL_PTS) void k_lloyd_assign(const double *__restric
     const int r = blockIdx.y, chunk = blockIdx.x, t = threadIdx.x;
     const int i = chunk * LL_PTS + t;
     const int nchunk = gridDim.x;
+    const int stride_n = n;
+    if (skip_done != nullptr && skip_done[r] != 0) return;      // a restart that has converged: nothing reads its partials again
+    if (xoff != nullptr) {
+        const int g = r / rpg;
+        n = npts[g];
+        X += (size_t)xoff[g] * D;
+        if (chunk * LL_PTS >= n) return;        // (uniform for the workgroup)
+    }
     for (int e = t; e < K * D; e += LL_PTS) s_c[e] = C[(size_t)r * K * D + e];
     const int rows = min(LL_PTS, n - chunk * LL_PTS);
 #pragma unroll 4
@@ -1073,7 +1086,7 @@ __global__ __launch_bounds__(LL_PTS) void k_lloyd_assign(const double *__restric
             for (int c = 0; c < D; c++) { const double df = s_x[t * D + c] - s_c[k * D + c]; d2 += df * df; }
             if (d2 < best) { best = d2; arg = k; }
         }
-        if (labels) labels[(size_t)r * n + i] = arg;
+        if (labels) labels[(size_t)r * stride_n + i] = arg;
     }
     s_lab[t] = arg;
     const double inertia = block_sum_d(i < n ? best : 0.0, s_red);       // (includes the barrier after s_lab)
@@ -1093,18 +1106,26 @@ __global__ __launch_bounds__(LL_PTS) void k_lloyd_assign(const double *__restric
 
 __global__ __launch_bounds__(256) void k_lloyd_update(const double *__restrict__ part, int nchunk, int D, int K,
                                                       double tol, double *__restrict__ C, int *__restrict__ done,
-                                                      double *__restrict__ inertia) {
+                                                      double *__restrict__ inertia, const int *__restrict__ npts, int rpg,
+                                                      const double *__restrict__ tolv, int skip_done) {
     __shared__ double s_new[LL_MAXK * (LL_MAXD + 1)];
     __shared__ double s_red[16];
     const int r = blockIdx.x, t = threadIdx.x;
+    if (skip_done && done[r] != 0) return;       // frozen: centres and inertia stay (the caller measures the final inertia with skip_done = 0)
     const size_t stride = (size_t)K * (D + 1) + 1;
+    const int slots = nchunk;                    // partial slots per restart (the largest group's chunk count)
+    if (npts != nullptr) {
+        const int g = r / rpg;
+        nchunk = (npts[g] + LL_PTS - 1) / LL_PTS;
+        tol = tolv[g];
+    }
     for (int pq = t; pq < K * (D + 1); pq += 256) {
         double acc = 0.0;
-        for (int ch = 0; ch < nchunk; ch++) acc += part[((size_t)r * nchunk + ch) * stride + pq];
+        for (int ch = 0; ch < nchunk; ch++) acc += part[((size_t)r * slots + ch) * stride + pq];
         s_new[pq] = acc;
     }
     double in = 0.0;
-    for (int ch = t; ch < nchunk; ch += 256) in += part[((size_t)r * nchunk + ch) * stride + K * (D + 1)];
+    for (int ch = t; ch < nchunk; ch += 256) in += part[((size_t)r * slots + ch) * stride + K * (D + 1)];
     in = block_sum_d(in, s_red);
     __syncthreads();
     double sh = 0.0;
@@ -2283,9 +2304,29 @@ int spadot_lloyd_step(const double *X, double *C, int n, int D, int K, int R, do
     hipStream_t st_ = (hipStream_t)stream;
     const int nchunk = (n + LL_PTS - 1) / LL_PTS;
     const size_t lds = sizeof(double) * ((size_t)K * D + (size_t)LL_PTS * D);      // <= 8 KB + 64 KB
-    hipLaunchKernelGGL(k_lloyd_assign, dim3(nchunk, R), dim3(LL_PTS), lds, st_, X, (const double *)C, n, D, K, part, labels);
+    hipLaunchKernelGGL(k_lloyd_assign, dim3(nchunk, R), dim3(LL_PTS), lds, st_, X, (const double *)C, n, D, K, part, labels,
+                       (const int *)nullptr, (const int *)nullptr, 1, (const int *)nullptr);
     if (update)
-        hipLaunchKernelGGL(k_lloyd_update, dim3(R), dim3(256), 0, st_, (const double *)part, nchunk, D, K, tol, C, done, inertia);
+        hipLaunchKernelGGL(k_lloyd_update, dim3(R), dim3(256), 0, st_, (const double *)part, nchunk, D, K, tol, C, done, inertia,
+                           (const int *)nullptr, 1, (const double *)nullptr, 0);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+int spadot_lloyd_step_groups(const double *X, double *C, const int *xoff, const int *npts, int n_max, int groups, int rpg, int D,
+                             int K, const double *tol, double *part, int *done, double *inertia, int update, int skip_done,
+                             void *stream) {
+    if (n_max <= 0 || groups <= 0 || rpg <= 0 || D <= 0 || D > LL_MAXD || K <= 0 || K > LL_MAXK || (long long)groups * rpg > 65535)
+        return -22;
+    if (!X || !C || !xoff || !npts || !tol || !part || !done || !inertia) return -22;
+    if ((size_t)K * D + (size_t)LL_PTS * D > 7936) return -22;
+    hipStream_t st_ = (hipStream_t)stream;
+    const int nchunk = (n_max + LL_PTS - 1) / LL_PTS, R = groups * rpg;
+    const size_t lds = sizeof(double) * ((size_t)K * D + (size_t)LL_PTS * D);
+    hipLaunchKernelGGL(k_lloyd_assign, dim3(nchunk, R), dim3(LL_PTS), lds, st_, X, (const double *)C, n_max, D, K, part,
+                       (int *)nullptr, xoff, npts, rpg, skip_done ? (const int *)done : (const int *)nullptr);
+    if (update)
+        hipLaunchKernelGGL(k_lloyd_update, dim3(R), dim3(256), 0, st_, (const double *)part, nchunk, D, K, 0.0, C, done, inertia,
+                           npts, rpg, tol, skip_done);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 

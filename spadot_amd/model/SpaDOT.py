@@ -156,7 +156,7 @@ class SpaDOT(nn.Module):
         svgp = self.svgp_dict[str(tp)]
         q_mu, q_var = self.SVGPEncoder(Y)
         bc = svgp.batch_constants(X, key=("all", str(tp)))
-        p_m, _, _ = svgp.posterior(bc, q_mu, q_var)
+        p_m, _, _ = svgp.posterior(bc, q_mu, q_var, want_var=False)
         g_mu, _ = self.GATEncoder(Y, edge_index)
         lat = torch.cat((p_m.float(), g_mu), dim=1)
         return lat.detach().cpu().numpy() if as_numpy else lat.detach()

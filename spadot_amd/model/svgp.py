@@ -237,9 +237,11 @@ class SVGP(nn.Module):
             self._k2j = ((K_mm @ K_mm) / self.jitter).unsqueeze(0)
         return self._k2j
 
-    def posterior(self, bc_train, mu, var, bc_test=None, want_logdet_A=False):
+    def posterior(self, bc_train, mu, var, bc_test=None, want_logdet_A=False, want_var=True):
         """Posterior mean and variance at the test points for all latent dims at once.
-        mu, var: [b, L] (encoder output at the training points).  Returns (p_m, p_v, extras)."""
+        mu, var: [b, L] (encoder output at the training points).  Returns (p_m, p_v, extras); want_var=False skips the
+        variance (p_v = None): the per-epoch inference only reads the means (SpaDOT.py:121), and K_nm S_l for b = N_t
+        rows is the larger of its two batched products."""
         mu, var = mu.to(F64), var.to(F64)
         bt = bc_train if bc_test is None else bc_test
         W = 1.0 / var
@@ -251,6 +253,8 @@ class SVGP(nn.Module):
         t = torch.einsum("bm,bl->lm", bc_train.K_nm, mu * W)              # K_mn (y / noise)
         St = torch.einsum("lmn,ln->lm", S_inv, t)
         p_m = bc_train.c * (bt.K_nm @ St.T)                                # [b_test, L]
+        if not want_var:
+            return p_m, None, (S_inv, St, logdet_A)
         KS = torch.einsum("bm,lmn->lbn", bt.K_nm, S_inv)                  # [L, b_test, m]
         p_v = bt.ktilde.unsqueeze(1) + rowdot(KS, bt.K_nm).T
         return p_m, p_v, (S_inv, St, logdet_A)

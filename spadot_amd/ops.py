@@ -1178,6 +1178,18 @@ def lloyd_steps(X, C, tol, done, inertia, part, steps):
                                      _stream()), "spadot_lloyd_step")
 
 
+def lloyd_steps_groups(X, C, xoff, npts, n_max, groups, rpg, tol, done, inertia, part, steps, update=True, skip_done=False):
+    """`steps` Lloyd iterations for several data sets at once (spadot_lloyd_step_groups): X [sum n, D] fp64, C [groups * rpg, K,
+    D], xoff / npts int32 [groups], tol fp64 [groups] device tensors; C / done / inertia updated in place."""
+    D = X.shape[1]
+    K = C.shape[1]
+    lib = model_lib()
+    for _ in range(steps):
+        _check(lib.spadot_lloyd_step_groups(_p(X), _p(C), _p(xoff), _p(npts), int(n_max), int(groups), int(rpg), D, K, _p(tol),
+                                            _p(part), _p(done), _p(inertia), 1 if update else 0, 1 if skip_done else 0, _stream()),
+               "spadot_lloyd_step_groups")
+
+
 def knn(coords, kk):
     """Indices [n, kk] (int32, device) of the kk nearest points of every point, itself included, ordered by
     (distance, index); brute force in fp64 on the device (include/spadot_model.h: spadot_knn)."""

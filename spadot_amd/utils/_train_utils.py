@@ -14,6 +14,7 @@ What differs from the reference, on purpose (SURVEY 7 "hard parts", App. D):
 import os
 import random
 from collections import OrderedDict
+from collections.abc import Mapping
 from time import time
 
 import numpy as np
@@ -187,11 +188,39 @@ def _assign_or_copy(store, key, value):
     return cur is not None
 
 
+class _IndexToLabel(Mapping):
+    """{global spot index: label} of one time point (the reference's kmeans_index_dict[tp], SpaDOT.py:49) as a read-only
+    mapping whose dict is built from its two arrays on first use: nothing on the training path reads it (the step gets
+    its labels from the device mirror), and building 10^4-entry dicts for every time point every epoch cost
+    milliseconds of pure Python."""
+
+    def __init__(self, idx, labels):
+        self._pending, self._d = (np.asarray(idx), np.asarray(labels)), None
+
+    def _dict(self):
+        if self._d is None:
+            idx, labels = self._pending
+            self._d, self._pending = dict(zip(idx.tolist(), labels.tolist())), None
+        return self._d
+
+    def __getitem__(self, k):
+        return self._dict()[k]
+
+    def __iter__(self):
+        return iter(self._dict())
+
+    def __len__(self):
+        return len(self._pending[0]) if self._d is None else len(self._d)
+
+    def __repr__(self):
+        return repr(self._dict())
+
+
 def _set_kmeans_state(model, tp, centers, labels, global_idx, device):
     """Stores the reference's three dicts (SpaDOT.py:47-50) and their device mirror."""
     model.kmeans_center_dict[tp] = centers
     model.kmeans_cluster_dict[tp] = labels.tolist()
-    model.kmeans_index_dict[tp] = dict(zip(np.asarray(global_idx).tolist(), labels.tolist()))
+    model.kmeans_index_dict[tp] = _IndexToLabel(global_idx, labels)
     if not hasattr(model, "_kmeans_dev"):
         model._kmeans_dev, model._gamma_dev = {}, {}
     cl = sorted(set(labels.tolist()))
@@ -213,19 +242,25 @@ def _update_Kmeans(model, model_config, dataloader_dict, timepoints=None):
     model.eval()
     device = torch.device(model_config["device"])
     backend = model_config.get("kmeans_backend", "device")
+    tps = [tp for tp in dataloader_dict["datasets"] if timepoints is None or tp in timepoints]
     with torch.no_grad():
-        for tp in dataloader_dict["datasets"]:
-            if timepoints is not None and tp not in timepoints:
-                continue
+        if backend == "device":
+            # all inferences first (no host synchronisation between them), then ONE batched fit for all time points
+            # (spadot_amd.kmeans.fit_many: selection rounds and Lloyd iterations of all T x n_init restarts together)
+            from ..kmeans import fit_many
+            lat = []
+            for tp in tps:
+                loc, Y, ix = dataloader_dict["datasets"][tp]
+                lat.append(model.all_latent_samples(loc, Y, dataloader_dict["graphs"][tp], tp, as_numpy=False))
+            fits = fit_many(lat, model_config["n_clusters"], random_state=model_config["seed"], n_init=10) if lat else []
+            for tp, km in zip(tps, fits):
+                _set_kmeans_state(model, tp, km.cluster_centers_, km.labels_, dataloader_dict["datasets"][tp][2], device)
+            return
+        for tp in tps:
             loc, Y, ix = dataloader_dict["datasets"][tp]
-            if backend == "device":
-                from ..kmeans import KMeansDevice
-                latent = model.all_latent_samples(loc, Y, dataloader_dict["graphs"][tp], tp, as_numpy=False)
-                km = KMeansDevice(model_config["n_clusters"], random_state=model_config["seed"], n_init=10).fit(latent)
-            else:
-                from sklearn.cluster import KMeans
-                latent = model.all_latent_samples(loc, Y, dataloader_dict["graphs"][tp], tp)
-                km = KMeans(n_clusters=model_config["n_clusters"], random_state=model_config["seed"], n_init=10).fit(latent)
+            from sklearn.cluster import KMeans
+            latent = model.all_latent_samples(loc, Y, dataloader_dict["graphs"][tp], tp)
+            km = KMeans(n_clusters=model_config["n_clusters"], random_state=model_config["seed"], n_init=10).fit(latent)
             _set_kmeans_state(model, tp, km.cluster_centers_, km.labels_, ix, device)
 
 

@@ -408,6 +408,34 @@ def test_device_kmeans_vs_sklearn():
     assert kmh.inertia_ <= 1.01 * skh.inertia_
 
 
+def test_device_kmeans_fit_many_matches_fit_per_data_set():
+    """spadot_amd.kmeans.fit_many (the per-epoch K-means of ALL time points as one batched fit: _update_Kmeans) against
+    KMeansDevice.fit on each data set alone, ragged sizes: the same partition and inertia (centres to rounding: batched
+    products may round differently), labels = the exact nearest-centre rule, deterministic."""
+    from sklearn.metrics import adjusted_rand_score
+    from spadot_amd.kmeans import KMeansDevice, fit_many
+    rng = np.random.default_rng(4)
+    Xs = []
+    for n in (1500, 700, 2300, 257):
+        cen = 3.0 * rng.normal(size=(10, 20))
+        Xs.append(torch.as_tensor(cen[rng.integers(0, 10, n)] + 0.5 * rng.normal(size=(n, 20)), device=DEV))
+    many = fit_many(Xs, 10, random_state=1993, n_init=10)
+    again = fit_many(Xs, 10, random_state=1993, n_init=10)
+    assert len(many) == 4
+    for X, km, km2 in zip(Xs, many, again):
+        one = KMeansDevice(10, random_state=1993, n_init=10).fit(X)
+        assert km.labels_.dtype == np.int32 and km.labels_.shape == (X.shape[0],) and km.cluster_centers_.shape == (10, 20)
+        assert km.inertia_ == pytest.approx(one.inertia_, rel=1e-9)
+        assert adjusted_rand_score(one.labels_, km.labels_) > 0.9999
+        order = np.argsort(km.cluster_centers_[:, 0]); order1 = np.argsort(one.cluster_centers_[:, 0])
+        np.testing.assert_allclose(km.cluster_centers_[order], one.cluster_centers_[order1], rtol=1e-9, atol=1e-9)
+        Xh = X.cpu().numpy()
+        d = ((Xh[:, None, :] - km.cluster_centers_[None]) ** 2).sum(-1)
+        np.testing.assert_array_equal(km.labels_, d.argmin(1).astype(np.int32))
+        np.testing.assert_array_equal(km.labels_, km2.labels_)
+        np.testing.assert_array_equal(km.cluster_centers_, km2.cluster_centers_)
+
+
 @pytest.mark.parametrize("n_ind", [1100, 1500])
 def test_training_with_more_inducing_points_than_one_sweep_takes(tmp_path, capsys, n_ind):
     """The default inducing-point load (1200 over two time points -> m ~ 600 each; here ~550 and ~750) is beyond one

@@ -1,5 +1,5 @@
-"""Where the per-epoch _update_Kmeans goes after some training (cfg3): inference per time point, k-means++ seeding, Lloyd
-iterations (count, seconds), final assignment + host copies."""
+"""Where the per-epoch _update_Kmeans goes after some training (cfg3): inference per time point, the batched fit of all
+time points (spadot_amd.kmeans.fit_many) against one KMeansDevice.fit per time point, host-side state updates."""
 import os, sys, time, types, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from spadot_amd.synthetic import make_dataset
@@ -28,13 +28,23 @@ model.eval()
 def timed(fn):
     torch.cuda.synchronize(); t0 = time.perf_counter(); r = fn(); torch.cuda.synchronize(); return r, (time.perf_counter() - t0) * 1e3
 with torch.no_grad():
-    for _ in range(5):
-        _, ms = timed(lambda: tu._update_Kmeans(model, cfg, dd)); print(f"_update_Kmeans: {ms:.1f} ms")
-    loc, Y, ix = dd["datasets"][0]
-    lat, ms = timed(lambda: model.all_latent_samples(loc, Y, dd["graphs"][0], 0, as_numpy=False)); print(f"all_latent_samples: {ms:.2f} ms")
+    for _ in range(4):
+        _, ms = timed(lambda: tu._update_Kmeans(model, cfg, dd)); print(f"_update_Kmeans: {ms:.1f} ms", flush=True)
+    lats = []
+    for t in range(T):
+        loc, Y, ix = dd["datasets"][t]
+        lat, ms = timed(lambda: model.all_latent_samples(loc, Y, dd["graphs"][t], t, as_numpy=False)); print(f"all_latent_samples tp {t}: {ms:.2f} ms")
+        lats.append(lat)
+    for _ in range(3):
+        fits, ms = timed(lambda: km_mod.fit_many(lats, cfg["n_clusters"], random_state=cfg["seed"], n_init=10)); print(f"fit_many (5 time points): {ms:.2f} ms, n_iter {fits[0].n_iter_}")
     K = km_mod.KMeansDevice(cfg["n_clusters"], random_state=cfg["seed"], n_init=10)
-    X = lat.to(torch.float64); mean = X.mean(0); Xc = (X - mean).contiguous(); xsq = (Xc * Xc).sum(1)
-    import numpy as np
-    seeds = np.random.RandomState(K.seed).randint(np.iinfo(np.int32).max, size=K.n_init)
-    C, ms = timed(lambda: K._init_centers(Xc, xsq, seeds)); print(f"k-means++ seeding (10 restarts): {ms:.2f} ms")
-    _, ms = timed(lambda: K.fit(lat)); print(f"fit total: {ms:.2f} ms, n_iter {K.n_iter_}")
+    for t in range(2):
+        _, ms = timed(lambda: K.fit(lats[t])); print(f"KMeansDevice.fit tp {t}: {ms:.2f} ms, n_iter {K.n_iter_}")
+    _, ms = timed(lambda: [tu._set_kmeans_state(model, t, fits[t].cluster_centers_, fits[t].labels_, dd["datasets"][t][2], cfg["device"]) for t in range(T)])
+    print(f"_set_kmeans_state x 5: {ms:.2f} ms")
+    # pieces of fit_many under the torch profiler's eyes: count launches
+    from torch.profiler import profile, ProfilerActivity
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        km_mod.fit_many(lats, cfg["n_clusters"], random_state=cfg["seed"], n_init=10)
+        torch.cuda.synchronize()
+    print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=14, max_name_column_width=60))
