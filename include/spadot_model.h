@@ -230,6 +230,18 @@ int spadot_sqerr_backward(const void *g1, const void *y, const void *yhat, long 
 int spadot_kmeans_assign(const void *x, const void *centers, int n, int k, int d, int dtype, int *labels,
                          void *stream);
 
+/* Small fp32 products of the MLP stages with a small footprint (32 x 32 tiles, 256 threads, 8 KB of LDS): they find room on a
+ * compute unit beside the GAT branch's GEMMs, where the library's 256 x 64 macro tiles waited 150-185 us for a whole unit.
+ *   C [M x N] (row stride ldc) = sum_k a(m, k) b(k, n) (+ bias[n] when bias != NULL), k ascending (fixed order):
+ *   mode 0: a = A[m * lda + k], b = B[k * ldb + n]   (dx = g W)
+ *   mode 1: a = A[m * lda + k], b = B[n * ldb + k]   (y = x W^T + bias: the forward map of nn.Linear)
+ *   mode 2: a = A[k * lda + m], b = B[k * ldb + n]   (dW = g^T x)
+ * `batch` such products in one launch, entry z using A + z strideA, B + z strideB, C + z strideC (elements): a long
+ * contraction (mode 2 over hundreds of rows) is cut into row slices whose partial results the caller adds in slice order.
+ * Meant for products of at most a few hundred MFLOP. */
+int spadot_sgemm_small(int mode, const float *A, int lda, const float *B, int ldb, float *C, int ldc, int M, int N, int K,
+                       const float *bias, int batch, long long strideA, long long strideB, long long strideC, void *stream);
+
 /* One Lloyd iteration of K-means for R restarts at once (fp64, no atomics: two fits of the same data are bitwise
  * identical).  X [n, D] (centred data), C [R, K, D] centres (updated in place unless done[r]), part: work space of
  * R * ceil(n/256) * (K*(D+1) + 1) doubles, done [R] int flags (set when the squared centre shift <= tol), inertia [R]
@@ -269,7 +281,9 @@ int spadot_knn(const double *x, int n, int d, int kk, int *out, void *stream);
  *                                att_dst: the logits' own gradient path);                                plan by source
  *                                with att_part (mode 1; h_rows = the layer's input h): block b also leaves the partial sums
  *                                sum_rows ds_src[row] h[row] at att_part[b * part_width + 0 ..] and the ds_dst ones at
- *                                [.. + H C ..] -- the attention-vector gradients up to a column sum over the blocks
+ *                                [.. + H C ..] -- the attention-vector gradients up to a column sum over the blocks;
+ *                                rows pad_from .. pad_to - 1 of `out` (allocated past the last node so that the next GEMM
+ *                                sees a row count that is a multiple of 128) are written as zeros
  *   spadot_gat_edge_dot          g_pre = g_out * (act ? LeakyReLU'(out) : 1) (written), dz[e] = <g_pre[row], h[col]> through
  *                                plan_cell [chunk][32 rows][16] -> edge position or -1; with bias_part block b leaves the
  *                                column sums of its 32 rows of g_pre at bias_part[b * part_width + part_col ..] (the bias
@@ -284,7 +298,7 @@ int spadot_gat_alpha(const float *s_src, const float *s_dst, const int *rowptr, 
 int spadot_gat_aggregate(const void *x, int dtype, const void *acell, const int *plan_rows, const int *plan_sptr,
                          const int *plan_cols, int nb, int max_cols, int H, int C, int mode, const float *vec_a,
                          const float *vec_b, int act, const float *ds_src, const float *ds_dst, void *out,
-                         const void *h_rows, float *att_part, int part_width, void *stream);
+                         const void *h_rows, float *att_part, int part_width, int pad_from, int pad_to, void *stream);
 int spadot_gat_edge_dot(const void *g_out, const void *out, const void *h, int dtype, const int *plan_rows,
                         const int *plan_sptr, const int *plan_cols, const int *plan_cell, int nb, int max_cols, int H,
                         int C, int act, void *g_pre, float *dz, float *bias_part, int part_width, int part_col, void *stream);

@@ -137,7 +137,7 @@ def model_lib():
         "spadot_gat_softmax_backward": [vp, vp, vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp],
         "spadot_gat_ds_src": [vp, vp, vp, ci, ci, vp, vp],
         "spadot_gat_mfma_supported": [ci, ci, ci, ci],
-        "spadot_gat_aggregate": [vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp, vp, vp, ci, vp],
+        "spadot_gat_aggregate": [vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp, vp, vp, ci, ci, ci, vp],
         "spadot_gat_edge_dot": [vp, vp, vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, ci, ci, vp],
         "spadot_gemm_tn_bf16": [vp, ci, vp, ci, vp, ci, ci, ci, ci, vp],
         "spadot_gemm_nn_bf16": [vp, ci, vp, ci, vp, ci, ci, ci, ci, vp],
@@ -176,6 +176,7 @@ def model_lib():
         "spadot_sqerr_forward": [vp, vp, ll, cd, ci, vp, vp, vp],
         "spadot_sqerr_backward": [vp, vp, vp, ll, cd, ci, vp, vp],
         "spadot_kmeans_assign": [vp, vp, ci, ci, ci, ci, vp, vp],
+        "spadot_sgemm_small": [ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, vp, ci, ll, ll, ll, vp],
         "spadot_lloyd_step": [vp, vp, ci, ci, ci, ci, cd, vp, vp, vp, vp, ci, vp],
         "spadot_lloyd_step_groups": [vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, ci, ci, vp],
         "spadot_colsum": [vp, ci, ci, vp, vp],

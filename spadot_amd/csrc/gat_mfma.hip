@@ -248,7 +248,8 @@ __global__ __launch_bounds__(NT, 2) void k_gat_agg(
     const float *__restrict__ vec_b,      // MODE 1: att_dst [H*C]
     int act, const float *__restrict__ ds_src, const float *__restrict__ ds_dst, __bf16 *__restrict__ out,
     const __bf16 *__restrict__ hrows,     // MODE 1, optional: h (the layer's input rows), for the attention-vector gradients
-    float *__restrict__ att_part, int part_width) {   // MODE 1: [nb][part_width] partials: src at column 0, dst at column H*C
+    float *__restrict__ att_part, int part_width,     // MODE 1: [nb][part_width] partials: src at column 0, dst at column H*C
+    int pad_from, int pad_to) {           // rows pad_from .. pad_to - 1 of `out` are set to zero (row padding for the next GEMM)
     using namespace agg;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *ring = smem;
@@ -261,6 +262,16 @@ __global__ __launch_bounds__(NT, 2) void k_gat_agg(
     const int b = item / H, hd = item - b * H;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (b == 0 && pad_to > pad_from) {
+        // The output is allocated with its row count rounded up (the library's GEMMs run 10-17 % faster on M % 128 == 0:
+        // tools/gemm_mpad.py); the rows past the last node must read as zeros there (a weight gradient sums over ALL rows).
+        // Block 0's workgroup of each head clears its 1 KiB slice of them.
+        const size_t HCp = (size_t)H * C;
+        for (int k = tid; k < (pad_to - pad_from) * PPR; k += NT) {
+            const int r = pad_from + k / PPR, pc = k - (k / PPR) * PPR;
+            *reinterpret_cast<uint4 *>(out + (size_t)r * HCp + (size_t)hd * C + (size_t)pc * 8) = make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
     const int s0 = sptr[b], ncol = sptr[b + 1] - s0, nch = ncol / KSTEP;
     const int q0 = s0 / KSTEP;                                            // first global chunk of this block
     for (int k = tid; k < ncol; k += NT) sids[k] = pcol[s0 + k];
@@ -581,14 +592,15 @@ int spadot_gat_ds_src(const float *dz, const int *rowptr_t, const int *eid_t, in
         }                                                                                                          \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), agg::LDS_BYTES, st_, (const __bf16 *)x, (const __bf16 *)acell, plan_rows, \
                            plan_sptr, plan_cols, nb, H, vec_a, vec_b, act, ds_src, ds_dst, (__bf16 *)out,          \
-                           (const __bf16 *)h_rows, att_part, part_width);                                          \
+                           (const __bf16 *)h_rows, att_part, part_width, pad_from, pad_to);                        \
     } while (0)
 
 int spadot_gat_aggregate(const void *x, int dtype, const void *acell, const int *plan_rows, const int *plan_sptr,
                          const int *plan_cols, int nb, int max_cols, int H, int C, int mode, const float *vec_a,
                          const float *vec_b, int act, const float *ds_src, const float *ds_dst, void *out,
-                         const void *h_rows, float *att_part, int part_width, void *stream) {
+                         const void *h_rows, float *att_part, int part_width, int pad_from, int pad_to, void *stream) {
     if (!spadot_gat_mfma_supported(dtype, H, C, max_cols) || nb <= 0 || (mode != 0 && mode != 1)) return -22;
+    if (pad_from < 0 || pad_to < pad_from || pad_to - pad_from > 4096) return -22;
     if (!x || !acell || !plan_rows || !plan_sptr || !plan_cols || !vec_a || !out) return -22;
     if (mode == 1 && (!vec_b || !ds_src || !ds_dst)) return -22;
     if (att_part && (mode != 1 || !h_rows || part_width < 2 * H * C || ((uintptr_t)h_rows & 15))) return -22;

@@ -1042,6 +1042,67 @@ __global__ __launch_bounds__(KNN_T) void k_knn(const double *__restrict__ x, int
 }
 
 // ------------------------------------------------------------------------------------------
+// Small fp32 products of the MLP stages (b x 256 -> 64 -> 20 and their gradients: a few MFLOP each) with a SMALL
+// FOOTPRINT: 256 threads, 8.4 KB of LDS, ~40 registers.  The library runs some of these shapes with 256 x 64 macro tiles
+// (80 KB of LDS, a quarter of a compute unit's registers per wave): eight such workgroups on the side stream waited
+// 150-185 us for a whole compute unit to drain beside the first GAT layer's weight-gradient GEMM, and the optimizer
+// waited for them (rocprofv3 timeline, round 3).  These tiles slot in wherever four waves fit.
+//   C [M x N] = sum_k a(m, k) b(k, n) (+ bias[n]),  32 x 32 tile per workgroup, thread = 2 x 2 outputs, K in steps of 32:
+//   MODE 0 (NN): a = A[m, k], b = B[k, n]      dx = g W
+//   MODE 1 (NT): a = A[m, k], b = B[n, k]      y = x W^T (+ bias)
+//   MODE 2 (TN): a = A[k, m], b = B[k, n]      dW = g^T x        (fixed summation order: k ascending)
+// ------------------------------------------------------------------------------------------
+// blockIdx.z = batch entry (operands and result advance by their batch strides): a long contraction is cut into slices
+// whose partial results the caller adds in slice order.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_sgemm_small(const float *__restrict__ A, int lda, const float *__restrict__ B, int ldb,
+                                                     float *__restrict__ C, int ldc, int M, int N, int K,
+                                                     const float *__restrict__ bias, long long sA, long long sB, long long sC) {
+    __shared__ float As[32][33], Bs[32][33];          // As[k][m], Bs[k][n]
+    A += (size_t)blockIdx.z * sA; B += (size_t)blockIdx.z * sB; C += (size_t)blockIdx.z * sC;
+    const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const int lr = t >> 5, lc = t & 31;               // loader: rows lr + 8 r (r = 0..3), column lc (the contiguous index)
+    float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    for (int k0 = 0; k0 < K; k0 += 32) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = lr + 8 * r;
+            if (MODE == 2) {          // A[k, m]: m contiguous
+                const int k = k0 + row, m = m0 + lc;
+                As[row][lc] = (k < K && m < M) ? A[(size_t)k * lda + m] : 0.f;
+            } else {                  // A[m, k]: k contiguous
+                const int m = m0 + row, k = k0 + lc;
+                As[lc][row] = (m < M && k < K) ? A[(size_t)m * lda + k] : 0.f;
+            }
+            if (MODE == 1) {          // B[n, k]: k contiguous
+                const int n = n0 + row, k = k0 + lc;
+                Bs[lc][row] = (n < N && k < K) ? B[(size_t)n * ldb + k] : 0.f;
+            } else {                  // B[k, n]: n contiguous
+                const int k = k0 + row, n = n0 + lc;
+                Bs[row][lc] = (k < K && n < N) ? B[(size_t)k * ldb + n] : 0.f;
+            }
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int k = 0; k < 32; k++) {
+            const float a0 = As[k][2 * ty], a1 = As[k][2 * ty + 1];
+            const float b0 = Bs[k][2 * tx], b1 = Bs[k][2 * tx + 1];
+            acc[0][0] = fmaf(a0, b0, acc[0][0]); acc[0][1] = fmaf(a0, b1, acc[0][1]);
+            acc[1][0] = fmaf(a1, b0, acc[1][0]); acc[1][1] = fmaf(a1, b1, acc[1][1]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int m = m0 + 2 * ty + i, n = n0 + 2 * tx + j;
+            if (m < M && n < N) C[(size_t)m * ldc + n] = acc[i][j] + (bias ? bias[n] : 0.f);
+        }
+}
+
+// ------------------------------------------------------------------------------------------
 // Lloyd iterations of K-means for R restarts at once (fp64, deterministic: no atomics).
 //   k_lloyd_assign: block = (restart r, chunk of 256 points): nearest centre per point (first minimum wins),
 //                   per-block cluster sums / counts / inertia in a fixed order -> part[r][chunk][K*(D+1) + 1]
@@ -2285,6 +2346,20 @@ int spadot_kmeans_assign(const void *x, const void *centers, int n, int k, int d
     FP_DISPATCH(dtype,
                 hipLaunchKernelGGL(k_kmeans_assign<float>, g, dim3(256), 0, st_, (const float *)x, (const float *)centers, n, k, d, labels),
                 hipLaunchKernelGGL(k_kmeans_assign<double>, g, dim3(256), 0, st_, (const double *)x, (const double *)centers, n, k, d, labels));
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+int spadot_sgemm_small(int mode, const float *A, int lda, const float *B, int ldb, float *C, int ldc, int M, int N, int K,
+                       const float *bias, int batch, long long strideA, long long strideB, long long strideC, void *stream) {
+    if (mode < 0 || mode > 2 || !A || !B || !C || M <= 0 || N <= 0 || K <= 0 || ldc < N) return -22;
+    if ((mode == 2 ? lda < M : lda < K) || (mode == 1 ? ldb < K : ldb < N)) return -22;
+    if (batch < 1 || batch > 65535 || strideA < 0 || strideB < 0 || strideC < 0) return -22;
+    const dim3 grid((unsigned)((N + 31) / 32), (unsigned)((M + 31) / 32), (unsigned)batch);
+    if (grid.y > 65535u) return -22;
+    hipStream_t st_ = (hipStream_t)stream;
+    if (mode == 0) hipLaunchKernelGGL(k_sgemm_small<0>, grid, dim3(256), 0, st_, A, lda, B, ldb, C, ldc, M, N, K, bias, strideA, strideB, strideC);
+    else if (mode == 1) hipLaunchKernelGGL(k_sgemm_small<1>, grid, dim3(256), 0, st_, A, lda, B, ldb, C, ldc, M, N, K, bias, strideA, strideB, strideC);
+    else hipLaunchKernelGGL(k_sgemm_small<2>, grid, dim3(256), 0, st_, A, lda, B, ldb, C, ldc, M, N, K, bias, strideA, strideB, strideC);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 

@@ -12,7 +12,7 @@ import torch.nn.functional as F
 
 from ..graph import build_batch_graph
 from ..ops import (BatchGraph, bn_act, cast_rows, dense_cd, first_map_seeds, first_map_seeds_ok, gat_edge, head_fc, head_fc_ok,
-                   linear_bias, weight_image)
+                   hidden_map, linear_bias, weight_image)
 
 
 FIRST_MAP_OWN_WGRAD = [__import__("os").environ.get("SPADOT_FIRST_MAP_WGRAD", "1") == "1"]    # [False]: library (A/B runs)
@@ -64,6 +64,8 @@ class SVGPEncoder(nn.Module):
             elif (i == 0 and self.compute_dtype == torch.bfloat16 and FIRST_MAP_OWN_WGRAD[0]
                   and first_map_seeds_ok(h, lin.weight, x_bf16)):
                 h = first_map_seeds(h, lin.weight, x_bf16)
+            elif i > 0 and h.dtype == torch.float32 and h.shape[1] == lin.in_features:
+                h = hidden_map(h, lin.weight)              # (same product; its backward dodges a library tile that stalls)
             else:
                 h = F.linear(h[:, :lin.in_features].float(), lin.weight)
             h = bn_act(h, lin.bias, bn, act.negative_slope)

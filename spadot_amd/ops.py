@@ -111,7 +111,8 @@ class _GATEdgeMFMA(torch.autograd.Function):
         a_d = att_dst.reshape(H, C).contiguous().float()
         bias_f = bias.contiguous().float()
         n, nt = graph.n, graph.n_tgt
-        assert h.shape == (n, H * C), (h.shape, n, H, C)
+        # h may carry rows past the last node (row padding, see _cache_batch_inputs): every kernel indexes rows by node id
+        assert h.shape[0] >= n and h.shape[1] == H * C, (h.shape, n, H, C)
         dev = h.device
         s_src = torch.empty((n, H), dtype=torch.float32, device=dev)
         s_dst = torch.empty((n, H), dtype=torch.float32, device=dev)
@@ -120,9 +121,12 @@ class _GATEdgeMFMA(torch.autograd.Function):
         img = pt.weight_image(H)
         _check(lib.spadot_gat_alpha(_p(s_src), _p(s_dst), _p(graph.rowptr), _p(graph.col), _p(pt.cellq), nt, H, _p(alpha), _p(img),
                                     _stream()), "spadot_gat_alpha")
-        out = torch.empty((nt, H * C), dtype=h.dtype, device=dev)
+        # a padded input whose nodes are all targets (the first layer) hands its padding on: the next dense map then also
+        # sees a row count that is a multiple of 128; the kernel writes the pad rows as zeros
+        out_rows = h.shape[0] if (nt == n and h.shape[0] - n <= 4096) else nt
+        out = torch.empty((out_rows, H * C), dtype=h.dtype, device=dev)
         _check(lib.spadot_gat_aggregate(_p(h), DT_BF16, _p(img), _p(pt.rows), _p(pt.sptr), _p(pt.cols), pt.nb, pt.max_cols, H, C, 0,
-                                        _p(bias_f), None, int(act), None, None, _p(out), None, None, 0, _stream()),
+                                        _p(bias_f), None, int(act), None, None, _p(out), None, None, 0, nt, out_rows, _stream()),
                "spadot_gat_aggregate")
         ctx.save_for_backward(h, s_src, s_dst, out, alpha, a_s, a_d)
         ctx.graph, ctx.H, ctx.C, ctx.act, ctx.plans = graph, H, C, act, plans
@@ -163,10 +167,14 @@ class _GATEdgeMFMA(torch.autograd.Function):
                                                H, _p(dz), _p(ds_dst), _p(img), _stream()), "spadot_gat_softmax_backward")
         ds_src = torch.empty((n, H), dtype=torch.float32, device=dev)
         _check(lib.spadot_gat_ds_src(_p(dz), _p(graph.rowptr_t), _p(graph.eid_t), n, H, _p(ds_src), _stream()), "spadot_gat_ds_src")
-        dh = torch.empty_like(h)
+        dh = torch.empty_like(h)                  # (h's pad rows, if any, get a zero gradient: written by the kernel)
+        pad_ok = h.shape[0] - n <= 4096
+        if not pad_ok:
+            dh[n:].zero_()
         _check(lib.spadot_gat_aggregate(_p(g_pre), DT_BF16, _p(img), _p(ps.rows), _p(ps.sptr), _p(ps.cols), ps.nb, ps.max_cols, H, C, 1,
                                         _p(a_s), _p(a_d), 0, _p(ds_src), _p(ds_dst), _p(dh), _p(h) if fold else None,
-                                        _p(part) if fold else None, W3, _stream()), "spadot_gat_aggregate")
+                                        _p(part) if fold else None, W3, n, h.shape[0] if pad_ok else n, _stream()),
+               "spadot_gat_aggregate")
         datt = torch.empty((3, H * C), dtype=torch.float32, device=dev)
         if fold:
             _check(lib.spadot_colsum(_p(part), part.shape[0], W3, _p(datt), _stream()), "spadot_colsum")
@@ -194,7 +202,7 @@ class _GATEdge(torch.autograd.Function):
         a_d = att_dst.reshape(H, C).contiguous().float()
         bias_f = bias.contiguous().float()
         n, nt = graph.n, graph.n_tgt        # targets are the first nt nodes (nt < n: seeds-only last layer)
-        assert h.shape == (n, H * C), (h.shape, n, H, C)
+        assert h.shape[0] >= n and h.shape[1] == H * C, (h.shape, n, H, C)      # (rows past n: padding, never read)
         s_src = torch.empty((n, H), dtype=torch.float32, device=h.device)
         s_dst = torch.empty((n, H), dtype=torch.float32, device=h.device)
         _check(lib.spadot_gat_logits(_p(h), _DT[h.dtype], _p(a_s), _p(a_d), n, H, C, _p(s_src), _p(s_dst), _stream()),
@@ -232,6 +240,8 @@ class _GATEdge(torch.autograd.Function):
                                               _p(graph.rowptr), _p(graph.col), nt, H, C, int(ctx.concat), int(ctx.act),
                                               _p(g_pre), _p(dz), _p(ds_dst), _stream()), "spadot_gat_backward_target")
         dh = torch.empty_like(h)
+        if h.shape[0] > n:
+            dh[n:].zero_()                    # pad rows of the input: zero gradient
         ds_src = torch.empty((n, H), dtype=torch.float32, device=h.device)
         _check(lib.spadot_gat_backward_source(_p(g_pre), _DT[h.dtype], _p(alpha), _p(dz), _p(graph.rowptr_t),
                                               _p(graph.col_t), _p(graph.eid_t), n, H, C, _p(dh), _p(ds_src),
@@ -474,6 +484,80 @@ def _small_weight_grad(g, x):
     if M >= 256 and M % 8 == 0 and min(N, K) >= 64 and N * K <= 65536:
         return torch.bmm(g.view(8, M // 8, N).transpose(1, 2), x.view(8, M // 8, K)).sum(0)
     return g.t() @ x
+
+
+SGEMM_SMALL = [__import__("os").environ.get("SPADOT_SGEMM_SMALL", "1") == "1"]     # [False]: the library for the small fp32 products
+
+
+def sgemm_small_ok(*ts):
+    """The small fp32 products of the MLP stages take csrc's k_sgemm_small: contiguous fp32 device matrices, small work."""
+    return SGEMM_SMALL[0] and all(t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.is_contiguous() for t in ts)
+
+
+def sgemm_small(mode, A, B, bias=None):
+    """mode 0: A [M, K] . B [K, N]; mode 1: A [M, K] . B[N, K]^T (+ bias [N]); mode 2: A[K, M]^T . B [K, N]  -> fp32 [M, N]
+    (include/spadot_model.h: spadot_sgemm_small -- small tiles that find room beside the GAT branch's GEMMs)."""
+    _need_cuda(A, B, bias)
+    if mode == 0:
+        (M, K), N = A.shape, B.shape[1]
+    elif mode == 1:
+        (M, K), N = A.shape, B.shape[0]
+    else:
+        (K, M), N = A.shape, B.shape[1]
+    C = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    _check(model_lib().spadot_sgemm_small(mode, _p(A), A.shape[1], _p(B), B.shape[1], _p(C), N, M, N, K,
+                                          _p(bias) if bias is not None else None, 1, 0, 0, 0, _stream()), "spadot_sgemm_small")
+    return C
+
+
+def wgrad_small(g, x, slices=8):
+    """g^T x [N, K] for g [M, N], x [M, K] (fp32) as `slices` row slices in ONE launch of k_sgemm_small (mode 2) and a
+    fixed-order sum of the partial results: 8 x (N / 32) x (K / 32) small workgroups instead of the library's handful of
+    256 x 64 macro tiles (which waited 150-180 us for a whole compute unit beside the GAT branch's GEMMs)."""
+    _need_cuda(g, x)
+    M, N = g.shape
+    K = x.shape[1]
+    S = slices if (M % slices == 0 and M // slices >= 32) else 1
+    Ms = M // S
+    part = torch.empty((S, N, K), dtype=torch.float32, device=g.device)
+    _check(model_lib().spadot_sgemm_small(2, _p(g), N, _p(x), K, _p(part), K, N, K, Ms, None, S, Ms * N, Ms * K, N * K, _stream()),
+           "spadot_sgemm_small")
+    return part.sum(0) if S > 1 else part[0]
+
+
+_SMALL_WORK = 1 << 27        # multiply-adds up to which a product counts as small (0.27 GFLOP)
+
+
+class _HiddenMap(torch.autograd.Function):
+    """h W^T for a small hidden -> hidden map of the SVGP encoder (b x 256 -> 64 at the default sizes; fp32, no bias: the next
+    BatchNorm kernel folds it in).  The forward is the library's product as before; BOTH gradients go through k_sgemm_small
+    (dx = g W as 128 workgroups of 32 x 32 outputs, dW = g^T x as 8 row slices x 16 such workgroups + a fixed-order sum):
+    for these shapes (512 x 64 . 64 x 256, and 64 x 512 . 512 x 256) the library picks 256 x 64 macro tiles whose eight
+    workgroups each need most of a compute unit's LDS and registers -- on the side stream beside the first GAT layer's
+    weight-gradient GEMM they waited for that GEMM to end (150-185 us for 17 MFLOP, and the optimizer waited for them:
+    rocprofv3 timeline, round 3).  (One workgroup per output tile walking the whole contraction lost too: 72-97 us.)"""
+
+    @staticmethod
+    def forward(ctx, x, W):
+        ctx.save_for_backward(x, W)
+        return torch.nn.functional.linear(x, W)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W = ctx.saved_tensors
+        g = g.contiguous()
+        dx = dW = None
+        if ctx.needs_input_grad[0]:
+            small = sgemm_small_ok(g, W) and g.shape[0] * W.shape[0] * W.shape[1] <= _SMALL_WORK
+            dx = sgemm_small(0, g, W) if small else g @ W
+        if ctx.needs_input_grad[1]:
+            small = sgemm_small_ok(g, x) and g.shape[0] * W.shape[0] * W.shape[1] <= _SMALL_WORK
+            dW = wgrad_small(g, x) if small else g.t() @ x
+        return dx, dW
+
+
+def hidden_map(x, W):
+    return _HiddenMap.apply(x.contiguous(), W)
 
 
 class _LinearBias(torch.autograd.Function):

@@ -639,3 +639,29 @@ def test_gat_edge_full_size_vs_torch_scatter(ops):
     # bitwise reproducible (no atomics in the HIP path)
     out2 = ops.gat_edge(h, s1, s2, bias, g, H, C, True, True)
     assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 64, 256), (512, 20, 64), (235, 33, 70), (1, 1, 1), (64, 256, 512)])
+def test_sgemm_small_three_modes_match_fp64(ops, M, N, K):
+    """csrc k_sgemm_small (the MLP stages' small fp32 products with a small footprint): y = x W^T + b, dx = g W, dW = g^T x
+    against fp64, ragged sizes included; bitwise repeatable; and through the autograd functions that use it."""
+    rng = np.random.default_rng(M + N + K)
+    x = T(rng.normal(size=(M, K))).float().to(DEV); W = T(rng.normal(size=(N, K))).float().to(DEV)
+    b = T(rng.normal(size=N)).float().to(DEV); g = T(rng.normal(size=(M, N))).float().to(DEV)
+    with pytest.raises(RuntimeError):
+        ops.sgemm_small(1, x.cpu(), W, b)                       # a host tensor is refused before anything is launched
+    y = ops.sgemm_small(1, x, W, b)
+    np.testing.assert_allclose(y.cpu().numpy(), (x.double() @ W.double().T + b.double()).cpu().numpy(), rtol=2e-5, atol=2e-5 * K ** 0.5)
+    dx = ops.sgemm_small(0, g, W)
+    np.testing.assert_allclose(dx.cpu().numpy(), (g.double() @ W.double()).cpu().numpy(), rtol=2e-5, atol=2e-5 * N ** 0.5)
+    dW = ops.sgemm_small(2, g, x)
+    np.testing.assert_allclose(dW.cpu().numpy(), (g.double().T @ x.double()).cpu().numpy(), rtol=2e-5, atol=2e-5 * M ** 0.5)
+    assert torch.equal(dW, ops.sgemm_small(2, g, x))
+    dWs = ops.wgrad_small(g, x)                                     # row slices in one launch + a fixed-order sum
+    np.testing.assert_allclose(dWs.cpu().numpy(), (g.double().T @ x.double()).cpu().numpy(), rtol=2e-5, atol=2e-5 * M ** 0.5)
+    assert torch.equal(dWs, ops.wgrad_small(g, x))
+    # autograd: hidden_map gives the library's values and gradients
+    xr = x.clone().requires_grad_(True); Wr = W.clone().requires_grad_(True)
+    (ops.hidden_map(xr, Wr) * g).sum().backward()
+    np.testing.assert_allclose(xr.grad.cpu().numpy(), dx.cpu().numpy(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(Wr.grad.cpu().numpy(), (g.double().T @ x.double()).cpu().numpy(), rtol=2e-5, atol=2e-5 * M ** 0.5)
