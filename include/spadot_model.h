@@ -283,7 +283,10 @@ int spadot_knn(const double *x, int n, int d, int kk, int *out, void *stream);
  *                                sum_rows ds_src[row] h[row] at att_part[b * part_width + 0 ..] and the ds_dst ones at
  *                                [.. + H C ..] -- the attention-vector gradients up to a column sum over the blocks;
  *                                rows pad_from .. pad_to - 1 of `out` (allocated past the last node so that the next GEMM
- *                                sees a row count that is a multiple of 128) are written as zeros
+ *                                sees a row count that is a multiple of 128) are written as zeros; with dz (mode 1) the
+ *                                workgroup sums dz over the outgoing edges of its own rows itself (transposed CSR rowptr_t /
+ *                                eid_t: what spadot_gat_ds_src computes in a launch of its own), ds_src may then be NULL and
+ *                                ds_src_out (may be NULL) receives the sums
  *   spadot_gat_edge_dot          g_pre = g_out * (act ? LeakyReLU'(out) : 1) (written), dz[e] = <g_pre[row], h[col]> through
  *                                plan_cell [chunk][32 rows][16] -> edge position or -1; with bias_part block b leaves the
  *                                column sums of its 32 rows of g_pre at bias_part[b * part_width + part_col ..] (the bias
@@ -298,7 +301,8 @@ int spadot_gat_alpha(const float *s_src, const float *s_dst, const int *rowptr, 
 int spadot_gat_aggregate(const void *x, int dtype, const void *acell, const int *plan_rows, const int *plan_sptr,
                          const int *plan_cols, int nb, int max_cols, int H, int C, int mode, const float *vec_a,
                          const float *vec_b, int act, const float *ds_src, const float *ds_dst, void *out,
-                         const void *h_rows, float *att_part, int part_width, int pad_from, int pad_to, void *stream);
+                         const void *h_rows, float *att_part, int part_width, int pad_from, int pad_to, const float *dz,
+                         const int *rowptr_t, const int *eid_t, float *ds_src_out, void *stream);
 int spadot_gat_edge_dot(const void *g_out, const void *out, const void *h, int dtype, const int *plan_rows,
                         const int *plan_sptr, const int *plan_cols, const int *plan_cell, int nb, int max_cols, int H,
                         int C, int act, void *g_pre, float *dz, float *bias_part, int part_width, int part_col, void *stream);

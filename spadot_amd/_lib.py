@@ -137,7 +137,7 @@ def model_lib():
         "spadot_gat_softmax_backward": [vp, vp, vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp],
         "spadot_gat_ds_src": [vp, vp, vp, ci, ci, vp, vp],
         "spadot_gat_mfma_supported": [ci, ci, ci, ci],
-        "spadot_gat_aggregate": [vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp, vp, vp, ci, ci, ci, vp],
+        "spadot_gat_aggregate": [vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, vp],
         "spadot_gat_edge_dot": [vp, vp, vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, ci, ci, vp],
         "spadot_gemm_tn_bf16": [vp, ci, vp, ci, vp, ci, ci, ci, ci, vp],
         "spadot_gemm_nn_bf16": [vp, ci, vp, ci, vp, ci, ci, ci, ci, vp],

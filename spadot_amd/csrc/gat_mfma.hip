@@ -232,6 +232,12 @@ constexpr int ATILEB = 2048;                        // hi (1 KiB) | lo (1 KiB)
 #ifndef AGG_RING
 #define AGG_RING 3
 #endif
+#ifndef AGG_WGS
+#define AGG_WGS 2                                   // workgroups per compute unit the register allocation is held to
+#endif
+#ifndef EDOT_WGS
+#define EDOT_WGS 4
+#endif
 constexpr int RING = AGG_RING;                      // chunks of LDS ring: RING - 1 in flight while one is multiplied
 constexpr int MAXC = 1024 - ROWS;                   // longest column list of a block (ids + row ids = 4 KiB)
 constexpr int LDS_RING = RING * CHUNKB;             // 52224 >= 32 * OUTB
@@ -241,7 +247,7 @@ constexpr int LDS_BYTES = LDS_RING + RING * ATILEB + MAXC * 4 + ROWS * 4;
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
 
 template <int MODE>
-__global__ __launch_bounds__(NT, 2) void k_gat_agg(
+__global__ __launch_bounds__(NT, AGG_WGS) void k_gat_agg(
     const __bf16 *__restrict__ X, const __bf16 *__restrict__ acell, const int *__restrict__ prow,
     const int *__restrict__ sptr, const int *__restrict__ pcol, int nb, int H,
     const float *__restrict__ vec_a,      // MODE 0: bias [H*C]; MODE 1: att_src [H*C]
@@ -249,7 +255,9 @@ __global__ __launch_bounds__(NT, 2) void k_gat_agg(
     int act, const float *__restrict__ ds_src, const float *__restrict__ ds_dst, __bf16 *__restrict__ out,
     const __bf16 *__restrict__ hrows,     // MODE 1, optional: h (the layer's input rows), for the attention-vector gradients
     float *__restrict__ att_part, int part_width,     // MODE 1: [nb][part_width] partials: src at column 0, dst at column H*C
-    int pad_from, int pad_to) {           // rows pad_from .. pad_to - 1 of `out` are set to zero (row padding for the next GEMM)
+    int pad_from, int pad_to,             // rows pad_from .. pad_to - 1 of `out` are set to zero (row padding for the next GEMM)
+    const float *__restrict__ dz, const int *__restrict__ rowptr_t, const int *__restrict__ eid_t,   // MODE 1, optional: see ds_own
+    float *__restrict__ ds_src_out) {
     using namespace agg;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *ring = smem;
@@ -277,6 +285,25 @@ __global__ __launch_bounds__(NT, 2) void k_gat_agg(
     for (int k = tid; k < ncol; k += NT) sids[k] = pcol[s0 + k];
     if (tid < ROWS) rid[tid] = prow[b * ROWS + tid];
     __syncthreads();
+    // MODE 1 with dz: this workgroup sums d(logit) over the OUTGOING edges of its own 32 rows for its head (ds_src: what
+    // k_gat_dsrc did in a launch of its own) -- lane group of 8 per row, fixed order inside a lane, butterfly across.
+    __shared__ float ds_own[ROWS];
+    const bool own_ds = MODE == 1 && dz != nullptr;
+    if (own_ds) {
+        const int r = tid >> 3, l8 = tid & 7;              // 32 rows x 8 lanes
+        const int node = rid[r];
+        float acc_ = 0.f;
+        if (node >= 0) {
+            const int p0 = rowptr_t[node], p1 = rowptr_t[node + 1];
+            for (int p = p0 + l8; p < p1; p += 8) acc_ += dz[(size_t)eid_t[p] * H + hd];
+        }
+        acc_ += __shfl_xor(acc_, 1, 64); acc_ += __shfl_xor(acc_, 2, 64); acc_ += __shfl_xor(acc_, 4, 64);
+        if (l8 == 0) {
+            ds_own[r] = acc_;
+            if (node >= 0 && ds_src_out != nullptr) ds_src_out[(size_t)node * H + hd] = acc_;
+        }
+        __syncthreads();
+    }
 
     const size_t hoff = (size_t)hd * C;
     const size_t HC = (size_t)H * C;
@@ -371,7 +398,7 @@ __global__ __launch_bounds__(NT, 2) void k_gat_agg(
         const int node = rid[t];
         float sa = 0.f, sb = 0.f;
         if (MODE == 1 && node >= 0) {
-            sa = ds_src[(size_t)node * H + hd];
+            sa = own_ds ? ds_own[t] : ds_src[(size_t)node * H + hd];
             sb = ds_dst[(size_t)node * H + hd];
         }
 #pragma unroll
@@ -412,7 +439,7 @@ __global__ __launch_bounds__(NT, 2) void k_gat_agg(
         float *dsl = reinterpret_cast<float *>(sids);                     // (the column ids are no longer needed)
         if (tid < ROWS) {
             const int node = rid[tid];
-            dsl[tid] = node >= 0 ? ds_src[(size_t)node * H + hd] : 0.f;
+            dsl[tid] = node >= 0 ? (own_ds ? ds_own[tid] : ds_src[(size_t)node * H + hd]) : 0.f;
             dsl[ROWS + tid] = node >= 0 ? ds_dst[(size_t)node * H + hd] : 0.f;
         }
         __syncthreads();
@@ -458,7 +485,7 @@ __global__ __launch_bounds__(NT, 2) void k_gat_agg(
 //   wave, wave + 4, ...; the raw d(alpha) values go to dz through the plan's cell map (one writer per edge).
 // ------------------------------------------------------------------------------------------------------------------
 template <int NTW>
-__global__ __launch_bounds__(NT, 4) void k_gat_edot(const __bf16 *__restrict__ g_out, const __bf16 *__restrict__ outp,
+__global__ __launch_bounds__(NT, EDOT_WGS) void k_gat_edot(const __bf16 *__restrict__ g_out, const __bf16 *__restrict__ outp,
                                                     const __bf16 *__restrict__ Xh, const int *__restrict__ prow,
                                                     const int *__restrict__ sptr, const int *__restrict__ pcol,
                                                     const int *__restrict__ cell, int nb, int H, int act,
@@ -592,17 +619,20 @@ int spadot_gat_ds_src(const float *dz, const int *rowptr_t, const int *eid_t, in
         }                                                                                                          \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), agg::LDS_BYTES, st_, (const __bf16 *)x, (const __bf16 *)acell, plan_rows, \
                            plan_sptr, plan_cols, nb, H, vec_a, vec_b, act, ds_src, ds_dst, (__bf16 *)out,          \
-                           (const __bf16 *)h_rows, att_part, part_width, pad_from, pad_to);                        \
+                           (const __bf16 *)h_rows, att_part, part_width, pad_from, pad_to, dz, rowptr_t, eid_t,    \
+                           ds_src_out);                                                                            \
     } while (0)
 
 int spadot_gat_aggregate(const void *x, int dtype, const void *acell, const int *plan_rows, const int *plan_sptr,
                          const int *plan_cols, int nb, int max_cols, int H, int C, int mode, const float *vec_a,
                          const float *vec_b, int act, const float *ds_src, const float *ds_dst, void *out,
-                         const void *h_rows, float *att_part, int part_width, int pad_from, int pad_to, void *stream) {
+                         const void *h_rows, float *att_part, int part_width, int pad_from, int pad_to, const float *dz,
+                         const int *rowptr_t, const int *eid_t, float *ds_src_out, void *stream) {
     if (!spadot_gat_mfma_supported(dtype, H, C, max_cols) || nb <= 0 || (mode != 0 && mode != 1)) return -22;
     if (pad_from < 0 || pad_to < pad_from || pad_to - pad_from > 4096) return -22;
     if (!x || !acell || !plan_rows || !plan_sptr || !plan_cols || !vec_a || !out) return -22;
-    if (mode == 1 && (!vec_b || !ds_src || !ds_dst)) return -22;
+    if (mode == 1 && (!vec_b || !ds_dst || (!ds_src && !dz))) return -22;
+    if (dz && (mode != 1 || !rowptr_t || !eid_t)) return -22;
     if (att_part && (mode != 1 || !h_rows || part_width < 2 * H * C || ((uintptr_t)h_rows & 15))) return -22;
     hipStream_t st_ = (hipStream_t)stream;
     const unsigned grid = 8u * (unsigned)((nb * H + 7) / 8);

@@ -126,8 +126,8 @@ class _GATEdgeMFMA(torch.autograd.Function):
         out_rows = h.shape[0] if (nt == n and h.shape[0] - n <= 4096) else nt
         out = torch.empty((out_rows, H * C), dtype=h.dtype, device=dev)
         _check(lib.spadot_gat_aggregate(_p(h), DT_BF16, _p(img), _p(pt.rows), _p(pt.sptr), _p(pt.cols), pt.nb, pt.max_cols, H, C, 0,
-                                        _p(bias_f), None, int(act), None, None, _p(out), None, None, 0, nt, out_rows, _stream()),
-               "spadot_gat_aggregate")
+                                        _p(bias_f), None, int(act), None, None, _p(out), None, None, 0, nt, out_rows,
+                                        None, None, None, None, _stream()), "spadot_gat_aggregate")
         ctx.save_for_backward(h, s_src, s_dst, out, alpha, a_s, a_d)
         ctx.graph, ctx.H, ctx.C, ctx.act, ctx.plans = graph, H, C, act, plans
         ctx.bias_dtype, ctx.att_shape, ctx.att_dtype = bias.dtype, att_src.shape, att_src.dtype
@@ -165,16 +165,21 @@ class _GATEdgeMFMA(torch.autograd.Function):
         img = ps.weight_image(H)
         _check(lib.spadot_gat_softmax_backward(_p(alpha), _p(s_src), _p(s_dst), _p(graph.rowptr), _p(graph.col), _p(ps.cellq), nt, n,
                                                H, _p(dz), _p(ds_dst), _p(img), _stream()), "spadot_gat_softmax_backward")
-        ds_src = torch.empty((n, H), dtype=torch.float32, device=dev)
-        _check(lib.spadot_gat_ds_src(_p(dz), _p(graph.rowptr_t), _p(graph.eid_t), n, H, _p(ds_src), _stream()), "spadot_gat_ds_src")
+        # ds_src[j] = sum of dz over the outgoing edges of j: taken by the source-side product's workgroups for their own rows
+        # (GAT_FOLD_ATT; spadot_gat_ds_src as a launch of its own otherwise)
+        ds_src = None
+        if not fold:
+            ds_src = torch.empty((n, H), dtype=torch.float32, device=dev)
+            _check(lib.spadot_gat_ds_src(_p(dz), _p(graph.rowptr_t), _p(graph.eid_t), n, H, _p(ds_src), _stream()), "spadot_gat_ds_src")
         dh = torch.empty_like(h)                  # (h's pad rows, if any, get a zero gradient: written by the kernel)
         pad_ok = h.shape[0] - n <= 4096
         if not pad_ok:
             dh[n:].zero_()
         _check(lib.spadot_gat_aggregate(_p(g_pre), DT_BF16, _p(img), _p(ps.rows), _p(ps.sptr), _p(ps.cols), ps.nb, ps.max_cols, H, C, 1,
                                         _p(a_s), _p(a_d), 0, _p(ds_src), _p(ds_dst), _p(dh), _p(h) if fold else None,
-                                        _p(part) if fold else None, W3, n, h.shape[0] if pad_ok else n, _stream()),
-               "spadot_gat_aggregate")
+                                        _p(part) if fold else None, W3, n, h.shape[0] if pad_ok else n,
+                                        _p(dz) if fold else None, _p(graph.rowptr_t) if fold else None,
+                                        _p(graph.eid_t) if fold else None, None, _stream()), "spadot_gat_aggregate")
         datt = torch.empty((3, H * C), dtype=torch.float32, device=dev)
         if fold:
             _check(lib.spadot_colsum(_p(part), part.shape[0], W3, _p(datt), _stream()), "spadot_colsum")
