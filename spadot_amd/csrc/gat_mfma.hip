@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void k_gat_dsrc(const float *__restrict__ dz, 
 // order: k_gat_alpha wrote it).  Both go global -> LDS by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave instruction,
 // no registers): per chunk every wave issues 4 row pieces (rows 4 wave .. 4 wave + 3) and one half-wave piece of the
 // weight tile, FIVE vector-memory operations, so "chunk c has landed" is s_waitcnt vmcnt(5) while chunk c + 1 is in
-// flight (vmcnt counts in issue order) and vmcnt(0) on the last chunk.  LDS: ring of 3 chunks (row stride 1088 B: the
+// flight (vmcnt counts in issue order) and vmcnt(0) on the last chunk.  LDS: ring of AGG_RING chunks (row stride 1088 B: the
 // transposed reads are bank-conflict free) + 3 weight tiles + the column ids.  One raw s_barrier per chunk:
 //     wait(chunk it) ; barrier ; request chunk it + 2 into the slot chunk it - 1 just left ; multiply chunk it
 // (__syncthreads() would drain the DMAs: its fence waits for vmcnt(0)).  No ordinary global load lives inside the loop
@@ -230,7 +230,7 @@ constexpr int CHUNKB = KSTEP * ROWB;                // 17408
 constexpr int OUTB = 2 * C + 16;                    // epilogue image row stride (bytes)
 constexpr int ATILEB = 2048;                        // hi (1 KiB) | lo (1 KiB)
 #ifndef AGG_RING
-#define AGG_RING 3
+#define AGG_RING 2                                  // round 3, tools/agg_variants.py: 2: 45.2 us, 3: 47.5 us, 4: 65 us (80 KB: one workgroup per CU)
 #endif
 #ifndef AGG_WGS
 #define AGG_WGS 2                                   // workgroups per compute unit the register allocation is held to
@@ -285,25 +285,8 @@ __global__ __launch_bounds__(NT, AGG_WGS) void k_gat_agg(
     for (int k = tid; k < ncol; k += NT) sids[k] = pcol[s0 + k];
     if (tid < ROWS) rid[tid] = prow[b * ROWS + tid];
     __syncthreads();
-    // MODE 1 with dz: this workgroup sums d(logit) over the OUTGOING edges of its own 32 rows for its head (ds_src: what
-    // k_gat_dsrc did in a launch of its own) -- lane group of 8 per row, fixed order inside a lane, butterfly across.
     __shared__ float ds_own[ROWS];
     const bool own_ds = MODE == 1 && dz != nullptr;
-    if (own_ds) {
-        const int r = tid >> 3, l8 = tid & 7;              // 32 rows x 8 lanes
-        const int node = rid[r];
-        float acc_ = 0.f;
-        if (node >= 0) {
-            const int p0 = rowptr_t[node], p1 = rowptr_t[node + 1];
-            for (int p = p0 + l8; p < p1; p += 8) acc_ += dz[(size_t)eid_t[p] * H + hd];
-        }
-        acc_ += __shfl_xor(acc_, 1, 64); acc_ += __shfl_xor(acc_, 2, 64); acc_ += __shfl_xor(acc_, 4, 64);
-        if (l8 == 0) {
-            ds_own[r] = acc_;
-            if (node >= 0 && ds_src_out != nullptr) ds_src_out[(size_t)node * H + hd] = acc_;
-        }
-        __syncthreads();
-    }
 
     const size_t hoff = (size_t)hd * C;
     const size_t HC = (size_t)H * C;
@@ -363,9 +346,49 @@ __global__ __launch_bounds__(NT, AGG_WGS) void k_gat_agg(
         }
     };
 
+    // MODE 1 with att_part: the attention-vector gradients d att_src[c] = sum_j ds_src[j] h[j, c], d att_dst likewise with
+    // ds_dst (k_gat_datt_part took a pass of its own over h and g for them: 25 us per layer).  This block's 32 rows of h
+    // are requested HERE, 16 bytes per thread and row, in front of the first chunk requests (older in the in-order queue,
+    // so the counted waits of the loop are unaffected), and consumed behind the epilogue.
+    u32x4 hv[8];
+    if (MODE == 1 && att_part != nullptr) {
+        const int pc = tid & 63, rg = tid >> 6;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int node = rid[8 * rg + u];
+            hv[u] = node >= 0 ? *reinterpret_cast<const u32x4 *>(hrows + (size_t)node * HC + hoff + (size_t)pc * 8) : u32x4{0u, 0u, 0u, 0u};
+        }
+    }
 #pragma unroll
     for (int c = 0; c < RING - 1; c++)
         if (c < nch) request(c);
+    // MODE 1 with dz: this workgroup sums d(logit) over the OUTGOING edges of its own 32 rows for its head (ds_src: what
+    // k_gat_dsrc did in a launch of its own) -- a group of 8 lanes per row, fixed order inside a lane, butterfly across.  The
+    // three dependent loads (row pointer, edge id, dz) run while the first chunks are in flight; their waits let those land.
+    if (own_ds) {
+        const int r = tid >> 3, l8 = tid & 7;              // 32 rows x 8 lanes
+        const int node = rid[r];
+        float acc_ = 0.f;
+        if (node >= 0) {
+            const int p0 = rowptr_t[node], p1 = rowptr_t[node + 1];
+            // the first 32 edges of a row: four edge ids, then four dz values, each set of loads in flight together (a
+            // plain loop is a chain of dependent round trips: ~8 of them cost this workgroup more than its first chunk)
+            int e4[4];
+            float d4[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const int p = p0 + l8 + 8 * k; e4[k] = p < p1 ? eid_t[p] : -1; }
+#pragma unroll
+            for (int k = 0; k < 4; k++) d4[k] = e4[k] >= 0 ? dz[(size_t)e4[k] * H + hd] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; k++) acc_ += d4[k];
+            for (int p = p0 + l8 + 32; p < p1; p += 8) acc_ += dz[(size_t)eid_t[p] * H + hd];
+        }
+        acc_ += __shfl_xor(acc_, 1, 64); acc_ += __shfl_xor(acc_, 2, 64); acc_ += __shfl_xor(acc_, 4, 64);
+        if (l8 == 0) {
+            ds_own[r] = acc_;                              // (read in the epilogue, behind the loop's barriers)
+            if (node >= 0 && ds_src_out != nullptr) ds_src_out[(size_t)node * H + hd] = acc_;
+        }
+    }
     for (int it = 0; it < nch; it++) {
         // chunk `it` has landed when at most the 5-operation groups of the younger chunks in flight are outstanding
         const int younger = min(nch - 1 - it, RING - 2);
@@ -376,19 +399,6 @@ __global__ __launch_bounds__(NT, AGG_WGS) void k_gat_agg(
         __builtin_amdgcn_s_barrier();
         if (it + RING - 1 < nch) request(it + RING - 1);
         multiply(it);
-    }
-
-    // MODE 1 with att_part: the attention-vector gradients d att_src[c] = sum_j ds_src[j] h[j, c], d att_dst likewise with
-    // ds_dst (k_gat_datt_part took a pass of its own over h and g for them: 25 us per layer).  This block's 32 rows of h
-    // are requested here, 16 bytes per thread and row, and consumed behind the epilogue.
-    u32x4 hv[8];
-    if (MODE == 1 && att_part != nullptr) {
-        const int pc = tid & 63, rg = tid >> 6;
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int node = rid[8 * rg + u];
-            hv[u] = node >= 0 ? *reinterpret_cast<const u32x4 *>(hrows + (size_t)node * HC + hoff + (size_t)pc * 8) : u32x4{0u, 0u, 0u, 0u};
-        }
     }
 
     // ---- epilogue: accumulators -> bf16 image in LDS (the ring is free) -> whole 16-byte pieces to global memory
