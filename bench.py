@@ -21,6 +21,7 @@ wall time.
 
 Prints ONE JSON line on rank 0.
 """
+import contextlib
 import argparse
 import json
 import os
@@ -225,12 +226,13 @@ def epoch_block(tu, model, opt, cfg, dd, stepper, T, beta1, torch):
     nsteps = sum(len(dd["dataloaders"][t]) for _, t in order)
 
     def run_steps():
-        for tp_i, tp in order:
-            for bi in range(len(dd["dataloaders"][tp])):
-                if stepper is not None:
-                    stepper.step(tp_i, tp, bi, epoch, beta1)
-                else:
-                    tu.training_step(model, opt, cfg, dd, tp_i, tp, bi, epoch, beta1)
+        with (stepper.chained() if stepper is not None else contextlib.nullcontext()):      # as train_SpaDOT's epoch loop does
+            for tp_i, tp in order:
+                for bi in range(len(dd["dataloaders"][tp])):
+                    if stepper is not None:
+                        stepper.step(tp_i, tp, bi, epoch, beta1)
+                    else:
+                        tu.training_step(model, opt, cfg, dd, tp_i, tp, bi, epoch, beta1)
 
     t0 = time.perf_counter()
     for _ in range(2 if stepper is not None else 0):      # first visits: eager, then capture (epochs 0 and 1 of a real run)
@@ -374,7 +376,8 @@ def _main(real_stdout):
         dd = tu.prepare_dataloader(data, cfg)
         del data
         model = SpaDOT.SpaDOT(cfg, dd).to(dev)
-        opt = FlatAdamW(model.parameters(), lr=cfg["lr"], last=model.GATEncoder.first_layer_parameters())
+        opt = FlatAdamW(model.parameters(), lr=cfg["lr"], last=model.GATEncoder.first_layer_parameters(),
+                        first=model.SVGPEncoder.parameters())
         tu._update_Kmeans(model, cfg, dd)          # labels/centres so the K-means and OT terms are live
         tu._update_OT_matrix(model, cfg)
         setup_s = time.perf_counter() - t_setup
@@ -422,16 +425,19 @@ def _main(real_stdout):
                     step(i)
             torch.cuda.synchronize()
             setup_s += time.perf_counter() - t_cap
-        for i in range(args.warmup):
-            step(i)
+        chain = state["stepper"].chained if state["stepper"] is not None else contextlib.nullcontext
+        with chain():                                # consecutive steps, like the inner loop of train_SpaDOT's epoch
+            for i in range(args.warmup):
+                step(i)
         # `repeats` timed regions of EXACTLY `steps` steps each, every one bracketed by barrier + synchronize and
         # reduced with MAX over ranks; `value` is the median region (spread reported beside it)
         regions = []
         for rep in range(max(1, args.repeats)):
             barrier()
             t0 = time.perf_counter()
-            for i in range(args.steps):
-                last = step(args.warmup + i)
+            with chain():
+                for i in range(args.steps):
+                    last = step(args.warmup + i)
             barrier()
             regions.append(max_over_ranks(time.perf_counter() - t0))
         el = float(np.median(regions))

@@ -333,6 +333,12 @@ int spadot_gemm_nn_bf16(const void *A, int lda, const void *B, int ldb, void *C,
 long long spadot_gemm_wgrad_bf16_workspace(int M, int N, int K, int slices);
 int spadot_gemm_wgrad_bf16(const void *G, int ldg, const void *X, int ldx, float *dW, int ldw, int M, int N, int K,
                            int slices, float *workspace, const void *zero_row, void *stream);
+/* The same with the tile width along K chosen by the caller: tile_k = 256 (the entry points above) or 192 (256 x 192 tiles:
+ * for shapes whose square-tile grid leaves the chip partly empty, e.g. 2048 x 3072 -- 96 square tiles x 2 slices = 192
+ * workgroups, but 128 x 2 = 256 of these).  X columns up to the next multiple of tile_k must be readable. */
+long long spadot_gemm_wgrad_bf16_workspace_tiled(int M, int N, int K, int slices, int tile_k);
+int spadot_gemm_wgrad_bf16_tiled(const void *G, int ldg, const void *X, int ldx, float *dW, int ldw, int M, int N, int K,
+                                 int slices, int tile_k, float *workspace, const void *zero_row, void *stream);
 
 /* ---- hidden stages of the decoder as one launch each way (csrc/mlp_chain.hip) -------------------------------------------
  * /root/reference/SpaDOT/model/decoder.py:3-20: [Linear, LayerNorm, LeakyReLU] x n_layers on x [b, dims[0]] (fp32);
@@ -408,6 +414,16 @@ int spadot_clip_adamw_images_dev(float *param, const float *grad, float *exp_avg
                                  double beta1, double beta2, double eps, double weight_decay, double max_norm, double *scratch,
                                  float *sumsq, int *step_dev, const float *grad_scale_dev, const spadot_weight_images *images,
                                  void *stream);
+/* The same update in two parts: the gradient norm + step count (once per step), then the element update of a RANGE
+ * [offset, offset + count) of the flat buffers (offset, count multiples of 4; `images` may be NULL; image offsets refer to
+ * the whole buffer).  A caller can update the parameters something is waiting for first and the rest afterwards: same
+ * arithmetic per element, bit-identical to the one-call form (_train_utils.py:214-217). */
+int spadot_grad_norm_step_dev(const float *grad, long long count, double *scratch, float *sumsq, int *step_dev, void *stream);
+int spadot_adamw_range_dev(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long long offset, long long count,
+                           double lr, double beta1, double beta2, double eps, double weight_decay, double max_norm,
+                           const float *sumsq, const int *step_dev, const float *grad_scale_dev, const spadot_weight_images *images,
+                           void *stream);
+
 int spadot_adamw_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
                       const float *sumsq, long long count, double lr, double beta1, double beta2,
                       double eps, double weight_decay, double max_norm, int step, void *stream);

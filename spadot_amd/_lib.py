@@ -142,6 +142,7 @@ def model_lib():
         "spadot_gemm_tn_bf16": [vp, ci, vp, ci, vp, ci, ci, ci, ci, vp],
         "spadot_gemm_nn_bf16": [vp, ci, vp, ci, vp, ci, ci, ci, ci, vp],
         "spadot_gemm_wgrad_bf16": [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, vp, vp, vp],
+        "spadot_gemm_wgrad_bf16_tiled": [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp],
         "spadot_mlp_chain_supported": [ci, vp],
         "spadot_headfc_forward": [vp, vp, vp, ci, ci, ci, vp, vp],
         "spadot_headfc_backward": [vp, vp, vp, ci, ci, ci, vp, vp, vp, vp],
@@ -185,6 +186,8 @@ def model_lib():
         "spadot_grad_sumsq": [vp, ll, vp, vp, vp],
         "spadot_clip_adamw_dev": [vp, vp, vp, vp, ll, cd, cd, cd, cd, cd, cd, vp, vp, vp, vp, vp, vp],
         "spadot_clip_adamw_images_dev": [vp, vp, vp, vp, ll, cd, cd, cd, cd, cd, cd, vp, vp, vp, vp, ctypes.POINTER(WeightImages), vp],
+        "spadot_grad_norm_step_dev": [vp, ll, vp, vp, vp, vp],
+        "spadot_adamw_range_dev": [vp, vp, vp, vp, ll, ll, cd, cd, cd, cd, cd, cd, vp, vp, vp, ctypes.POINTER(WeightImages), vp],
         "spadot_adamw_step": [vp, vp, vp, vp, vp, ll, cd, cd, cd, cd, cd, cd, ci, vp],
         "spadot_adamw_step_dev": [vp, vp, vp, vp, vp, ll, cd, cd, cd, cd, cd, cd, vp, vp],
     }
@@ -194,5 +197,7 @@ def model_lib():
         fn.restype = ci
     lib.spadot_gemm_wgrad_bf16_workspace.argtypes = [ci, ci, ci, ci]
     lib.spadot_gemm_wgrad_bf16_workspace.restype = ll
+    lib.spadot_gemm_wgrad_bf16_workspace_tiled.argtypes = [ci, ci, ci, ci, ci]
+    lib.spadot_gemm_wgrad_bf16_workspace_tiled.restype = ll
     lib._spadot_ready = True
     return lib

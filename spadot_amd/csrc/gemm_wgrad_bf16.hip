@@ -16,6 +16,10 @@
 //   * rows past M come from a zero row (they must contribute nothing);
 //   * the accumulators leave as 128-byte row segments (the k index is on the lanes).  S > 1: every workgroup writes its
 //     partial tile and a second launch (k_wgrad_reduce) adds the partials in slice order: a fixed order, no atomics.
+//   * a second instantiation with 256 x 192 output tiles (waves as 4 (n) x 2 (k), wave tile 64 x 96 = 2 x 3 MFMA tiles) for
+//     shapes the square tile leaves the chip a quarter empty on: 2048 x 3072 is 96 square tiles (x 2 slices = 192 workgroups)
+//     but 128 of these (x 2 = 256: one round).  Same staging (the X image keeps 512-byte rows, the 64 columns behind the
+//     tile come from the zero row), same pipeline.
 #include <hip/hip_runtime.h>
 #include <cstdint>
 
@@ -34,6 +38,8 @@ constexpr int STAGEB = 2 * OPB;                         // G chunk | X chunk
 constexpr int LDS_BYTES = 2 * STAGEB;                   // two stages: 128 KiB
 constexpr int PIECES = 8;                               // LDS-DMA instructions per wave and stage (64 in all, 2 rows each)
 
+// WGN x WGK waves, TI x TJ MFMA tiles (32 x 32) per wave: WGN * TI = 8 (256 rows of dW), tile width TKE = 32 WGK TJ columns
+template <int WGN, int WGK, int TI, int TJ>
 __global__ __launch_bounds__(NT, 1) void k_gemm_wgrad_bf16(const __bf16 *__restrict__ G, int ldg, const __bf16 *__restrict__ X,
                                                           int ldx, float *__restrict__ dW, int ldw, int M, int N, int K,
                                                           int ktiles, int S, int chunks_per_slice,
@@ -41,10 +47,13 @@ __global__ __launch_bounds__(NT, 1) void k_gemm_wgrad_bf16(const __bf16 *__restr
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tile = blockIdx.x / S, slice = blockIdx.x - tile * S;
     const int tn = tile / ktiles, tk = tile - tn * ktiles;
-    const int n0 = tn * TN, k0 = tk * TK;
+    static_assert(WGN * WGK == 8 && WGN * TI == 8 && WGK * TJ * 32 <= TK, "wave grid");
+    constexpr int TKE = 32 * WGK * TJ;                             // columns of dW a tile owns (256 or 192)
+    constexpr int RD = 2 * (TI + TJ);                              // LDS reads of one fragment set
+    const int n0 = tn * TN, k0 = tk * TKE;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave >> 2, wk = wave & 3;                       // wave grid 2 (n) x 4 (k)
+    const int wn = wave / WGK, wk = wave - wn * WGK;               // wave grid WGN (n) x WGK (k)
     const unsigned lds0 = (unsigned)(size_t)smem;
     const int nchunk_all = (M + CH - 1) / CH;
     const int c_begin = slice * chunks_per_slice, c_end = min(nchunk_all, c_begin + chunks_per_slice);
@@ -55,6 +64,7 @@ __global__ __launch_bounds__(NT, 1) void k_gemm_wgrad_bf16(const __bf16 *__restr
     // This wave's pieces: q = wave + 8 u.  Per lane a byte offset inside the operand (the chunk's first row is added per stage).
     size_t poff[PIECES];
     int prow[PIECES];
+    bool pzero = false;                                            // X columns behind a narrow tile: zeros (never read)
 #pragma unroll
     for (int u = 0; u < PIECES; u++) {
         const int q = wave + 8 * u, qq = q & 31;
@@ -62,15 +72,19 @@ __global__ __launch_bounds__(NT, 1) void k_gemm_wgrad_bf16(const __bf16 *__restr
         const int chunk = (lane & 31) ^ ((row & 3) << 2);
         prow[u] = row;
         poff[u] = u < 4 ? ((size_t)row * ldg + n0) * 2 + chunk * 16 : ((size_t)row * ldx + k0) * 2 + chunk * 16;
+        if (u >= 4 && chunk * 8 >= TKE) pzero = true;              // (row & 3 is the same for every piece of a lane)
     }
     auto request = [&](int ks) __attribute__((always_inline)) {
+#ifdef WGRAD_PROBE_NO_DMA                               // timing probe only (wrong results): nothing staged
+        return;
+#endif
         const int m0 = (c_begin + ks) * CH;
         const unsigned base = lds0 + (unsigned)(ks & 1) * STAGEB + (unsigned)wave * 1024u;
 #pragma unroll
         for (int u = 0; u < PIECES; u++) {
             const char *src = (u < 4 ? reinterpret_cast<const char *>(G) + (size_t)m0 * ldg * 2
                                      : reinterpret_cast<const char *>(X) + (size_t)m0 * ldx * 2) + poff[u];
-            if (m0 + prow[u] >= M) src = reinterpret_cast<const char *>(zrow) + (lane & 31) * 16;      // rows past M: zeros
+            if (m0 + prow[u] >= M || (u >= 4 && pzero)) src = reinterpret_cast<const char *>(zrow) + (lane & 31) * 16;   // rows past M: zeros
             const unsigned dst = __builtin_amdgcn_readfirstlane(base + (unsigned)(u & 3) * 8192u + (u < 4 ? 0u : (unsigned)OPB));
             unsigned keep;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -78,11 +92,11 @@ __global__ __launch_bounds__(NT, 1) void k_gemm_wgrad_bf16(const __bf16 *__restr
         }
     };
 
-    f16v acc[4][2];
+    f16v acc[TI][TJ];
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < TI; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++)
+        for (int j = 0; j < TJ; j++)
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
 
@@ -91,45 +105,61 @@ __global__ __launch_bounds__(NT, 1) void k_gemm_wgrad_bf16(const __bf16 *__restr
     // 8 hh + qq, and + 4 for the second read).  Column byte offset of tile t: 64 t' + 32 g16 + 8 pp with its 64-byte granule
     // index XORed with (row & 3) = qq.
     const int hh = lane >> 5, g16 = (lane >> 4) & 1, qq = (lane & 15) >> 2, pp = lane & 3;
-    unsigned ga[4], xb[2];
+    unsigned ga[TI], xb[TJ];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int gran = (wn * 4 + i) ^ qq;                          // (256 wn + 64 i) / 64, low two bits ^ qq
-        ga[i] = lds0 + (unsigned)((8 * hh + qq) * ROWB + ((wn * 4 + i) & ~3) * 64 + (gran & 3) * 64 + 32 * g16 + 8 * pp);
+    for (int i = 0; i < TI; i++) {
+        const int g = wn * TI + i;                                   // 64-byte granule (32 columns) of the G image
+        ga[i] = lds0 + (unsigned)((8 * hh + qq) * ROWB + (g & ~3) * 64 + ((g ^ qq) & 3) * 64 + 32 * g16 + 8 * pp);
     }
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
-        const int g = wk * 2 + j;                                    // (128 wk + 64 j) / 64
+    for (int j = 0; j < TJ; j++) {
+        const int g = wk * TJ + j;                                   // granule of the X image
         xb[j] = lds0 + (unsigned)OPB + (unsigned)((8 * hh + qq) * ROWB + (g & ~3) * 64 + ((g ^ qq) & 3) * 64 + 32 * g16 + 8 * pp);
     }
-    auto read_frags = [&](unsigned stage_off, int ss, s4v (&a)[4][2], s4v (&b)[2][2]) __attribute__((always_inline)) {
+    auto read_frags = [&](unsigned stage_off, int ss, s4v (&a)[TI][2], s4v (&b)[TJ][2]) __attribute__((always_inline)) {
         const unsigned so = stage_off + (unsigned)ss * (16 * ROWB);
+#ifdef WGRAD_PROBE_NO_READS                             // timing probe only (wrong results): no LDS reads
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
+        for (int j = 0; j < TJ; j++) b[j][0] = b[j][1] = s4v{(short)so, 1, 2, 3};
+#pragma unroll
+        for (int i = 0; i < TI; i++) a[i][0] = a[i][1] = s4v{(short)so, 1, 2, 3};
+        return;
+#endif
+#pragma unroll
+        for (int j = 0; j < TJ; j++) {
             asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(b[j][0]) : "v"(xb[j] + so));
             asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(b[j][1]) : "v"(xb[j] + so));
         }
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < TI; i++) {
             asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(a[i][0]) : "v"(ga[i] + so));
             asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(a[i][1]) : "v"(ga[i] + so));
         }
     };
-    auto mma = [&](const s4v (&a)[4][2], const s4v (&b)[2][2]) __attribute__((always_inline)) {
+    auto mma = [&](const s4v (&a)[TI][2], const s4v (&b)[TJ][2]) __attribute__((always_inline)) {
         __builtin_amdgcn_s_setprio(1);
-        bf8 bf[2];
+        bf8 bf[TJ];
 #pragma unroll
-        for (int j = 0; j < 2; j++) bf[j] = __builtin_bit_cast(bf8, __builtin_shufflevector(b[j][0], b[j][1], 0, 1, 2, 3, 4, 5, 6, 7));
+        for (int j = 0; j < TJ; j++) bf[j] = __builtin_bit_cast(bf8, __builtin_shufflevector(b[j][0], b[j][1], 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < TI; i++) {
             const bf8 af = __builtin_bit_cast(bf8, __builtin_shufflevector(a[i][0], a[i][1], 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
-            for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < TJ; j++) {
+#ifdef WGRAD_PROBE_NO_MFMA                              // timing probe only (wrong results): the fragments stay live, no matrix op
+                asm volatile("" ::"v"(af), "v"(bf[j]));
+#else
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[j], acc[i][j], 0, 0, 0);
+#endif
+            }
         }
         __builtin_amdgcn_s_setprio(0);
     };
     auto frags_ready = [&]() __attribute__((always_inline)) {      // the OLDER of the two fragment sets in flight has landed
-        asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+#ifdef WGRAD_PROBE_NO_READS
+        return;
+#endif
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(RD) : "memory");
         __builtin_amdgcn_sched_barrier(0);
     };
 
@@ -144,7 +174,7 @@ __global__ __launch_bounds__(NT, 1) void k_gemm_wgrad_bf16(const __bf16 *__restr
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
-        s4v a0[4][2], b0[2][2], a1[4][2], b1[2][2];
+        s4v a0[TI][2], b0[TJ][2], a1[TI][2], b1[TJ][2];
         read_frags(0u, 0, a0, b0);
         for (int P = 0; P < nk; P++) {
             const unsigned so = (unsigned)(P & 1) * STAGEB;
@@ -164,7 +194,7 @@ __global__ __launch_bounds__(NT, 1) void k_gemm_wgrad_bf16(const __bf16 *__restr
                 __builtin_amdgcn_s_barrier();
                 if (P + 2 < nk) request(P + 2);
                 read_frags((unsigned)((P + 1) & 1) * STAGEB, 0, a0, b0);
-                asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(RD) : "memory");
             } else {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
@@ -173,49 +203,49 @@ __global__ __launch_bounds__(NT, 1) void k_gemm_wgrad_bf16(const __bf16 *__restr
         }
     }
 
-    // ---- epilogue.  acc[i][j][e]: row n = n0 + 128 wn + 32 i + (e & 3) + 8 (e >> 2) + 4 hh, column k = k0 + 64 wk + 32 j + (lane & 31)
-    const int kcol = k0 + wk * 64 + (lane & 31);
-    auto row_of = [&](int i, int e) { return n0 + wn * 128 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * hh; };
+    // ---- epilogue.  acc[i][j][e]: row n = n0 + 32 (wn TI + i) + (e & 3) + 8 (e >> 2) + 4 hh, column k = k0 + 32 (wk TJ + j) + (lane & 31)
+    const int lk = (wk * TJ) * 32 + (lane & 31);
     if (S == 1) {
 #pragma unroll
-        for (int i = 0; i < 4; i++)
+        for (int i = 0; i < TI; i++)
 #pragma unroll
-            for (int j = 0; j < 2; j++)
+            for (int j = 0; j < TJ; j++)
 #pragma unroll
                 for (int e = 0; e < 16; e++) {
-                    const int n = row_of(i, e), k = kcol + 32 * j;
+                    const int n = n0 + (wn * TI + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh, k = k0 + lk + 32 * j;
                     if (n < N && k < K) dW[(size_t)n * ldw + k] = acc[i][j][e];
                 }
         return;
     }
-    // partial tile of this slice: part[slice][tile][256][256]
-    float *mine = part + ((size_t)slice * gridDim.x / S + tile) * (size_t)(TN * TK);
-    const int lk = wk * 64 + (lane & 31);
+    // partial tile of this slice: part[slice][tile][256][TKE]
+    float *mine = part + ((size_t)slice * gridDim.x / S + tile) * (size_t)(TN * TKE);
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < TI; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++)
+        for (int j = 0; j < TJ; j++)
 #pragma unroll
             for (int e = 0; e < 16; e++) {
-                const int ln = wn * 128 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * hh;
-                mine[(size_t)ln * TK + lk + 32 * j] = acc[i][j][e];
+                const int ln = (wn * TI + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                mine[(size_t)ln * TKE + lk + 32 * j] = acc[i][j][e];
             }
 }
 
 // S > 1: dW = sum of the S partial tiles in slice order (a fixed order; no atomics, no hand-over between workgroups -- the
 // last-arriver form of this sum, one workgroup per tile re-reading three partial tiles behind a device-scope release, took
 // 226 us against 83 us for the GEMM itself).  One 16-byte piece per thread, S independent loads.
+template <int TKE>
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ part, int S, int tiles, int ktiles,
                                                       float *__restrict__ dW, int ldw, int N, int K) {
-    const int tile = blockIdx.x >> 6;
-    const int idx4 = ((blockIdx.x & 63) << 8) + threadIdx.x;        // 16384 pieces per 256 x 256 tile
-    const int ln = idx4 >> 6, c4 = idx4 & 63;
+    constexpr int RP = TKE / 4;                                     // 16-byte pieces per tile row = 256-thread blocks per tile
+    const int tile = blockIdx.x / RP;
+    const int idx4 = (blockIdx.x - tile * RP) * 256 + threadIdx.x;  // 256 RP pieces per 256 x TKE tile
+    const int ln = idx4 / RP, c4 = idx4 - ln * RP;
     const int tn = tile / ktiles, tk = tile - tn * ktiles;
-    const int n = tn * TN + ln, k = tk * TK + 4 * c4;
+    const int n = tn * TN + ln, k = tk * TKE + 4 * c4;
     float4 v[8];
 #pragma unroll
     for (int s_ = 0; s_ < 8; s_++)
-        v[s_] = s_ < S ? reinterpret_cast<const float4 *>(part + ((size_t)s_ * tiles + tile) * (size_t)(TN * TK))[idx4]
+        v[s_] = s_ < S ? reinterpret_cast<const float4 *>(part + ((size_t)s_ * tiles + tile) * (size_t)(TN * TKE))[idx4]
                        : make_float4(0.f, 0.f, 0.f, 0.f);
     float4 sum = v[0];
 #pragma unroll
@@ -244,37 +274,58 @@ static int effective_slices(int M, int slices, int *cps_out) {
 }  // namespace
 
 // floats of caller-owned workspace a call with these arguments needs (0: a single slice writes dW directly)
-extern "C" long long spadot_gemm_wgrad_bf16_workspace(int M, int N, int K, int slices) {
-    if (M <= 0 || N <= 0 || K <= 0 || N % TN != 0) return -22;
+extern "C" long long spadot_gemm_wgrad_bf16_workspace_tiled(int M, int N, int K, int slices, int tile_k) {
+    if (M <= 0 || N <= 0 || K <= 0 || N % TN != 0 || (tile_k != 256 && tile_k != 192)) return -22;
     const int S = effective_slices(M, slices, nullptr);
-    const long long tiles = (long long)(N / TN) * ((K + TK - 1) / TK);
-    return S > 1 ? (long long)S * tiles * TN * TK : 0;
+    const long long tiles = (long long)(N / TN) * ((K + tile_k - 1) / tile_k);
+    return S > 1 ? (long long)S * tiles * TN * tile_k : 0;
 }
 
-extern "C" int spadot_gemm_wgrad_bf16(const void *G, int ldg, const void *X, int ldx, float *dW, int ldw, int M, int N, int K,
-                                      int slices, float *workspace, const void *zero_row, void *stream) {
+extern "C" long long spadot_gemm_wgrad_bf16_workspace(int M, int N, int K, int slices) {
+    return spadot_gemm_wgrad_bf16_workspace_tiled(M, N, K, slices, 256);
+}
+
+template <int WGN, int WGK, int TI, int TJ>
+static int launch_wgrad(const void *G, int ldg, const void *X, int ldx, float *dW, int ldw, int M, int N, int K, int ktiles, int ntiles,
+                        int S, int cps, float *workspace, const void *zero_row, hipStream_t stream) {
+    constexpr int TKE = 32 * WGK * TJ;
+    static bool attr_set = false;
+    auto kern = k_gemm_wgrad_bf16<WGN, WGK, TI, TJ>;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return -5;
+        attr_set = true;
+    }
+    const int tiles = ntiles * ktiles;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * S)), dim3(NT), LDS_BYTES, stream, (const __bf16 *)G, ldg, (const __bf16 *)X, ldx, dW,
+                       ldw, M, N, K, ktiles, S, cps, (const __bf16 *)zero_row, workspace);
+    if (S > 1)
+        hipLaunchKernelGGL(k_wgrad_reduce<TKE>, dim3((unsigned)tiles * (unsigned)(TKE / 4)), dim3(256), 0, stream, (const float *)workspace, S,
+                           tiles, ktiles, dW, ldw, N, K);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+// tile_k: 256 (square tiles) or 192 (256 x 192 tiles: for shapes whose square-tile grid leaves the chip partly empty)
+extern "C" int spadot_gemm_wgrad_bf16_tiled(const void *G, int ldg, const void *X, int ldx, float *dW, int ldw, int M, int N, int K,
+                                            int slices, int tile_k, float *workspace, const void *zero_row, void *stream) {
     if (M <= 0 || N <= 0 || K <= 0 || N % TN != 0 || ldg < N || ldx < K || ldw < K || ldg % 8 || ldx % 8) return -22;
+    if (tile_k != 256 && tile_k != 192) return -22;
     if (((uintptr_t)G & 15) || ((uintptr_t)X & 15) || ((uintptr_t)dW & 15) || (ldw % 4)) return -22;
     if (!zero_row || ((uintptr_t)zero_row & 15)) return -22;
-    // the X image reads whole 256-column tiles: the row stride must cover the last (partial) tile
-    const int ktiles = (K + TK - 1) / TK, ntiles = N / TN;
-    if (ldx < ktiles * TK) return -22;
+    // the X image reads whole tiles: the row stride must cover the last (partial) tile
+    const int ktiles = (K + tile_k - 1) / tile_k, ntiles = N / TN;
+    if (ldx < ktiles * tile_k) return -22;
     // the LDS-DMA source offsets are 32-bit: an operand image must stay below 4 GiB
     if ((size_t)M * ldg * 2 >= ((size_t)1 << 32) || (size_t)M * ldx * 2 >= ((size_t)1 << 32)) return -22;
     int cps = 0;
     const int S = effective_slices(M, slices, &cps);
-    const int tiles = ntiles * ktiles;
-    if (tiles > 4096) return -22;
+    if (ntiles * ktiles > 4096) return -22;
     if (S > 1 && (!workspace || ((uintptr_t)workspace & 15))) return -22;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)k_gemm_wgrad_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return -5;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(k_gemm_wgrad_bf16, dim3((unsigned)(tiles * S)), dim3(NT), LDS_BYTES, (hipStream_t)stream, (const __bf16 *)G, ldg,
-                       (const __bf16 *)X, ldx, dW, ldw, M, N, K, ktiles, S, cps, (const __bf16 *)zero_row, workspace);
-    if (S > 1)
-        hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)tiles * 64u), dim3(256), 0, (hipStream_t)stream, (const float *)workspace, S,
-                           tiles, ktiles, dW, ldw, N, K);
-    return hipGetLastError() == hipSuccess ? 0 : -5;
+    if (tile_k == 256)
+        return launch_wgrad<2, 4, 4, 2>(G, ldg, X, ldx, dW, ldw, M, N, K, ktiles, ntiles, S, cps, workspace, zero_row, (hipStream_t)stream);
+    return launch_wgrad<4, 2, 2, 3>(G, ldg, X, ldx, dW, ldw, M, N, K, ktiles, ntiles, S, cps, workspace, zero_row, (hipStream_t)stream);
+}
+
+extern "C" int spadot_gemm_wgrad_bf16(const void *G, int ldg, const void *X, int ldx, float *dW, int ldw, int M, int N, int K,
+                                      int slices, float *workspace, const void *zero_row, void *stream) {
+    return spadot_gemm_wgrad_bf16_tiled(G, ldg, X, ldx, dW, ldw, M, N, K, slices, 256, workspace, zero_row, stream);
 }

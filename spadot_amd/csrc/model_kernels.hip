@@ -1358,7 +1358,8 @@ __global__ __launch_bounds__(256) void k_adamw_img(float *__restrict__ p, const 
                                                    const float *__restrict__ sumsq, long long count, float lr,
                                                    float b1, float b2, float eps, float wd, float max_norm,
                                                    const int *__restrict__ step_dev, const float *__restrict__ grad_scale,
-                                                   spadot_weight_images imgs) {
+                                                   spadot_weight_images imgs, long long base) {
+    // base: index of p[0] in the flat buffer the image offsets refer to (a launch over a sub-range of it)
     const double t = (double)step_dev[0];
     const float bc1 = (float)(1.0 - pow((double)b1, t));
     const float bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, t));
@@ -1386,7 +1387,7 @@ __global__ __launch_bounds__(256) void k_adamw_img(float *__restrict__ p, const 
         for (int s_ = 0; s_ < 8; s_++) {
             if (s_ >= imgs.n) break;
             const spadot_weight_image W = imgs.w[s_];
-            const unsigned long long d = (unsigned long long)(k - W.offset);
+            const unsigned long long d = (unsigned long long)(k + base - W.offset);
             if (d < (unsigned long long)W.rows * (unsigned long long)W.K) {
                 const unsigned row = (unsigned)d / (unsigned)W.K;                    // (d < 2^31: checked on the host)
                 const unsigned col = (unsigned)d - row * (unsigned)W.K;
@@ -2478,7 +2479,45 @@ int spadot_clip_adamw_images_dev(float *param, const float *grad, float *exp_avg
     const int nb = (int)(want4 < 4096 ? want4 : 4096);
     hipLaunchKernelGGL(k_adamw_img, dim3(nb), dim3(256), 0, st_, param, grad, exp_avg, exp_avg_sq, (const float *)sumsq, count,
                        (float)lr, (float)beta1, (float)beta2, (float)eps, (float)weight_decay, (float)max_norm,
-                       (const int *)step_dev, grad_scale_dev, *images);
+                       (const int *)step_dev, grad_scale_dev, *images, 0ll);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+// The two halves of spadot_clip_adamw_images_dev as entry points of their own, so that a caller can update a RANGE of the
+// flat buffer first (and let whoever needs only those parameters start) and the rest afterwards: the same launches, the
+// same arithmetic per element -- bit-identical parameters whatever the split.
+int spadot_grad_norm_step_dev(const float *grad, long long count, double *scratch, float *sumsq, int *step_dev, void *stream) {
+    if (count <= 0 || !scratch || !sumsq || !step_dev || ((uintptr_t)grad & 15)) return -22;
+    hipStream_t st_ = (hipStream_t)stream;
+    const long long want4 = (count / 4 + 255) / 256;
+    const int nb2 = (int)(want4 < 1 ? 1 : (want4 < 2048 ? want4 : 2048));
+    hipLaunchKernelGGL(k_sumsq_part_u<4>, dim3(nb2), dim3(256), 0, st_, grad, count, scratch);
+    hipLaunchKernelGGL(k_final_sum_step, dim3(1), dim3(1024), 0, st_, (const double *)scratch, nb2, sumsq, step_dev);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+int spadot_adamw_range_dev(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long long offset, long long count,
+                           double lr, double beta1, double beta2, double eps, double weight_decay, double max_norm,
+                           const float *sumsq, const int *step_dev, const float *grad_scale_dev, const spadot_weight_images *images,
+                           void *stream) {
+    if (offset < 0 || count <= 0 || (offset & 3) || (count & 3) || !step_dev || !sumsq) return -22;
+    if (((uintptr_t)grad & 15) || ((uintptr_t)param & 15) || ((uintptr_t)exp_avg & 15) || ((uintptr_t)exp_avg_sq & 15)) return -22;
+    spadot_weight_images none;
+    none.n = 0;
+    const spadot_weight_images *tab = images ? images : &none;
+    if (tab->n < 0 || tab->n > 8) return -22;
+    for (int s_ = 0; s_ < tab->n; s_++) {
+        const spadot_weight_image &W = tab->w[s_];
+        if (!W.image || ((uintptr_t)W.image & 7) || W.rows <= 0 || W.K <= 0 || (W.K & 3) || W.Kp < W.K || (W.Kp & 3) || (W.offset & 3) ||
+            W.offset < 0 || (long long)W.rows * W.K >= (1ll << 31))
+            return -22;
+    }
+    hipStream_t st_ = (hipStream_t)stream;
+    const long long want4 = (count / 4 + 255) / 256;
+    const int nb = (int)(want4 < 4096 ? want4 : 4096);
+    hipLaunchKernelGGL(k_adamw_img, dim3(nb), dim3(256), 0, st_, param + offset, grad + offset, exp_avg + offset, exp_avg_sq + offset,
+                       sumsq, count, (float)lr, (float)beta1, (float)beta2, (float)eps, (float)weight_decay, (float)max_norm,
+                       step_dev, grad_scale_dev, *tab, offset);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 

@@ -310,6 +310,23 @@ GEMM_DGRAD = [__import__("os").environ.get("SPADOT_GEMM_DGRAD", "1") == "1"]
 GEMM_DGRAD_MIN_WGS = [int(__import__("os").environ.get("SPADOT_GEMM_DGRAD_MIN_WGS", "240"))]
 GEMM_MAX_WGS = [int(__import__("os").environ.get("SPADOT_GEMM_MAXWG", "256"))]   # own GEMM only up to this many tiles (CUs left free)
 GEMM_OWN = [True]                                  # [False]: gemm_tn() itself goes to the library (tests)
+# "Kp:Mmin[:Mmax],..." -- forward maps with that (padded) contraction width and row count go through the own kernel.  Default:
+# the second GAT layer at the benchmarked batch shape (~10^4 rows x 2048 -> 2048: 256 tiles, one round).  In the step the
+# library's 504 tiles of 160 x 256 run that map in 123-137 us (90 alone: it shares the chip with the SVGP branch's inverse and
+# its last round is then a third full), the own kernel's one round gave +1.1 % of the step (same-box A/B, round 3).  The first
+# layer (Kp 3072, beside the SVGP encoder's short launches) and the third (8031 rows: stream-K in the library, 1.18 PFLOP/s)
+# measured better on the library.  "none" = library everywhere.
+GEMM_FWD_SHAPES = [[tuple(int(v) for v in t.split(":")) for t in
+                    __import__("os").environ.get("SPADOT_GEMM_FWD_SHAPES", "2048:9000").split(",") if t and t != "none"]]
+
+
+def _own_forward(M, Kp):
+    if GEMM_FWD[0]:
+        return True
+    for t in GEMM_FWD_SHAPES[0]:
+        if t[0] == Kp and M >= t[1] and (len(t) < 3 or M <= t[2]):
+            return True
+    return False
 
 
 def gemm_tn(x, w):
@@ -349,34 +366,57 @@ def _zero_row(device):
     return z
 
 
+WGRAD_TILE_K = [int(__import__("os").environ.get("SPADOT_WGRAD_TILE_K", "0"))]    # 0: chosen per shape; 256 / 192: forced
+
+
+def wgrad_plan(N, K, Kp):
+    """(tile_k, slices, workgroups) of csrc/gemm_wgrad_bf16.hip for a [N x K] weight gradient, or None (library): the tile
+    width whose grid fills more of the chip's 256 compute units in one round; the narrow tile only where it gains a fifth
+    (it reuses each staged byte less)."""
+    best = None
+    for tk in ((256, 192) if WGRAD_TILE_K[0] == 0 else (WGRAD_TILE_K[0],)):
+        kt = (K + tk - 1) // tk
+        if Kp < kt * tk:
+            continue
+        tiles = (N // 256) * kt
+        if tiles == 0 or tiles > 256:
+            wgs, slices = tiles, 1
+        else:
+            slices = min(8, max(1, 256 // tiles))
+            wgs = tiles * slices
+        fill = wgs / (256.0 * ((wgs + 255) // 256)) if wgs else 0.0
+        score = fill * (1.0 if tk == 256 else 0.85)
+        if best is None or score > best[0]:
+            best = (score, tk, slices, wgs)
+    if best is None or best[3] < WGRAD_MIN_WGS[0]:
+        return None
+    return best[1], best[2], best[3]
+
+
 def wgrad_bf16(g, x, K, out=None):
     """g^T x[:, :K] -> fp32 [N, K] for g [M, N], x [M, Kp >= K] (bf16): csrc/gemm_wgrad_bf16.hip where its conditions hold
-    (N % 256 == 0, the X rows readable up to the next multiple of 256 columns), else the library."""
+    (N % 256 == 0, the X rows readable up to the next multiple of the tile width), else the library."""
     M, N = g.shape
     Kp = x.shape[1]
-    kt = (K + 255) // 256
     if (WGRAD_OWN[0] and g.is_cuda and g.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and g.is_contiguous()
-            and x.is_contiguous() and N % 256 == 0 and Kp >= kt * 256 and Kp % 8 == 0 and M >= 1024 and N >= 1024 and K >= 1024):
+            and x.is_contiguous() and N % 256 == 0 and Kp % 8 == 0 and M >= 1024 and N >= 1024 and K >= 1024):
         if out is None:
             out = torch.empty((N, K), dtype=torch.float32, device=g.device)
-        tiles = 0
-        if out.is_contiguous() and out.dtype == torch.float32 and out.shape == (N, K):
-            tiles = (N // 256) * kt
-            if tiles * max(1, 256 // tiles) < WGRAD_MIN_WGS[0]:
-                tiles = 0                      # too few workgroups for the chip (2048 x 3000: 96 tiles x 2): library
-        if tiles:
+        plan = wgrad_plan(N, K, Kp) if (out.is_contiguous() and out.dtype == torch.float32 and out.shape == (N, K)) else None
+        if plan is not None:
+            tile_k, slices, _ = plan
             lib = model_lib()
-            slices = max(1, 256 // tiles)
-            need = int(lib.spadot_gemm_wgrad_bf16_workspace(M, N, K, slices))
+            need = int(lib.spadot_gemm_wgrad_bf16_workspace_tiled(M, N, K, slices, tile_k))
             # the split-contraction partials belong to THIS call: under capture they come out of the capturing graph's
             # pool, so graphs replayed on different streams never share them and nothing a graph points at is ever freed
             ws = torch.empty(max(need, 4), dtype=torch.float32, device=g.device) if need >= 0 else None
-            rc = -22 if ws is None else lib.spadot_gemm_wgrad_bf16(g.data_ptr(), N, x.data_ptr(), Kp, out.data_ptr(), K, M, N, K,
-                                                                  slices, ws.data_ptr(), _zero_row(g.device).data_ptr(), _stream())
+            rc = -22 if ws is None else lib.spadot_gemm_wgrad_bf16_tiled(g.data_ptr(), N, x.data_ptr(), Kp, out.data_ptr(), K, M, N, K,
+                                                                        slices, tile_k, ws.data_ptr(), _zero_row(g.device).data_ptr(),
+                                                                        _stream())
             if rc == 0:
                 return out
             if rc != -22:
-                _check(rc, "spadot_gemm_wgrad_bf16")
+                _check(rc, "spadot_gemm_wgrad_bf16_tiled")
     if out is not None:
         return torch.mm(g.t(), x[:, :K], out_dtype=torch.float32, out=out)
     return torch.mm(g.t(), x[:, :K], out_dtype=torch.float32)
@@ -400,7 +440,7 @@ class _DenseCD(torch.autograd.Function):
         # directly (FlatAdamW.backward then has nothing to copy for this parameter)
         g = W.grad
         ctx.wgrad = g if (g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.shape == W.shape) else None
-        return gemm_tn(x, wbuf) if GEMM_FWD[0] else torch.nn.functional.linear(x, wbuf)
+        return gemm_tn(x, wbuf) if _own_forward(x.shape[0], Kp) else torch.nn.functional.linear(x, wbuf)
 
     @staticmethod
     def backward(ctx, g):
@@ -1295,15 +1335,21 @@ class FlatAdamW:
     flat fp32 parameter buffer.  Parameters of `module` are re-pointed into the flat buffer (so the
     gradient all-reduce of the data-parallel path is a single collective over `flat_grad`)."""
 
-    def __init__(self, params, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_norm=0.3, last=None):
+    def __init__(self, params, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_norm=0.3, last=None, first=None):
         """last: parameters to place at the END of the flat buffers (the update is element-wise, so the order is free).
         The data-parallel path puts the parameters whose gradients arrive last in the backward pass there -- the
         first GAT layer's -- so that `flat_grad[:tail_offset]` can be all-reduced while they are still being
-        computed (GraphedStepper, bucketed exchange)."""
+        computed (GraphedStepper, bucketed exchange).
+        first: parameters to place at the START: step_head() updates them alone, step_rest() the others -- the SVGP
+        encoder's go there, so that the next step's SVGP branch (the long pole of the forward pass) can start while the
+        bulk of the update is still streaming (GraphedStepper.chained)."""
         params = [p for p in params if p.requires_grad]
         tail_ids = {id(p) for p in (last or [])}
-        params = [p for p in params if id(p) not in tail_ids] + [p for p in params if id(p) in tail_ids]
+        head_ids = {id(p) for p in (first or [])} - tail_ids
+        params = ([p for p in params if id(p) in head_ids] + [p for p in params if id(p) not in tail_ids and id(p) not in head_ids]
+                  + [p for p in params if id(p) in tail_ids])
         n_tail = sum(1 for p in params if id(p) in tail_ids)
+        n_head = sum(1 for p in params if id(p) in head_ids)
         assert params and all(p.is_cuda and p.dtype == torch.float32 for p in params), \
             "FlatAdamW needs fp32 parameters on the MI355X"
         dev = params[0].device
@@ -1326,6 +1372,7 @@ class FlatAdamW:
         self.params, self.count = params, tot
         self.tail_offset = offs[len(params) - n_tail] if n_tail else None     # start of the `last` group (16-byte aligned)
         self.tail_params = params[len(params) - n_tail:] if n_tail else []
+        self.head_count = (offs[n_head] if n_head < len(params) else tot) if n_head else 0     # elements of the `first` group
         self.lr, self.betas, self.eps, self.weight_decay, self.max_norm = lr, betas, eps, weight_decay, max_norm
         self.t = 0
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)   # device-side step count (graph replays)
@@ -1451,3 +1498,23 @@ class FlatAdamW:
                                                  self.eps, self.weight_decay, self.max_norm, _p(self.scratch), _p(self.sumsq),
                                                  _p(self.step_dev), _p(self._counter), _p(self.grad_scale), _stream()),
                "spadot_clip_adamw_dev")
+
+    def _update_range(self, lo, hi):
+        tab = ctypes.byref(self._images_struct()) if self._images else None
+        _check(model_lib().spadot_adamw_range_dev(_p(self.flat_param), _p(self.flat_grad), _p(self.exp_avg), _p(self.exp_avg_sq),
+                                                  lo, hi - lo, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
+                                                  self.max_norm, _p(self.sumsq), _p(self.step_dev), _p(self.grad_scale), tab,
+                                                  _stream()), "spadot_adamw_range_dev")
+
+    def step_head(self):
+        """First part of step() in two parts: gradient norm + step count, then the update of the `first` group alone.
+        step_rest() must follow.  Together they leave the bits step() leaves (same arithmetic per element)."""
+        assert self.head_count > 0 and self.count % 4 == 0
+        self.t += 1
+        _check(model_lib().spadot_grad_norm_step_dev(_p(self.flat_grad), self.count, _p(self.scratch), _p(self.sumsq),
+                                                     _p(self.step_dev), _stream()), "spadot_grad_norm_step_dev")
+        self._update_range(0, self.head_count)
+
+    def step_rest(self):
+        if self.head_count < self.count:
+            self._update_range(self.head_count, self.count)

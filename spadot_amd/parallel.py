@@ -31,6 +31,7 @@ process / single device); the design follows SURVEY 8(e):
     This turns the reference's sequential one-step-per-batch schedule into synchronous steps with P
     batches per update: 1-GPU runs are the parity-checked ones (SURVEY 8e caveat).
 """
+import contextlib
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -286,7 +287,8 @@ def train_SpaDOT_parallel(dataloader_dict, model_config, verbose=False):
     if P > 1:
         for t in list(model.parameters()) + [b for b in model.buffers()]:
             dist.broadcast(t.data, src=0)
-    opt = FlatAdamW(model.parameters(), lr=model_config["lr"], last=model.GATEncoder.first_layer_parameters())
+    opt = FlatAdamW(model.parameters(), lr=model_config["lr"], last=model.GATEncoder.first_layer_parameters(),
+                    first=model.SVGPEncoder.parameters())
     sync, sync_async = make_grad_sync(opt)
     beta1s = tu._beta_cycle_linear(model_config["maxiter"], stop=model_config["beta1"])
     order = list(enumerate(model_config["timepoints"]))
@@ -319,9 +321,10 @@ def train_SpaDOT_parallel(dataloader_dict, model_config, verbose=False):
                 acc.append(tu.forward_backward(model, model_config, dataloader_dict, tp_i, tp, bi, epoch, beta1,
                                                optimizer=opt))
 
-        _, n_mine = run_epoch(plan, batches_per_tp, order, compute_grad, opt.zero_grad, opt.flat_grad,
-                              stepper.update if stepper is not None else opt.step, exchange=exchange,
-                              set_grad_scale=lambda x: opt.grad_scale.fill_(x))
+        with (stepper.chained() if stepper is not None else contextlib.nullcontext()):
+            _, n_mine = run_epoch(plan, batches_per_tp, order, compute_grad, opt.zero_grad, opt.flat_grad,
+                                  stepper.update if stepper is not None else opt.step, exchange=exchange,
+                                  set_grad_scale=lambda x: opt.grad_scale.fill_(x))
         losses[epoch] = torch.stack(acc).mean(0).cpu().tolist() if acc else None
         average_buffers(model, weight=n_mine)
         # inference + K-means refit of a time point on ONE rank; centres (and, where other ranks train on that time

@@ -11,6 +11,7 @@ What differs from the reference, on purpose (SURVEY 7 "hard parts", App. D):
   * backward(retain_graph=True) is not replicated (App. D.11);
   * only the first growth solve of compute_transport_map is run (it is the one returned, App. D.1).
 """
+import contextlib
 import os
 import random
 from collections import OrderedDict
@@ -460,6 +461,11 @@ class GraphedStepper:
                 model.register_load_state_dict_post_hook(lambda mod, incompatible: optimizer.refresh_images())
                 object.__setattr__(model, "_image_refresh_hook", True)
         self._images_version = getattr(optimizer, "images_version", 0)
+        # update in two graphs around an event (see update(), chained()); needs FlatAdamW(first=...)
+        self.split_update = bool(model_config.get("split_update", os.environ.get("SPADOT_SPLIT_UPDATE", "1") == "1"))
+        self._head_event, self._head_ready, self._chain = None, False, False
+        # the update's four launches issued directly instead of as graphs (A/B: a graph boundary costs ~15-20 us of idle stream)
+        self.eager_update = bool(model_config.get("eager_update", os.environ.get("SPADOT_EAGER_UPDATE", "0") == "1"))
 
     def _body(self, tp_i, tp, bi, epoch, with_update=True):
         losses = forward_backward(self.model, self.cfg, self.dd, tp_i, tp, bi, epoch, self.beta1_t,
@@ -480,20 +486,58 @@ class GraphedStepper:
 
     def update(self):
         """clip + AdamW as its own graph (data-parallel path: after the gradient exchange): eager once, then one
-        replayed graph shared by all keys."""
+        replayed graph shared by all keys.  With an optimizer that has a `first` group (the SVGP encoder's parameters:
+        FlatAdamW(first=...)) the update is TWO graphs -- gradient norm + the first group, then everything else -- with
+        an event between them that the next step's SVGP branch waits for instead of the whole update (chained())."""
         if getattr(self.opt, "images_version", 0) != self._images_version:     # the update's image table changed:
             self._images_version = self.opt.images_version                      # a captured launch carries the old one
             self.opt_graph = None if self.opt_graph in (None, False) else False
-        if not self.capturable:
-            self.opt.step()
-        elif self.opt_graph is None:
-            self.opt.step()
-            self.opt_graph = False                  # warmed up; capture on the next call
-        elif self.opt_graph is False:
-            self.opt_graph, _ = self._capture(self.opt.step)
-            self.opt_graph.replay()
+        split = self.split_update and getattr(self.opt, "head_count", 0) > 0
+        if not split:
+            if not self.capturable:
+                self.opt.step()
+            elif self.opt_graph is None:
+                self.opt.step()
+                self.opt_graph = False                  # warmed up; capture on the next call
+            elif self.opt_graph is False:
+                self.opt_graph, _ = self._capture(self.opt.step)
+                self.opt_graph.replay()
+            else:
+                self.opt_graph.replay()
+            return
+        if self._head_event is None:
+            self._head_event = torch.cuda.Event()
+        main = torch.cuda.current_stream()
+        if not self.capturable or self.opt_graph is None or self.eager_update:
+            self.opt.step_head()
+            self._head_event.record(main)
+            self.opt.step_rest()
+            if self.capturable and not self.eager_update:
+                self.opt_graph = False
         else:
-            self.opt_graph.replay()
+            if self.opt_graph is False:
+                ga, _ = self._capture(self.opt.step_head)
+                gb, _ = self._capture(self.opt.step_rest)
+                self.opt_graph = (ga, gb)
+            self.opt_graph[0].replay()
+            self._head_event.record(main)
+            self.opt_graph[1].replay()
+        self._head_ready = True
+
+    @contextlib.contextmanager
+    def chained(self):
+        """Consecutive step() calls with NOTHING else enqueued in between that reads or writes the SVGP encoder (its
+        parameters, BatchNorm statistics) or the side stream's buffers -- the inner loop of an epoch.  Inside, the SVGP branch of
+        step k + 1 waits only for the part of step k's update that writes ITS parameters (update()'s first graph), and runs
+        beside the rest of the update and the first GAT GEMM instead of behind them: that branch (~0.6-0.7 ms beside the
+        GAT GEMMs: encoder, 2 L inverses of m x m) bounded the forward pair of most steps by 0.12-0.23 ms (rocprofv3
+        timeline, round 3).  The first step of a chain, and every step outside one, waits for the whole stream."""
+        prev = self._chain
+        self._chain, self._head_ready = True, False
+        try:
+            yield self
+        finally:
+            self._chain, self._head_ready = prev, False
 
     def _run(self, tp_i, tp, bi, epoch, beta1, with_update):
         if getattr(self.model, "_state_version", 0) != self.version:      # a state tensor was re-allocated
@@ -616,7 +660,11 @@ class GraphedStepper:
         # (rocprofv3 timeline, profiles/r02).  The side stream's wait on `main` is recorded before the GAT launch, so it
         # covers the work in front of the pair, not the GAT graph itself.
         if two_streams:
-            side.wait_stream(main)
+            if self._chain and self._head_ready and self._head_event is not None:
+                side.wait_event(self._head_event)        # (chained(): the previous step's update of the SVGP encoder)
+            else:
+                side.wait_stream(main)
+            self._head_ready = False
         if self.issue_order[0] == "m" and two_streams:
             fns[0]()
             with torch.cuda.stream(side):
@@ -732,7 +780,7 @@ def train_SpaDOT(dataloader_dict, model_config, verbose=True):
     import pandas as pd
     device = torch.device(model_config["device"])
     model = SpaDOT.SpaDOT(model_config, dataloader_dict).to(device)
-    optimizer = FlatAdamW(model.parameters(), lr=model_config["lr"])
+    optimizer = FlatAdamW(model.parameters(), lr=model_config["lr"], first=model.SVGPEncoder.parameters())
     stepper = GraphedStepper(model, optimizer, model_config, dataloader_dict) if model_config.get("use_hip_graphs", True) else None
     if stepper is not None:
         stepper.clone_output = False          # the loop below adds every step's losses to `tot` right away
@@ -751,17 +799,19 @@ def train_SpaDOT(dataloader_dict, model_config, verbose=True):
         ep_start = time()
         random.shuffle(tp_indexed_list)
         acc = {}
-        for tp_i, tp in tp_indexed_list:
-            if tp not in dataloader_dict["dataloaders"]:
-                continue
-            nb = len(dataloader_dict["dataloaders"][tp])
-            tot = torch.zeros(len(LOSS_NAMES), dtype=torch.float32, device=device)
-            for bi in range(nb):
-                if stepper is not None:
-                    tot += stepper.step(tp_i, tp, bi, epoch, beta1).float()
-                else:
-                    tot += training_step(model, optimizer, model_config, dataloader_dict, tp_i, tp, bi, epoch, beta1).float()
-            acc[tp] = tot / nb
+        # (one chain: between two steps of an epoch only the loss accumulation is enqueued -- GraphedStepper.chained)
+        with (stepper.chained() if stepper is not None else contextlib.nullcontext()):
+            for tp_i, tp in tp_indexed_list:
+                if tp not in dataloader_dict["dataloaders"]:
+                    continue
+                nb = len(dataloader_dict["dataloaders"][tp])
+                tot = torch.zeros(len(LOSS_NAMES), dtype=torch.float32, device=device)
+                for bi in range(nb):
+                    if stepper is not None:
+                        tot += stepper.step(tp_i, tp, bi, epoch, beta1).float()
+                    else:
+                        tot += training_step(model, optimizer, model_config, dataloader_dict, tp_i, tp, bi, epoch, beta1).float()
+                acc[tp] = tot / nb
         for tp, v in acc.items():                      # one device->host read per time point per epoch
             for name, val in zip(LOSS_NAMES, v.cpu().tolist()):
                 loss_dict[epoch][name] += val

@@ -84,14 +84,19 @@ def test_dense_map_uses_own_gemm_and_matches_library():
     np.testing.assert_allclose(a.float().cpu().numpy(), b.float().cpu().numpy(), rtol=2 ** -7, atol=2e-3)
 
 
-@pytest.mark.parametrize("M,N,K,Kp,slices", [
-    (64, 256, 256, 256, 1),            # one chunk, one tile, no slicing
-    (100, 256, 256, 256, 2),           # rows past M in the second chunk come from the zero row
-    (1000, 512, 300, 512, 3),          # partial last column tile, three slices (one chunk short of even)
-    (9980, 2048, 2048, 2048, 4),       # layer-2 shape: 64 tiles x 4 slices
-    (9980, 2048, 3000, 3072, 2),       # layer-1 shape: 96 tiles x 2 slices, output row stride 3000
+@pytest.mark.parametrize("M,N,K,Kp,slices,tile_k", [
+    (64, 256, 256, 256, 1, 256),            # one chunk, one tile, no slicing
+    (100, 256, 256, 256, 2, 256),           # rows past M in the second chunk come from the zero row
+    (1000, 512, 300, 512, 3, 256),          # partial last column tile, three slices (one chunk short of even)
+    (9980, 2048, 2048, 2048, 4, 256),       # layer-2 shape: 64 tiles x 4 slices
+    (9980, 2048, 3000, 3072, 2, 256),       # layer-1 shape: 96 tiles x 2 slices, output row stride 3000
+    (64, 256, 192, 192, 1, 192),            # 256 x 192 tiles: one tile whose X rows END at the tile (columns behind: zero row)
+    (100, 256, 400, 576, 2, 192),           # partial third column tile, rows past M
+    (1000, 512, 300, 384, 3, 192),
+    (9980, 2048, 3000, 3072, 2, 192),       # layer-1 shape: 128 tiles x 2 slices = one round of the chip
+    (10112, 2048, 3000, 3072, 2, 192),      # the same with rows padded to a multiple of 128
 ])
-def test_wgrad_matches_fp32_reference(M, N, K, Kp, slices):
+def test_wgrad_matches_fp32_reference(M, N, K, Kp, slices, tile_k):
     """csrc/gemm_wgrad_bf16.hip: dW = G^T X in fp32 from bf16 operands.  fp32 accumulation over M products in the kernel's own
     order: within 2e-6 * sum |g x| (+ 1e-6 relative) of the fp64 value; the same bits on every launch (slice order is fixed)."""
     from spadot_amd import _lib
@@ -101,14 +106,16 @@ def test_wgrad_matches_fp32_reference(M, N, K, Kp, slices):
     X = torch.zeros((M, Kp), device=DEV, dtype=torch.bfloat16)
     X[:, :K] = (torch.randn((M, K), device=DEV, generator=g) * 0.5).bfloat16()
     outs = []
-    need = int(lib.spadot_gemm_wgrad_bf16_workspace(M, N, K, slices))
+    need = int(lib.spadot_gemm_wgrad_bf16_workspace_tiled(M, N, K, slices, tile_k))
     assert need >= 0 and (need == 0) == (slices <= 1 or M <= 64)
+    if tile_k == 256:
+        assert need == int(lib.spadot_gemm_wgrad_bf16_workspace(M, N, K, slices))
     zrow = torch.zeros(256, device=DEV, dtype=torch.bfloat16)
     for _ in range(2):
         dW = torch.full((N, K), float("nan"), device=DEV)
         ws = torch.full((max(need, 4),), float("nan"), device=DEV)          # caller-owned partials: the library keeps no state
-        rc = lib.spadot_gemm_wgrad_bf16(G.data_ptr(), N, X.data_ptr(), Kp, dW.data_ptr(), K, M, N, K, slices,
-                                        ws.data_ptr(), zrow.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        rc = lib.spadot_gemm_wgrad_bf16_tiled(G.data_ptr(), N, X.data_ptr(), Kp, dW.data_ptr(), K, M, N, K, slices, tile_k,
+                                              ws.data_ptr(), zrow.data_ptr(), torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         assert rc == 0
         outs.append(dW)
@@ -140,6 +147,10 @@ def test_wgrad_refuses_what_it_does_not_cover():
     assert lib.spadot_gemm_wgrad_bf16_workspace(512, 256, 256, 4) == 4 * 65536
     assert lib.spadot_gemm_wgrad_bf16(G.data_ptr(), 256, X.data_ptr(), 256, dW.data_ptr(), 256, 512, 256, 256, 4, None, z.data_ptr(), st) == -22
     assert lib.spadot_gemm_wgrad_bf16(G.data_ptr(), 256, X.data_ptr(), 256, dW.data_ptr(), 256, 512, 256, 256, 1, None, None, st) == -22
+    # tile widths other than 256 / 192; X rows that end inside the last 192-wide tile
+    assert lib.spadot_gemm_wgrad_bf16_tiled(G.data_ptr(), 256, X.data_ptr(), 256, dW.data_ptr(), 256, 512, 256, 256, 1, 128, None, z.data_ptr(), st) == -22
+    assert lib.spadot_gemm_wgrad_bf16_tiled(G.data_ptr(), 256, X.data_ptr(), 256, dW.data_ptr(), 256, 512, 256, 256, 1, 192, None, z.data_ptr(), st) == -22
+    assert lib.spadot_gemm_wgrad_bf16_workspace_tiled(512, 256, 256, 4, 192) == 4 * 2 * 256 * 192
 
 
 @pytest.mark.parametrize("M,N,K", [(1, 256, 64), (321, 512, 192), (2000, 2048, 2048), (9980, 2048, 2048)])

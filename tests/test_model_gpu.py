@@ -427,6 +427,47 @@ def test_flat_adamw_keeps_bf16_weight_images_current(ops):
     assert torch.equal(img2, pb[2].detach().bfloat16())
 
 
+def test_flat_adamw_update_in_two_parts_is_bit_identical(ops):
+    """FlatAdamW(first=...): the `first` group sits at the start of the flat buffers whatever the order of the parameters, and
+    step_head() + step_rest() (gradient norm + the first group, then everything else: spadot_grad_norm_step_dev,
+    spadot_adamw_range_dev) leave the bits step() leaves -- parameters, both moments, the step count, maintained images."""
+    torch.manual_seed(5)
+    shapes = [(64, 20), (20,), (48, 24), (7, 12), (5,), (16, 8)]
+    base = [torch.randn(s, device=DEV) for s in shapes]
+    pa = [p.clone().requires_grad_(True) for p in base]
+    pb = [p.clone().requires_grad_(True) for p in base]
+    oa = ops.FlatAdamW(pa, lr=1e-2, max_norm=0.3)
+    ob = ops.FlatAdamW(pb, lr=1e-2, max_norm=0.3, first=[pb[3], pb[2]], last=[pb[0]])
+    assert oa.head_count == 0 and ob.head_count == 48 * 24 + 7 * 12
+    assert [id(p) for p in ob.params] == [id(pb[i]) for i in (2, 3, 1, 4, 5, 0)]
+    assert pb[2].data_ptr() == ob.flat_param.data_ptr() and ob.tail_offset == ob.count - 64 * 20
+    ia, ib = (torch.zeros((48, 32), dtype=torch.bfloat16, device=DEV) for _ in range(2))      # an image INSIDE the first group
+    ja, jb = (torch.zeros((64, 20), dtype=torch.bfloat16, device=DEV) for _ in range(2))      # and one in the rest
+    assert oa.maintain_image(pa[2], ia) and ob.maintain_image(pb[2], ib) and oa.maintain_image(pa[0], ja) and ob.maintain_image(pb[0], jb)
+    for step in range(4):
+        grads = [torch.randn(s, device=DEV) * (3.0 if step % 2 else 0.01) for s in shapes]
+        for q, r, gr in zip(pa, pb, grads):
+            q.grad.copy_(gr); r.grad.copy_(gr)
+        oa.step()
+        ob.step_head(); ob.step_rest()
+        torch.cuda.synchronize()
+        for q, r in zip(pa, pb):
+            assert torch.equal(q.detach(), r.detach())
+        assert int(oa.step_dev.item()) == int(ob.step_dev.item()) == step + 1 and torch.equal(oa.sumsq, ob.sumsq)
+        assert torch.equal(ia, ib) and torch.equal(ja, jb) and torch.equal(ib[:, :24], pb[2].detach().bfloat16())
+    # the moments too (compared through the parameters' views: the two buffers are ordered differently)
+    for q, r in zip(pa, pb):
+        oq = (q.data_ptr() - oa.flat_param.data_ptr()) // 4
+        orr = (r.data_ptr() - ob.flat_param.data_ptr()) // 4
+        n = q.numel()
+        assert torch.equal(oa.exp_avg[oq:oq + n], ob.exp_avg[orr:orr + n]) and torch.equal(oa.exp_avg_sq[oq:oq + n], ob.exp_avg_sq[orr:orr + n])
+    lib = ops.model_lib()
+    z = torch.zeros(8, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.spadot_adamw_range_dev(z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), 2, 4, 1e-3, 0.9, 0.999, 1e-8, 1e-2, 0.3,
+                                      ob.sumsq.data_ptr(), ob.step_dev.data_ptr(), None, None, st) == -22          # offset % 4
+
+
 # ------------------------------------------------------------------ fused small-MLP stages
 
 @pytest.mark.parametrize("b,F_,dt", [(512, 256, torch.float32), (37, 70, torch.float32), (512, 256, torch.bfloat16), (300, 64, torch.float32)])

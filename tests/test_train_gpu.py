@@ -154,6 +154,53 @@ def test_graphed_steps_match_eager_steps(monkeypatch):
         np.testing.assert_allclose(p1, p0, rtol=0, atol=5e-4)      # 8 AdamW steps of lr 3e-4 each
 
 
+def test_chained_steps_leave_the_bits_unchained_steps_leave(monkeypatch):
+    """GraphedStepper.chained(): the SVGP branch of step k + 1 waits for the FIRST graph of step k's update (gradient norm + the
+    SVGP encoder's parameters: FlatAdamW(first=...)) instead of the whole update.  Same launches on the same two streams,
+    only one wait is earlier: parameters, BatchNorm statistics and losses must agree with the unchained run and with the
+    one-graph update (split_update off) to the run-to-run noise of the step itself (a few ulp: 1e-7 relative, measured with
+    tools/chain_check.py -- the library's small GEMMs are not bit-repeatable); a branch that read the encoder's parameters
+    one update late would be off by ~1e-4."""
+    from spadot_amd.model import SpaDOT
+    from spadot_amd.ops import FlatAdamW
+    from spadot_amd.synthetic import make_dataset
+    from spadot_amd.utils import _train_utils as tu, _utils
+    monkeypatch.setattr(torch, "randn_like", lambda x, **k: torch.zeros_like(x))
+    data = make_dataset(2, 1200, 40, seed=3)
+    cfg = _small_config()
+    cfg.update(input_dim=40, timepoints=[0, 1], device=torch.device(DEV), staged_graphs=True)
+    results = []
+    for mode in ("one_graph", "unchained", "chained"):
+        _utils.set_seed(7)
+        cfg["split_update"] = mode != "one_graph"
+        dd = tu.prepare_dataloader(data, cfg)
+        model = SpaDOT.SpaDOT(cfg, dd).to(DEV)
+        opt = FlatAdamW(model.parameters(), lr=cfg["lr"], first=model.SVGPEncoder.parameters())
+        assert opt.head_count == sum((p.numel() + 3) // 4 * 4 for p in model.SVGPEncoder.parameters())
+        tu._update_Kmeans(model, cfg, dd)
+        tu._update_OT_matrix(model, cfg)
+        model.train()
+        stepper = tu.GraphedStepper(model, opt, cfg, dd)
+        losses = []
+        import contextlib
+        for rep in range(5):                       # visit 1 eager, visit 2 capture + replay, then replays
+            with (stepper.chained() if mode == "chained" else contextlib.nullcontext()):
+                for bi in range(2):
+                    losses.append(stepper.step(1, 1, bi, 5, 0.3).clone())
+        torch.cuda.synchronize()
+        assert isinstance(stepper.opt_graph, tuple) == (mode != "one_graph")
+        bn = torch.cat([b.detach().double().reshape(-1) for b in model.SVGPEncoder.buffers()])
+        named = {n: p.detach().clone() for n, p in model.named_parameters()}
+        results.append((torch.stack(losses), named, bn, int(opt.step_dev.item())))
+    l0, p0, b0, s0 = results[0]
+    for l1, p1, b1, s1 in results[1:]:
+        assert s0 == s1 == 10
+        assert float(((l0 - l1).abs() / (l0.abs() + 1e-6)).max()) < 5e-6
+        assert float((b0 - b1).abs().max()) < 2e-6
+        for n in p0:
+            assert float((p0[n] - p1[n]).abs().max()) < 2e-6, n
+
+
 def test_flat_backward_with_in_place_weight_gradients_matches_autograd():
     """bf16 compute: the GAT dense maps write their fp32 weight gradient straight into the flat buffer inside
     FlatAdamW.backward; the buffer must equal what plain autograd returns for every parameter, and a plain

@@ -70,7 +70,7 @@ if __name__ == "__main__" and "wgrad" not in sys.argv:
             assert r["max_err"] <= 2 ** -7 * r["scale"] + 1e-3, r
 
 
-def run_wgrad(M, N, K, Kp, slices, reps=30):
+def run_wgrad(M, N, K, Kp, slices, tile_k=256, reps=30):
     """csrc/gemm_wgrad_bf16.hip against the library's g^T x (fp32 out), interleaved rounds."""
     lib = _lib.model_lib()
     g = torch.Generator(device="cuda").manual_seed(M + K)
@@ -90,10 +90,10 @@ def run_wgrad(M, N, K, Kp, slices, reps=30):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / n * 1e3
 
-    ws = torch.empty(max(4, int(lib.spadot_gemm_wgrad_bf16_workspace(M, N, K, slices))), device="cuda:0")
+    ws = torch.empty(max(4, int(lib.spadot_gemm_wgrad_bf16_workspace_tiled(M, N, K, slices, tile_k))), device="cuda:0")
     zrow = torch.zeros(256, device="cuda:0", dtype=torch.bfloat16)
-    mine = lambda: lib.spadot_gemm_wgrad_bf16(G.data_ptr(), N, X.data_ptr(), Kp, dW.data_ptr(), K, M, N, K, slices,
-                                              ws.data_ptr(), zrow.data_ptr(), st)
+    mine = lambda: lib.spadot_gemm_wgrad_bf16_tiled(G.data_ptr(), N, X.data_ptr(), Kp, dW.data_ptr(), K, M, N, K, slices, tile_k,
+                                                    ws.data_ptr(), zrow.data_ptr(), st)
     libf = lambda: torch.mm(G.t(), X[:, :K], out_dtype=torch.float32, out=ref)
     assert mine() == 0
     timed(mine, 10), timed(libf, 10)
@@ -104,11 +104,11 @@ def run_wgrad(M, N, K, Kp, slices, reps=30):
     t_mine, t_lib = sorted(tm)[3], sorted(tl)[3]
     fl = 2.0 * M * N * K
     err = (dW - ref).abs().max().item() / (ref.abs().max().item() + 1e-30)
-    return dict(kind="wgrad", M=M, N=N, K=K, slices=slices, us=round(t_mine, 1), us_library=round(t_lib, 1),
+    return dict(kind="wgrad", M=M, N=N, K=K, slices=slices, tile_k=tile_k, us=round(t_mine, 1), us_library=round(t_lib, 1),
                 tflops=round(fl / t_mine / 1e6, 1), tflops_library=round(fl / t_lib / 1e6, 1), max_rel_diff_vs_library=err)
 
 
 if __name__ == "__main__" and "wgrad" in sys.argv:
-    for shp in [(9980, 2048, 2048, 2048, 4), (8031, 2048, 2048, 2048, 4), (9980, 2048, 3000, 3072, 2), (9980, 2048, 2048, 2048, 2),
-                (9980, 2048, 2048, 2048, 1)]:
+    for shp in [(9980, 2048, 2048, 2048, 4), (8031, 2048, 2048, 2048, 4), (9980, 2048, 3000, 3072, 2), (9980, 2048, 3000, 3072, 2, 192),
+                (10112, 2048, 3000, 3072, 2, 192), (10112, 2048, 3000, 3072, 2), (512, 256, 3000, 3072, 8), (512, 256, 3000, 3072, 8, 192)]:
         print(json.dumps(run_wgrad(*shp)), flush=True)
