@@ -40,6 +40,10 @@ tail -1 $O/train.json > $P/train_cfg3_bf16_bench_under_rocprof.json
 python3 tools/mfma_summary.py $O/mfma $P/train_cfg3_bf16_mfma_counters.json $P/train_cfg3_bf16_mfma_counters.csv > $O/mfma_summary.txt
 python3 tools/sink_profile_meta.py $O/sink $P/sinkhorn_cfg3_f32_profile_meta.json
 SPADOT_MFMA_SUMMARY=$P/train_cfg3_bf16_mfma_counters.json python3 tools/prof_summary.py $O/train 40 40 $P/train_cfg3_bf16_families.json > $P/train_cfg3_bf16_per_step_breakdown.txt
+# every kernel of one step with its HIP queue, start and duration: the last step of the trace and the one three steps
+# earlier (another time point, i.e. another number of inducing points)
+python3 tools/prof_timeline.py $O/train 0 1 > $P/train_cfg3_bf16_step_timeline.txt
+python3 tools/prof_timeline.py $O/train 0 3 > $P/train_cfg3_bf16_step_timeline_other_timepoint.txt
 # GEMM evidence: the box's bare-MFMA rate, the library on the step's shapes, csrc/gemm_bf16.hip against the library
 {
   echo "== tools/mfma_peak.hip (bare v_mfma loops, this box)"
