@@ -238,6 +238,9 @@ constexpr int ATILEB = 2048;                        // hi (1 KiB) | lo (1 KiB)
 #ifndef EDOT_WGS
 #define EDOT_WGS 4
 #endif
+#ifndef EDOT_PAD
+#define EDOT_PAD 1                                  // 0 (with -DEDOT_WGS=5): unpadded, XOR-swizzled G tile, five workgroups per CU
+#endif
 constexpr int RING = AGG_RING;                      // chunks of LDS ring: RING - 1 in flight while one is multiplied
 constexpr int MAXC = 1024 - ROWS;                   // longest column list of a block (ids + row ids = 4 KiB)
 constexpr int LDS_RING = RING * CHUNKB;             // 52224 >= 32 * OUTB
@@ -501,20 +504,25 @@ __global__ __launch_bounds__(NT, EDOT_WGS) void k_gat_edot(const __bf16 *__restr
                                                     const int *__restrict__ cell, int nb, int H, int act,
                                                     __bf16 *__restrict__ g_pre, float *__restrict__ dz,
                                                     float *__restrict__ bias_part, int part_width, int part_col) {
-    constexpr int C = 128 * NTW, PPR = C / 8, GS = 2 * C + 16;
+    // G tile in LDS: 32 rows x 2 C bytes, rows padded by 16 bytes against bank conflicts (EDOT_PAD = 1: 33 280 bytes, four
+    // workgroups per compute unit) or unpadded with 16-byte chunk c of row r stored at chunk c ^ (r & 15) (EDOT_PAD = 0: 32 KiB,
+    // five workgroups fit the 160 KiB, so that the 1248 (block, head) items of a 312-block layer could all be resident at
+    // once).  Same-box A/B, round 3 (profiles/r03/ab_edot_layout.txt): no difference -- backward 216 / 204 us against 218 /
+    // 213 us in tools/gat_bench.py, 554.9 / 555.0 against 555.6 / 555.8 steps/s -- so the padded form stays.
+    constexpr int C = 128 * NTW, PPR = C / 8, GS = 2 * C + 16 * EDOT_PAD, XM = EDOT_PAD ? 0 : 15;
     __shared__ __attribute__((aligned(16))) unsigned char gt[ROWS * GS];
-    __shared__ int rid[ROWS];
     const int item = xcd_item(nb * H);
     if (item >= nb * H) return;
     const int b = item / H, hd = item - b * H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t hoff = (size_t)hd * C, HC = (size_t)H * C;
-    if (tid < ROWS) rid[tid] = prow[b * ROWS + tid];
-    __syncthreads();
+    int nodes[2 * NTW];
+#pragma unroll
+    for (int m = 0; m < 2 * NTW; m++) nodes[m] = prow[b * ROWS + (m * NT + tid) / PPR];
 #pragma unroll
     for (int m = 0; m < 2 * NTW; m++) {
         const int pi = m * NT + tid, r = pi / PPR, pc = pi - r * PPR;
-        const int node = rid[r];
+        const int node = nodes[m];
         uint4 g = make_uint4(0u, 0u, 0u, 0u);
         if (node >= 0) {
             const size_t off = (size_t)node * HC + hoff + (size_t)pc * 8;
@@ -534,7 +542,7 @@ __global__ __launch_bounds__(NT, EDOT_WGS) void k_gat_edot(const __bf16 *__restr
             }
             *reinterpret_cast<uint4 *>(g_pre + off) = g;
         }
-        *reinterpret_cast<uint4 *>(gt + (size_t)r * GS + (size_t)pc * 16) = g;
+        *reinterpret_cast<uint4 *>(gt + (size_t)r * GS + (size_t)((pc ^ (r & XM)) * 16)) = g;
     }
     __syncthreads();
     if (bias_part != nullptr && C == 2 * NT) {
@@ -543,7 +551,7 @@ __global__ __launch_bounds__(NT, EDOT_WGS) void k_gat_edot(const __bf16 *__restr
         float b0 = 0.f, b1 = 0.f;
 #pragma unroll 8
         for (int r = 0; r < ROWS; r++) {
-            const unsigned w2 = *reinterpret_cast<const unsigned *>(gt + (size_t)r * GS + (size_t)tid * 4);
+            const unsigned w2 = *reinterpret_cast<const unsigned *>(gt + (size_t)r * GS + (size_t)(((tid >> 2) ^ (r & XM)) * 16 + (tid & 3) * 4));
             b0 += __uint_as_float(w2 << 16);
             b1 += __uint_as_float(w2 & 0xffff0000u);
         }
@@ -555,7 +563,8 @@ __global__ __launch_bounds__(NT, EDOT_WGS) void k_gat_edot(const __bf16 *__restr
     for (int nt = wave; nt < ntile; nt += 4) {
         const int sid = pcol[s0 + nt * 32 + sl];
         const __bf16 *xrow = Xh + (size_t)sid * HC + hoff + 16 * hh;
-        const unsigned char *grow = gt + (size_t)sl * GS + 32 * hh;
+        const unsigned char *grow = gt + (size_t)sl * GS;
+        const int gx = sl & XM;                                       // this row's chunk XOR
         f16v acc;
 #pragma unroll
         for (int i = 0; i < 16; i++) acc[i] = 0.f;
@@ -563,8 +572,8 @@ __global__ __launch_bounds__(NT, EDOT_WGS) void k_gat_edot(const __bf16 *__restr
         for (int kp = 0; kp < C / 32; kp++) {
             const bf8 x0 = *reinterpret_cast<const bf8 *>(xrow + kp * 32);
             const bf8 x1 = *reinterpret_cast<const bf8 *>(xrow + kp * 32 + 8);
-            const bf8 a0 = *reinterpret_cast<const bf8 *>(grow + kp * 64);
-            const bf8 a1 = *reinterpret_cast<const bf8 *>(grow + kp * 64 + 16);
+            const bf8 a0 = *reinterpret_cast<const bf8 *>(grow + (((kp * 4 + 2 * hh) ^ gx) * 16));
+            const bf8 a1 = *reinterpret_cast<const bf8 *>(grow + (((kp * 4 + 2 * hh + 1) ^ gx) * 16));
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, x0, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, x1, acc, 0, 0, 0);
         }

@@ -1091,8 +1091,10 @@ SWEEP_MAX_M = 310      # largest matrix the register/LDS-resident sweep kernel t
 
 # sizes up to this go to one sweep launch, larger ones are split in two (measured, 10 matrices, graph replay: one launch
 # 0.204 ms at m = 236 but 0.54 / 0.56 ms at 300 / 310, where two blocks take 0.26 / 0.27 ms; m = 600: 0.68 ms as 4 blocks
-# against 1.26 ms as 2; tools/spd_split.py)
-_SPLIT = [256]
+# against 1.26 ms as 2; tools/spd_split.py).  279 = the largest m whose 9 x 9 tiles stay in registers.  Alone the two-block
+# form wins from ~256 on, but its ~25 short launches queue behind the GAT branch's GEMM workgroups inside the step: with m =
+# 261 / 262 (two of the benchmark's five time points) one launch gave 559.3 / 561.8 steps/s against 557.3 / 556.8 (same box).
+_SPLIT = [int(__import__("os").environ.get("SPADOT_SWEEP_SPLIT", "279"))]
 
 
 def _sweep_kernel(A):

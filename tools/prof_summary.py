@@ -53,8 +53,11 @@ def main():
     top = int(sys.argv[3]) if len(sys.argv) > 3 else 30
     f = max(glob.glob(d + '/**/*kernel_trace.csv', recursive=True), key=os.path.getmtime)
     rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
-    # the timed region: the last `steps` occurrences of the AdamW kernel close a step each
-    idx = [i for i, r in enumerate(rows) if 'k_adamw' in r['Kernel_Name']]
+    # the timed region: the last `steps` occurrences of the step-count kernel close a step each (one per update, whether the
+    # update is one AdamW launch or two; traces older than that kernel: the AdamW launch)
+    idx = [i for i, r in enumerate(rows) if 'k_final_sum_step' in r['Kernel_Name']]
+    if not idx:
+        idx = [i for i, r in enumerate(rows) if 'k_adamw' in r['Kernel_Name']]
     first = idx[-steps - 1] + 1
     sel = rows[first:idx[-1] + 1]
     wall = (int(sel[-1]['End_Timestamp']) - int(sel[0]['Start_Timestamp'])) / steps / 1e3
