@@ -26,6 +26,23 @@ SWEEP_DIRECT_M = _SPLIT[0]      # up to here one sweep launch takes the matrices
 F64 = torch.float64
 
 
+def _contract_rows(K, Y):
+    """sum_b K[b, :]^T Y[b, :] -> [L, m] for K [b, m], Y [b, L] (einsum "bm,bl->lm").  For a whole time point (b = N_t ~ 10^4) the
+    library runs this 236 x 20 output as ONE workgroup walking all b rows (0.29 ms for 0.09 GFLOP, a sixth of the per-epoch
+    inference of a time point); in slabs of rows it is a batched product + a fixed-order sum over the slabs (two launches)."""
+    b, m = K.shape
+    L = Y.shape[1]
+    slab = 256
+    if b < 8 * slab:
+        return torch.einsum("bm,bl->lm", K, Y)
+    nfull = b // slab
+    part = torch.bmm(Y[:nfull * slab].reshape(nfull, slab, L).transpose(1, 2), K[:nfull * slab].reshape(nfull, slab, m))   # [nfull, L, m]
+    t = part.sum(0)
+    if nfull * slab < b:
+        t = t + Y[nfull * slab:].T @ K[nfull * slab:]
+    return t
+
+
 class Kernel(nn.Module):
     """svgp.py:107-125."""
 
@@ -250,7 +267,7 @@ class SVGP(nn.Module):
             S_inv, logdet_A = self._sigma_inv(bc_train, W, True)
         else:
             S_inv = self._sigma_inv(bc_train, W)
-        t = torch.einsum("bm,bl->lm", bc_train.K_nm, mu * W)              # K_mn (y / noise)
+        t = _contract_rows(bc_train.K_nm, mu * W)                          # K_mn (y / noise)  [L, m]
         St = torch.einsum("lmn,ln->lm", S_inv, t)
         p_m = bc_train.c * (bt.K_nm @ St.T)                                # [b_test, L]
         if not want_var:

@@ -289,6 +289,22 @@ def test_composite_forward_and_gradients_match_reference(ops):
             np.testing.assert_allclose(sd[k[9:]].cpu().numpy(), g[k], rtol=1e-4, atol=1e-6, err_msg=k)
 
 
+def test_whole_time_point_row_contraction_in_slabs(ops):
+    """svgp._contract_rows: K_mn (y / noise) over a whole time point's rows (10^4) as slabs + a fixed-order sum equals the
+    plain contraction (fp64: 1e-12 of the summed magnitudes), remainder rows included; small batches keep the plain form."""
+    from spadot_amd.model.svgp import _contract_rows
+    g = torch.Generator(device=DEV).manual_seed(11)
+    for b in (10000, 2048, 2300, 512):
+        K = torch.rand((b, 236), dtype=torch.float64, device=DEV, generator=g)
+        Y = torch.randn((b, 20), dtype=torch.float64, device=DEV, generator=g) * 50.0
+        t = _contract_rows(K, Y)
+        ref = torch.einsum("bm,bl->lm", K.cpu(), Y.cpu())
+        mag = torch.einsum("bm,bl->lm", K.cpu().abs(), Y.cpu().abs())
+        assert t.shape == (20, 236)
+        assert bool(((t.cpu() - ref).abs() <= 1e-12 * mag).all())
+        assert torch.equal(t, _contract_rows(K, Y))
+
+
 def test_all_latent_samples_matches_reference(ops):
     g = load_golden("model_composite.npz")
     m = _model(g)

@@ -42,6 +42,13 @@ with torch.no_grad():
         _, ms = timed(lambda: K.fit(lats[t])); print(f"KMeansDevice.fit tp {t}: {ms:.2f} ms, n_iter {K.n_iter_}")
     _, ms = timed(lambda: [tu._set_kmeans_state(model, t, fits[t].cluster_centers_, fits[t].labels_, dd["datasets"][t][2], cfg["device"]) for t in range(T)])
     print(f"_set_kmeans_state x 5: {ms:.2f} ms")
+    from torch.profiler import profile, ProfilerActivity
+    loc, Y, ix = dd["datasets"][1]
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        model.all_latent_samples(loc, Y, dd["graphs"][1], 1, as_numpy=False)
+        torch.cuda.synchronize()
+    print("== all_latent_samples, one time point")
+    print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=25, max_name_column_width=70))
     # pieces of fit_many under the torch profiler's eyes: count launches
     from torch.profiler import profile, ProfilerActivity
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
