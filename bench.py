@@ -237,6 +237,9 @@ def epoch_block(tu, model, opt, cfg, dd, stepper, T, beta1, torch):
     t0 = time.perf_counter()
     for _ in range(2 if stepper is not None else 0):      # first visits: eager, then capture (epochs 0 and 1 of a real run)
         run_steps()
+        tu._update_Kmeans(model, cfg, dd)                 # (its phases are replayed as graphs from the second call on, too)
+        tu._update_OT_matrix(model, cfg)
+        model.train()
     torch.cuda.synchronize()
     warm_s = time.perf_counter() - t0
     random.shuffle(order)
