@@ -316,6 +316,69 @@ def test_full_size_step_staged_replay_matches_the_eager_step_bf16():
             np.testing.assert_allclose(gb.cpu().numpy(), ga.cpu().numpy(), rtol=2e-3, atol=2e-4 * scale)
 
 
+def test_full_size_chained_replay_matches_unchained_replay_bf16():
+    """The bench shape again (10 000 spots x 3 000 genes, bf16, replayed staged graphs), where the two streams really
+    overlap: twelve steps inside GraphedStepper.chained() -- the SVGP branch of a step starts beside the previous step's
+    update of everything but its own parameters -- against the same twelve steps unchained, from the same parameters,
+    moments, BatchNorm statistics and step count.  Agreement to a few times the step's own run-to-run noise (the same
+    sequence run twice: the library's small GEMMs are not bit-repeatable); a branch that read the SVGP encoder one update
+    late would differ in the fourth digit."""
+    from spadot_amd.model import SpaDOT
+    from spadot_amd.ops import FlatAdamW
+    from spadot_amd.synthetic import make_dataset
+    from spadot_amd.utils import _train_utils as tu, _utils
+    data = make_dataset(2, 10000, 3000, seed=1993)
+    cfg = _utils.load_model_config(types.SimpleNamespace(config=None))
+    cfg.update(input_dim=3000, timepoints=[0, 1], device=torch.device(DEV), compute_dtype=torch.bfloat16,
+               inducing_point_nums=480, staged_graphs=True)
+    _utils.set_seed(cfg["seed"])
+    dd = tu.prepare_dataloader(data, cfg)
+    del data
+    model = SpaDOT.SpaDOT(cfg, dd).to(DEV)
+    opt = FlatAdamW(model.parameters(), lr=cfg["lr"], first=model.SVGPEncoder.parameters())
+    tu._update_Kmeans(model, cfg, dd)
+    tu._update_OT_matrix(model, cfg)
+    model.train()
+    model.fixed_noise = (torch.zeros((512, 10), device=DEV), torch.zeros((512, 10), device=DEV))
+    st = tu.GraphedStepper(model, opt, cfg, dd)
+    ep = cfg["ot_epoch"]
+    bufs = [b for b in model.buffers()]
+    state0 = (opt.flat_param.clone(), [b.clone() for b in bufs])
+
+    def restore():
+        torch.cuda.synchronize()
+        opt.flat_param.copy_(state0[0])
+        opt.exp_avg.zero_(); opt.exp_avg_sq.zero_(); opt.step_dev.zero_()
+        for b, v in zip(bufs, state0[1]):
+            b.copy_(v)
+        opt.refresh_images()
+        torch.cuda.synchronize()
+
+    def run(chained):
+        import contextlib
+        restore()
+        losses = []
+        with (st.chained() if chained else contextlib.nullcontext()):
+            for k in range(12):
+                losses.append(st.step(1, 1, k % 4, ep, 0.5).clone())
+        torch.cuda.synchronize()
+        return torch.stack(losses).double(), opt.flat_param.detach().double().clone(), torch.cat([b.detach().double().reshape(-1) for b in bufs])
+
+    for _ in range(2):                                          # eager visit, then capture: every graph of the four batches exists
+        for bi in range(4):
+            st.step(1, 1, bi, ep, 0.5)
+    assert isinstance(st.opt_graph, tuple)
+    a, a2, b = run(False), run(False), run(True)
+
+    def dist(x, y):
+        return (float(((x[0] - y[0]).abs() / (x[0].abs() + 1e-6)).max()), float((x[1] - y[1]).abs().max()), float((x[2] - y[2]).abs().max()))
+
+    noise, diff = dist(a, a2), dist(a, b)
+    print("run-to-run", noise, "chained vs unchained", diff)
+    assert int(opt.step_dev.item()) == 12
+    assert diff[0] <= max(5 * noise[0], 2e-5) and diff[1] <= max(5 * noise[1], 2e-6) and diff[2] <= max(5 * noise[2], 2e-5)
+
+
 def test_bucketed_exchange_splits_the_backward_without_changing_the_gradient():
     """Optimizer built with the first GAT layer's parameters last + an async exchange hook: the staged replay cuts
     the GAT backward at the first layer's output, hands `flat_grad[:tail_offset]` to the exchange BEFORE that layer's
