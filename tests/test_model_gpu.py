@@ -216,7 +216,8 @@ def test_reduction_kernels_gradients_vs_torch(ops):
     np.testing.assert_allclose(yh.grad.cpu().numpy(), (3.0 * -2.0 / 33 * (y - yh.detach())).cpu().numpy(), rtol=1e-6)
 
 
-@pytest.mark.parametrize("L,m", [(1, 1), (3, 17), (10, 217), (10, 236), (4, 248), (3, 279), (3, 310), (2, 311), (2, 389), (10, 600), (2, 621), (2, 870), (1, 1300)])
+@pytest.mark.parametrize("L,m", [(1, 1), (3, 17), (3, 95), (3, 96), (4, 100), (3, 128), (10, 204), (10, 217), (10, 236), (4, 248), (40, 256), (3, 257), (40, 261),
+                                 (5, 272), (3, 273), (3, 279), (3, 288), (2, 289), (3, 310), (2, 311), (2, 389), (10, 600), (2, 621), (2, 870), (1, 1300)])
 def test_spd_inverse_logdet_vs_torch(ops, L, m):
     """Batched SPD inverse + logdet (sweep kernel: register tiles up to 279, + LDS border up to 310; recursive two-block elimination beyond) against
     torch.linalg on matrices conditioned like the SVGP's Sigma_l (jitter 1e-2, cond ~1e6)."""
