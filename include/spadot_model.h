@@ -321,6 +321,15 @@ int spadot_gemm_tn_bf16(const void *A, int lda, const void *B, int ldb, void *C,
 /* The same kernel with B stored [K x N] (contraction index = row; transposed LDS reads for that operand): C = A . B, the
  * input gradient of a dense map (dx = g W with W the [N_out x K_in] weight image).  Same shape conditions. */
 int spadot_gemm_nn_bf16(const void *A, int lda, const void *B, int ldb, void *C, int ldc, int M, int N, int K, void *stream);
+/* spadot_gemm_tn_bf16 with the LAST `tail_row_tiles` row panels (320 rows each) cut into `slices` (2..8) slices of the
+ * contraction; fp32 partial tiles in the caller's `workspace` (spadot_gemm_bf16_split_workspace floats, 16-byte aligned),
+ * added in slice order and rounded once to bf16 by a second launch: bit-reproducible.  For a map whose grid is exactly one
+ * round of workgroups and that shares the chip with another stream's long kernel (the second GAT layer beside the SVGP
+ * branch's inverse: 40 of 256 compute units busy): 216 whole + 160 quarter tiles take 1.25 tile times instead of 2. */
+long long spadot_gemm_bf16_split_workspace(int M, int N, int tail_row_tiles, int slices);
+int spadot_gemm_tn_bf16_split(const void *A, int lda, const void *B, int ldb, void *C, int ldc, int M, int N, int K,
+                              int tail_row_tiles, int slices, float *workspace, void *stream);
+
 
 /* ---- weight gradient of a GAT layer's dense map on the matrix cores (csrc/gemm_wgrad_bf16.hip) ---------------------------
  * dW [N x K] (fp32, row stride ldw) = G^T X with G [M x N] (bf16, ldg) and X [M x >= K] (bf16, ldx; columns K .. the next

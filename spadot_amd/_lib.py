@@ -141,6 +141,7 @@ def model_lib():
         "spadot_gat_edge_dot": [vp, vp, vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, ci, ci, vp],
         "spadot_gemm_tn_bf16": [vp, ci, vp, ci, vp, ci, ci, ci, ci, vp],
         "spadot_gemm_nn_bf16": [vp, ci, vp, ci, vp, ci, ci, ci, ci, vp],
+        "spadot_gemm_tn_bf16_split": [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, vp],
         "spadot_gemm_wgrad_bf16": [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, vp, vp, vp],
         "spadot_gemm_wgrad_bf16_tiled": [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp],
         "spadot_mlp_chain_supported": [ci, vp],
@@ -195,6 +196,8 @@ def model_lib():
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = ci
+    lib.spadot_gemm_bf16_split_workspace.argtypes = [ci, ci, ci, ci]
+    lib.spadot_gemm_bf16_split_workspace.restype = ll
     lib.spadot_gemm_wgrad_bf16_workspace.argtypes = [ci, ci, ci, ci]
     lib.spadot_gemm_wgrad_bf16_workspace.restype = ll
     lib.spadot_gemm_wgrad_bf16_workspace_tiled.argtypes = [ci, ci, ci, ci, ci]

@@ -57,13 +57,29 @@ typedef short s4v __attribute__((ext_vector_type(4)));
 template <bool BT>
 __global__ __launch_bounds__(NT, 1) void k_gemm_bf16(const __bf16 *__restrict__ A, int lda, const __bf16 *__restrict__ B,
                                                     int ldb, __bf16 *__restrict__ C, int ldc, int M, int N, int K,
-                                                    int mtiles, int ntiles) {
+                                                    int mtiles, int ntiles, int full_items, int S, int nk_slice,
+                                                    float *__restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // tile of this workgroup: the ntiles column tiles of one row panel are consecutive work items of one XCD
+    // tile of this workgroup: the ntiles column tiles of one row panel are consecutive work items of one XCD.  Items
+    // 0 .. full_items - 1 are whole tiles (the grid's first 8 ceil(full_items / 8) workgroups); the tiles behind them (the last
+    // row panels: launch_gemm_split) are cut into S slices of the contraction, one workgroup each, which leave fp32 partial
+    // tiles for k_gemm_tail_reduce -- when part of the chip is busy with another stream's long kernel, the second round of
+    // workgroups is then a quarter of a tile long instead of a whole one.
     const int total = mtiles * ntiles;
-    const int per_xcd = (total + 7) >> 3;
-    const int item = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
-    if (item >= total) return;
+    const int full_grid = 8 * ((full_items + 7) >> 3);
+    int item, slice = 0;
+    if ((int)blockIdx.x < full_grid) {
+        const int per_xcd = (full_items + 7) >> 3;
+        item = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+        if (item >= full_items) return;
+    } else {
+        const int t = (int)blockIdx.x - full_grid;
+        item = full_items + t / S;
+        slice = t - (t / S) * S;
+        if (item >= total) return;
+    }
+    const bool sliced = item >= full_items;
+    const int ks0 = sliced ? slice * nk_slice : 0;                // first 64-wide K-step of this workgroup
     const int mt = item / ntiles, nt = item - mt * ntiles;
     const int m0 = mt * BM, n0 = nt * BN;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -92,8 +108,8 @@ __global__ __launch_bounds__(NT, 1) void k_gemm_bf16(const __bf16 *__restrict__ 
     }
     auto request = [&](int ks) __attribute__((always_inline)) {
         const unsigned base = lds0 + (unsigned)(ks % STAGES) * STAGEB + (unsigned)wave * 1024u;
-        const char *ga = reinterpret_cast<const char *>(A) + (size_t)ks * ROWB;
-        const char *gb = reinterpret_cast<const char *>(B) + (BT ? (size_t)ks * BK * ldb * 2 : (size_t)ks * ROWB);
+        const char *ga = reinterpret_cast<const char *>(A) + (size_t)(ks0 + ks) * ROWB;
+        const char *gb = reinterpret_cast<const char *>(B) + (BT ? (size_t)(ks0 + ks) * BK * ldb * 2 : (size_t)(ks0 + ks) * ROWB);
 #pragma unroll
         for (int u = 0; u < PIECES; u++) {
             unsigned keep;
@@ -183,7 +199,7 @@ __global__ __launch_bounds__(NT, 1) void k_gemm_bf16(const __bf16 *__restrict__ 
     // Two stages of K = 64: stage P + 1 lands while stage P is multiplied; once every wave has read the LAST fragments of stage
     // P (the barrier in front of its fourth k-step), stage P + 2 is requested into that slot:
     //   rd s1 | mma s0 | rd s2 | mma s1 | rd s3 | mma s2 | wait(P + 1 landed) barrier request(P + 2) | rd (P + 1) s0 | mma s3
-    const int nk = K / BK;
+    const int nk = sliced ? min(nk_slice, K / BK - ks0) : K / BK;
     request(0);
     if (1 < nk) {
         request(1);
@@ -221,8 +237,34 @@ __global__ __launch_bounds__(NT, 1) void k_gemm_bf16(const __bf16 *__restrict__ 
         mma(a1, b1);
     }
 
-    // ---- epilogue: per wave and 32-row tile, accumulators -> bf16 [32 x 64] patch in LDS -> 128-byte row pieces
     __syncthreads();
+    if (sliced) {
+        // ---- a slice's epilogue: the fp32 partial tile [320 x 256] of (tail tile, slice), through a per-wave [32 x 64] fp32 patch
+        // (8 KiB) so that the global stores are whole 256-byte row pieces
+        float *tile = part + ((size_t)(item - full_items) * S + slice) * (size_t)(BM * BN);
+        unsigned char *patch = smem + (size_t)wave * 8192;
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int n = j * 32 + 8 * g + 4 * hh;
+                    *reinterpret_cast<float4 *>(patch + r * 256 + n * 4) =
+                        make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int p = 0; p < 8; p++) {
+                const int pr = p * 4 + (lane >> 4), pc = lane & 15;   // 4 rows per pass, 16 x 16 B per row
+                const float4 v = *reinterpret_cast<const float4 *>(patch + pr * 256 + pc * 16);
+                *reinterpret_cast<float4 *>(tile + (size_t)(wm * 160 + i * 32 + pr) * BN + wn * 64 + pc * 4) = v;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        return;
+    }
+    // ---- epilogue: per wave and 32-row tile, accumulators -> bf16 [32 x 64] patch in LDS -> 128-byte row pieces
     unsigned char *patch = smem + (size_t)wave * 4096;            // 32 rows x 128 B, private to the wave
     // element (row m, column n) of acc[i][j]: lane m (+32: hh), register e -> n = (e & 3) + 8 (e >> 2) + 4 hh
 #pragma unroll
@@ -247,6 +289,27 @@ __global__ __launch_bounds__(NT, 1) void k_gemm_bf16(const __bf16 *__restrict__ 
     }
 }
 
+// the S fp32 partial tiles of every sliced tile, added in slice order (fixed order: bit-reproducible) and rounded once to bf16;
+// one thread per 8 consecutive columns
+__global__ __launch_bounds__(256) void k_gemm_tail_reduce(const float *__restrict__ part, int S, int ntiles, int first_mt,
+                                                         __bf16 *__restrict__ C, int ldc, int M) {
+    const int t = blockIdx.x / (BM / 8);                          // tail tile; 8 rows x 32 column groups per workgroup
+    const int row = (blockIdx.x - t * (BM / 8)) * 8 + (threadIdx.x >> 5), cg = threadIdx.x & 31;
+    const int mt = first_mt + t / ntiles, nt = t - (t / ntiles) * ntiles;
+    const int gm = mt * BM + row;
+    if (gm >= M) return;
+    const float *src = part + (size_t)t * S * (size_t)(BM * BN) + (size_t)row * BN + cg * 8;
+    float4 a = *reinterpret_cast<const float4 *>(src), b = *reinterpret_cast<const float4 *>(src + 4);
+    for (int s_ = 1; s_ < S; s_++) {
+        const float4 c = *reinterpret_cast<const float4 *>(src + (size_t)s_ * (BM * BN));
+        const float4 d = *reinterpret_cast<const float4 *>(src + (size_t)s_ * (BM * BN) + 4);
+        a.x += c.x; a.y += c.y; a.z += c.z; a.w += c.w;
+        b.x += d.x; b.y += d.y; b.z += d.z; b.w += d.w;
+    }
+    *reinterpret_cast<uint4 *>(C + (size_t)gm * ldc + nt * BN + cg * 8) =
+        make_uint4(pack2(a.x, a.y), pack2(a.z, a.w), pack2(b.x, b.y), pack2(b.z, b.w));
+}
+
 }  // namespace
 
 template <bool BT>
@@ -264,7 +327,43 @@ static int launch_gemm(const void *A, int lda, const void *B, int ldb, void *C, 
     const int mtiles = (M + BM - 1) / BM, ntiles = N / BN;
     const unsigned grid = 8u * (unsigned)((mtiles * ntiles + 7) / 8);
     hipLaunchKernelGGL(k_gemm_bf16<BT>, dim3(grid), dim3(NT), LDS_BYTES, (hipStream_t)stream, (const __bf16 *)A, lda,
-                       (const __bf16 *)B, ldb, (__bf16 *)C, ldc, M, N, K, mtiles, ntiles);
+                       (const __bf16 *)B, ldb, (__bf16 *)C, ldc, M, N, K, mtiles, ntiles, mtiles * ntiles, 1, K / BK, (float *)nullptr);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+// floats of caller-owned workspace spadot_gemm_tn_bf16_split needs
+extern "C" long long spadot_gemm_bf16_split_workspace(int M, int N, int tail_row_tiles, int slices) {
+    if (M <= 0 || N <= 0 || N % BN != 0 || tail_row_tiles < 1 || slices < 2 || slices > 8) return -22;
+    const int mtiles = (M + BM - 1) / BM;
+    if (tail_row_tiles > mtiles) return -22;
+    return (long long)tail_row_tiles * (N / BN) * slices * BM * BN;
+}
+
+// spadot_gemm_tn_bf16 with the LAST `tail_row_tiles` row panels (320 rows each) cut into `slices` slices of the contraction: the
+// whole tiles come first in the grid, the slices behind them, then k_gemm_tail_reduce adds the fp32 partials (slice order)
+// and rounds once.  For a GEMM of exactly one round of workgroups that has to share the chip: with 40 of the 256 compute
+// units busy, 216 whole tiles + 160 quarter tiles take 1.25 tile times where 256 whole tiles take 2.
+extern "C" int spadot_gemm_tn_bf16_split(const void *A, int lda, const void *B, int ldb, void *C, int ldc, int M, int N, int K,
+                                         int tail_row_tiles, int slices, float *workspace, void *stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || N % BN != 0 || K % BK != 0 || lda < K || ldb < K || ldc < N) return -22;
+    if (((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((uintptr_t)C & 15) || lda % 8 || ldb % 8 || ldc % 8) return -22;
+    if ((size_t)M * lda * 2 >= ((size_t)1 << 32) || (size_t)N * ldb * 2 >= ((size_t)1 << 32)) return -22;
+    const int mtiles = (M + BM - 1) / BM, ntiles = N / BN, nk = K / BK;
+    if (tail_row_tiles < 1 || tail_row_tiles > mtiles || slices < 2 || slices > 8 || slices > nk) return -22;
+    if (!workspace || ((uintptr_t)workspace & 15)) return -22;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)k_gemm_bf16<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return -5;
+        attr_set = true;
+    }
+    const int nk_slice = (nk + slices - 1) / slices;
+    const int S = (nk + nk_slice - 1) / nk_slice;                  // no empty slice
+    const int full_items = (mtiles - tail_row_tiles) * ntiles, tail_tiles = tail_row_tiles * ntiles;
+    const unsigned grid = 8u * (unsigned)((full_items + 7) / 8) + (unsigned)(tail_tiles * S);
+    hipLaunchKernelGGL(k_gemm_bf16<false>, dim3(grid), dim3(NT), LDS_BYTES, (hipStream_t)stream, (const __bf16 *)A, lda,
+                       (const __bf16 *)B, ldb, (__bf16 *)C, ldc, M, N, K, mtiles, ntiles, full_items, S, nk_slice, workspace);
+    hipLaunchKernelGGL(k_gemm_tail_reduce, dim3((unsigned)(tail_tiles * (BM / 8))), dim3(256), 0, (hipStream_t)stream,
+                       (const float *)workspace, S, ntiles, mtiles - tail_row_tiles, (__bf16 *)C, ldc, M);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 

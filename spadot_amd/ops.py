@@ -310,6 +310,10 @@ GEMM_DGRAD = [__import__("os").environ.get("SPADOT_GEMM_DGRAD", "1") == "1"]
 GEMM_DGRAD_MIN_WGS = [int(__import__("os").environ.get("SPADOT_GEMM_DGRAD_MIN_WGS", "240"))]
 GEMM_MAX_WGS = [int(__import__("os").environ.get("SPADOT_GEMM_MAXWG", "256"))]   # own GEMM only up to this many tiles (CUs left free)
 GEMM_OWN = [True]                                  # [False]: gemm_tn() itself goes to the library (tests)
+# compute units the OTHER stream holds while a forward map runs (the SVGP branch's inverse: one 512-thread workgroup per
+# matrix, 2 L = 40 of them for ~0.25 ms): gemm_tn() then cuts the row panels beyond one round of the free units into slices
+# of the contraction (spadot_gemm_tn_bf16_split).  0 = never.
+GEMM_BUSY_CUS = [int(__import__("os").environ.get("SPADOT_GEMM_BUSY_CUS", "40"))]
 # "Kp:Mmin[:Mmax],..." -- forward maps with that (padded) contraction width and row count go through the own kernel.  Default:
 # the second GAT layer at the benchmarked batch shape (~10^4 rows x 2048 -> 2048: 256 tiles, one round).  In the step the
 # library's 504 tiles of 160 x 256 run that map in 123-137 us (90 alone: it shares the chip with the SVGP branch's inverse and
@@ -339,7 +343,22 @@ def gemm_tn(x, w):
             and w.is_contiguous() and N % 256 == 0 and K % 64 == 0 and w.shape[1] == K and M >= 2560 and N >= 1024
             and ((M + 319) // 320) * (N // 256) <= GEMM_MAX_WGS[0]):
         out = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
-        rc = model_lib().spadot_gemm_tn_bf16(x.data_ptr(), K, w.data_ptr(), K, out.data_ptr(), N, M, N, K, _stream())
+        lib = model_lib()
+        # a grid of exactly one round that will share the chip (GEMM_BUSY_CUS compute units held by the other stream's
+        # inverse): the row panels that would form a second round are cut into quarter tiles along the contraction
+        mt, nt_ = (M + 319) // 320, N // 256
+        tail = mt - (256 - GEMM_BUSY_CUS[0]) // nt_ if GEMM_BUSY_CUS[0] > 0 else 0
+        if 0 < tail < mt and mt * nt_ > 256 - GEMM_BUSY_CUS[0] and K >= 4 * 64:
+            need = int(lib.spadot_gemm_bf16_split_workspace(M, N, tail, 4))
+            if need > 0:
+                ws = torch.empty(need, dtype=torch.float32, device=x.device)
+                rc = lib.spadot_gemm_tn_bf16_split(x.data_ptr(), K, w.data_ptr(), K, out.data_ptr(), N, M, N, K, tail, 4,
+                                                   ws.data_ptr(), _stream())
+                if rc == 0:
+                    return out
+                if rc != -22:
+                    _check(rc, "spadot_gemm_tn_bf16_split")
+        rc = lib.spadot_gemm_tn_bf16(x.data_ptr(), K, w.data_ptr(), K, out.data_ptr(), N, M, N, K, _stream())
         if rc == 0:
             return out
         if rc != -22:

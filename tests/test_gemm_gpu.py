@@ -84,6 +84,48 @@ def test_dense_map_uses_own_gemm_and_matches_library():
     np.testing.assert_allclose(a.float().cpu().numpy(), b.float().cpu().numpy(), rtol=2 ** -7, atol=2e-3)
 
 
+@pytest.mark.parametrize("M,N,K,tail,slices", [
+    (640, 256, 256, 1, 2),             # two row panels, the second in two slices
+    (1000, 512, 192, 2, 3),            # rows past M in the sliced panels; 3 K-steps in 3 slices
+    (10112, 2048, 2048, 5, 4),         # the second GAT layer at the bench shape: 216 whole tiles + 40 x 4 slices
+    (9980, 2048, 2048, 5, 4),
+    (700, 256, 512, 3, 8),             # every panel sliced
+])
+def test_gemm_tn_with_sliced_tail_panels_matches_the_whole_tile_form(M, N, K, tail, slices):
+    """spadot_gemm_tn_bf16_split: the last row panels as slices of the contraction + one fp32 sum per element -- every row of
+    the whole panels is bit-identical to spadot_gemm_tn_bf16, the sliced rows agree with an fp64 product like the whole-tile
+    form does (one rounding to bf16 of an fp32 sum), repeats are bit-identical, bad arguments are refused."""
+    from spadot_amd import _lib
+    lib = _lib.model_lib()
+    g = torch.Generator(device=DEV).manual_seed(M + K)
+    A = (torch.randn((M, K), device=DEV, generator=g) * 0.5).bfloat16()
+    B = (torch.randn((N, K), device=DEV, generator=g) * 0.3).bfloat16()
+    st = torch.cuda.current_stream().cuda_stream
+    ref_whole = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
+    assert lib.spadot_gemm_tn_bf16(A.data_ptr(), K, B.data_ptr(), K, ref_whole.data_ptr(), N, M, N, K, st) == 0
+    need = int(lib.spadot_gemm_bf16_split_workspace(M, N, tail, slices))
+    mt = (M + 319) // 320
+    assert need == tail * (N // 256) * slices * 320 * 256
+    outs = []
+    for _ in range(2):
+        C = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+        ws = torch.full((need,), float("nan"), device=DEV)
+        assert lib.spadot_gemm_tn_bf16_split(A.data_ptr(), K, B.data_ptr(), K, C.data_ptr(), N, M, N, K, tail, slices, ws.data_ptr(), st) == 0
+        torch.cuda.synchronize()
+        outs.append(C)
+    C = outs[0]
+    assert torch.equal(C, outs[1]) and torch.isfinite(C.float()).all()
+    whole_rows = (mt - tail) * 320
+    assert torch.equal(C[:whole_rows], ref_whole[:whole_rows])
+    ref = (A.double() @ B.double().t())
+    scale = float(ref.abs().max())
+    assert float((C.double() - ref).abs().max()) <= 2 ** -7 * scale + 1e-3
+    assert float((C[whole_rows:].double() - ref_whole[whole_rows:].double()).abs().max()) <= 2 ** -7 * scale + 1e-3
+    assert lib.spadot_gemm_tn_bf16_split(A.data_ptr(), K, B.data_ptr(), K, C.data_ptr(), N, M, N, K, mt + 1, slices, ws.data_ptr(), st) == -22
+    assert lib.spadot_gemm_tn_bf16_split(A.data_ptr(), K, B.data_ptr(), K, C.data_ptr(), N, M, N, K, tail, 9, ws.data_ptr(), st) == -22
+    assert lib.spadot_gemm_tn_bf16_split(A.data_ptr(), K, B.data_ptr(), K, C.data_ptr(), N, M, N, K, tail, slices, None, st) == -22
+
+
 @pytest.mark.parametrize("M,N,K,Kp,slices,tile_k", [
     (64, 256, 256, 256, 1, 256),            # one chunk, one tile, no slicing
     (100, 256, 256, 256, 2, 256),           # rows past M in the second chunk come from the zero row
