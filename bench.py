@@ -190,7 +190,7 @@ def roofline_train(dd, unit, cfg, G, compute_dtype, n_params, live_ms_per_step):
     gemm_us = us("gemm_bf16_library", "gemm_bf16_own") if compute_dtype == "bf16" else us("gemm_f32_library")
     gat_us, opt_us = us("gat_edge"), us("optimizer")
     out["source"] = (f"kernel microseconds REPLAYED from {os.path.relpath(fam_path, ROOT)} (rocprofv3 --kernel-trace of "
-                     f"`bench.py --leg train`, {prof['steps']} steps, {prof['wall_us_per_step']:.0f} us/step under the profiler); "
+                     f"`bench.py --leg train`, {prof['steps']} steps, {prof.get('wall_us_per_step_without_profiler_stalls', prof['wall_us_per_step']):.0f} us/step under the profiler); "
                      "algorithmic flops / bytes computed live from this run's batch")
     out["profile_head"] = prof.get("head")
     out["profile_source_sha16"] = prof.get("source_sha16")
