@@ -205,7 +205,7 @@ def roofline_train(dd, unit, cfg, G, compute_dtype, n_params, live_ms_per_step):
                      "unit": "GB/s", "frac": gat_bytes / max(gat_us, 1e-9) / 1e3 / HBM_PEAK_GBS},
         "optimizer": {"bound": "hbm", "us_per_step": opt_us, "achieved": opt_bytes / max(opt_us, 1e-9) / 1e3, "peak": HBM_PEAK_GBS,
                       "unit": "GB/s", "frac": opt_bytes / max(opt_us, 1e-9) / 1e3 / HBM_PEAK_GBS},
-        "svgp_sweep": {"bound": "latency (2L = 20 workgroups, fp64 vector FMA)", "us_per_step": us("svgp_sweep")},
+        "svgp_sweep": {"bound": "latency (2 L = 40 workgroups, one per matrix; fp64 vector FMA)", "us_per_step": us("svgp_sweep")},
         "gemm_f64_svgp": {"bound": "latency (m x m, b x m fp64 library GEMMs)", "us_per_step": us("gemm_f64_library")},
         "small_kernels": {"bound": "launch latency", "us_per_step": us("own_small", "torch_glue"),
                           "launches_per_step": sum(fam.get(k, {}).get("launches_per_step", 0.0) for k in ("own_small", "torch_glue")),

@@ -21,7 +21,9 @@
 // (library 119 us); built without the DMA 99 us, without the MFMAs 67 us, with neither 39 us, skeleton 19 us -- i.e. the MFMAs
 // alone run at 1.57 PFLOP/s, the rate of a bare v_mfma_f32_32x32x16_bf16 loop on random data on this chip
 // (tools/mfma_peak.hip: 1.59-1.78), and the DMA (885 MB per GEMM from L2 at ~18 TB/s) hides behind them but for ~11 us.
-// Inside the training step it does not pay (spadot_amd/ops.py: GEMM_FWD), so the step keeps the library by default.
+// Inside the training step it pays for the SECOND layer's map (with its last row panels cut into contraction slices beside the
+// SVGP inverse: launch_gemm_split below) and for that layer's input gradient; the first layer's map stays on the library
+// (spadot_amd/ops.py: GEMM_FWD_SHAPES, GEMM_BUSY_CUS).
 #include <hip/hip_runtime.h>
 #include <cstdint>
 

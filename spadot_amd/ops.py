@@ -304,7 +304,9 @@ def cast_rows(pairs):
 # alone it beats the library at the layer shapes (9980 x 2048 x 3072: 110 vs 119 us, x 2048: 80 vs 90 us), inside the step it
 # loses (forward maps: 476 vs 489 steps/s; dx: 485 vs 490) -- its 256 workgroups hold every compute unit's registers and LDS
 # for the whole GEMM, and the latency-bound SVGP branch on the other stream, which bounds the forward pair, waits behind them;
-# the library's ~800 short-lived workgroups let that branch's small kernels in.  So both uses are opt-in.
+# the library's ~800 short-lived workgroups let that branch's small kernels in.  (Round 2: both uses opt-in.  Round 3: the
+# second layer's forward map and input gradient take it by default -- GEMM_FWD_SHAPES, GEMM_BUSY_CUS below -- the first
+# layer's, measured again in every form, stays on the library.)
 GEMM_FWD = [__import__("os").environ.get("SPADOT_GEMM_FWD", "0") == "1"]
 GEMM_DGRAD = [__import__("os").environ.get("SPADOT_GEMM_DGRAD", "1") == "1"]
 GEMM_DGRAD_MIN_WGS = [int(__import__("os").environ.get("SPADOT_GEMM_DGRAD_MIN_WGS", "240"))]
