@@ -195,8 +195,8 @@ def roofline_train(dd, unit, cfg, G, compute_dtype, n_params, live_ms_per_step):
     out["profile_head"] = prof.get("head")
     out["profile_source_sha16"] = prof.get("source_sha16")
     out["stale_profile"] = prof.get("source_sha16") != source_fingerprint()      # True: the tree changed since it was profiled
-    if "mfma" in prof:
-        out["mfma_counters"] = prof["mfma"]
+    if "mfma" in prof:          # at most four kernels' MFMA-busy fractions travel in the line; the table stays in profiles/
+        out["mfma_busy_top"] = mfma_top(prof["mfma"])
     out["families"] = {
         "gemm_" + compute_dtype: {"bound": "mfma", "us_per_step": gemm_us, "achieved": gemm_flops / max(gemm_us, 1e-9) / 1e6,
                                   "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -268,19 +268,129 @@ def epoch_block(tu, model, opt, cfg, dd, stepper, T, beta1, torch):
                     "(_train_utils.py:230-231)"}
 
 
+
+# ------------------------------------------------------------------------------ the ONE stdout line
+
+LINE_LIMIT = 6000      # the driver keeps the tail of stdout (r03: 8.6 KB); a longer line cannot be parsed
+REQUIRED_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")
+
+
+def mfma_top(table, n=4):
+    """The `n` kernels with the most MFMA-busy cycles per profiled run of a tools/mfma_summary.py table
+    ({"kernels": [{"kernel", "launches", "SQ_VALU_MFMA_BUSY_CYCLES", "mfma_util"}, ...]}), as {short name: mfma_util}."""
+    items = []
+    for r in (table.get("kernels", []) if isinstance(table, dict) else table):
+        name = str(r.get("kernel", "?")).replace("void (anonymous namespace)::", "").split("(")[0]
+        if name.startswith("Cijk_"):                                   # library GEMM: keep the macro-tile token
+            mt = [t for t in name.split("_") if t.startswith("MT")]
+            name = "lib_" + (mt[0] if mt else name[:24])
+        w = float(r.get("launches", 1)) * float(r.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0))
+        if r.get("mfma_util") is not None:
+            items.append((w, name[:40], float(r["mfma_util"])))
+    items.sort(reverse=True)
+    out = {}
+    for _, nm, u in items:
+        if nm not in out and len(out) < n:
+            out[nm] = round(u, 3)
+    return out
+
+
+def _r(x, sig=6):
+    """Floats to `sig` significant digits (recursively): the line is read by people and parsers, not re-used as input."""
+    if isinstance(x, float):
+        return float(f"{x:.{sig}g}") if x == x and abs(x) != float("inf") else None
+    if isinstance(x, dict):
+        return {k: _r(v, sig) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, sig) for v in x]
+    return x
+
+
+def _pick(d, *keys):
+    return {k: d[k] for k in keys if d is not None and k in d}
+
+
+def compact_line(full, detail_file=None):
+    """The record that goes to stdout: every key the contract names, the two extra objects (`roofline`, `cpu_baseline`)
+    and one-number summaries of everything else; the full record (long `what` / `source` / `note` texts, per-repeat
+    timings, per-loss errors, kernel tables) is written to `detail_file`.  Raises if the line would exceed LINE_LIMIT."""
+    o = _pick(full, "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "dtype_detail", "data")
+    cfg = full.get("config", {})
+    tr = cfg.get("train", {})
+    o["config"] = {"workload": cfg.get("workload"), "parallelism": cfg.get("parallelism")}
+    o["config"].update(_pick(tr, "n_sub", "E_sub", "m_inducing", "params", "hip_graphs", "staged_graphs",
+                             "bucketed_grad_exchange", "units_in_schedule", "setup_s"))
+    if "repeats" in tr:
+        o["config"]["repeats_ms_per_step"] = _pick(tr["repeats"], "n", "min", "max", "spread_pct")
+    o.update(_pick(full, "rccl_ranks", "rank_devices"))
+    if isinstance(o.get("rank_devices"), list) and len(set(o["rank_devices"])) == 1:
+        o["rank_devices"] = [o["rank_devices"][0]]                      # identical GPUs: name it once
+    roof = full.get("roofline")
+    if roof is not None:
+        o["roofline"] = _pick(roof, "bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "alg_bytes_per_launch",
+                              "profile_kernel_us", "stale_profile")
+        if "kernel_ms" in roof and "kernel" in roof:
+            o["roofline"]["kernel_us_events"] = 1e3 * roof["kernel_ms"].get(roof["kernel"][2:], float("nan"))
+        if "traffic_source" in roof:
+            o["roofline"]["traffic_source"] = ("REJECTED (below algorithmic bytes)" if roof["traffic_source"].startswith("REJECTED")
+                                               else "replayed from the committed --pmc summary in profiles/")
+    rt = full.get("roofline_train")
+    if rt is not None:
+        fams = {}
+        for k, v in rt.get("families", {}).items():
+            fams[k] = _pick(v, "us_per_step", "frac", "launches_per_step")
+            if "bound" in v:
+                fams[k]["bound"] = v["bound"].split(" ")[0]
+        o["roofline_train"] = {"families": fams}
+        o["roofline_train"].update(_pick(rt, "launches_per_step", "stale_profile", "mfma_busy_top"))
+        if "under_12us" in rt:
+            o["roofline_train"]["under_12us"] = rt["under_12us"]
+        if "algorithmic" in rt:
+            o["roofline_train"]["algorithmic"] = rt["algorithmic"]
+    if "epoch" in full:
+        o["epoch"] = _pick(full["epoch"], "steps", "steps_s", "update_kmeans_s", "update_ot_matrix_s", "steps_per_s_whole_epoch",
+                           "steps_per_s_reference_cadence", "kmeans_backend")
+    if "parity_check" in full:
+        o["parity_check"] = _pick(full["parity_check"], "max_rel_loss_err", "latent_rel_l2_err", "grad_cos_min", "grad_cos_min_param",
+                                  "grad_rel_l2_max", "grad_cos_global")
+    if "sinkhorn" in full:
+        o["sinkhorn"] = _pick(full["sinkhorn"], "value", "unit", "ms_per_iter", "problem", "storage", "full_solve_s", "full_solve_iters",
+                              "iters_per_s_with_convergence_checks", "pair_end_to_end_s", "cost_setup_s")
+    if "parity_check_sinkhorn" in full:
+        o["parity_check_sinkhorn"] = _pick(full["parity_check_sinkhorn"], "stage_iters_equal", "stage_iters_max_diff", "marginal_rel_err",
+                                           "plan_rel_err_top", "entries_compared", "oracle_solve_s")
+    for k in ("cpu_baseline", "cpu_baseline_sinkhorn"):
+        if k in full:
+            o[k] = dict(_pick(full[k], "value", "unit", "cores", "kind"), sample=str(full[k].get("sample", ""))[:200])
+    if detail_file:
+        o["detail_file"] = detail_file
+    o = _r(o)
+    line = json.dumps(o, separators=(",", ":"))
+    if len(line) >= LINE_LIMIT:
+        raise RuntimeError(f"bench line is {len(line)} characters (limit {LINE_LIMIT}): move detail into the side file")
+    return o, line
+
+
+def write_detail(full, n_gpus):
+    """The full record as a side file (gpurun_out/ when the repo is writable, else the temp dir); returns its path or None."""
+    import tempfile
+    for base in (os.path.join(ROOT, "gpurun_out"), tempfile.gettempdir()):
+        try:
+            os.makedirs(base, exist_ok=True)
+            p = os.path.join(base, f"bench_detail_{n_gpus}gpu.json")
+            with open(p, "w") as f:
+                json.dump(full, f, indent=1)
+            return os.path.relpath(p, ROOT) if p.startswith(ROOT) else p
+        except OSError:
+            continue
+    return None
+
+
 # ------------------------------------------------------------------------------ main
 
-def main():
-    # stdout carries exactly ONE line (the JSON); everything the library prints goes to stderr
-    real_stdout = sys.stdout
-    sys.stdout = sys.stderr
-    try:
-        _main(real_stdout)
-    finally:
-        sys.stdout = real_stdout
-
-
-def _main(real_stdout):
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -297,7 +407,84 @@ def _main(real_stdout):
     ap.add_argument("--leg", default="both", choices=["both", "train", "sinkhorn"])
     ap.add_argument("--no-sinkhorn-parity", action="store_true",
                     help="skip the whole-solve oracle check of the Sinkhorn leg (about a minute of one host thread)")
-    args = ap.parse_args()
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="launcher rehearsal: start the ranks, run the all-reduce-of-ones proof on the chosen backend, print the "
+                         "line's header and exit -- no GPU is touched (tests/test_bench_line_cpu.py, SPADOT_BENCH_BACKEND=gloo)")
+    return ap.parse_args(argv)
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: THIS process has made no GPU call (torch
+    is not even imported yet), so it may start the N ranks itself -- as children, `python -m torch.distributed.run`, the
+    command the driver uses -- relay rank 0's one stdout line and leave with their exit code.  Never an exec."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    print("[bench] launching:", " ".join(cmd), file=sys.stderr, flush=True)
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    for ln in proc.stdout.splitlines():
+        if not ln.startswith("{"):
+            print(ln, file=sys.stderr)
+    if proc.returncode == 0 and len(lines) != 1:
+        print(f"[bench] expected ONE JSON line from rank 0, got {len(lines)}", file=sys.stderr)
+        return 3
+    if lines:
+        print(lines[-1], flush=True)
+    return proc.returncode
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, argv))
+    # stdout carries exactly ONE line (the JSON); everything the library prints goes to stderr
+    real_stdout = sys.stdout
+    sys.stdout = sys.stderr
+    try:
+        _main(real_stdout, args)
+    finally:
+        sys.stdout = real_stdout
+
+
+def _rendezvous_only(args, real_stdout):
+    """The launcher's rehearsal: process group on the chosen backend, the all-reduce-of-ones proof, header line."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    backend = os.environ.get("SPADOT_BENCH_BACKEND", "nccl")
+    ranks = 1
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend)
+        ones = torch.ones(1, device="cpu" if backend == "gloo" else f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}")
+        dist.all_reduce(ones)
+        ranks = int(ones.item())
+    ok = ranks == world == args.gpus
+    if rank == 0:
+        print(json.dumps({"metric": METRIC, "n_gpus": world, "rccl_ranks": ranks, "backend": backend, "rendezvous_only": True,
+                          "value": None}), file=real_stdout, flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    if not ok:
+        print(f"[bench] world {world} / all-reduce of ones {ranks} / --gpus {args.gpus} disagree", file=sys.stderr)
+        sys.exit(4)
+
+
+def _main(real_stdout, args):
+    if args.rendezvous_only:
+        return _rendezvous_only(args, real_stdout)
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}: refusing to print a line whose "
+              "n_gpus is not the one asked for", file=sys.stderr)
+        sys.exit(4)
 
     import torch
     import torch.distributed as dist
@@ -325,7 +512,9 @@ def _main(real_stdout):
         ones = torch.ones(1, device=dev)
         dist.all_reduce(ones)
         rccl_ranks = int(ones.item())
-        assert rccl_ranks == world == dist.get_world_size(), (rccl_ranks, world)
+        if not (rccl_ranks == world == dist.get_world_size() == args.gpus):
+            print(f"[bench] rank {rank}: all-reduce of ones = {rccl_ranks}, world {world}, --gpus {args.gpus}", file=sys.stderr)
+            sys.exit(4)
         rank_devices = [None] * world
         dist.all_gather_object(rank_devices, f"{local_rank}:{torch.cuda.get_device_properties(local_rank).name}")
 
@@ -549,21 +738,21 @@ def _main(real_stdout):
             out.update(value=train_res["value"], unit="training steps/s", ms_per_step=train_res["ms_per_step"])
         else:
             out.update(value=sk_res["value"], unit="Sinkhorn iters/s", ms_per_step=sk_res["ms_per_iter"] * ITERS_PER_STEP)
-        out["dtype"] = (f"{args.compute_dtype} GAT branch + linears, f32 parameters/optimizer, f64 SVGP algebra; "
-                        f"Sinkhorn {args.ot_storage} kernel matrix with f64 scalings")
+        out["dtype"] = args.compute_dtype
+        out["dtype_detail"] = (f"{args.compute_dtype} GAT branch + linears, f32 parameters/optimizer, f64 SVGP algebra; "
+                               f"Sinkhorn {args.ot_storage} kernel matrix with f64 scalings")
         name = "cfg3" if (T, N, G) == (5, 10000, 3000) else "custom shape"
         out["config"] = {"workload": f"{name}: {T} time points x {N} spots x {G} genes, batch 512, k=30, 1200 inducing points; "
                                      f"Sinkhorn pair problem {N}x{N}",
                          "train": {k: v for k, v in (train_res or {}).items()
                                    if k not in ("cpu_baseline", "parity_check", "roofline_train", "epoch")},
                          "parallelism": "1 GPU" if world == 1 else (
-                             f"{world} ranks (one per GPU, backend {backend}, all-reduce of ones = {rccl_ranks}): the job's "
-                             f"(time point, batch) units dealt to the ranks for the whole run -- batch bi of time point t on rank "
-                             f"({N // 512 + (1 if N % 512 else 0)} t + bi) mod {world} -- every rank holds all {T} time points' rows "
-                             "and K-means state and builds, caches and captures only its own batches; one step = one batch per "
-                             "rank, flat-gradient all-reduce (sum, update on the mean) in two buckets, the first overlapped with "
-                             "the backward pass; the timed steps draw from time points 1.. (all loss terms active); pair solves: "
-                             "rank r solves pair (r mod " + str(T - 1) + ", r mod " + str(T - 1) + " + 1), no collective")}
+                             f"dp{world}: (time point, batch) units dealt round-robin to {world} ranks (one per GPU, backend "
+                             f"{backend}), one batch per rank per step, flat-gradient all-reduce (sum, update on the mean) in 2 "
+                             f"buckets, the first beside the backward pass. Per-rank replication cost: every rank holds all {T} "
+                             f"time points' rows ({T * N * G * (2 if args.compute_dtype == 'bf16' else 4) / 1e9:.2f} GB) and, per epoch, "
+                             f"refits all {T} K-means and solves all {T - 1} centre-pair OT problems redundantly (no broadcast); "
+                             f"Sinkhorn leg: rank r solves its own {N}x{N} pair, no collective")}
         out["rccl_ranks"] = rccl_ranks
         if train_res is not None:
             out["rank_timepoints"] = owned_all
@@ -581,7 +770,8 @@ def _main(real_stdout):
             out["cpu_baseline"] = cb
             if train_res and sk_res and "cpu_baseline" in sk_res and "cpu_baseline" in train_res:
                 out["cpu_baseline_sinkhorn"] = sk_res["cpu_baseline"]
-        print(json.dumps(out), file=real_stdout, flush=True)
+        _, line = compact_line(out, write_detail(out, world))
+        print(line, file=real_stdout, flush=True)
     if world > 1:
         dist.destroy_process_group()
 
