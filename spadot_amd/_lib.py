@@ -31,6 +31,42 @@ def _load(name):
     return lib
 
 
+class _Checked:
+    """A library entry whose call is refused unless it carries exactly the declared number of arguments.
+
+    ctypes only rejects a cdecl call with too FEW arguments; one with too many goes through, and a C entry that has grown
+    parameters the Python call site does not pass yet reads whatever the stack holds in their place -- on the GPU that
+    is a kernel dereferencing a host address (the round-3 `k_sgemm_small` fault).  The header, the
+    argtypes here and every call site must agree; tests/test_abi_cpu.py checks the first two against each other on CPU."""
+    __slots__ = ("fn", "n", "name")
+
+    def __init__(self, fn, name):
+        self.fn, self.n, self.name = fn, len(fn.argtypes), name
+
+    @property
+    def argtypes(self):
+        return self.fn.argtypes
+
+    @property
+    def restype(self):
+        return self.fn.restype
+
+    def __call__(self, *args):
+        if len(args) != self.n:
+            raise TypeError(f"{self.name} takes {self.n} arguments (include/*.h), {len(args)} given")
+        return self.fn(*args)
+
+
+def _seal(lib):
+    """Every spadot_* entry that has argtypes becomes a _Checked wrapper; one without argtypes is an error here."""
+    for name, fn in list(vars(lib).items()):
+        if name.startswith("spadot_") and not isinstance(fn, _Checked):
+            if fn.argtypes is None and name not in ("spadot_ot_version", "spadot_model_version"):
+                raise RuntimeError(f"{name}: no argtypes declared in spadot_amd/_lib.py")
+            if fn.argtypes is not None:
+                setattr(lib, name, _Checked(fn, name))
+
+
 class OTConfig(ctypes.Structure):
     """struct spadot_ot_config (include/spadot_ot.h)."""
     _fields_ = [("lambda1", ctypes.c_double), ("lambda2", ctypes.c_double), ("epsilon", ctypes.c_double),
@@ -117,6 +153,7 @@ def ot_lib():
     lib.spadot_ot_small_max.restype = ci
     lib.spadot_ot_small_solve.argtypes = [ci, ctypes.POINTER(OTSmallProblem), ci, ci, ctypes.POINTER(OTConfig), vp, vp]
     lib.spadot_ot_small_solve.restype = ci
+    _seal(lib)
     lib._spadot_ready = True
     return lib
 
@@ -133,6 +170,7 @@ def model_lib():
         "spadot_gat_backward_target": [vp, vp, vp, ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp],
         "spadot_gat_backward_source": [vp, ci, vp, vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, vp, vp],
         "spadot_gat_logits": [vp, ci, vp, vp, ci, ci, ci, vp, vp, vp],
+        "spadot_gat_att_grad": [vp, ci, vp, vp, ci, ci, ci, vp, ci, vp, vp, vp, ci, vp],
         "spadot_gat_alpha": [vp, vp, vp, vp, vp, ci, ci, vp, vp, vp],
         "spadot_gat_softmax_backward": [vp, vp, vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp],
         "spadot_gat_ds_src": [vp, vp, vp, ci, ci, vp, vp],
@@ -202,5 +240,6 @@ def model_lib():
     lib.spadot_gemm_wgrad_bf16_workspace.restype = ll
     lib.spadot_gemm_wgrad_bf16_workspace_tiled.argtypes = [ci, ci, ci, ci, ci]
     lib.spadot_gemm_wgrad_bf16_workspace_tiled.restype = ll
+    _seal(lib)
     lib._spadot_ready = True
     return lib

@@ -65,3 +65,78 @@ def test_missing_library_is_a_loud_error(tmp_path, monkeypatch):
     monkeypatch.setattr(_lib, "_CACHE", {})
     with pytest.raises(_lib.NativeLibraryMissing):
         _lib._load("libspadot_ot.so")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# header prototypes against the ctypes declarations (the round-3 k_sgemm_small fault was a call whose
+# Python side and C side disagreed about the parameter list; this is the check that catches that without a GPU)
+
+def prototypes(header_path):
+    """{name: [type class per parameter]} for every function prototype of a header; classes: 'ptr', 'int', 'll', 'double',
+    'float'."""
+    src = open(header_path).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", "", src)
+    src = re.sub(r"typedef\s+struct\s+\w+\s*\{.*?\}\s*\w+\s*;", "", src, flags=re.S)
+    out = {}
+    for name, params in re.findall(r"\b([A-Za-z_]\w*)\s*\(([^;{]*)\)\s*;", src):
+        params = params.strip()
+        kinds = []
+        if params and params != "void":
+            for prm in params.split(","):
+                prm = " ".join(prm.split())
+                if "*" in prm or "[" in prm:
+                    kinds.append("ptr")
+                elif re.search(r"\blong long\b", prm) or "int64_t" in prm or "size_t" in prm:
+                    kinds.append("ll")
+                elif re.search(r"\bdouble\b", prm):
+                    kinds.append("double")
+                elif re.search(r"\bfloat\b", prm):
+                    kinds.append("float")
+                elif re.search(r"\b(int|unsigned)\b", prm):
+                    kinds.append("int")
+                else:
+                    kinds.append("?" + prm)
+        out[name] = kinds
+    return out
+
+
+def ctype_class(t):
+    if t in (ctypes.c_void_p, ctypes.c_char_p) or hasattr(t, "contents") or getattr(t, "_type_", None) == "P":
+        return "ptr"
+    if isinstance(t, type) and issubclass(t, ctypes._Pointer):
+        return "ptr"
+    return {ctypes.c_int: "int", ctypes.c_uint: "int", ctypes.c_longlong: "ll", ctypes.c_ulonglong: "ll", ctypes.c_size_t: "ll",
+            ctypes.c_double: "double", ctypes.c_float: "float"}.get(t, "?" + repr(t))
+
+
+@pytest.mark.parametrize("header,loader", [("spadot_model.h", "model_lib"), ("spadot_ot.h", "ot_lib")])
+def test_every_spadot_entry_has_argtypes_that_match_its_prototype(header, loader):
+    from spadot_amd import _lib
+    lib = getattr(_lib, loader)()
+    protos = {n: k for n, k in prototypes(os.path.join(ROOT, "include", header)).items() if n.startswith("spadot_")}
+    assert len(protos) >= 10
+    bad = []
+    for name, kinds in sorted(protos.items()):
+        fn = getattr(lib, name)
+        if name.endswith("_version"):
+            continue
+        if fn.argtypes is None:
+            bad.append(f"{name}: declared in {header}, no argtypes in _lib.py")
+            continue
+        got = [ctype_class(t) for t in fn.argtypes]
+        if got != kinds:
+            bad.append(f"{name}: header {kinds} != argtypes {got}")
+        elif not isinstance(fn, _lib._Checked):
+            bad.append(f"{name}: not sealed (a call with surplus arguments would go through)")
+    assert not bad, "\n".join(bad)
+
+
+def test_a_call_with_the_wrong_argument_count_is_refused_before_it_reaches_the_library():
+    from spadot_amd import _lib
+    lib = _lib.model_lib()
+    n = len(lib.spadot_sgemm_small.argtypes)
+    with pytest.raises(TypeError, match="spadot_sgemm_small takes"):
+        lib.spadot_sgemm_small(*([0] * (n - 4)))        # the pre-batch call form against the batched entry
+    with pytest.raises(TypeError):
+        lib.spadot_sgemm_small(*([0] * (n + 1)))
