@@ -37,7 +37,9 @@ def _stale(src, out, extra_deps):
 def build_all(force=False, verbose=True):
     inc = os.path.join(HERE, "..", "..", "include")
     headers = [os.path.join(inc, f) for f in os.listdir(inc)] if os.path.isdir(inc) else []
-    built = []
+    headers += [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith(".h")]       # csrc's own shared headers
+    built, jobs, links = [], [], []
+    defs = os.environ.get("SPADOT_BUILD_DEFS", "").split()      # e.g. "-DAGG_RING=4" (A/B builds on the GPU box)
     for out, srcs in TARGETS.items():
         o = os.path.join(HERE, out)
         paths = [os.path.join(HERE, s) for s in srcs]
@@ -46,17 +48,22 @@ def build_all(force=False, verbose=True):
             for s, name in zip(paths, srcs):          # one object per translation unit, then one link
                 obj = s[:-4] + ".o"
                 if force or _stale(s, obj, headers):
-                    defs = os.environ.get("SPADOT_BUILD_DEFS", "").split()      # e.g. "-DAGG_RING=4" (A/B builds on the GPU box)
-                    cmd = [HIPCC] + [f for f in FLAGS if f != "-shared"] + EXTRA.get(name, []) + defs + ["-c", "-o", obj, s]
-                    if verbose:
-                        print(" ".join(cmd), flush=True)
-                    subprocess.check_call(cmd)
+                    jobs.append([HIPCC] + [f for f in FLAGS if f != "-shared"] + EXTRA.get(name, []) + defs + ["-c", "-o", obj, s])
                 objs.append(obj)
-            cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", o] + objs
-            if verbose:
-                print(" ".join(cmd), flush=True)
-            subprocess.check_call(cmd)
+            links.append([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", o] + objs)
         built.append(o)
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    if jobs:                                          # translation units are independent: compile them side by side
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(len(jobs), int(os.environ.get("SPADOT_BUILD_JOBS", "4")))) as ex:
+            list(ex.map(run, jobs))
+    for cmd in links:
+        run(cmd)
     return built
 
 

@@ -25,6 +25,7 @@
 #include <type_traits>
 
 #include "../../include/spadot_model.h"
+#include "per_device.h"
 
 namespace {
 
@@ -631,7 +632,7 @@ int spadot_gat_ds_src(const float *dz, const int *rowptr_t, const int *eid_t, in
 #define AGG_LAUNCH(MODE)                                                                                           \
     do {                                                                                                           \
         auto kern = k_gat_agg<MODE>;                                                                               \
-        static bool attr_set = false;                                                                              \
+        static PerDeviceFlag attr_set;                                                                                   \
         if (!attr_set) {                                                                                           \
             if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, agg::LDS_BYTES) != hipSuccess) return -5; \
             attr_set = true;                                                                                       \

@@ -28,6 +28,7 @@
 #include <cstdint>
 
 #include "../../include/spadot_model.h"
+#include "per_device.h"
 
 #ifndef GEMM_ABLATE
 #define GEMM_ABLATE 0        // experiments only: 1 = no DMA after the prologue, 2 = no MFMA, 4 = no fragment reads
@@ -321,7 +322,7 @@ static int launch_gemm(const void *A, int lda, const void *B, int ldb, void *C, 
     // the per-lane LDS-DMA source offsets are 32-bit (row * row stride in bytes): an operand image of 4 GiB or more would
     // wrap and read the wrong rows -- refused, the callers then use the library
     if ((size_t)M * lda * 2 >= ((size_t)1 << 32) || (size_t)(BT ? K : N) * ldb * 2 >= ((size_t)1 << 32)) return -22;
-    static bool attr_set = false;
+    static PerDeviceFlag attr_set;     
     if (!attr_set) {
         if (hipFuncSetAttribute((const void *)k_gemm_bf16<BT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return -5;
         attr_set = true;
@@ -353,7 +354,7 @@ extern "C" int spadot_gemm_tn_bf16_split(const void *A, int lda, const void *B, 
     const int mtiles = (M + BM - 1) / BM, ntiles = N / BN, nk = K / BK;
     if (tail_row_tiles < 1 || tail_row_tiles > mtiles || slices < 2 || slices > 8 || slices > nk) return -22;
     if (!workspace || ((uintptr_t)workspace & 15)) return -22;
-    static bool attr_set = false;
+    static PerDeviceFlag attr_set;     
     if (!attr_set) {
         if (hipFuncSetAttribute((const void *)k_gemm_bf16<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return -5;
         attr_set = true;

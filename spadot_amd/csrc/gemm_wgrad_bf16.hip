@@ -24,6 +24,7 @@
 #include <cstdint>
 
 #include "../../include/spadot_model.h"
+#include "per_device.h"
 
 namespace {
 
@@ -289,7 +290,7 @@ template <int WGN, int WGK, int TI, int TJ>
 static int launch_wgrad(const void *G, int ldg, const void *X, int ldx, float *dW, int ldw, int M, int N, int K, int ktiles, int ntiles,
                         int S, int cps, float *workspace, const void *zero_row, hipStream_t stream) {
     constexpr int TKE = 32 * WGK * TJ;
-    static bool attr_set = false;
+    static PerDeviceFlag attr_set;     
     auto kern = k_gemm_wgrad_bf16<WGN, WGK, TI, TJ>;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return -5;

@@ -18,6 +18,7 @@
 #include <cstdint>
 
 #include "../../include/spadot_model.h"
+#include "per_device.h"
 
 namespace {
 
@@ -607,7 +608,7 @@ int spadot_mlp_chain_backward(const float *dy, const float *x, int b, int n_laye
     int rows, width;
     if (spadot_mlp_chain_workspace(b, n_layers, dims, &rows, &width)) return -22;
     constexpr int LDS_BWD = LDS_BWD_FLOATS * (int)sizeof(float);
-    static bool attr_set = false;
+    static PerDeviceFlag attr_set;     
     if (!attr_set) {
         if (hipFuncSetAttribute((const void *)k_mlp_chain_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BWD) != hipSuccess) return -5;
         attr_set = true;
@@ -636,7 +637,7 @@ int spadot_bias_sqerr_backward(const float *g1, const float *o, const float *bia
 
 int spadot_headfc_forward(const void *h_bf16, const float *W, const float *bias, int b, int K, int N, float *out, void *stream) {
     if (b <= 0 || K <= 0 || K % 8 || N <= 0 || N > FC_MAXN || (size_t)N * K * 4 > 65536) return -22;
-    static bool attr_set = false;
+    static PerDeviceFlag attr_set;     
     if (!attr_set) {
         if (hipFuncSetAttribute((const void *)k_headfc_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, 65536) != hipSuccess) return -5;
         attr_set = true;

@@ -13,6 +13,7 @@
 #include <cstdlib>
 
 #include "../../include/spadot_model.h"
+#include "per_device.h"
 
 namespace {
 
@@ -2079,7 +2080,7 @@ int spadot_spd_inverse_logdet2(const double *A, int Lsrc, int L, int m, const do
     const size_t lds = sizeof(double) * (2 * ((size_t)T * CS + 1) + (size_t)m + 16 + (size_t)(TS * TS - RS * RS) * SWEEP_NT);
 #define SWEEP_CASE(N)                                                                                         \
     case N: {                                                                                                 \
-        static bool attr_set = false;                                                                         \
+        static PerDeviceFlag attr_set;                                                                              \
         if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_spd_sweep<N>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; } \
         hipLaunchKernelGGL(k_spd_sweep<N>, dim3(L), dim3(SWEEP_NT), lds, st_, A, m, T, Ainv, logdet, Lsrc, add0, add1);         \
     } break;
@@ -2286,7 +2287,7 @@ int spadot_cluster_losses_forward(const float *z, const long long *labels_all, c
     chunk = (chunk + 7) / 8 * 8;
     size_t lds = sizeof(float) * (size_t)chunk * D + sizeof(int) * (size_t)chunk;
     if (K <= CL_KREG && D <= 512) lds += sizeof(float) * (size_t)(512 / D) * K * (D + 1);
-    static bool attr_set = false;
+    static PerDeviceFlag attr_set;     
     if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_cluster_losses_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); attr_set = true; }
     hipLaunchKernelGGL(k_cluster_losses_fwd, dim3(1), dim3(512), lds, (hipStream_t)stream, z, labels_all, seed_ids, centres,
                        prev_centres, gamma, cluster_list, b, D, K, Kp, Kl, do_km, do_ot, out2, work, chunk);
@@ -2367,7 +2368,7 @@ int spadot_sgemm_small(int mode, const float *A, int lda, const float *B, int ld
 int spadot_knn(const double *x, int n, int d, int kk, int *out, void *stream) {
     if (n <= 0 || d <= 0 || d > KNN_MAXD || kk <= 0 || kk > n || kk > 128) return -22;
     const size_t lds = sizeof(double) * KNN_T * KNN_MAXD + (sizeof(double) + sizeof(int)) * (size_t)kk * KNN_T;
-    static bool attr_set = false;
+    static PerDeviceFlag attr_set;     
     if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_knn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
     hipLaunchKernelGGL(k_knn, dim3((n + KNN_T - 1) / KNN_T), dim3(KNN_T), lds, (hipStream_t)stream, x, n, d, kk, out);
     return hipGetLastError() == hipSuccess ? 0 : -5;

@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "../../include/spadot_ot.h"
+#include "per_device.h"
 
 // Error handling: no HIP failure ends the host process.  Every HIP call is checked; a failure unwinds to the C entry
 // point, which reports it on stderr and returns SPADOT_EHIP (part B: int results), NaN (part A: double / float results,
@@ -1239,7 +1240,7 @@ struct IterParams { double eps, tau, l1, l2, al1, al2; };
 
 template <typename T, int VPT, int R, typename WT, bool WRS>
 void launch_fused_k(spadot_ot_solver *s, const IterParams &P, int *flag) {
-    static bool attr_set = false;
+    static PerDeviceFlag attr_set;     
     auto kern = k_fused_pass<T, VPT, R, WT, WRS>;
     if (!attr_set) {
         HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1281,7 +1282,7 @@ template <> void fused_pass_T<double>(spadot_ot_solver *s, const IterParams &P, 
 
 template <typename T, int VPT, int R, typename WT = double>
 void launch_fused_rowdot(spadot_ot_solver *s) {
-    static bool attr_set = false;
+    static PerDeviceFlag attr_set;     
     auto kern = k_fused_rowdot<T, VPT, R, WT>;
     if (!attr_set) {
         HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

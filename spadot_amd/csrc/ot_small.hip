@@ -26,6 +26,7 @@
 #include <cstdio>
 
 #include "../../include/spadot_ot.h"
+#include "per_device.h"
 
 namespace {
 
@@ -273,8 +274,9 @@ __global__ __launch_bounds__(64) void k_ot_small(SmallBatch B, int d, int divide
             const int i = t / J, j = t - i * J;
             P.plan_dev[t] = (K[i * ldk + j] * wa[i] * wb[j]) / (double)J;
         }
-    if (P.gamma_rownorm_dev != nullptr) {
-        // _train_utils.py:299-300: gamma / gamma.sum(axis=1), NaN / inf -> 0
+    if (P.gamma_rownorm_dev != nullptr && !(status & 2)) {
+        // _train_utils.py:299-300: gamma / gamma.sum(axis=1), NaN / inf -> 0.  (A solve that ended on the iteration cap did
+        // not converge: the tensor the OT-loss kernel reads keeps the previous plan until the caller's fallback rewrites it.)
         double rsum = 0.0;
         if (lane < I) {
             const double *kr = K + lane * ldk;
@@ -324,7 +326,7 @@ int spadot_ot_small_solve(int nprob, const spadot_ot_small_problem *probs, int d
         return -5;
     }
     const size_t lds = sizeof(double) * (2 * (size_t)SMALL_MAX * (SMALL_MAX + 1) + 4 * SMALL_MAX + 2 * (size_t)SMALL_MAX * SMALL_MAX_D);
-    static bool attr_set = false;
+    static PerDeviceFlag attr_set;     
     if (!attr_set) {
         if (hipFuncSetAttribute((const void *)k_ot_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             (void)hipGetLastError();

@@ -147,8 +147,19 @@ class SpaDOT(nn.Module):
             self._svgp_stream = st
         return st
 
+    def _break_step_chains(self):
+        """Entries that read or write the encoders between two training steps end any GraphedStepper chain (the next
+        step's SVGP branch waits for the whole stream again): _train_utils.GraphedStepper.barrier."""
+        for st in tuple(getattr(self, "_steppers", ())):
+            st.barrier()
+
+    def train(self, mode=True):
+        self._break_step_chains()
+        return super().train(mode)
+
     def all_latent_samples(self, X, Y, edge_index, tp, as_numpy=True):
         """Posterior means of the whole time point (SpaDOT.py:96-123); no N_t x N_t intermediates."""
+        self._break_step_chains()
         X = torch.as_tensor(X).to(self.device)
         Y = torch.as_tensor(Y).to(self.device)
         if not isinstance(edge_index, BatchGraph):

@@ -160,9 +160,16 @@ class GATEncoder(nn.Module):
                      (self.gat3.lin.weight, weight_image(self.gat3.lin.weight, HC, torch.bfloat16, self.gat3))]
             # training under an optimizer that keeps the images current (ops.FlatAdamW.maintain_image: the update kernel
             # stores the bf16 copy of every new weight): no cast launch at the head of the step
-            opt = getattr(self, "_image_optimizer", None) if self.training else None
-            if opt is None or not all(opt.maintain_image(W, im) for W, im in pairs):
+            # -- but only while that optimizer still owns the weights (a second FlatAdamW over this model re-points them:
+            # the pin is dropped) and nothing else has written them since the images were cast (sync_images)
+            opt = getattr(self, "_image_optimizer", None)
+            if opt is not None and not all(opt.owns(W) for W, _ in pairs):
+                object.__setattr__(self, "_image_optimizer", None)
+                opt = None
+            if opt is None or not self.training or not all(opt.maintain_image(W, im) for W, im in pairs):
                 cast_rows([(W.detach(), im) for W, im in pairs])
+            else:
+                opt.sync_images()
             fresh = True
         h = self.gat1.dense(x, fresh)
         if after_first_dense is not None:

@@ -1406,19 +1406,38 @@ class FlatAdamW:
         # bf16 images of weight matrices that step() keeps current (maintain_image); images_version changes whenever the
         # set does, so that a captured optimizer graph (whose launch carries the table by value) can be dropped
         self._images, self._image_table, self.images_version = [], None, 0
+        self._image_stamps = {}          # image address -> (flat buffer version, parameter version) when it was last cast
 
     # ---- bf16 weight images kept current by the update itself ------------------------------------------------------
+    def owns(self, param):
+        """True while `param`'s storage is a slice of THIS optimizer's flat parameter buffer (a later FlatAdamW over the same
+        module re-points the parameters into its own buffer: this one then owns nothing and must not be trusted to keep
+        anything about them current)."""
+        lo = self.flat_param.data_ptr()
+        return param.is_cuda and lo <= param.data_ptr() < lo + 4 * self.count
+
+    def _stamp(self, param):
+        # torch's version counters: in-place writes through the parameter (load_state_dict, dist.broadcast(p), p.copy_) bump
+        # the parameter's, writes through the flat buffer (flat_param.copy_, a broadcast of the flat buffer) the buffer's;
+        # this optimizer's own update kernels go through neither.  (A write through `p.data` is invisible to both: call
+        # refresh_images() after one.)
+        return (self.flat_param._version, param._version)
+
     def maintain_image(self, param, image):
         """From now on every step() also writes bf16(param) into `image` [rows, Kp >= K] (a persistent tensor, e.g.
         ops.weight_image): the dense maps that read the image need no cast launch per step.  The image is brought up to
-        date here.  Returns False (nothing registered) when the pair does not fit the kernel's conditions."""
-        if any(im.data_ptr() == image.data_ptr() for _, im in self._images):
+        date here.  Returns False (nothing registered) when the pair does not fit the kernel's conditions or the parameter
+        is not (or no longer) this optimizer's."""
+        if not self.owns(param):
+            return False
+        if any(im.data_ptr() == image.data_ptr() and p is param for p, im in self._images):
             return True
         idx = next((i for i, p in enumerate(self.params) if p is param), None)
         rows, K = (int(param.shape[0]), int(param.shape[1])) if param.dim() == 2 else (0, 0)
         ok = (idx is not None and param.dim() == 2 and image.dtype == torch.bfloat16 and image.is_contiguous()
               and image.dim() == 2 and image.shape[0] == rows and image.shape[1] >= K and K % 4 == 0 and image.shape[1] % 4 == 0
-              and rows * K < 2 ** 31 and image.data_ptr() % 8 == 0 and len(self._images) < 8 and self.count % 4 == 0)
+              and rows * K < 2 ** 31 and image.data_ptr() % 8 == 0 and len(self._images) < 8 and self.count % 4 == 0
+              and not any(im.data_ptr() == image.data_ptr() for _, im in self._images))
         if not ok:
             return False
         self._images.append((param, image))
@@ -1437,6 +1456,19 @@ class FlatAdamW:
         if pairs:
             with torch.no_grad():
                 cast_rows(pairs)
+        for p, im in self._images:
+            if only is None or any(im is o for o in only):
+                self._image_stamps[im.data_ptr()] = self._stamp(p)
+
+    def sync_images(self):
+        """Self-validation of the images: re-cast every registered image whose parameter was written by
+        anything torch can see since the image was last brought up to date.  A handful of integer compares when nothing
+        happened; GraphedStepper calls it in front of every step (a replayed graph holds no cast launch), the GAT encoder
+        in its eager forward.  Returns the number of images refreshed."""
+        stale = [im for p, im in self._images if self._image_stamps.get(im.data_ptr()) != self._stamp(p)]
+        if stale:
+            self.refresh_images(stale)
+        return len(stale)
 
     def _images_struct(self):
         if self._image_table is None:

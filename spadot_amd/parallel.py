@@ -166,6 +166,8 @@ def average_buffers(module, weight=1.0):
     _, P = world()
     if P == 1:
         return
+    if hasattr(module, "_break_step_chains"):         # writes BatchNorm statistics between steps: end any stepper chain
+        module._break_step_chains()
     bufs = [b for n, b in module.named_buffers() if b.is_floating_point()]
     if not bufs:
         return
@@ -274,14 +276,19 @@ def train_SpaDOT_parallel(dataloader_dict, model_config, verbose=False):
     from .utils import _train_utils as tu
     rank, P = world()
     device = torch.device(model_config["device"])
-    plan = plan_from_counts(model_config["timepoints"], dataloader_dict["N_train"], model_config["batch_size"], P, rank,
-                            model_config.get("shard_granularity", "batch"))
+    gran = model_config.get("shard_granularity")
+    if gran is None:
+        # not stated: a loader prepared through configure_shard carries 'owned_batches' (batch units); one prepared the
+        # older way -- owned_timepoints only, whole time points -- keeps meaning the time-point plan
+        gran = "batch" if "owned_batches" in model_config or "owned_batches" in dataloader_dict else "timepoint"
+    plan = plan_from_counts(model_config["timepoints"], dataloader_dict["N_train"], model_config["batch_size"], P, rank, gran)
     for tp in model_config["timepoints"]:          # the loader this rank was given must cover its share of the plan
         mine = plan.owned_batches(tp)
         have = dataloader_dict["dataloaders"].get(tp, [])
         if mine and (len(have) != plan.batches_per_tp[tp] or any(have[bi] is None for bi in mine)):
             raise ValueError(f"rank {rank}: the dataloader lacks batches of time point {tp} that the shard plan gives it "
-                             "(call parallel.configure_shard before prepare_dataloader)")
+                             f"(granularity '{gran}': call parallel.configure_shard before prepare_dataloader, or set "
+                             "shard_granularity='timepoint' for a loader that holds whole time points)")
     model = SpaDOT.SpaDOT(model_config, dataloader_dict).to(device)
     # identical replicas: broadcast rank 0's initial parameters and buffers
     if P > 1:
@@ -293,7 +300,11 @@ def train_SpaDOT_parallel(dataloader_dict, model_config, verbose=False):
     beta1s = tu._beta_cycle_linear(model_config["maxiter"], stop=model_config["beta1"])
     order = list(enumerate(model_config["timepoints"]))
     batches_per_tp = plan.batches_per_tp           # (from the spot counts: the same on every rank, no collective)
-    refit = [tp for tp in plan.owned_timepoints() if tp in dataloader_dict["datasets"]]
+    refit = list(plan.owned_timepoints())
+    missing = [tp for tp in refit if tp not in dataloader_dict["datasets"]]
+    if missing:         # (its centres and labels would be gathered as all-zero from this rank, silently)
+        raise ValueError(f"rank {rank}: time points {missing} are this rank's to refit but their rows are not in "
+                         "dataloader_dict['datasets']")
     losses = {}
     # replayed hipGraphs, as in the single-replica trainer: one forward+backward graph per (time point, batch),
     # the all-reduce of the flat gradient between replays (not captured), one clip + AdamW graph

@@ -79,9 +79,11 @@ def optimal_transport_duality_gap(C, G, lambda1, lambda2, epsilon, batch_size, t
         solver.close()
 
 
-def compute_transport_map(a, b, config, C=None, G=None, *, device=None):
+def compute_transport_map(a, b, config, C=None, G=None, *, device=None, skip_small=False):
     """Transport map between two latent point clouds (ot_solvers.py:95-121).  `device` (extension): the HIP device to
-    solve on; default = this module's `device` switch."""
+    solve on; default = this module's `device` switch.  `skip_small` (extension): go straight to the streaming solver --
+    the fallback of a batched small solve that hit its iteration cap passes it, so that the capped kernel (which cannot
+    be stopped: up to 6 x 2^20 iterations on one wavefront) is not spun a second time on the same problem."""
     device = device if device is not None else globals()["device"]
     if C is None:
         xa = torch.as_tensor(a.detach() if isinstance(a, torch.Tensor) else np.asarray(a))
@@ -89,7 +91,7 @@ def compute_transport_map(a, b, config, C=None, G=None, *, device=None):
         I, J = int(xa.shape[0]), int(xb.shape[0])
     else:
         I, J = C.shape
-    if use_small_solver and small_problem_ok(I, J, None if C is not None else int(xa.shape[1])):
+    if use_small_solver and not skip_small and small_problem_ok(I, J, None if C is not None else int(xa.shape[1])):
         first = _compute_transport_map_small(xa if C is None else None, xb if C is None else None, config, C, G, I, device)
         if first is not None:
             return first

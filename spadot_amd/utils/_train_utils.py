@@ -314,7 +314,8 @@ def _update_OT_matrix(model, model_config):
             model.gammas[key] = gamma
         return
     for key, (a, b) in zip(keys, pairs):
-        gamma = compute_transport_map(a, b, model_config["ot_config"], G=None, device=device)
+        # (plans is None: a pair exceeded the small solver's range or hit its iteration cap -- not through it again)
+        gamma = compute_transport_map(a, b, model_config["ot_config"], G=None, device=device, skip_small=True)
         _set_gamma(model, key, gamma, device)
 
 
@@ -458,12 +459,24 @@ class GraphedStepper:
                 and hasattr(optimizer, "maintain_image"):
             object.__setattr__(model.GATEncoder, "_image_optimizer", optimizer)
             if not getattr(model, "_image_refresh_hook", False):
-                model.register_load_state_dict_post_hook(lambda mod, incompatible: optimizer.refresh_images())
+                # (whichever optimizer is pinned WHEN a state_dict is loaded, not the one that was pinned first)
+                def _refresh(mod, incompatible):
+                    o = getattr(mod.GATEncoder, "_image_optimizer", None)
+                    if o is not None:
+                        o.refresh_images()
+                model.register_load_state_dict_post_hook(_refresh)
                 object.__setattr__(model, "_image_refresh_hook", True)
         self._images_version = getattr(optimizer, "images_version", 0)
         # update in two graphs around an event (see update(), chained()); needs FlatAdamW(first=...)
         self.split_update = bool(model_config.get("split_update", os.environ.get("SPADOT_SPLIT_UPDATE", "1") == "1"))
         self._head_event, self._head_ready, self._chain = None, False, False
+        # the model knows its steppers (weakly): its public entries that touch the encoder between steps break the chain
+        import weakref
+        reg = getattr(model, "_steppers", None)
+        if reg is None:
+            reg = weakref.WeakSet()
+            object.__setattr__(model, "_steppers", reg)
+        reg.add(self)
         # the update's four launches issued directly instead of as graphs (A/B: a graph boundary costs ~15-20 us of idle stream)
         self.eager_update = bool(model_config.get("eager_update", os.environ.get("SPADOT_EAGER_UPDATE", "0") == "1"))
 
@@ -538,6 +551,15 @@ class GraphedStepper:
             yield self
         finally:
             self._chain, self._head_ready = prev, False
+
+    def barrier(self):
+        """Call after enqueuing ANYTHING between two steps of a chain that reads or writes the SVGP encoder (parameters,
+        BatchNorm statistics) or side-stream tensors on the main stream -- an EMA or logging read of the weights, an eval
+        forward, average_buffers: the next step's SVGP branch then waits for the whole main stream again instead of only
+        for the previous update's first graph.  model.eval() / model.train(), all_latent_samples and
+        parallel.average_buffers call it themselves (SpaDOT._steppers); user hooks belong outside `with chained()` or
+        must call this."""
+        self._head_ready = False
 
     def _run(self, tp_i, tp, bi, epoch, beta1, with_update):
         if getattr(self.model, "_state_version", 0) != self.version:      # a state tensor was re-allocated
@@ -754,6 +776,10 @@ class GraphedStepper:
         return self._run(tp_i, tp, bi, epoch, beta1, False)
 
     def step(self, tp_i, tp, bi, epoch, beta1):
+        # (a replayed graph holds no weight-cast launch: anything torch saw writing the GAT weights since their bf16 images
+        # were cast -- load_state_dict, a broadcast, flat_param.copy_ -- is caught here; three integer compares otherwise)
+        if getattr(self.model.GATEncoder, "_image_optimizer", None) is self.opt:
+            self.opt.sync_images()
         if self.grad_sync is None:                  # single replica: the optimizer step is part of the step graph
             return self._run(tp_i, tp, bi, epoch, beta1, True)
         res = self.fb(tp_i, tp, bi, epoch, beta1)
@@ -776,7 +802,9 @@ def training_step(model, optimizer, model_config, dataloader_dict, tp_i, tp, bi,
 
 def train_SpaDOT(dataloader_dict, model_config, verbose=True):
     """_train_utils.py:155-236.  Returns (model, loss_df) with loss_df indexed like the reference's
-    (columns = epochs, rows = loss names; train.py:38 writes its transpose)."""
+    (columns = epochs, rows = loss names; train.py:38 writes its transpose).
+    The steps of an epoch run inside GraphedStepper.chained(): anything a caller adds BETWEEN two steps that touches the
+    SVGP encoder (weights, BatchNorm statistics) belongs outside the chain or must call stepper.barrier()."""
     import pandas as pd
     device = torch.device(model_config["device"])
     model = SpaDOT.SpaDOT(model_config, dataloader_dict).to(device)

@@ -611,3 +611,81 @@ def test_cfg4_shape_eight_ragged_timepoints_train_end_to_end(tmp_path, capsys):
     assert z["X"].shape == (sum(counts), 20) and np.isfinite(z["X"]).all()
     steps = sum(-(-c // 256) for c in counts)
     assert steps == 25
+
+
+def test_weight_images_follow_every_writer_of_the_weights():
+    """the GAT encoder skips its per-step bf16 weight cast while an optimizer keeps the images current.
+    The fast path must validate itself: (1) a SECOND FlatAdamW over the same model (the eager path after a stepper) re-points
+    the parameters -- the first optimizer no longer owns them, the pin is dropped and the forward casts again; (2) a write
+    the optimizer did not make (load_state_dict, p.copy_, flat_param.copy_) is caught in front of the next replayed step.
+    Checked on the images themselves: after each event + one forward/step the images equal bf16(weights)."""
+    from spadot_amd.model import SpaDOT
+    from spadot_amd.ops import FlatAdamW
+    from spadot_amd.synthetic import make_dataset
+    from spadot_amd.utils import _train_utils as tu, _utils
+    data = make_dataset(2, 1500, 256, seed=11)
+    cfg = _utils.load_model_config(types.SimpleNamespace(config=None))
+    cfg.update(input_dim=256, timepoints=[0, 1], device=torch.device(DEV), compute_dtype=torch.bfloat16,
+               inducing_point_nums=120, n_clusters=4, kmeans_backend="sklearn")
+    _utils.set_seed(5)
+    dd = tu.prepare_dataloader(data, cfg)
+    model = SpaDOT.SpaDOT(cfg, dd).to(DEV)
+    opt = FlatAdamW(model.parameters(), lr=cfg["lr"], first=model.SVGPEncoder.parameters())
+    tu._update_Kmeans(model, cfg, dd)
+    tu._update_OT_matrix(model, cfg)
+    model.train()
+    enc = model.GATEncoder
+    st = tu.GraphedStepper(model, opt, cfg, dd)
+    ep = cfg["ot_epoch"]
+
+    def images_current(after_update=True):
+        """max |image - bf16(weight)| over the three layers (the images the NEXT forward would read)."""
+        from spadot_amd.ops import weight_image
+        torch.cuda.synchronize()
+        worst = 0.0
+        for layer, K in ((enc.gat1, 256), (enc.gat2, enc.gat2.in_channels), (enc.gat3, enc.gat2.in_channels)):
+            W = layer.lin.weight.detach()
+            im = weight_image(layer.lin.weight, K, torch.bfloat16, layer)
+            worst = max(worst, float((im[:, :W.shape[1]].float() - W.to(torch.bfloat16).float()).abs().max()))
+        return worst
+
+    for _ in range(3):                                    # eager, capture, replay: the optimizer now maintains the images
+        for bi in range(2):
+            st.step(1, 1, bi, ep, 0.5)
+    assert enc._image_optimizer is opt and len(opt._images) == 3
+    assert images_current() == 0.0
+
+    # (2a) load_state_dict between two replayed steps
+    sd = {k: (v.clone() + 0.01 if k.endswith("lin.weight") else v.clone()) for k, v in model.state_dict().items()}
+    model.load_state_dict(sd)
+    assert images_current() == 0.0                         # the post hook of whichever optimizer is pinned
+    # (2b) a write through the parameter and one through the flat buffer: caught by step()'s sync
+    with torch.no_grad():
+        enc.gat2.lin.weight.mul_(1.25)
+    assert images_current() > 0.0
+    st.step(1, 1, 0, ep, 0.5)
+    assert images_current() == 0.0
+    opt.flat_param.mul_(0.9)
+    assert images_current() > 0.0
+    st.step(1, 1, 1, ep, 0.5)
+    assert images_current() == 0.0
+
+    # (1) a second optimizer + the eager step on the same model
+    opt2 = FlatAdamW(model.parameters(), lr=cfg["lr"])
+    assert not opt.owns(enc.gat1.lin.weight) and opt2.owns(enc.gat1.lin.weight)
+    before = enc.gat1.lin.weight.detach().clone()
+    for bi in range(2):
+        tu.training_step(model, opt2, cfg, dd, 1, 1, bi, ep, 0.5)
+    torch.cuda.synchronize()
+    assert enc._image_optimizer is None                    # the stale pin is gone
+    assert float((enc.gat1.lin.weight.detach() - before).abs().max()) > 0.0
+    # the eager path casts the images at the head of every forward (nobody maintains them now): behind the last update
+    # they lag, the next forward brings them up to date
+    batch = dd["dataloaders"][1][0]
+    assert batch.y is not None and images_current() > 0.0
+    with torch.no_grad():
+        enc.pre_head(batch.y, batch.graph, rows=batch.batch_size)
+    assert images_current() == 0.0
+    # a maintain_image() on the optimizer that lost the parameters is refused
+    from spadot_amd.ops import weight_image
+    assert not opt.maintain_image(enc.gat1.lin.weight, weight_image(enc.gat1.lin.weight, 256, torch.bfloat16, enc.gat1))
