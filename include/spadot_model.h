@@ -296,6 +296,45 @@ int spadot_knn(const double *x, int n, int d, int kk, int *out, void *stream);
  *   spadot_gat_ds_src            ds_src[j] = sum of dz over the outgoing edges of j (transposed CSR)
  * spadot_gat_mfma_supported(dtype, H, C, max_cols) tells whether a plan whose longest column list is max_cols can run. */
 int spadot_gat_mfma_supported(int dtype, int H, int C, int max_cols);
+
+/* ---- The last GAT layer for the seeds only, aggregate-first (csrc/gat_tail.hip, round 4) -----------------------------
+ * Replaces, for gat3 = GATConv(H*C -> C, heads = H, concat = False) (encoder.py:45,58; PyG GATConv semantics)
+ * whose targets are the first n_tgt << n nodes (only the seeds' rows reach the loss, SpaDOT.py:82), the dense map over
+ * ALL n source rows by dense maps over the n_tgt aggregated rows:
+ *     out_i = 1/H sum_h ( sum_j alpha_ij^h x_j ) W_h^T + bias,   e_ij^h = leaky_relu_0.2( x_j . w_src^h + x_i . w_dst^h ),
+ *     w_src^h = W_h^T att_src^h, w_dst^h = W_h^T att_dst^h          (W_h = rows h C .. h C + C - 1 of lin.weight [H C, K]).
+ * dtype: 0 = fp32, 1 = bf16 rows (x, A, dA, dx, O); K <= 2048, K % 8 == 0, H in {1, 2, 4, 8}; everything else fp32.
+ * s [n][2 H]: s[j][2 h] = x_j . w_src^h, s[j][2 h + 1] = x_j . w_dst^h.  CSR by target (rowptr [n_tgt + 1], col) and by
+ * source (rowptr_t [n + 1], col_t = target, eid_t = position of the edge in the by-target order), self loops included.
+ *   spadot_gat_tail_wvec             wv [2 H][K] from W, att (part: workspace of slices * 2 H * K floats)
+ *   spadot_gat_tail_logits           s = x wv^T for all n rows
+ *   spadot_gat_tail_aggregate        alpha [E][H] (softmax over the incoming edges of each target: exp(e - max) / (sum + 1e-16))
+ *                                    and A [H][n_tgt][K] = sum_j alpha x_j
+ *   spadot_gat_tail_headmean         out [n_tgt][C] = 1/H sum_h O[h] + bias            (O [H][n_tgt][C] = A_h W_h^T, a library GEMM)
+ *   spadot_gat_tail_colsum_rows      column sums of g [rows][C] in fp32 (the bias gradient)
+ *   spadot_gat_tail_edge_backward    dz [E][H] = d logit per edge (through aggregation, softmax and leaky_relu), ds_dst [n_tgt][H]
+ *   spadot_gat_tail_source_backward  dx [rows_out][lddx] (rows n .. rows_out - 1 zero), ds_src [n][H]
+ *   spadot_gat_tail_dwvec            per-block partials [spadot_gat_tail_dwvec_rows(n)][2 H][K] of d wv (spadot_colsum adds them)
+ *   spadot_gat_tail_wvec_backward    dW (+)= att (x) d wv per row of W, datt = W d wv
+ * All sums in fixed orders, no atomics: repeated calls are bit-identical. */
+int spadot_gat_tail_supported(int dtype, int H, int K);
+int spadot_gat_tail_wvec(const float *W, int ldw, const float *att_src, const float *att_dst, int H, int C, int K, float *part,
+                         int slices, float *wv, void *stream);
+int spadot_gat_tail_logits(const void *x, int dtype, int ldx, const float *wv, int n, int H, int K, float *s, void *stream);
+int spadot_gat_tail_aggregate(const void *x, int dtype, int ldx, const float *s, const int *rowptr, const int *col, int n_tgt, int H,
+                              int K, void *A, float *alpha, void *stream);
+int spadot_gat_tail_headmean(const void *O, int dtype, const float *bias, int n_tgt, int H, int C, void *out, void *stream);
+int spadot_gat_tail_colsum_rows(const void *g, int dtype, int rows, int C, float *out, void *stream);
+int spadot_gat_tail_edge_backward(const void *x, int dtype, int ldx, const void *dA, const float *s, const float *alpha, const int *rowptr,
+                                  const int *col, int n_tgt, int H, int K, float *dz, float *ds_dst, void *stream);
+int spadot_gat_tail_source_backward(const void *dA, int dtype, const float *alpha, const float *dz, const float *ds_dst, const float *wv,
+                                    const int *rowptr_t, const int *col_t, const int *eid_t, int n, int n_tgt, int rows_out, int H, int K,
+                                    void *dx, int lddx, float *ds_src, void *stream);
+int spadot_gat_tail_dwvec_rows(int n);
+int spadot_gat_tail_dwvec(const void *x, int dtype, int ldx, const float *ds_src, const float *ds_dst, int n, int n_tgt, int H, int K,
+                          float *part, void *stream);
+int spadot_gat_tail_wvec_backward(const float *W, int ldw, const float *att_src, const float *att_dst, const float *dwv, int H, int C, int K,
+                                  float *dW, int lddw, int accumulate, float *datt_src, float *datt_dst, void *stream);
 int spadot_gat_alpha(const float *s_src, const float *s_dst, const int *rowptr, const int *col, const int *cellq, int n_tgt,
                      int H, float *alpha, void *acell, void *stream);
 int spadot_gat_aggregate(const void *x, int dtype, const void *acell, const int *plan_rows, const int *plan_sptr,

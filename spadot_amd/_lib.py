@@ -175,6 +175,17 @@ def model_lib():
         "spadot_gat_softmax_backward": [vp, vp, vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp],
         "spadot_gat_ds_src": [vp, vp, vp, ci, ci, vp, vp],
         "spadot_gat_mfma_supported": [ci, ci, ci, ci],
+        "spadot_gat_tail_supported": [ci, ci, ci],
+        "spadot_gat_tail_wvec": [vp, ci, vp, vp, ci, ci, ci, vp, ci, vp, vp],
+        "spadot_gat_tail_logits": [vp, ci, ci, vp, ci, ci, ci, vp, vp],
+        "spadot_gat_tail_aggregate": [vp, ci, ci, vp, vp, vp, ci, ci, ci, vp, vp, vp],
+        "spadot_gat_tail_headmean": [vp, ci, vp, ci, ci, ci, vp, vp],
+        "spadot_gat_tail_colsum_rows": [vp, ci, ci, ci, vp, vp],
+        "spadot_gat_tail_edge_backward": [vp, ci, ci, vp, vp, vp, vp, vp, ci, ci, ci, vp, vp, vp],
+        "spadot_gat_tail_source_backward": [vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, ci, vp, vp],
+        "spadot_gat_tail_dwvec_rows": [ci],
+        "spadot_gat_tail_dwvec": [vp, ci, ci, vp, vp, ci, ci, ci, ci, vp, vp],
+        "spadot_gat_tail_wvec_backward": [vp, ci, vp, vp, vp, ci, ci, ci, vp, ci, ci, vp, vp, vp],
         "spadot_gat_aggregate": [vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, vp],
         "spadot_gat_edge_dot": [vp, vp, vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, ci, ci, vp],
         "spadot_gemm_tn_bf16": [vp, ci, vp, ci, vp, ci, ci, ci, ci, vp],

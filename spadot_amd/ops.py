@@ -272,6 +272,127 @@ def gat_edge(h, att_src, att_dst, bias, graph, heads, channels, concat=True, act
     return _GATEdge.apply(h, att_src, att_dst, bias, graph, heads, channels, concat, act)
 
 
+# ----------------------------------------------------------------------------- last GAT layer for the seeds, aggregate-first
+
+GAT_TAIL = [__import__("os").environ.get("SPADOT_GAT_TAIL", "1") == "1"]       # [False]: dense map over all source rows + gat_edge
+_BMM_OUT_DTYPE = [None]     # whether torch.bmm takes out_dtype= (probed on the first call)
+
+
+def _bmm_f32(a, b, out=None):
+    """fp32 [B, M, N] = a [B, M, K] . b [B, K, N] with fp32 accumulation AND fp32 result from bf16 operands (the weight
+    gradient goes straight into the optimizer's flat gradient buffer, no bf16 round trip)."""
+    if a.dtype == torch.float32:
+        return torch.bmm(a, b, out=out) if out is not None else torch.bmm(a, b)
+    if _BMM_OUT_DTYPE[0] is None:
+        try:
+            torch.bmm(a[:1, :1], b[:1, :, :1], out_dtype=torch.float32)
+            _BMM_OUT_DTYPE[0] = True
+        except (TypeError, RuntimeError):
+            _BMM_OUT_DTYPE[0] = False
+    if _BMM_OUT_DTYPE[0]:
+        if out is not None:
+            return torch.bmm(a, b, out_dtype=torch.float32, out=out)
+        return torch.bmm(a, b, out_dtype=torch.float32)
+    r = torch.bmm(a.float(), b.float())
+    if out is not None:
+        out.copy_(r)
+        return out
+    return r
+
+
+def gat_tail_ok(x, W, graph, H, C, concat):
+    """Whether the aggregate-first form (csrc/gat_tail.hip) takes this layer: head mean, far fewer targets than source rows,
+    K = W.shape[1] <= 2048 input channels."""
+    if not (GAT_TAIL[0] and not concat and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and x.dim() == 2 and x.is_contiguous()):
+        return False
+    K = W.shape[1]
+    return bool(graph.n_tgt * 4 <= graph.n and x.shape[0] >= graph.n and x.shape[1] >= K and x.shape[1] % 8 == 0 and C % 8 == 0
+                and W.shape[0] == H * C and W.is_contiguous() and model_lib().spadot_gat_tail_supported(_DT[x.dtype], H, K))
+
+
+class _GATTail(torch.autograd.Function):
+    """GATConv(concat = False) for targets = the first n_tgt nodes, aggregate-first (include/spadot_model.h,
+    spadot_gat_tail_*): logits from w = W_h^T att (no dense map over the source rows), A_h = sum_j alpha x_j for the
+    targets, O_h = A_h W_h^T on n_tgt rows (one batched library GEMM), head mean + bias.  Backward: the mirror image --
+    dA_h = g / H W_h and dW_h = (g / H)^T A_h as batched GEMMs on n_tgt rows, per-edge d alpha = <dA, x_j>, softmax backward,
+    dx by the transposed CSR, d w = dS^T x as per-block partials + one fixed-order column sum, and the chain through
+    w = W_h^T att folded into dW (rank-2 update per head) and datt = W_h d w."""
+
+    @staticmethod
+    def forward(ctx, x, W, wimg, att_src, att_dst, bias, graph, H, C):
+        _need_cuda(x, W, att_src, att_dst, bias)
+        lib = model_lib()
+        dt = _DT[x.dtype]
+        n, nt, K, Kp = graph.n, graph.n_tgt, W.shape[1], x.shape[1]
+        dev = x.device
+        a_s = att_src.reshape(H * C).contiguous().float()
+        a_d = att_dst.reshape(H * C).contiguous().float()
+        Wd = W.detach()
+        S = 16
+        part = torch.empty(S * 2 * H * K, dtype=torch.float32, device=dev)
+        wv = torch.empty((2 * H, K), dtype=torch.float32, device=dev)
+        _check(lib.spadot_gat_tail_wvec(_p(Wd), K, _p(a_s), _p(a_d), H, C, K, _p(part), S, _p(wv), _stream()), "spadot_gat_tail_wvec")
+        s = torch.empty((n, 2 * H), dtype=torch.float32, device=dev)
+        _check(lib.spadot_gat_tail_logits(_p(x), dt, Kp, _p(wv), n, H, K, _p(s), _stream()), "spadot_gat_tail_logits")
+        A = torch.empty((H, nt, K), dtype=x.dtype, device=dev)
+        alpha = torch.empty((graph.E, H), dtype=torch.float32, device=dev)
+        _check(lib.spadot_gat_tail_aggregate(_p(x), dt, Kp, _p(s), _p(graph.rowptr), _p(graph.col), nt, H, K, _p(A), _p(alpha), _stream()),
+               "spadot_gat_tail_aggregate")
+        # O_h = A_h W_h^T on the n_tgt aggregated rows: [H, nt, K] x [H, K, C]  (W_h = rows h C .. of the weight (image))
+        Wg = (wimg if x.dtype != torch.float32 else Wd).view(H, C, -1)[:, :, :K]
+        O = torch.bmm(A, Wg.transpose(1, 2))
+        out = torch.empty((nt, C), dtype=x.dtype, device=dev)
+        _check(lib.spadot_gat_tail_headmean(_p(O), dt, _p(bias.detach().contiguous().float()), nt, H, C, _p(out), _stream()),
+               "spadot_gat_tail_headmean")
+        ctx.save_for_backward(x, Wd, Wg, a_s, a_d, wv, s, A, alpha)
+        ctx.graph, ctx.H, ctx.C = graph, H, C
+        ctx.bias_dtype, ctx.att_shape, ctx.att_dtype = bias.dtype, att_src.shape, att_src.dtype
+        g = W.grad
+        ctx.wgrad = g if (g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.shape == W.shape) else None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = model_lib()
+        x, Wd, Wg, a_s, a_d, wv, s, A, alpha = ctx.saved_tensors
+        graph, H, C = ctx.graph, ctx.H, ctx.C
+        dt = _DT[x.dtype]
+        n, nt, K, Kp = graph.n, graph.n_tgt, Wd.shape[1], x.shape[1]
+        dev = x.device
+        g = g.contiguous()
+        dbias = torch.empty(C, dtype=torch.float32, device=dev)
+        _check(lib.spadot_gat_tail_colsum_rows(_p(g), _DT[g.dtype], nt, C, _p(dbias), _stream()), "spadot_gat_tail_colsum_rows")
+        gs = (g * (1.0 / H)).to(x.dtype)                                   # d O_h = g / H for every head
+        dA = torch.bmm(gs.unsqueeze(0).expand(H, nt, C), Wg)              # [H, nt, K]
+        direct = ctx.wgrad is not None and _DIRECT_GRAD[0]
+        dW = ctx.wgrad if direct else torch.empty((H * C, K), dtype=torch.float32, device=dev)
+        _bmm_f32(gs.t().unsqueeze(0).expand(H, C, nt), A, out=dW.view(H, C, K))
+        dz = torch.empty((graph.E, H), dtype=torch.float32, device=dev)
+        ds_dst = torch.empty((nt, H), dtype=torch.float32, device=dev)
+        _check(lib.spadot_gat_tail_edge_backward(_p(x), dt, Kp, _p(dA), _p(s), _p(alpha), _p(graph.rowptr), _p(graph.col), nt, H, K,
+                                                 _p(dz), _p(ds_dst), _stream()), "spadot_gat_tail_edge_backward")
+        dx = torch.empty_like(x) if Kp == K else torch.zeros_like(x)      # (pad columns of the input: zero gradient)
+        ds_src = torch.empty((n, H), dtype=torch.float32, device=dev)
+        _check(lib.spadot_gat_tail_source_backward(_p(dA), dt, _p(alpha), _p(dz), _p(ds_dst), _p(wv), _p(graph.rowptr_t), _p(graph.col_t),
+                                                   _p(graph.eid_t), n, nt, x.shape[0], H, K, _p(dx), Kp, _p(ds_src), _stream()),
+               "spadot_gat_tail_source_backward")
+        R = int(lib.spadot_gat_tail_dwvec_rows(n))
+        part = torch.empty((R, 2 * H * K), dtype=torch.float32, device=dev)
+        _check(lib.spadot_gat_tail_dwvec(_p(x), dt, Kp, _p(ds_src), _p(ds_dst), n, nt, H, K, _p(part), _stream()), "spadot_gat_tail_dwvec")
+        dwv = torch.empty(2 * H * K, dtype=torch.float32, device=dev)
+        _check(lib.spadot_colsum(_p(part), R, 2 * H * K, _p(dwv), _stream()), "spadot_colsum")
+        datt = torch.empty((2, H * C), dtype=torch.float32, device=dev)
+        _check(lib.spadot_gat_tail_wvec_backward(_p(Wd), K, _p(a_s), _p(a_d), _p(dwv), H, C, K, _p(dW), K, 1, _p(datt),
+                                                 ctypes.c_void_p(datt.data_ptr() + 4 * H * C), _stream()), "spadot_gat_tail_wvec_backward")
+        return (dx, dW, None, datt[0].view(ctx.att_shape).to(ctx.att_dtype), datt[1].view(ctx.att_shape).to(ctx.att_dtype),
+                dbias.to(ctx.bias_dtype), None, None, None)
+
+
+def gat_tail(x, W, wimg, att_src, att_dst, bias, graph, heads, channels):
+    """The whole GATConv(concat = False) layer -- dense map included -- for the first graph.n_tgt nodes as targets."""
+    return _GATTail.apply(x, W, wimg, att_src, att_dst, bias, graph, heads, channels)
+
+
 # ----------------------------------------------------------------------------- dense maps in the compute dtype
 
 _DIRECT_GRAD = [False]     # True only inside FlatAdamW.backward (a plain .backward() would ADD the returned view to itself)

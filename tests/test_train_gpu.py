@@ -646,6 +646,7 @@ def test_weight_images_follow_every_writer_of_the_weights():
         for layer, K in ((enc.gat1, 256), (enc.gat2, enc.gat2.in_channels), (enc.gat3, enc.gat2.in_channels)):
             W = layer.lin.weight.detach()
             im = weight_image(layer.lin.weight, K, torch.bfloat16, layer)
+            assert bool(torch.isfinite(W).all()), "weights went non-finite: the test's perturbations are too large"
             worst = max(worst, float((im[:, :W.shape[1]].float() - W.to(torch.bfloat16).float()).abs().max()))
         return worst
 
@@ -656,16 +657,16 @@ def test_weight_images_follow_every_writer_of_the_weights():
     assert images_current() == 0.0
 
     # (2a) load_state_dict between two replayed steps
-    sd = {k: (v.clone() + 0.01 if k.endswith("lin.weight") else v.clone()) for k, v in model.state_dict().items()}
+    sd = {k: (v.clone() * 1.03 if k.endswith("lin.weight") else v.clone()) for k, v in model.state_dict().items()}
     model.load_state_dict(sd)
     assert images_current() == 0.0                         # the post hook of whichever optimizer is pinned
     # (2b) a write through the parameter and one through the flat buffer: caught by step()'s sync
     with torch.no_grad():
-        enc.gat2.lin.weight.mul_(1.25)
+        enc.gat2.lin.weight.mul_(1.05)
     assert images_current() > 0.0
     st.step(1, 1, 0, ep, 0.5)
     assert images_current() == 0.0
-    opt.flat_param.mul_(0.9)
+    opt.flat_param.mul_(0.97)
     assert images_current() > 0.0
     st.step(1, 1, 1, ep, 0.5)
     assert images_current() == 0.0
