@@ -242,6 +242,10 @@ int spadot_kmeans_assign(const void *x, const void *centers, int n, int k, int d
 int spadot_sgemm_small(int mode, const float *A, int lda, const float *B, int ldb, float *C, int ldc, int M, int N, int K,
                        const float *bias, int batch, long long strideA, long long strideB, long long strideC, void *stream);
 
+/* Measurement aid: buf[slot] = the device's constant-rate timestamp counter (100 MHz: 10 ns units) when the launch runs.
+ * Launched at the head and the end of a captured stage it dates the stage on the GPU with no profiler attached. */
+int spadot_stamp(unsigned long long *buf, int slot, void *stream);
+
 /* One Lloyd iteration of K-means for R restarts at once (fp64, no atomics: two fits of the same data are bitwise
  * identical).  X [n, D] (centred data), C [R, K, D] centres (updated in place unless done[r]), part: work space of
  * R * ceil(n/256) * (K*(D+1) + 1) doubles, done [R] int flags (set when the squared centre shift <= tol), inertia [R]

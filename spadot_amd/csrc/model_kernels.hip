@@ -1103,6 +1103,13 @@ __global__ __launch_bounds__(256) void k_sgemm_small(const float *__restrict__ A
         }
 }
 
+
+// One device timestamp (constant-rate 100 MHz counter) into buf[slot]: a one-thread launch placed at the head and the end
+// of a captured stage gives the stage's start / end on the GPU without a profiler attached (tools/stage_stamps.py).
+__global__ void k_stamp(unsigned long long *buf, int slot) {
+    if (threadIdx.x == 0) buf[slot] = wall_clock64();
+}
+
 // ------------------------------------------------------------------------------------------
 // Lloyd iterations of K-means for R restarts at once (fp64, deterministic: no atomics).
 //   k_lloyd_assign: block = (restart r, chunk of 256 points): nearest centre per point (first minimum wins),
@@ -2362,6 +2369,12 @@ int spadot_sgemm_small(int mode, const float *A, int lda, const float *B, int ld
     if (mode == 0) hipLaunchKernelGGL(k_sgemm_small<0>, grid, dim3(256), 0, st_, A, lda, B, ldb, C, ldc, M, N, K, bias, strideA, strideB, strideC);
     else if (mode == 1) hipLaunchKernelGGL(k_sgemm_small<1>, grid, dim3(256), 0, st_, A, lda, B, ldb, C, ldc, M, N, K, bias, strideA, strideB, strideC);
     else hipLaunchKernelGGL(k_sgemm_small<2>, grid, dim3(256), 0, st_, A, lda, B, ldb, C, ldc, M, N, K, bias, strideA, strideB, strideC);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+int spadot_stamp(unsigned long long *buf, int slot, void *stream) {
+    if (!buf || slot < 0) return -22;
+    hipLaunchKernelGGL(k_stamp, dim3(1), dim3(64), 0, (hipStream_t)stream, buf, slot);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 

@@ -1474,6 +1474,12 @@ def knn(coords, kk):
     return out
 
 
+def stamp(buf, slot):
+    """buf[slot] (int64 device tensor) = the device timestamp counter (10 ns units) at this point of the current stream
+    (include/spadot_model.h: spadot_stamp); capturable."""
+    _check(model_lib().spadot_stamp(_p(buf), int(slot), _stream()), "spadot_stamp")
+
+
 class FlatAdamW:
     """clip_grad_norm_(max_norm) + AdamW.step (_train_utils.py:214-217) as two HIP kernels over ONE
     flat fp32 parameter buffer.  Parameters of `module` are re-pointed into the flat buffer (so the

@@ -470,6 +470,8 @@ class GraphedStepper:
         # update in two graphs around an event (see update(), chained()); needs FlatAdamW(first=...)
         self.split_update = bool(model_config.get("split_update", os.environ.get("SPADOT_SPLIT_UPDATE", "1") == "1"))
         self._head_event, self._head_ready, self._chain = None, False, False
+        self.stamps = (torch.zeros(32, dtype=torch.int64, device=next(model.parameters()).device)
+                       if os.environ.get("SPADOT_STAMPS") == "1" else None)
         # the model knows its steppers (weakly): its public entries that touch the encoder between steps break the chain
         import weakref
         reg = getattr(model, "_steppers", None)
@@ -529,8 +531,21 @@ class GraphedStepper:
                 self.opt_graph = False
         else:
             if self.opt_graph is False:
-                ga, _ = self._capture(self.opt.step_head)
-                gb, _ = self._capture(self.opt.step_rest)
+                head, rest = self.opt.step_head, self.opt.step_rest
+                if self.stamps is not None:
+                    from ..ops import stamp
+
+                    def head():
+                        stamp(self.stamps, 12)
+                        self.opt.step_head()
+                        stamp(self.stamps, 13)
+
+                    def rest():
+                        stamp(self.stamps, 14)
+                        self.opt.step_rest()
+                        stamp(self.stamps, 15)
+                ga, _ = self._capture(head)
+                gb, _ = self._capture(rest)
                 self.opt_graph = (ga, gb)
             self.opt_graph[0].replay()
             self._head_event.record(main)
@@ -646,10 +661,25 @@ class GraphedStepper:
             opt.backward_partial([st["h2"]], [st["gh2"]], P["gat_rest"])
 
         if self.overlap:
-            return gat_fwd, svgp_fwd, tail, svgp_bwd, gat_bwd_hi, gat_bwd_lo
-        if self.split_bwd:
-            return gat_fwd, svgp_fwd, tail, svgp_bwd, gat_bwd_top, gat_bwd_rest
-        return gat_fwd, svgp_fwd, tail, svgp_bwd, gat_bwd
+            fns = (gat_fwd, svgp_fwd, tail, svgp_bwd, gat_bwd_hi, gat_bwd_lo)
+        elif self.split_bwd:
+            fns = (gat_fwd, svgp_fwd, tail, svgp_bwd, gat_bwd_top, gat_bwd_rest)
+        else:
+            fns = (gat_fwd, svgp_fwd, tail, svgp_bwd, gat_bwd)
+        if self.stamps is not None:
+            # measurement aid (SPADOT_STAMPS=1): a device timestamp at the head and the end of every stage graph
+            # (slots 2 k, 2 k + 1), read back by tools/stage_stamps.py -- when each stage really starts with no profiler attached
+            from ..ops import stamp
+
+            def stamped(k, fn):
+                def run():
+                    stamp(self.stamps, 2 * k)
+                    r = fn()
+                    stamp(self.stamps, 2 * k + 1)
+                    return r
+                return run
+            fns = tuple(stamped(k, fn) for k, fn in enumerate(fns))
+        return fns
 
     def _param_groups(self):
         if self._groups is None:
