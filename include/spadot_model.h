@@ -242,6 +242,17 @@ int spadot_kmeans_assign(const void *x, const void *centers, int n, int k, int d
 int spadot_sgemm_small(int mode, const float *A, int lda, const float *B, int ldb, float *C, int ldc, int M, int N, int K,
                        const float *bias, int batch, long long strideA, long long strideB, long long strideC, void *stream);
 
+/* Small batched fp64 products on the fp64 matrix cores (csrc/gemm_f64.hip; the m x m / b x m algebra of svgp.py:62-104):
+ *   C[z] = alpha op(A[z]) op(B[z]) + beta C0[z]          z < batch, operands advance by their batch strides (elements; 0 = shared)
+ *   mode 0: a(i, k) = A[i lda + k], b(k, j) = B[k ldb + j];  mode 1: b(k, j) = B[j ldb + k];  mode 2: a(i, k) = A[k lda + i], b as mode 0
+ * C0 may be NULL (no addend) and may alias nothing that is written; rowscale (mode 2 only, may be NULL): the rows of A are
+ * scaled along the contraction, a(i, k) = A[k lda + i] rowscale[z stride_rs + k ldrs]  (K_mn diag(w_l) K_nm without the
+ * scaled copy).  64 x 64 tiles, 256 threads, 35 KB of LDS; sums in ascending k: repeated calls are bit-identical. */
+int spadot_dgemm_small(int mode, const double *A, int lda, long long strideA, const double *B, int ldb, long long strideB,
+                       double *C, int ldc, long long strideC, const double *C0, int ldc0, long long strideC0,
+                       const double *rowscale, int ldrs, long long stride_rs, double alpha, double beta, int M, int N, int K,
+                       int batch, void *stream);
+
 /* Measurement aid: buf[slot] = the device's constant-rate timestamp counter (100 MHz: 10 ns units) when the launch runs.
  * Launched at the head and the end of a captured stage it dates the stage on the GPU with no profiler attached. */
 int spadot_stamp(unsigned long long *buf, int slot, void *stream);

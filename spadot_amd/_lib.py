@@ -234,6 +234,7 @@ def model_lib():
         "spadot_cast_rows_multi": [vp, vp, vp, vp, vp, ci, vp],
         "spadot_knn": [vp, ci, ci, ci, vp, vp],
         "spadot_stamp": [vp, ci, vp],
+        "spadot_dgemm_small": [ci, vp, ci, ll, vp, ci, ll, vp, ci, ll, vp, ci, ll, vp, ci, ll, cd, cd, ci, ci, ci, ci, vp],
         "spadot_grad_sumsq": [vp, ll, vp, vp, vp],
         "spadot_clip_adamw_dev": [vp, vp, vp, vp, ll, cd, cd, cd, cd, cd, cd, vp, vp, vp, vp, vp, vp],
         "spadot_clip_adamw_images_dev": [vp, vp, vp, vp, ll, cd, cd, cd, cd, cd, cd, vp, vp, vp, vp, ctypes.POINTER(WeightImages), vp],

@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from .._lib import model_lib
-from ..ops import _SPLIT, _check, _p, _stream, elbo_reduce, kernel_matrix, rowdot, spd_inverse_logdet
+from ..ops import DGEMM_SMALL, _SPLIT, _check, _p, _stream, dgemm_small, elbo_reduce, kernel_matrix, rowdot, spd_inverse_logdet
 
 SWEEP_DIRECT_M = _SPLIT[0]      # up to here one sweep launch takes the matrices as they are (ops._spd_inverse_logdet_nograd)
 
@@ -103,8 +103,14 @@ class _SVGPCore(torch.autograd.Function):
                 _check(lib.spadot_svgp_pre2(_p(z), _p(Kn), b, L, m, _p(mu), _p(var), _p(w), _p(muw), _p(A), _stream()),
                        "spadot_svgp_pre2")
                 G = torch.empty((L, m, m), dtype=F64, device=z.device)
-                torch.baddbmm(G, A.transpose(1, 2), Kn.unsqueeze(0).expand(L, b, m), beta=0.0, alpha=c, out=G)
-                t = muw.T @ Kn                                               # [L, m]
+                if DGEMM_SMALL[0]:
+                    # G_l = c K_mn diag(w_l) K_nm and t = (mu w)^T K_nm on the fp64 matrix cores (csrc/gemm_f64.hip: 64 x 64 tiles
+                    # with a small footprint; the library's 64 x 32 / 16 x 16 tiles took 35 + 32 us in front of the inverse)
+                    dgemm_small(2, A, Kn, out=G, alpha=c)
+                    t = dgemm_small(2, muw, Kn)                              # [L, m]
+                else:
+                    torch.baddbmm(G, A.transpose(1, 2), Kn.unsqueeze(0).expand(L, b, m), beta=0.0, alpha=c, out=G)
+                    t = muw.T @ Kn                                           # [L, m]
                 X = torch.empty((2 * L, m, m), dtype=F64, device=z.device)
                 ld = torch.empty(2 * L, dtype=F64, device=z.device)
                 _check(lib.spadot_spd_inverse_logdet2(_p(G), L, 2 * L, m, _p(rc.KjI), _p(rc.K2j), _p(X), _p(ld), _stream()),
@@ -137,7 +143,7 @@ class _SVGPCore(torch.autograd.Function):
         smpart = torch.empty(L * nparts, dtype=F64, device=dev)
         _check(lib.spadot_svgp_mid(_p(S), _p(t.contiguous()), _p(rc.M), _p(X2), L, m, 2 * b, _p(r), _p(Mr), _p(raw), _p(sm),
                                    _p(smpart), L * nparts, _stream()), "spadot_svgp_mid")
-        X2S = torch.matmul(X2, S)                                            # [L, 2b, m]
+        X2S = dgemm_small(0, X2, S) if DGEMM_SMALL[0] else torch.matmul(X2, S)     # [L, 2b, m]
         rd = rowdot(X2S, X2)                                                 # [L, 2b]
         p_m, mv, p_v, tr = (torch.empty((b, L), dtype=F64, device=dev) for _ in range(4))
         out4 = torch.empty(4, dtype=F64, device=dev)
@@ -175,14 +181,26 @@ class _SVGPCore(torch.autograd.Function):
                                              _p(p_m), _p(p_v), _p(bc.ktilde), _p(Mr), _p(rc.M), b, L, m, c, ctx.bN, _p(g_mu),
                                              _p(g_var), _p(G1), _p(G2T), _p(g_kl), _p(gMr), _p(gM), _stream()),
                "spadot_svgp_post_backward")
-        dr = gMr.addmm_(G1.T, X2, alpha=c)                                   # [L, m] (in place: no copy of gMr in front of the GEMM)
-        dt = torch.bmm(S, dr.unsqueeze(2)).squeeze(2)                        # [L, m]
-        A2 = X2.unsqueeze(0) * G2T.unsqueeze(2)                              # [L, 2b, m]
-        D = torch.baddbmm(gM.expand(L, m, m), A2.transpose(1, 2), X2.unsqueeze(0).expand(L, 2 * b, m))
-        KS = X2S[:, :b].contiguous()                                         # [L, b, m] = K_nm S_l
-        q1 = rowdot(torch.bmm(KS, D).reshape(1, L * b, m), KS.reshape(L * b, m)).reshape(L, b)
-        q2 = rowdot(torch.matmul(Kn, S2), Kn)                                # diag(K_nm S2 K_mn)  [L, b]
-        Kdt = Kn @ dt.T                                                      # [b, L]
+        if DGEMM_SMALL[0]:
+            # the same six products on csrc/gemm_f64.hip: the addends (gMr, gM) enter as C0, the diagonal scaling of
+            # D_l = X2^T diag(G2_l) X2 + gM rides on the operand load (no scaled copy of X2 per latent dimension)
+            dr = dgemm_small(2, G1, X2, C0=gMr, alpha=c, beta=1.0)                               # [L, m]
+            dt = dgemm_small(0, S, dr.unsqueeze(2)).squeeze(2)                                   # [L, m]
+            D = dgemm_small(2, X2, X2, C0=gM, rowscale=G2T, out=torch.empty((L, m, m), dtype=F64, device=dev))
+            KS = X2S[:, :b]                                                                      # [L, b, m] = K_nm S_l (a view)
+            KSD = dgemm_small(0, KS, D)
+            q1 = rowdot(KSD.reshape(1, L * b, m), KS.contiguous().reshape(L * b, m)).reshape(L, b)
+            q2 = rowdot(dgemm_small(0, Kn, S2), Kn)                                              # diag(K_nm S2 K_mn)  [L, b]
+            Kdt = dgemm_small(1, Kn, dt)                                                         # [b, L]
+        else:
+            dr = gMr.addmm_(G1.T, X2, alpha=c)                               # [L, m] (in place: no copy of gMr in front of the GEMM)
+            dt = torch.bmm(S, dr.unsqueeze(2)).squeeze(2)                    # [L, m]
+            A2 = X2.unsqueeze(0) * G2T.unsqueeze(2)                          # [L, 2b, m]
+            D = torch.baddbmm(gM.expand(L, m, m), A2.transpose(1, 2), X2.unsqueeze(0).expand(L, 2 * b, m))
+            KS = X2S[:, :b].contiguous()                                     # [L, b, m] = K_nm S_l
+            q1 = rowdot(torch.bmm(KS, D).reshape(1, L * b, m), KS.reshape(L * b, m)).reshape(L, b)
+            q2 = rowdot(torch.matmul(Kn, S2), Kn)                            # diag(K_nm S2 K_mn)  [L, b]
+            Kdt = Kn @ dt.T                                                  # [b, L]
         _check(lib.spadot_svgp_grad_tail(_p(q1), _p(q2), _p(Kdt), _p(p_v), _p(bc.ktilde), _p(p_m), _p(mu), _p(w), _p(g_kl),
                                          _p(g_mu), _p(g_var), b, L, c, None, None, _p(dz), _stream()), "spadot_svgp_grad_tail")
         return dz, None, None, None, None

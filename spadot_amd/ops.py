@@ -673,6 +673,56 @@ def _small_weight_grad(g, x):
     return g.t() @ x
 
 
+DGEMM_SMALL = [__import__("os").environ.get("SPADOT_DGEMM_SMALL", "1") == "1"]     # [False]: the library for the SVGP branch's fp64 products
+
+
+def _mat3(t):
+    """(pointer tensor, ld, batch stride, batch, rows, cols) of a 2-D or 3-D fp64 tensor whose rows are contiguous."""
+    if t.dim() == 2:
+        assert t.stride(1) == 1 or t.shape[1] == 1
+        return t, t.stride(0), 0, 1, t.shape[0], t.shape[1]
+    assert t.dim() == 3 and (t.stride(2) == 1 or t.shape[2] == 1)
+    return t, t.stride(1), (t.stride(0) if t.shape[0] > 1 else 0), t.shape[0], t.shape[1], t.shape[2]
+
+
+def dgemm_small(mode, A, B, out=None, C0=None, alpha=1.0, beta=1.0, rowscale=None):
+    """fp64  C[z] = alpha op(A[z]) op(B[z]) + beta C0[z]  on the fp64 matrix cores (include/spadot_model.h: spadot_dgemm_small).
+    mode 0: A [.., M, K] B [.., K, N];  mode 1: A [.., M, K] B [.., N, K];  mode 2: A [.., K, M] B [.., K, N].  2-D operands are
+    shared by all batch entries; rowscale (mode 2): [K] or [batch, K]-like view (any strides) scaling A's rows."""
+    _need_cuda(A, B)
+    assert A.dtype == torch.float64 and B.dtype == torch.float64
+    A_, lda, sA, bA, rA, cA = _mat3(A)
+    B_, ldb, sB, bB, rB, cB = _mat3(B)
+    M, K = (cA, rA) if mode == 2 else (rA, cA)
+    N = rB if mode == 1 else cB
+    assert (cB if mode == 1 else rB) == K, (A.shape, B.shape, mode)
+    batch = max(bA, bB, out.shape[0] if (out is not None and out.dim() == 3) else 1,
+                rowscale.shape[0] if (rowscale is not None and rowscale.dim() == 2) else 1)
+    assert bA in (1, batch) and bB in (1, batch)
+    if out is None:
+        out = torch.empty((batch, M, N) if (batch > 1 or A.dim() == 3 or B.dim() == 3) else (M, N), dtype=torch.float64, device=A.device)
+    C_, ldc, sC, bC, rC, cC = _mat3(out)
+    assert (rC, cC) == (M, N) and bC == batch and out.dtype == torch.float64
+    c0p, ldc0, sC0 = None, 0, 0
+    if C0 is not None:
+        C0_, ldc0, sC0, b0, r0, c0c = _mat3(C0)
+        assert (r0, c0c) == (M, N) and b0 in (1, batch) and C0.dtype == torch.float64
+        c0p = _p(C0_)
+    rsp, ldrs, srs = None, 0, 0
+    if rowscale is not None:
+        assert mode == 2 and rowscale.dtype == torch.float64
+        if rowscale.dim() == 1:
+            assert rowscale.shape[0] == K
+            ldrs, srs = rowscale.stride(0), 0
+        else:
+            assert rowscale.shape == (batch, K)
+            ldrs, srs = rowscale.stride(1), rowscale.stride(0)
+        rsp = _p(rowscale)
+    _check(model_lib().spadot_dgemm_small(mode, _p(A_), lda, sA, _p(B_), ldb, sB, _p(C_), ldc, sC, c0p, ldc0, sC0, rsp, ldrs, srs,
+                                          float(alpha), float(beta), M, N, K, batch, _stream()), "spadot_dgemm_small")
+    return out
+
+
 SGEMM_SMALL = [__import__("os").environ.get("SPADOT_SGEMM_SMALL", "1") == "1"]     # [False]: the library for the small fp32 products
 
 
