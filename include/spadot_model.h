@@ -242,6 +242,14 @@ int spadot_kmeans_assign(const void *x, const void *centers, int n, int k, int d
 int spadot_sgemm_small(int mode, const float *A, int lda, const float *B, int ldb, float *C, int ldc, int M, int N, int K,
                        const float *bias, int batch, long long strideA, long long strideB, long long strideC, void *stream);
 
+/* out [M, N] = A [M, K] B [N, K]^T (+ bias[n]) in fp32 with the contraction cut into `slices` slices (csrc/gemm_f32.hip: the
+ * forward maps of the small MLP stages, y = x W^T, encoder.py:7-34 -- a short output over a long contraction: 512 x 256 from
+ * K = 3000): one launch computes the slices' partial products (workspace: spadot_sgemm_nt_slices_workspace(M, N, slices)
+ * floats), a second adds them in slice order.  Bit-repeatable. */
+long long spadot_sgemm_nt_slices_workspace(int M, int N, int slices);
+int spadot_sgemm_nt_slices(const float *A, int lda, const float *B, int ldb, float *out, int ldo, const float *bias, int M, int N,
+                           int K, int slices, float *workspace, void *stream);
+
 /* Small batched fp64 products on the fp64 matrix cores (csrc/gemm_f64.hip; the m x m / b x m algebra of svgp.py:62-104):
  *   C[z] = alpha op(A[z]) op(B[z]) + beta C0[z]          z < batch, operands advance by their batch strides (elements; 0 = shared)
  *   mode 0: a(i, k) = A[i lda + k], b(k, j) = B[k ldb + j];  mode 1: b(k, j) = B[j ldb + k];  mode 2: a(i, k) = A[k lda + i], b as mode 0

@@ -234,6 +234,7 @@ def model_lib():
         "spadot_cast_rows_multi": [vp, vp, vp, vp, vp, ci, vp],
         "spadot_knn": [vp, ci, ci, ci, vp, vp],
         "spadot_stamp": [vp, ci, vp],
+        "spadot_sgemm_nt_slices": [vp, ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, vp, vp],
         "spadot_dgemm_small": [ci, vp, ci, ll, vp, ci, ll, vp, ci, ll, vp, ci, ll, vp, ci, ll, cd, cd, ci, ci, ci, ci, vp],
         "spadot_grad_sumsq": [vp, ll, vp, vp, vp],
         "spadot_clip_adamw_dev": [vp, vp, vp, vp, ll, cd, cd, cd, cd, cd, cd, vp, vp, vp, vp, vp, vp],
@@ -253,6 +254,8 @@ def model_lib():
     lib.spadot_gemm_wgrad_bf16_workspace.restype = ll
     lib.spadot_gemm_wgrad_bf16_workspace_tiled.argtypes = [ci, ci, ci, ci, ci]
     lib.spadot_gemm_wgrad_bf16_workspace_tiled.restype = ll
+    lib.spadot_sgemm_nt_slices_workspace.argtypes = [ci, ci, ci]
+    lib.spadot_sgemm_nt_slices_workspace.restype = ll
     _seal(lib)
     lib._spadot_ready = True
     return lib

@@ -626,6 +626,8 @@ class _FirstMapSeeds(torch.autograd.Function):
         ctx.K = K
         g = W.grad
         ctx.wgrad = g if (g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.shape == W.shape) else None
+        if sgemm_nt_slices_ok(x32, W):          # 512 x 3000 -> 256: 384 small workgroups instead of 57-72 us of library tiles
+            return sgemm_nt_slices(x32, W.detach())
         return torch.nn.functional.linear(x32[:, :K], W)
 
     @staticmethod
@@ -671,6 +673,30 @@ def _small_weight_grad(g, x):
     if M >= 256 and M % 8 == 0 and min(N, K) >= 64 and N * K <= 65536:
         return torch.bmm(g.view(8, M // 8, N).transpose(1, 2), x.view(8, M // 8, K)).sum(0)
     return g.t() @ x
+
+
+SGEMM_SLICES = [__import__("os").environ.get("SPADOT_SGEMM_SLICES", "1") == "1"]    # [False]: the library for the MLP stages' forward maps
+
+
+def sgemm_nt_slices_ok(x, W):
+    return bool(SGEMM_SLICES[0] and x.is_cuda and x.dtype == torch.float32 and W.dtype == torch.float32 and x.dim() == 2 and W.dim() == 2
+                and x.stride(1) == 1 and W.is_contiguous() and x.shape[1] >= W.shape[1] and x.shape[0] * W.shape[0] <= (1 << 20))
+
+
+def sgemm_nt_slices(x, W, bias=None, slices=None):
+    """x[:, :K] W^T (+ bias) for x [M, >= K], W [N, K] in fp32 with the contraction cut into slices (include/spadot_model.h:
+    spadot_sgemm_nt_slices): a short output over a long contraction as many small workgroups instead of one round of
+    library tiles walking all of K."""
+    M, (N, K) = x.shape[0], W.shape
+    if slices is None:          # enough slices for ~1.5 rounds of the chip's 256 compute units, at least 128 columns each
+        tiles = ((M + 63) // 64) * ((N + 63) // 64)
+        slices = max(1, min(K // 128 if K >= 256 else 1, (384 + tiles - 1) // tiles, 64))
+    lib = model_lib()
+    ws = torch.empty(int(lib.spadot_sgemm_nt_slices_workspace(M, N, slices)), dtype=torch.float32, device=x.device)
+    out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    _check(lib.spadot_sgemm_nt_slices(_p(x), x.stride(0), _p(W), K, _p(out), N, _p(bias) if bias is not None else None, M, N, K, slices,
+                                      _p(ws), _stream()), "spadot_sgemm_nt_slices")
+    return out
 
 
 DGEMM_SMALL = [__import__("os").environ.get("SPADOT_DGEMM_SMALL", "1") == "1"]     # [False]: the library for the SVGP branch's fp64 products
@@ -765,6 +791,9 @@ def wgrad_small(g, x, slices=8):
 _SMALL_WORK = 1 << 27        # multiply-adds up to which a product counts as small (0.27 GFLOP)
 
 
+HIDDEN_SLICES = [__import__("os").environ.get("SPADOT_HIDDEN_SLICES", "0") == "1"]   # the hidden map's forward on the sliced kernel too (A/B)
+
+
 class _HiddenMap(torch.autograd.Function):
     """h W^T for a small hidden -> hidden map of the SVGP encoder (b x 256 -> 64 at the default sizes; fp32, no bias: the next
     BatchNorm kernel folds it in).  The forward is the library's product as before; BOTH gradients go through k_sgemm_small
@@ -777,6 +806,8 @@ class _HiddenMap(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, W):
         ctx.save_for_backward(x, W)
+        if HIDDEN_SLICES[0] and sgemm_nt_slices_ok(x, W):
+            return sgemm_nt_slices(x, W.detach())
         return torch.nn.functional.linear(x, W)
 
     @staticmethod

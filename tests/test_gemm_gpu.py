@@ -264,3 +264,23 @@ def test_dgemm_small_matches_torch_fp64(mode, batch, M, N, K, shareA, shareB):
         rs_t = rs.t().contiguous()                                                               # [K, nb]
         gotv = ops.dgemm_small(2, As, Bs, rowscale=rs_t.t(), C0=C0)
         assert torch.equal(gotv, gotr)
+
+
+@pytest.mark.parametrize("M,N,K,ldx,slices", [(512, 256, 3000, 3072, None), (512, 64, 256, 256, 4), (235, 33, 70, 70, 3), (1, 1, 1, 1, 1),
+                                              (64, 20, 64, 64, None), (300, 130, 1001, 1001, 7)])
+def test_sgemm_nt_slices_matches_fp64(M, N, K, ldx, slices):
+    """csrc k_sgemm_nt_slices + k_slices_sum (y = x W^T + b with the contraction in slices) against fp64: the SVGP encoder's
+    first map shape with its zero-padded rows, ragged sizes, unaligned leading dimensions; bit-repeatable."""
+    from spadot_amd import ops
+    rng = np.random.default_rng(M + N + K)
+    x = torch.zeros((M, ldx), dtype=torch.float32, device=DEV)
+    x[:, :K] = torch.as_tensor(rng.normal(size=(M, K)), dtype=torch.float32)
+    W = torch.as_tensor(rng.normal(size=(N, K)), dtype=torch.float32, device=DEV)
+    b = torch.as_tensor(rng.normal(size=N), dtype=torch.float32, device=DEV)
+    assert ops.sgemm_nt_slices_ok(x, W)
+    y = ops.sgemm_nt_slices(x, W, b, slices)
+    ref = x[:, :K].double() @ W.double().T + b.double()
+    np.testing.assert_allclose(y.cpu().numpy(), ref.cpu().numpy(), rtol=2e-5, atol=2e-5 * K ** 0.5)
+    assert torch.equal(y, ops.sgemm_nt_slices(x, W, b, slices))
+    y0 = ops.sgemm_nt_slices(x, W, None, slices)
+    np.testing.assert_allclose(y0.cpu().numpy(), (ref - b.double()).cpu().numpy(), rtol=2e-5, atol=2e-5 * K ** 0.5)
