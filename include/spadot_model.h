@@ -329,8 +329,9 @@ int spadot_gat_mfma_supported(int dtype, int H, int C, int max_cols);
  * dtype: 0 = fp32, 1 = bf16 rows (x, A, dA, dx, O); K <= 2048, K % 8 == 0, H in {1, 2, 4, 8}; everything else fp32.
  * s [n][2 H]: s[j][2 h] = x_j . w_src^h, s[j][2 h + 1] = x_j . w_dst^h.  CSR by target (rowptr [n_tgt + 1], col) and by
  * source (rowptr_t [n + 1], col_t = target, eid_t = position of the edge in the by-target order), self loops included.
- *   spadot_gat_tail_wvec             wv [2 H][K] from W, att (part: workspace of slices * 2 H * K floats)
- *   spadot_gat_tail_logits           s = x wv^T for all n rows
+ *   spadot_gat_tail_wvec             wv [2 H][K] from W, att (part: workspace of slices * 2 H * K floats); whi / wlo (both or neither
+ *                                    NULL): bf16 images [2 H][K] with wv = whi + wlo to 16 bits, for the matrix-core logits
+ *   spadot_gat_tail_logits           s = x wv^T for all n rows (bf16 rows with whi / wlo and K % 32 == 0: on the matrix cores)
  *   spadot_gat_tail_aggregate        alpha [E][H] (softmax over the incoming edges of each target: exp(e - max) / (sum + 1e-16))
  *                                    and A [H][n_tgt][K] = sum_j alpha x_j
  *   spadot_gat_tail_headmean         out [n_tgt][C] = 1/H sum_h O[h] + bias            (O [H][n_tgt][C] = A_h W_h^T, a library GEMM)
@@ -342,8 +343,9 @@ int spadot_gat_mfma_supported(int dtype, int H, int C, int max_cols);
  * All sums in fixed orders, no atomics: repeated calls are bit-identical. */
 int spadot_gat_tail_supported(int dtype, int H, int K);
 int spadot_gat_tail_wvec(const float *W, int ldw, const float *att_src, const float *att_dst, int H, int C, int K, float *part,
-                         int slices, float *wv, void *stream);
-int spadot_gat_tail_logits(const void *x, int dtype, int ldx, const float *wv, int n, int H, int K, float *s, void *stream);
+                         int slices, float *wv, void *whi, void *wlo, void *stream);
+int spadot_gat_tail_logits(const void *x, int dtype, int ldx, const float *wv, const void *whi, const void *wlo, int n, int H, int K,
+                           float *s, void *stream);
 int spadot_gat_tail_aggregate(const void *x, int dtype, int ldx, const float *s, const int *rowptr, const int *col, int n_tgt, int H,
                               int K, void *A, float *alpha, void *stream);
 int spadot_gat_tail_headmean(const void *O, int dtype, const float *bias, int n_tgt, int H, int C, void *out, void *stream);

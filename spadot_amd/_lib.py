@@ -176,8 +176,8 @@ def model_lib():
         "spadot_gat_ds_src": [vp, vp, vp, ci, ci, vp, vp],
         "spadot_gat_mfma_supported": [ci, ci, ci, ci],
         "spadot_gat_tail_supported": [ci, ci, ci],
-        "spadot_gat_tail_wvec": [vp, ci, vp, vp, ci, ci, ci, vp, ci, vp, vp],
-        "spadot_gat_tail_logits": [vp, ci, ci, vp, ci, ci, ci, vp, vp],
+        "spadot_gat_tail_wvec": [vp, ci, vp, vp, ci, ci, ci, vp, ci, vp, vp, vp, vp],
+        "spadot_gat_tail_logits": [vp, ci, ci, vp, vp, vp, ci, ci, ci, vp, vp],
         "spadot_gat_tail_aggregate": [vp, ci, ci, vp, vp, vp, ci, ci, ci, vp, vp, vp],
         "spadot_gat_tail_headmean": [vp, ci, vp, ci, ci, ci, vp, vp],
         "spadot_gat_tail_colsum_rows": [vp, ci, ci, ci, vp, vp],

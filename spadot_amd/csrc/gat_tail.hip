@@ -131,7 +131,8 @@ __global__ __launch_bounds__(NT) void k_tail_wvec(const float *__restrict__ W, i
     *reinterpret_cast<float4 *>(p + K) = make_float4(ad_[0], ad_[1], ad_[2], ad_[3]);
 }
 
-__global__ __launch_bounds__(NT) void k_tail_wvec_fin(const float *__restrict__ part, int S, int total, float *__restrict__ wv) {
+__global__ __launch_bounds__(NT) void k_tail_wvec_fin(const float *__restrict__ part, int S, int total, float *__restrict__ wv,
+                                                      __bf16 *__restrict__ whi, __bf16 *__restrict__ wlo) {
     const int t = ((int)blockIdx.x * NT + (int)threadIdx.x) * 4;
     if (t >= total) return;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -140,6 +141,53 @@ __global__ __launch_bounds__(NT) void k_tail_wvec_fin(const float *__restrict__ 
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
     *reinterpret_cast<float4 *>(wv + t) = acc;
+    if (whi != nullptr) {        // w = hi + lo in bf16 (16 significant bits) for the matrix-core logits kernel
+        const float a[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const __bf16 h = (__bf16)a[e];
+            whi[t + e] = h;
+            wlo[t + e] = (__bf16)(a[e] - (float)h);
+        }
+    }
+}
+
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------------------------
+// The same logits on the matrix cores (bf16 rows, K % 32 == 0): a skinny product x [n x K] . w^T [K x Q] as
+// v_mfma_f32_16x16x32_bf16 tiles -- 16 rows of x per workgroup (A: row = lane & 15, k = 8 (lane >> 4) + j: one 16-byte load
+// per lane straight from global), w = hi + lo (B: col = lane & 15 = q, zero for q >= Q), the four waves taking every fourth
+// 32-wide slice of the contraction, one LDS exchange at the end.  Every load of a wave is independent of every other, so
+// the whole 33 MB of x is in flight at once: the vector form above is latency-bound (one row group per barrier pair).
+// ------------------------------------------------------------------------------------------------------------------
+template <int Q>
+__global__ __launch_bounds__(NT) void k_tail_logits_mfma(const __bf16 *__restrict__ x, int ldx, const __bf16 *__restrict__ whi,
+                                                         const __bf16 *__restrict__ wlo, int n, int K, float *__restrict__ s_out) {
+    __shared__ float red[4][16][17];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int j0 = (int)blockIdx.x * 16;
+    const int r = lane & 15, kq = lane >> 4;
+    const __bf16 *xr = x + (size_t)min(j0 + r, n - 1) * ldx + 8 * kq;
+    const bool bq = r < Q;
+    const __bf16 *wh = whi + (size_t)(bq ? r : 0) * K + 8 * kq, *wl = wlo + (size_t)(bq ? r : 0) * K + 8 * kq;
+    const bf8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int KC = K >> 5;
+#pragma unroll 8
+    for (int kc = w; kc < KC; kc += 4) {
+        const bf8 a = *reinterpret_cast<const bf8 *>(xr + 32 * kc);
+        const bf8 bh = bq ? *reinterpret_cast<const bf8 *>(wh + 32 * kc) : zero;
+        const bf8 bl = bq ? *reinterpret_cast<const bf8 *>(wl + 32 * kc) : zero;
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bl, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) red[w][4 * kq + i][r] = acc[i];          // C/D: col = lane & 15, row = 4 (lane >> 4) + i
+    __syncthreads();
+    const int rr = t >> 4, qq = t & 15;
+    if (qq < Q && j0 + rr < n) s_out[(size_t)(j0 + rr) * Q + qq] = red[0][rr][qq] + red[1][rr][qq] + red[2][rr][qq] + red[3][rr][qq];
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -293,19 +341,24 @@ __global__ __launch_bounds__(NT) void k_tail_headmean(const T *__restrict__ O, c
     store8<T>(out + idx, a);
 }
 
-// column sums of g [rows x C] (fp32 accumulation, rows in ascending order): block = 64 columns x 4 row groups
+// column sums of g [rows x C] (fp32 accumulation; fixed order: 16 interleaved row groups, then the groups in order):
+// block = 16 columns x 16 row groups
 template <typename T>
 __global__ __launch_bounds__(NT) void k_tail_colsum_rows(const T *__restrict__ g, int rows, int C, float *__restrict__ out) {
-    __shared__ float red[4][64];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int c = (int)blockIdx.x * 64 + lane;
-    const int per = (rows + 3) / 4, r0 = wid * per, r1 = min(rows, r0 + per);
+    __shared__ float red[16][17];
+    const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int c = (int)blockIdx.x * 16 + cl;
     float a = 0.f;
     if (c < C)
-        for (int r = r0; r < r1; r++) a += (float)g[(size_t)r * C + c];
-    red[wid][lane] = a;
+        for (int r = rg; r < rows; r += 16) a += (float)g[(size_t)r * C + c];
+    red[rg][cl] = a;
     __syncthreads();
-    if (wid == 0 && c < C) out[c] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+    if (rg == 0 && c < C) {
+        float tot = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; k++) tot += red[k][cl];
+        out[c] = tot;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -385,6 +438,71 @@ __global__ __launch_bounds__(NT, 2) void k_tail_edge_bwd(const T *__restrict__ x
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// The same kernel with its first phase on the matrix cores (bf16 rows, K % 32 == 0): d alpha[e][h] for 32 edges of the seed at
+// a time as two v_mfma_f32_16x16x32_bf16 tiles per 32-wide slice of the contraction (A: the edge's source row straight from
+// global, B: dA[h][i] for col = h < H, exact in bf16), the four waves taking every fourth slice, one LDS exchange per 32
+// edges -- instead of four edges per barrier pair with a load latency each.
+// ------------------------------------------------------------------------------------------------------------------
+template <int H>
+__global__ __launch_bounds__(NT) void k_tail_edge_bwd_mfma(const __bf16 *__restrict__ x, int ldx, const __bf16 *__restrict__ dA,
+                                                           const float *__restrict__ s, const float *__restrict__ alpha,
+                                                           const int *__restrict__ rowptr, const int *__restrict__ col, int n_tgt, int K,
+                                                           float *__restrict__ dz, float *__restrict__ ds_dst) {
+    constexpr int Q = 2 * H;
+    __shared__ float red[4][32][17];
+    const int i = blockIdx.x;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int p0 = rowptr[i], deg = rowptr[i + 1] - p0;
+    const int r = lane & 15, kq = lane >> 4;
+    const bool bq = r < H;
+    const __bf16 *gb = dA + ((size_t)(bq ? r : 0) * n_tgt + i) * K + 8 * kq;
+    const bf8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int KC = K >> 5;
+    for (int e0 = 0; e0 < deg; e0 += 32) {
+        const bool two = e0 + 16 < deg;                              // (uniform) a second block of 16 edges
+        const __bf16 *x0 = x + (size_t)col[p0 + min(e0 + r, deg - 1)] * ldx + 8 * kq;
+        const __bf16 *x1 = x + (size_t)col[p0 + min(e0 + 16 + r, deg - 1)] * ldx + 8 * kq;
+        f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+        for (int kc = w; kc < KC; kc += 4) {
+            const bf8 b = bq ? *reinterpret_cast<const bf8 *>(gb + 32 * kc) : zero;
+            const bf8 a0 = *reinterpret_cast<const bf8 *>(x0 + 32 * kc);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b, acc0, 0, 0, 0);
+            if (two) {
+                const bf8 a1 = *reinterpret_cast<const bf8 *>(x1 + 32 * kc);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b, acc1, 0, 0, 0);
+            }
+        }
+        __syncthreads();                                             // the previous 32 edges' readers are done
+#pragma unroll
+        for (int u = 0; u < 4; u++) { red[w][4 * kq + u][r] = acc0[u]; red[w][16 + 4 * kq + u][r] = acc1[u]; }
+        __syncthreads();
+        for (int u = t; u < 32 * H; u += NT) {
+            const int e = u / H, h = u - e * H;
+            if (e0 + e < deg) dz[(size_t)(p0 + e0 + e) * H + h] = red[0][e][h] + red[1][e][h] + red[2][e][h] + red[3][e][h];
+        }
+    }
+    __threadfence_block();
+    __syncthreads();                                                 // d alpha of every edge of this seed is in dz
+    for (int hd = w; hd < H; hd += 4) {
+        float dot = 0.f;
+        for (int e = lane; e < deg; e += WAVE) dot += alpha[(size_t)(p0 + e) * H + hd] * dz[(size_t)(p0 + e) * H + hd];
+        dot = wave_sum_f(dot);
+        const float sd = s[(size_t)i * Q + 2 * hd + 1];
+        float dsum = 0.f;
+        for (int e = lane; e < deg; e += WAVE) {
+            const size_t o = (size_t)(p0 + e) * H + hd;
+            const float raw = s[(size_t)col[p0 + e] * Q + 2 * hd] + sd;
+            const float d = alpha[o] * (dz[o] - dot) * (raw > 0.f ? 1.f : ATT_SLOPE);
+            dz[o] = d;
+            dsum += d;
+        }
+        dsum = wave_sum_f(dsum);
+        if (lane == 0) ds_dst[(size_t)i * H + hd] = dsum;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Source rows: dx_j[k] = sum_{e: j -> i} sum_h alpha[e][h] dA[h][i][k] + sum_h ( ds_src[j][h] w[2h][k] + ds_dst[j][h] w[2h+1][k] ),
 // ds_src[j][h] = sum_{e: j -> i} dz[e][h] (also stored), ds_dst = 0 for j >= n_tgt; rows n <= j < rows_out are written as zeros.
 // ------------------------------------------------------------------------------------------------------------------
@@ -393,11 +511,18 @@ __global__ __launch_bounds__(NT) void k_tail_src_bwd(const T *__restrict__ dA, c
                                                      const float *__restrict__ ds_dst, const float *__restrict__ wv,
                                                      const int *__restrict__ rowptr_t, const int *__restrict__ col_t,
                                                      const int *__restrict__ eid_t, int n, int n_tgt, int rows_out, int K,
-                                                     int rows_per_wg, T *__restrict__ dx, int lddx, float *__restrict__ ds_src) {
-    constexpr int Q = 2 * H;
+                                                     T *__restrict__ dx, int lddx, float *__restrict__ ds_src) {
+    constexpr int Q = 2 * H, ROWS = 8, MAXE = 128;
+    // the block's edge records are fetched ONCE, together, into LDS (row pointers -> edge ids / targets -> alpha, d logit:
+    // three dependent loads for the whole block instead of three per row); the row loop then only gathers dA rows
+    __shared__ int rp[ROWS + 1];
+    __shared__ int tg[MAXE];
+    __shared__ float al[MAXE][H], dl[MAXE][H];
     const int t = threadIdx.x;
     const int k = t * 8;
     const bool live = k < K;
+    const int j0 = (int)blockIdx.x * ROWS, j1 = min(rows_out, j0 + ROWS);
+    if (t <= ROWS) rp[t] = rowptr_t[min(j0 + t, n)];
     float w[Q][8];
 #pragma unroll
     for (int q = 0; q < Q; q++) {
@@ -406,26 +531,46 @@ __global__ __launch_bounds__(NT) void k_tail_src_bwd(const T *__restrict__ dA, c
 #pragma unroll
             for (int e = 0; e < 8; e++) w[q][e] = 0.f;
     }
-    const int j0 = (int)blockIdx.x * rows_per_wg, j1 = min(rows_out, j0 + rows_per_wg);
+    __syncthreads();
+    const int base = rp[0], nE = rp[ROWS] - base;
+    const bool staged = nE <= MAXE;
+    if (staged) {
+        for (int u = t; u < nE; u += NT) {
+            const int e = eid_t[base + u];
+            tg[u] = col_t[base + u];
+#pragma unroll
+            for (int h = 0; h < H; h++) { al[u][h] = alpha[(size_t)e * H + h]; dl[u][h] = dz[(size_t)e * H + h]; }
+        }
+        __syncthreads();
+    }
     for (int j = j0; j < j1; j++) {
         float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (j < n) {
             float dss[H], dsd[H];
 #pragma unroll
             for (int h = 0; h < H; h++) { dss[h] = 0.f; dsd[h] = j < n_tgt ? ds_dst[(size_t)j * H + h] : 0.f; }
-            const int q0 = rowptr_t[j], q1 = rowptr_t[j + 1];
+            const int q0 = rp[j - j0], q1 = rp[j - j0 + 1];
             for (int p = q0; p < q1; p++) {
-                const int e = eid_t[p], i = col_t[p];
+                int i;
+                float a[H];
+                if (staged) {
+                    i = tg[p - base];
 #pragma unroll
-                for (int h = 0; h < H; h++) {
-                    const float a = alpha[(size_t)e * H + h];
-                    dss[h] += dz[(size_t)e * H + h];
-                    if (live) {
-                        float gv[8];
-                        load8<T>(dA + ((size_t)h * n_tgt + i) * K + k, gv);
+                    for (int h = 0; h < H; h++) { a[h] = al[p - base][h]; dss[h] += dl[p - base][h]; }
+                } else {
+                    const int e = eid_t[p];
+                    i = col_t[p];
 #pragma unroll
-                        for (int q = 0; q < 8; q++) acc[q] = fmaf(a, gv[q], acc[q]);
-                    }
+                    for (int h = 0; h < H; h++) { a[h] = alpha[(size_t)e * H + h]; dss[h] += dz[(size_t)e * H + h]; }
+                }
+                if (live) {
+                    float gv[H][8];
+#pragma unroll
+                    for (int h = 0; h < H; h++) load8<T>(dA + ((size_t)h * n_tgt + i) * K + k, gv[h]);
+#pragma unroll
+                    for (int h = 0; h < H; h++)
+#pragma unroll
+                        for (int q = 0; q < 8; q++) acc[q] = fmaf(a[h], gv[h][q], acc[q]);
                 }
             }
 #pragma unroll
@@ -541,22 +686,32 @@ extern "C" {
 int spadot_gat_tail_supported(int dtype, int H, int K) { return ((dtype == DT_F32 || dtype == DT_BF16) && shape_ok(H, K)) ? 1 : 0; }
 
 int spadot_gat_tail_wvec(const float *W, int ldw, const float *att_src, const float *att_dst, int H, int C, int K, float *part,
-                         int slices, float *wv, void *stream) {
-    if (!W || !att_src || !att_dst || !part || !wv || !shape_ok(H, K) || C <= 0 || ldw < K || ldw % 4 || slices < 1 || slices > 64) return -22;
+                         int slices, float *wv, void *whi, void *wlo, void *stream) {
+    if (!W || !att_src || !att_dst || !part || !wv || !shape_ok(H, K) || C <= 0 || ldw < K || ldw % 4 || slices < 1 || slices > 64 ||
+        ((whi == nullptr) != (wlo == nullptr)))
+        return -22;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_tail_wvec, dim3((unsigned)((K / 4 + NT - 1) / NT), (unsigned)H, (unsigned)slices), dim3(NT), 0, st, W, ldw,
                        att_src, att_dst, H, C, K, slices, part);
     const int total = 2 * H * K;
-    hipLaunchKernelGGL(k_tail_wvec_fin, dim3((unsigned)((total / 4 + NT - 1) / NT)), dim3(NT), 0, st, part, slices, total, wv);
+    hipLaunchKernelGGL(k_tail_wvec_fin, dim3((unsigned)((total / 4 + NT - 1) / NT)), dim3(NT), 0, st, part, slices, total, wv, (__bf16 *)whi,
+                       (__bf16 *)wlo);
     return rc_last();
 }
 
-int spadot_gat_tail_logits(const void *x, int dtype, int ldx, const float *wv, int n, int H, int K, float *s, void *stream) {
+int spadot_gat_tail_logits(const void *x, int dtype, int ldx, const float *wv, const void *whi, const void *wlo, int n, int H, int K, float *s,
+                           void *stream) {
     if (!x || !wv || !s || n <= 0 || !spadot_gat_tail_supported(dtype, H, K) || ldx < K || ldx % 8) return -22;
     hipStream_t st = (hipStream_t)stream;
-    const int rows = 32, grid = (n + rows - 1) / rows;
+    if (dtype == DT_BF16 && whi && wlo && K % 32 == 0) {           // matrix cores: 16 rows per workgroup
+        const int grid = (n + 15) / 16;
+        TAIL_DISPATCH_H(H, hipLaunchKernelGGL((k_tail_logits_mfma<2 * HH>), dim3(grid), dim3(NT), 0, st, (const __bf16 *)x, ldx,
+                                              (const __bf16 *)whi, (const __bf16 *)wlo, n, K, s));
+        return rc_last();
+    }
+    const int rows = 8, grid = (n + rows - 1) / rows;
 #define LOGITS(T_) TAIL_DISPATCH_H(H, hipLaunchKernelGGL((k_tail_logits<T_, 2 * HH, (HH >= 8 ? 1 : (HH == 4 ? 2 : (HH == 2 ? 4 : 8)))>), dim3(grid), \
-                                                           dim3(NT), 0, st, (const T_ *)x, ldx, wv, n, K, rows, s))
+                                                          dim3(NT), 0, st, (const T_ *)x, ldx, wv, n, K, rows, s))
     if (dtype == DT_BF16) { LOGITS(__bf16); } else { LOGITS(float); }
 #undef LOGITS
     return rc_last();
@@ -586,7 +741,7 @@ int spadot_gat_tail_headmean(const void *O, int dtype, const float *bias, int n_
 int spadot_gat_tail_colsum_rows(const void *g, int dtype, int rows, int C, float *out, void *stream) {
     if (!g || !out || rows <= 0 || C <= 0 || (dtype != DT_F32 && dtype != DT_BF16)) return -22;
     hipStream_t st = (hipStream_t)stream;
-    const unsigned grid = (unsigned)((C + 63) / 64);
+    const unsigned grid = (unsigned)((C + 15) / 16);
     if (dtype == DT_BF16) hipLaunchKernelGGL(k_tail_colsum_rows<__bf16>, dim3(grid), dim3(NT), 0, st, (const __bf16 *)g, rows, C, out);
     else hipLaunchKernelGGL(k_tail_colsum_rows<float>, dim3(grid), dim3(NT), 0, st, (const float *)g, rows, C, out);
     return rc_last();
@@ -598,6 +753,11 @@ int spadot_gat_tail_edge_backward(const void *x, int dtype, int ldx, const void 
         ldx % 8)
         return -22;
     hipStream_t st = (hipStream_t)stream;
+    if (dtype == DT_BF16 && K % 32 == 0) {
+        TAIL_DISPATCH_H(H, hipLaunchKernelGGL((k_tail_edge_bwd_mfma<HH>), dim3(n_tgt), dim3(NT), 0, st, (const __bf16 *)x, ldx, (const __bf16 *)dA,
+                                              s, alpha, rowptr, col, n_tgt, K, dz, ds_dst));
+        return rc_last();
+    }
 #define EBWD(T_) TAIL_DISPATCH_H(H, hipLaunchKernelGGL((k_tail_edge_bwd<T_, HH, (HH >= 8 ? 2 : (HH == 4 ? 4 : 8))>), dim3(n_tgt), dim3(NT), 0, st, \
                                                          (const T_ *)x, ldx, (const T_ *)dA, s, alpha, rowptr, col, n_tgt, K, dz, ds_dst))
     if (dtype == DT_BF16) { EBWD(__bf16); } else { EBWD(float); }
@@ -614,7 +774,7 @@ int spadot_gat_tail_source_backward(const void *dA, int dtype, const float *alph
     hipStream_t st = (hipStream_t)stream;
     const int rows = 8, grid = (rows_out + rows - 1) / rows;
 #define SBWD(T_) TAIL_DISPATCH_H(H, hipLaunchKernelGGL((k_tail_src_bwd<T_, HH>), dim3(grid), dim3(NT), 0, st, (const T_ *)dA, alpha, dz, ds_dst, \
-                                                         wv, rowptr_t, col_t, eid_t, n, n_tgt, rows_out, K, rows, (T_ *)dx, lddx, ds_src))
+                                                         wv, rowptr_t, col_t, eid_t, n, n_tgt, rows_out, K, (T_ *)dx, lddx, ds_src))
     if (dtype == DT_BF16) { SBWD(__bf16); } else { SBWD(float); }
 #undef SBWD
     return rc_last();

@@ -328,12 +328,15 @@ class _GATTail(torch.autograd.Function):
         a_s = att_src.reshape(H * C).contiguous().float()
         a_d = att_dst.reshape(H * C).contiguous().float()
         Wd = W.detach()
-        S = 16
+        S = 32
         part = torch.empty(S * 2 * H * K, dtype=torch.float32, device=dev)
         wv = torch.empty((2 * H, K), dtype=torch.float32, device=dev)
-        _check(lib.spadot_gat_tail_wvec(_p(Wd), K, _p(a_s), _p(a_d), H, C, K, _p(part), S, _p(wv), _stream()), "spadot_gat_tail_wvec")
+        wsplit = torch.empty((2, 2 * H, K), dtype=torch.bfloat16, device=dev) if (x.dtype == torch.bfloat16 and K % 32 == 0) else None
+        whi, wlo = (wsplit[0], wsplit[1]) if wsplit is not None else (None, None)
+        _check(lib.spadot_gat_tail_wvec(_p(Wd), K, _p(a_s), _p(a_d), H, C, K, _p(part), S, _p(wv), _p(whi), _p(wlo), _stream()),
+               "spadot_gat_tail_wvec")
         s = torch.empty((n, 2 * H), dtype=torch.float32, device=dev)
-        _check(lib.spadot_gat_tail_logits(_p(x), dt, Kp, _p(wv), n, H, K, _p(s), _stream()), "spadot_gat_tail_logits")
+        _check(lib.spadot_gat_tail_logits(_p(x), dt, Kp, _p(wv), _p(whi), _p(wlo), n, H, K, _p(s), _stream()), "spadot_gat_tail_logits")
         A = torch.empty((H, nt, K), dtype=x.dtype, device=dev)
         alpha = torch.empty((graph.E, H), dtype=torch.float32, device=dev)
         _check(lib.spadot_gat_tail_aggregate(_p(x), dt, Kp, _p(s), _p(graph.rowptr), _p(graph.col), nt, H, K, _p(A), _p(alpha), _stream()),
