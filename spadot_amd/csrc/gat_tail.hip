@@ -170,18 +170,27 @@ __global__ __launch_bounds__(NT) void k_tail_logits_mfma(const __bf16 *__restric
     const int j0 = (int)blockIdx.x * 16;
     const int r = lane & 15, kq = lane >> 4;
     const __bf16 *xr = x + (size_t)min(j0 + r, n - 1) * ldx + 8 * kq;
-    const bool bq = r < Q;
-    const __bf16 *wh = whi + (size_t)(bq ? r : 0) * K + 8 * kq, *wl = wlo + (size_t)(bq ? r : 0) * K + 8 * kq;
-    const bf8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    // (columns q >= Q of the tile are never stored: their B lanes read row Q - 1 again -- every load unconditional, no
+    // divergent control flow in the loop, so the compiler can keep a batch of loads in flight)
+    const __bf16 *wh = whi + (size_t)min(r, Q - 1) * K + 8 * kq, *wl = wlo + (size_t)min(r, Q - 1) * K + 8 * kq;
     f4 acc = {0.f, 0.f, 0.f, 0.f};
     const int KC = K >> 5;
-#pragma unroll 8
-    for (int kc = w; kc < KC; kc += 4) {
-        const bf8 a = *reinterpret_cast<const bf8 *>(xr + 32 * kc);
-        const bf8 bh = bq ? *reinterpret_cast<const bf8 *>(wh + 32 * kc) : zero;
-        const bf8 bl = bq ? *reinterpret_cast<const bf8 *>(wl + 32 * kc) : zero;
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bh, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bl, acc, 0, 0, 0);
+    constexpr int UB = 8;                                       // slices per batch: UB x 3 x 16 bytes per lane in flight
+    for (int kc = w; kc < KC; kc += 4 * UB) {
+        bf8 a[UB], bh[UB], bl[UB];
+#pragma unroll
+        for (int u = 0; u < UB; u++) {
+            const int kk = (kc + 4 * u < KC) ? kc + 4 * u : w;  // (past the end: a valid slice again, its product is skipped)
+            a[u] = *reinterpret_cast<const bf8 *>(xr + 32 * kk);
+            bh[u] = *reinterpret_cast<const bf8 *>(wh + 32 * kk);
+            bl[u] = *reinterpret_cast<const bf8 *>(wl + 32 * kk);
+        }
+#pragma unroll
+        for (int u = 0; u < UB; u++)
+            if (kc + 4 * u < KC) {                              // wave-uniform
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u], bh[u], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u], bl[u], acc, 0, 0, 0);
+            }
     }
 #pragma unroll
     for (int i = 0; i < 4; i++) red[w][4 * kq + i][r] = acc[i];          // C/D: col = lane & 15, row = 4 (lane >> 4) + i
@@ -454,24 +463,29 @@ __global__ __launch_bounds__(NT) void k_tail_edge_bwd_mfma(const __bf16 *__restr
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int p0 = rowptr[i], deg = rowptr[i + 1] - p0;
     const int r = lane & 15, kq = lane >> 4;
-    const bool bq = r < H;
-    const __bf16 *gb = dA + ((size_t)(bq ? r : 0) * n_tgt + i) * K + 8 * kq;
-    const bf8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    const __bf16 *gb = dA + ((size_t)min(r, H - 1) * n_tgt + i) * K + 8 * kq;     // (columns h >= H are never stored: row H - 1 again)
     const int KC = K >> 5;
+    constexpr int UB = 8;
     for (int e0 = 0; e0 < deg; e0 += 32) {
         const bool two = e0 + 16 < deg;                              // (uniform) a second block of 16 edges
         const __bf16 *x0 = x + (size_t)col[p0 + min(e0 + r, deg - 1)] * ldx + 8 * kq;
         const __bf16 *x1 = x + (size_t)col[p0 + min(e0 + 16 + r, deg - 1)] * ldx + 8 * kq;
         f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-        for (int kc = w; kc < KC; kc += 4) {
-            const bf8 b = bq ? *reinterpret_cast<const bf8 *>(gb + 32 * kc) : zero;
-            const bf8 a0 = *reinterpret_cast<const bf8 *>(x0 + 32 * kc);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b, acc0, 0, 0, 0);
-            if (two) {
-                const bf8 a1 = *reinterpret_cast<const bf8 *>(x1 + 32 * kc);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b, acc1, 0, 0, 0);
+        for (int kc = w; kc < KC; kc += 4 * UB) {
+            bf8 b[UB], a0[UB], a1[UB];
+#pragma unroll
+            for (int u = 0; u < UB; u++) {
+                const int kk = (kc + 4 * u < KC) ? kc + 4 * u : w;
+                b[u] = *reinterpret_cast<const bf8 *>(gb + 32 * kk);
+                a0[u] = *reinterpret_cast<const bf8 *>(x0 + 32 * kk);
+                a1[u] = *reinterpret_cast<const bf8 *>(x1 + 32 * kk);      // (one block only: the last edge's row again, not stored)
             }
+#pragma unroll
+            for (int u = 0; u < UB; u++)
+                if (kc + 4 * u < KC) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[u], b[u], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[u], b[u], acc1, 0, 0, 0);
+                }
         }
         __syncthreads();                                             // the previous 32 edges' readers are done
 #pragma unroll
