@@ -62,18 +62,22 @@ class SVGPOracle:
     def k(self, x, y):
         return rbf_kernel(x, y, self.kernel_type, self.scale)
 
-    def approximate_posterior_params(self, x_test, x_train, y, noise):
-        """svgp.py:62-84.  Returns (mean[b_test], B[b_test], mu_hat[m], A_hat[m,m])."""
+    def approximate_posterior_params(self, x_test, x_train, y, noise, mean_only=False):
+        """svgp.py:62-84.  Returns (mean[b_test], B[b_test], mu_hat[m], A_hat[m,m]).  mean_only (checker convenience for
+        whole-time-point inference, SpaDOT.py:96-123 reads only the mean): the same formula for the mean, without the
+        N_t x N_t products behind B that nobody reads there -- returns (mean, None, None, None)."""
         b = x_train.shape[0]
         K_mm = self.k(self.z, self.z)
-        K_mm_inv = torch.linalg.inv(_jit(K_mm, self.jitter))
-        K_xx = torch.diagonal(self.k(x_test, x_test))
         K_xm = self.k(x_test, self.z)
         K_nm = self.k(x_train, self.z)
         c = self.N_train / b
         sigma_l = K_mm + c * (K_nm.T @ (K_nm / noise[:, None]))
         sigma_l_inv = torch.linalg.inv(_jit(sigma_l, self.jitter))
         mean = c * (K_xm @ (sigma_l_inv @ (K_nm.T @ (y / noise))))
+        if mean_only:
+            return mean, None, None, None
+        K_mm_inv = torch.linalg.inv(_jit(K_mm, self.jitter))
+        K_xx = torch.diagonal(self.k(x_test, x_test))
         B = K_xx + torch.diagonal(-(K_xm @ (K_mm_inv @ K_xm.T)) + K_xm @ (sigma_l_inv @ K_xm.T))
         mu_hat = c * ((K_mm @ (sigma_l_inv @ K_nm.T)) @ (y / noise))
         A_hat = K_mm @ (sigma_l_inv @ K_mm)
@@ -238,10 +242,11 @@ def spadot_forward(P, svgp, x, y, edge_index, batch_size, heads, noise_svgp, noi
     return (recon, svgp_kl, gat_kl, align, z), inter
 
 
-def all_latent_samples(P, svgp, X, Y, edge_index, heads, L):
-    """SpaDOT.py:96-123 (eval mode: BatchNorm running stats; posterior means, no noise)."""
+def all_latent_samples(P, svgp, X, Y, edge_index, heads, L, mean_only=False):
+    """SpaDOT.py:96-123 (eval mode: BatchNorm running stats; posterior means, no noise).  mean_only: see
+    SVGPOracle.approximate_posterior_params (full-size checks: the N_t x N_t intermediates are not formed)."""
     q_mu, q_var = svgp_encoder(P, Y, train=False)
-    pm = [svgp.approximate_posterior_params(X, X, q_mu[:, l], q_var[:, l])[0] for l in range(L)]
+    pm = [svgp.approximate_posterior_params(X, X, q_mu[:, l], q_var[:, l], mean_only=mean_only)[0] for l in range(L)]
     g_mu, _ = gat_encoder(P, Y, edge_index, heads)
     return torch.cat([torch.stack(pm, dim=1), g_mu], dim=1)
 

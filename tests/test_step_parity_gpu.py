@@ -21,7 +21,8 @@ Stated tolerances (the reference is fp64 on the CPU), asserted at abo
   bf16 compute (GAT branch and the two G-sized linears in bf16, fp32 accumulate): loss terms rtol 3e-4, latent relative
                 L2 <= 3e-3, gradient as a whole (the direction AdamW follows) cosine >= 0.99999; per parameter: the
                 attention vectors att_src / att_dst (2 048 numbers each, sums of bf16 products over ~10^4 nodes) cosine
-                >= 0.998 and relative L2 <= 0.1, every other parameter cosine >= 0.9998 and relative L2 <= 0.03.
+                >= 0.9985 and relative L2 <= 0.07 (round 4: tightened from 0.998 / 0.1), every other parameter cosine >= 0.9998
+                and relative L2 <= 0.03.
                 (Measured, round 2 final tree: loss terms 2.1e-5, latent 8.5e-4, whole gradient 0.999998; attention
                 vectors: worst cosine 0.99941 / relative L2 0.049 (gat3.att_dst); every other parameter: cosine >= 0.99996,
                 relative L2 <= 0.0087.)
@@ -127,7 +128,7 @@ def _assert_step_parity(rep, dtype, ref):
         assert rep["grad_cos_global"] >= 0.99999
         for name, (l2, cos) in rep["per_param"].items():
             if ".att_" in name:
-                assert cos >= 0.998 and l2 <= 0.1, (name, l2, cos)
+                assert cos >= 0.9985 and l2 <= 0.07, (name, l2, cos)
             else:
                 assert cos >= 0.9998 and l2 <= 0.03, (name, l2, cos)
     # a Linear bias in front of BatchNorm has a zero gradient in exact arithmetic: zero on the device as well
@@ -272,3 +273,104 @@ def test_cfg1_ragged_timepoints_partial_last_batches_match_the_oracle():
         lb = staged.fb(1, 1, 3, epoch, beta1)
         np.testing.assert_allclose(lb.cpu().numpy(), la.cpu().numpy(), rtol=1e-4, atol=1e-5)
         np.testing.assert_allclose(opt.flat_grad.cpu().numpy(), ga.cpu().numpy(), rtol=2e-3, atol=2e-4 * float(ga.abs().max()))
+
+
+def test_cfg4_width_step_staged_equals_eager_and_the_oracle_forward():
+    """BASELINE.json configs[3] width: MouseOrganogenesis has 9 281 SVGs (examples/MouseOrganogenesis_output/SVG_genes.txt of the
+    reference); the gene axis is padded to 9 344 in the cached batch rows.  (a) bf16, N_t = 10 000: the replayed staged step
+    equals the eager step, everything finite -- the K = 9 344 paths of the dense maps (library forward, both weight-gradient
+    tilings and their 4 GiB guards, the G-sized decoder map and k_bias_sqerr_* at G > 5 000).  (b) fp32, N_t = 2 000: one
+    forward against the fp64 oracle (7 loss terms, latent)."""
+    from oracle import model_oracle as mo, step_parity as sp
+    G = 9281
+    tu, cfg, dd, model, opt = _setup(2, 10000, G, 480, torch.bfloat16, kmeans_backend="device")
+    tp, epoch, beta1 = 1, cfg["ot_epoch"], 0.5
+    b0 = dd["dataloaders"][tp][0]
+    assert b0.graph.n > 9000 and b0.y is not None and b0.y.shape[1] == 9344 and b0.y.dtype == torch.bfloat16
+    model.fixed_noise = (torch.zeros((512, 10), device=DEV), torch.zeros((512, 10), device=DEV))
+    staged = tu.GraphedStepper(model, opt, dict(cfg, staged_graphs=True), dd)
+    for rep in range(3):
+        for bi in (0, 19):                                        # first and last (partial) batch
+            staged.beta1_t[1].fill_(-beta1)
+            la = tu.forward_backward(model, cfg, dd, 1, tp, bi, epoch, staged.beta1_t, optimizer=opt)
+            ga = opt.flat_grad.clone()
+            opt.flat_grad.fill_(7.0)
+            lb = staged.fb(1, tp, bi, epoch, beta1)
+            gb = opt.flat_grad
+            assert torch.isfinite(lb).all() and torch.isfinite(gb).all()
+            np.testing.assert_allclose(lb.cpu().numpy(), la.cpu().numpy(), rtol=1e-4, atol=1e-5)
+            scale = float(ga.abs().max())
+            np.testing.assert_allclose(gb.cpu().numpy(), ga.cpu().numpy(), rtol=2e-3, atol=2e-4 * scale)
+    assert (la.cpu().numpy()[[1, 3, 4, 5, 6]] > 0).all()
+    for k in range(3):
+        out = staged.step(1, tp, 0, epoch, beta1)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all() and torch.isfinite(opt.flat_param).all()
+    del tu, dd, model, opt, staged
+    torch.cuda.empty_cache()
+
+    tu, cfg, dd, model, opt = _setup(2, 2000, G, 480, torch.float32)
+    b0 = dd["dataloaders"][tp][0]
+    noise = sp.make_noise(b0.batch_size, seed=5)
+    inp = sp.oracle_inputs(model, dd, cfg, tp, 0, tp - 1)
+    w = (cfg["lambda1"], beta1, cfg["beta2"], cfg["omiga1"], cfg["omiga2"], cfg["omiga3"])
+    with torch.no_grad():
+        _, terms, z_ref = mo.step_loss(inp["P"], inp["svgp"], inp["x"], inp["y"], inp["ei"], inp["b"],
+                                       cfg["gat_attention_heads"], noise[0], noise[1], w, km=inp["km"], ot=inp["ot"])
+    want = np.array([float(terms[n]) for n in sp.LOSS_NAMES])
+    dl, dz, dg = sp.device_step(model, opt, cfg, dd, tu, 1, tp, 0, epoch, beta1, noise)
+    np.testing.assert_allclose(dl, want, rtol=1e-4, err_msg=str(sp.LOSS_NAMES))
+    np.testing.assert_allclose(dz, z_ref.numpy(), rtol=1e-4, atol=1e-4)
+    assert all(np.isfinite(v).all() for v in dg.values())
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_full_size_inference_matches_the_oracle(dtype):
+    """SpaDOT.py:96-123 at BASELINE.json's size: all_latent_samples of a whole time point (N_t = 10 000 spots x 3 000 genes) --
+    eval-mode BatchNorm (running statistics, moved by a few real training steps first), the SVGP posterior mean over all N_t
+    rows, the three GAT layers on the FULL graph -- against oracle/model_oracle.all_latent_samples on the same weights.  This
+    runs every epoch for every time point and feeds K-means (_train_utils.py:255-269).  Tolerances: latent relative L2
+    <= 1e-5 (fp32) / 3e-3 (bf16); K-means labels of the device latent from given centres = argmin in numpy on the same latent
+    (bit-exact), and against the ORACLE latent's labels at most 1 in 10^4 (fp32) / 1 % (bf16) of the spots differ (spots on a
+    cluster boundary)."""
+    from oracle import model_oracle as mo
+    from spadot_amd import ops
+    cdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    tu, cfg, dd, model, opt = _setup(2, 10000, 3000, 480, cdt, bf16_exact_inputs=True)
+    tp, epoch = 1, cfg["ot_epoch"]
+    for k in range(3):                                            # running statistics and weights leave their initial values
+        tu.training_step(model, opt, cfg, dd, 1, tp, k, epoch, 0.5)
+    torch.cuda.synchronize()
+    model.eval()
+    loc, Y, _ = dd["datasets"][tp]
+    g = dd["graphs"][tp]
+    with torch.no_grad():
+        lat = model.all_latent_samples(loc, Y, g, tp, as_numpy=False)
+    assert lat.shape == (10000, cfg["z_dim"]) and bool(torch.isfinite(lat).all())
+    P = {k: v.detach().cpu().double() for k, v in model.state_dict().items()}
+    assert float(P["SVGPEncoder.SVGP_encoder_net.1.running_mean"].abs().max()) > 0.0
+    sv = mo.SVGPOracle(dd["inducing_points"][tp], dd["N_train"][tp], kernel_type=cfg.get("kernel_type", "Gaussian"),
+                       scale=cfg.get("kernel_scale", 0.1))
+    tgt = torch.repeat_interleave(torch.arange(g.n), (g.rowptr[1:] - g.rowptr[:-1]).cpu().long())
+    ei = torch.stack([g.col.cpu().long(), tgt])
+    with torch.no_grad():
+        ref = mo.all_latent_samples(P, sv, torch.as_tensor(loc).cpu().double(), torch.as_tensor(Y).float().cpu().double(), ei,
+                                    cfg["gat_attention_heads"], cfg["z_dim"] // 2, mean_only=True).numpy()
+    got = lat.double().cpu().numpy()
+    rel = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
+    rel_s = float(np.linalg.norm(got[:, :10] - ref[:, :10]) / np.linalg.norm(ref[:, :10]))
+    rel_g = float(np.linalg.norm(got[:, 10:] - ref[:, 10:]) / np.linalg.norm(ref[:, 10:]))
+    print(json.dumps({"dtype": dtype, "latent_rel_l2": rel, "svgp_half": rel_s, "gat_half": rel_g}))
+    _report(f"inference_full_{dtype}", {"dtype": dtype, "latent_rel_l2": rel, "svgp_half": rel_s, "gat_half": rel_g})
+    assert rel <= (3e-3 if dtype == "bf16" else 1e-5), (rel, rel_s, rel_g)
+    # K-means assignment from given centres (the ones the setup's refit left behind)
+    cen = np.asarray(model.kmeans_center_dict[tp], dtype=np.float64)
+    lab_dev = ops.kmeans_assign(lat.double(), torch.as_tensor(cen, device=DEV)).cpu().numpy()
+    d_got = np.zeros((got.shape[0], cen.shape[0]))
+    for k in range(got.shape[1]):                                   # the kernel's order: dimensions ascending, fp64
+        d_got += (got[:, None, k] - cen[None, :, k]) ** 2
+    assert np.array_equal(lab_dev, d_got.argmin(1).astype(lab_dev.dtype))
+    lab_ref = ((ref[:, None, :] - cen[None]) ** 2).sum(-1).argmin(1)
+    frac = float((lab_dev != lab_ref).mean())
+    print(json.dumps({"label_mismatch_fraction_vs_oracle_latent": frac}))
+    assert frac <= (1e-2 if dtype == "bf16" else 1e-4), frac
