@@ -133,22 +133,16 @@ __global__ __launch_bounds__(NT) void k_tail_wvec(const float *__restrict__ W, i
 
 __global__ __launch_bounds__(NT) void k_tail_wvec_fin(const float *__restrict__ part, int S, int total, float *__restrict__ wv,
                                                       __bf16 *__restrict__ whi, __bf16 *__restrict__ wlo) {
-    const int t = ((int)blockIdx.x * NT + (int)threadIdx.x) * 4;
+    const int t = (int)blockIdx.x * NT + (int)threadIdx.x;          // one output per thread: total / 256 workgroups
     if (t >= total) return;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s = 0; s < S; s++) {
-        const float4 v = *reinterpret_cast<const float4 *>(part + (size_t)s * total + t);
-        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-    }
-    *reinterpret_cast<float4 *>(wv + t) = acc;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int s = 0; s < S; s++) acc += part[(size_t)s * total + t];
+    wv[t] = acc;
     if (whi != nullptr) {        // w = hi + lo in bf16 (16 significant bits) for the matrix-core logits kernel
-        const float a[4] = {acc.x, acc.y, acc.z, acc.w};
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            const __bf16 h = (__bf16)a[e];
-            whi[t + e] = h;
-            wlo[t + e] = (__bf16)(a[e] - (float)h);
-        }
+        const __bf16 h = (__bf16)acc;
+        whi[t] = h;
+        wlo[t] = (__bf16)(acc - (float)h);
     }
 }
 
@@ -708,7 +702,7 @@ int spadot_gat_tail_wvec(const float *W, int ldw, const float *att_src, const fl
     hipLaunchKernelGGL(k_tail_wvec, dim3((unsigned)((K / 4 + NT - 1) / NT), (unsigned)H, (unsigned)slices), dim3(NT), 0, st, W, ldw,
                        att_src, att_dst, H, C, K, slices, part);
     const int total = 2 * H * K;
-    hipLaunchKernelGGL(k_tail_wvec_fin, dim3((unsigned)((total / 4 + NT - 1) / NT)), dim3(NT), 0, st, part, slices, total, wv, (__bf16 *)whi,
+    hipLaunchKernelGGL(k_tail_wvec_fin, dim3((unsigned)((total + NT - 1) / NT)), dim3(NT), 0, st, part, slices, total, wv, (__bf16 *)whi,
                        (__bf16 *)wlo);
     return rc_last();
 }

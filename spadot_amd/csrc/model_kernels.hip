@@ -1415,6 +1415,7 @@ __global__ __launch_bounds__(256) void k_adamw_img(float *__restrict__ p, const 
 // Small-MLP stages: BatchNorm1d (training) + LeakyReLU, LayerNorm + LeakyReLU, each ONE launch forward and one
 // (LayerNorm: two) backward instead of the library's 4-5 and 3-4.  b rows <= a few thousand, F features <= 1024.
 // ------------------------------------------------------------------------------------------
+constexpr int BN_RPT = 32;                                           // rows a thread keeps in registers on the one-load path
 constexpr int BN_COLS = 16, BN_RG = 16, BN_NT = BN_COLS * BN_RG;      // 16 columns x 16 row lanes: 256-thread workgroups.  These
 // launches run on the side stream beside the GAT branch's GEMMs, whose waves fill the register files: a new workgroup
 // starts when a GEMM workgroup retires, and a 1024-thread one (64 row lanes, 30 % faster on an idle GPU) needs a whole
@@ -1447,6 +1448,47 @@ __global__ __launch_bounds__(BN_NT) void k_bn_act_fwd(const TX *__restrict__ x, 
     const int c = blockIdx.x * BN_COLS + cl;
     const bool on = c < F;
     const float add = (on && lb) ? lb[c] : 0.f;
+    if (b <= BN_RG * BN_RPT) {
+        // up to 512 rows (the training batch): a thread's 32 rows are loaded ONCE, all loads in flight together, and the three
+        // passes run out of registers -- the looped form below pays ~24 dependent memory latencies (18-33 us for 0.1-0.5 MB
+        // beside the GAT branch's GEMM, at the head of the step's forward critical chain; rocprofv3 timeline, round 4).
+        // Same values, same summation order: bit-identical to the looped form.
+        float v[BN_RPT];
+#pragma unroll
+        for (int r = 0; r < BN_RPT; r++) {
+            const int i = rg + r * BN_RG;
+            v[r] = (on && i < b) ? ld<TX>(x + (size_t)i * F + c) + add : 0.f;
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < BN_RPT; r++)
+            if (rg + r * BN_RG < b) s += v[r];
+        const float mean = bn_col_sum(s, sh, cl, rg) / (float)b;
+        float ss = 0.f;
+#pragma unroll
+        for (int r = 0; r < BN_RPT; r++)
+            if (rg + r * BN_RG < b) { const float d = v[r] - mean; ss += d * d; }
+        const float var = bn_col_sum(ss, sh, cl, rg) / (float)b;
+        const float invstd = rsqrtf(var + eps);
+        if (on) {
+            const float g = gamma[c] * invstd, o = beta[c];
+#pragma unroll
+            for (int r = 0; r < BN_RPT; r++) {
+                const int i = rg + r * BN_RG;
+                if (i < b) {
+                    const float u = (v[r] - mean) * g + o;
+                    y[(size_t)i * F + c] = u > 0.f ? u : slope * u;
+                }
+            }
+            if (rg == 0) {
+                save_mean[c] = mean; save_invstd[c] = invstd;
+                run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean;
+                run_var[c] = (1.f - momentum) * run_var[c] + momentum * var * ((float)b / (float)(b > 1 ? b - 1 : 1));
+            }
+        }
+        if (nbt && blockIdx.x == 0 && threadIdx.x == 0) nbt[0] += 1;
+        return;
+    }
     float s = 0.f;
     if (on)
 #pragma unroll 4
@@ -1487,6 +1529,34 @@ __global__ __launch_bounds__(BN_NT) void k_bn_act_bwd(const float *__restrict__ 
     const bool on = c < F;
     const float add = (on && lb) ? lb[c] : 0.f;
     const float mean = on ? save_mean[c] : 0.f, invstd = on ? save_invstd[c] : 0.f;
+    if (b <= BN_RG * BN_RPT) {          // one load of the thread's rows, both passes out of registers (see k_bn_act_fwd)
+        float dzv[BN_RPT], xh[BN_RPT];
+#pragma unroll
+        for (int r = 0; r < BN_RPT; r++) {
+            const int i = rg + r * BN_RG;
+            const bool in = on && i < b;
+            const size_t e = (size_t)(in ? i : 0) * F + (in ? c : 0);
+            const float dyv = in ? dy[e] : 0.f, yv = in ? y[e] : 0.f, xv = in ? ld<TX>(x + e) : 0.f;
+            dzv[r] = dyv * (yv > 0.f ? 1.f : slope);
+            xh[r] = (xv + add - mean) * invstd;
+        }
+        float sb = 0.f, sg = 0.f;
+#pragma unroll
+        for (int r = 0; r < BN_RPT; r++)
+            if (on && rg + r * BN_RG < b) { sb += dzv[r]; sg += dzv[r] * xh[r]; }
+        sb = bn_col_sum(sb, sh, cl, rg);
+        sg = bn_col_sum(sg, sh, cl, rg);
+        if (on) {
+            const float g = gamma[c] * invstd, mb = sb / (float)b, mg = sg / (float)b;
+#pragma unroll
+            for (int r = 0; r < BN_RPT; r++) {
+                const int i = rg + r * BN_RG;
+                if (i < b) st<TX>(dx + (size_t)i * F + c, g * (dzv[r] - mb - xh[r] * mg));
+            }
+            if (rg == 0) { dgamma[c] = sg; dbeta[c] = sb; }
+        }
+        return;
+    }
     float sb = 0.f, sg = 0.f;
     if (on)
 #pragma unroll 4

@@ -678,7 +678,9 @@ def _small_weight_grad(g, x):
     return g.t() @ x
 
 
-SGEMM_SLICES = [__import__("os").environ.get("SPADOT_SGEMM_SLICES", "1") == "1"]    # [False]: the library for the MLP stages' forward maps
+# Measured in the step (round 4, same box, tools/ab_step.sh): the sliced kernel took 65 + 8 us where the library takes 47-57 us beside
+# the GAT branch's first GEMM -- 16 dependent contraction steps per workgroup, each a memory latency under contention.  Off by default.
+SGEMM_SLICES = [__import__("os").environ.get("SPADOT_SGEMM_SLICES", "0") == "1"]    # [True]: the sliced kernel for the first map's forward
 
 
 def sgemm_nt_slices_ok(x, W):
@@ -702,7 +704,10 @@ def sgemm_nt_slices(x, W, bias=None, slices=None):
     return out
 
 
-DGEMM_SMALL = [__import__("os").environ.get("SPADOT_DGEMM_SMALL", "1") == "1"]     # [False]: the library for the SVGP branch's fp64 products
+# Measured in the step (round 4, same box): 554 steps/s with the own fp64 kernel under all nine products against 594 with the
+# library -- one prefetch stage and two barriers per 32-wide contraction step make it latency-bound beside the GAT GEMMs
+# (G_l: 52 us against 27-35, D_l: 255 us against 58 + 95).  Kept for its tests and as the base of a deeper pipeline; off by default.
+DGEMM_SMALL = [__import__("os").environ.get("SPADOT_DGEMM_SMALL", "0") == "1"]     # [True]: csrc/gemm_f64.hip under the SVGP branch's fp64 products
 
 
 def _mat3(t):
