@@ -110,16 +110,11 @@ class _SVGPCore(torch.autograd.Function):
                     t = dgemm_small(2, muw, Kn)                              # [L, m]
                 else:
                     torch.baddbmm(G, A.transpose(1, 2), Kn.unsqueeze(0).expand(L, b, m), beta=0.0, alpha=c, out=G)
-                    t = None
+                    t = muw.T @ Kn                                           # [L, m]
                 X = torch.empty((2 * L, m, m), dtype=F64, device=z.device)
                 ld = torch.empty(2 * L, dtype=F64, device=z.device)
                 _check(lib.spadot_spd_inverse_logdet2(_p(G), L, 2 * L, m, _p(rc.KjI), _p(rc.K2j), _p(X), _p(ld), _stream()),
                        "spadot_spd_inverse_logdet2")
-                if t is None:
-                    # t = (mu w)^T K_nm is read only behind the inverse: issued AFTER the sweep launch, it no longer sits in
-                    # front of the branch's long pole (13-32 us for 2.4 MFLOP on one or two workgroups; timeline, round 4) --
-                    # it runs beside the sweep's 2 L workgroups instead
-                    t = muw.T @ Kn                                           # [L, m]
                 return mu, var, w, X, ld, t
             _check(lib.spadot_svgp_pre(_p(z), b, L, _p(mu), _p(var), _p(w), _p(muw), _stream()), "spadot_svgp_pre")
             A = Kn.unsqueeze(0) * w.T.unsqueeze(2)                           # [L, b, m] = diag(w_l) K_nm
