@@ -12,6 +12,7 @@
 #include <cstdint>
 
 #include "../../include/spadot_model.h"
+#include "per_device.h"
 
 namespace {
 
@@ -81,6 +82,77 @@ __global__ __launch_bounds__(256) void k_sgemm_nt_slices(const float *__restrict
     }
 }
 
+// The same tile with its WHOLE slice of the contraction (<= 256 columns) staged in LDS at once: every global load of the
+// workgroup is issued before the first is consumed -- one memory latency per workgroup instead of one per 16-column step.
+// Under the GAT branch's GEMM a dependent load costs 3-5 us; the stepped form above pays 16 of them per workgroup (65 us for
+// the first map against the library's 47-57), this one pays one.  LDS: 2 x 256 x 68 floats = 136 KB (dynamic), k-major.
+// Load mapping: thread t takes rows (t & 15) + 16 (u & 3) and the float4 at k = 4 ((t >> 4) + 16 (u >> 2)), u < 16: the 64
+// lanes of a wave store 16 rows x 4 k-groups whose banks (4 k + row) mod 64 are all different (conflict-free transpose).
+constexpr int OS_KMAX = 256;
+__global__ __launch_bounds__(256) void k_sgemm_nt_oneshot(const float *__restrict__ A, int lda, const float *__restrict__ B, int ldb,
+                                                          float *__restrict__ part, int M, int N, int K, int kslice, int vec_ok,
+                                                          const float *__restrict__ bias, int direct_ld) {
+    extern __shared__ float os_lds[];
+    float (*As)[PITCH] = reinterpret_cast<float (*)[PITCH]>(os_lds);
+    float (*Bs)[PITCH] = reinterpret_cast<float (*)[PITCH]>(os_lds + OS_KMAX * PITCH);
+    const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN, z = blockIdx.z;
+    const int kbeg = z * kslice, kend = min(K, kbeg + kslice), kn = kend - kbeg;
+    const int r16 = t & 15, kq = t >> 4;
+    float4 va[16], vb[16];
+    // (K % 4 == 0 and 16-byte aligned rows are this kernel's conditions: a float4 unit is then wholly inside or wholly outside
+    // the slice.  Units outside are loaded from a clamped address and zeroed by a select: no branch between the 32 loads.)
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+        const int row = r16 + 16 * (u & 3), k = 4 * (kq + 16 * (u >> 2));
+        const bool ka = k < kn;
+        const int kc = kbeg + (ka ? k : 0);
+        const float4 a = *reinterpret_cast<const float4 *>(A + (size_t)min(m0 + row, M - 1) * lda + kc);
+        const float4 b = *reinterpret_cast<const float4 *>(B + (size_t)min(n0 + row, N - 1) * ldb + kc);
+        const bool oa = ka && m0 + row < M, ob = ka && n0 + row < N;
+        va[u] = make_float4(oa ? a.x : 0.f, oa ? a.y : 0.f, oa ? a.z : 0.f, oa ? a.w : 0.f);
+        vb[u] = make_float4(ob ? b.x : 0.f, ob ? b.y : 0.f, ob ? b.z : 0.f, ob ? b.w : 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+        const int row = r16 + 16 * (u & 3), k = 4 * (kq + 16 * (u >> 2));
+        if (k < kn) {
+            As[k][row] = va[u].x; As[k + 1][row] = va[u].y; As[k + 2][row] = va[u].z; As[k + 3][row] = va[u].w;
+            Bs[k][row] = vb[u].x; Bs[k + 1][row] = vb[u].y; Bs[k + 2][row] = vb[u].z; Bs[k + 3][row] = vb[u].w;
+        }
+    }
+    __syncthreads();
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = 0.f;
+    const int kr = (kn + 3) & ~3;                                 // (the slab is zero past kend up to the next multiple of 4)
+#pragma unroll 8
+    for (int k = 0; k < kr; k++) {
+        const float4 a = *reinterpret_cast<const float4 *>(&As[k][4 * ty]);
+        const float4 b = *reinterpret_cast<const float4 *>(&Bs[k][4 * tx]);
+        const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+    }
+    // one slice: straight to the result (row pitch direct_ld, + bias); several: this slice's partial
+    float *C = direct_ld ? part : part + (size_t)z * M * N;
+    const int ldc = direct_ld ? direct_ld : N;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int m = m0 + 4 * ty + i;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int n = n0 + 4 * tx + j;
+            if (n < N) C[(size_t)m * ldc + n] = acc[i][j] + ((direct_ld && bias) ? bias[n] : 0.f);
+        }
+    }
+}
+
 // out[m][n] = sum_z part[z][m][n] (+ bias[n]), slices in ascending order
 __global__ __launch_bounds__(256) void k_slices_sum(const float *__restrict__ part, int slices, int M, int N, const float *__restrict__ bias,
                                                     float *__restrict__ out, int ldo) {
@@ -101,14 +173,31 @@ extern "C" long long spadot_sgemm_nt_slices_workspace(int M, int N, int slices) 
 
 extern "C" int spadot_sgemm_nt_slices(const float *A, int lda, const float *B, int ldb, float *out, int ldo, const float *bias, int M, int N,
                                       int K, int slices, float *workspace, void *stream) {
-    if (!A || !B || !out || !workspace || M <= 0 || N <= 0 || K <= 0 || slices < 1 || slices > 256 || lda < K || ldb < K || ldo < N) return -22;
+    if (!A || !B || !out || M <= 0 || N <= 0 || K <= 0 || slices < 1 || slices > 256 || lda < K || ldb < K || ldo < N) return -22;
     int kslice = ((K + slices - 1) / slices + 3) / 4 * 4;           // slice starts on 16-byte boundaries
     const int used = (K + kslice - 1) / kslice;                       // (rounding can leave fewer slices than asked for)
+    if (used > 1 && !workspace) return -22;
     const int vec_ok = (lda % 4 == 0 && ldb % 4 == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0) ? 1 : 0;
     const dim3 grid((unsigned)((N + TN - 1) / TN), (unsigned)((M + TM - 1) / TM), (unsigned)used);
     if (grid.y > 65535u) return -22;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_sgemm_nt_slices, grid, dim3(256), 0, st, A, lda, B, ldb, workspace, M, N, K, kslice, vec_ok);
+    if (kslice <= OS_KMAX && vec_ok && K % 4 == 0) {                  // a whole slice fits the one-shot tile
+        constexpr int LDS_BYTES = 2 * OS_KMAX * PITCH * (int)sizeof(float);
+        static PerDeviceFlag attr_set;
+        if (!attr_set) {
+            if (hipFuncSetAttribute((const void *)k_sgemm_nt_oneshot, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return -5;
+            attr_set = true;
+        }
+        if (used == 1) {
+            hipLaunchKernelGGL(k_sgemm_nt_oneshot, grid, dim3(256), LDS_BYTES, st, A, lda, B, ldb, out, M, N, K, kslice, vec_ok, bias, ldo);
+            return hipGetLastError() == hipSuccess ? 0 : -5;
+        }
+        hipLaunchKernelGGL(k_sgemm_nt_oneshot, grid, dim3(256), LDS_BYTES, st, A, lda, B, ldb, workspace, M, N, K, kslice, vec_ok,
+                           (const float *)nullptr, 0);
+    } else {
+        if (!workspace) return -22;
+        hipLaunchKernelGGL(k_sgemm_nt_slices, grid, dim3(256), 0, st, A, lda, B, ldb, workspace, M, N, K, kslice, vec_ok);
+    }
     const size_t tot = (size_t)M * N;
     hipLaunchKernelGGL(k_slices_sum, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, workspace, used, M, N, bias, out, ldo);
     return hipGetLastError() == hipSuccess ? 0 : -5;

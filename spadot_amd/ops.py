@@ -678,9 +678,12 @@ def _small_weight_grad(g, x):
     return g.t() @ x
 
 
-# Measured in the step (round 4, same box, tools/ab_step.sh): the sliced kernel took 65 + 8 us where the library takes 47-57 us beside
-# the GAT branch's first GEMM -- 16 dependent contraction steps per workgroup, each a memory latency under contention.  Off by default.
-SGEMM_SLICES = [__import__("os").environ.get("SPADOT_SGEMM_SLICES", "0") == "1"]    # [True]: the sliced kernel for the first map's forward
+# The MLP stages' forward maps y = x W^T on csrc/gemm_f32.hip.  History (round 4, same box, tools/ab_step.sh): the first, stepped
+# form (16 dependent contraction steps per workgroup) took 65 + 8 us for the first map where the library takes 47-57 us beside
+# the GAT branch's first GEMM; the one-shot form (the whole slice of the contraction staged in LDS by loads that are all in
+# flight together) is what these switches select now.
+SGEMM_SLICES = [__import__("os").environ.get("SPADOT_SGEMM_SLICES", "1") == "1"]    # [False]: the library for the first map's forward
+HIDDEN_SLICES = [__import__("os").environ.get("SPADOT_HIDDEN_SLICES", "1") == "1"]  # the hidden map's forward and SVGP_fc on it too
 
 
 def sgemm_nt_slices_ok(x, W):
@@ -693,11 +696,11 @@ def sgemm_nt_slices(x, W, bias=None, slices=None):
     spadot_sgemm_nt_slices): a short output over a long contraction as many small workgroups instead of one round of
     library tiles walking all of K."""
     M, (N, K) = x.shape[0], W.shape
-    if slices is None:          # enough slices for ~1.5 rounds of the chip's 256 compute units, at least 128 columns each
-        tiles = ((M + 63) // 64) * ((N + 63) // 64)
-        slices = max(1, min(K // 128 if K >= 256 else 1, (384 + tiles - 1) // tiles, 64))
+    if slices is None:          # one slice up to 256 columns (one launch, no partials); beyond: slices of <= 256 columns, enough of
+        tiles = ((M + 63) // 64) * ((N + 63) // 64)         # them for ~1.5 rounds of the chip's 256 compute units
+        slices = 1 if K <= 256 else max((K + 251) // 252, min((384 + tiles - 1) // tiles, 64))
     lib = model_lib()
-    ws = torch.empty(int(lib.spadot_sgemm_nt_slices_workspace(M, N, slices)), dtype=torch.float32, device=x.device)
+    ws = torch.empty(int(lib.spadot_sgemm_nt_slices_workspace(M, N, slices)), dtype=torch.float32, device=x.device) if slices > 1 else None
     out = torch.empty((M, N), dtype=torch.float32, device=x.device)
     _check(lib.spadot_sgemm_nt_slices(_p(x), x.stride(0), _p(W), K, _p(out), N, _p(bias) if bias is not None else None, M, N, K, slices,
                                       _p(ws), _stream()), "spadot_sgemm_nt_slices")
@@ -799,9 +802,6 @@ def wgrad_small(g, x, slices=8):
 _SMALL_WORK = 1 << 27        # multiply-adds up to which a product counts as small (0.27 GFLOP)
 
 
-HIDDEN_SLICES = [__import__("os").environ.get("SPADOT_HIDDEN_SLICES", "0") == "1"]   # the hidden map's forward on the sliced kernel too (A/B)
-
-
 class _HiddenMap(torch.autograd.Function):
     """h W^T for a small hidden -> hidden map of the SVGP encoder (b x 256 -> 64 at the default sizes; fp32, no bias: the next
     BatchNorm kernel folds it in).  The forward is the library's product as before; BOTH gradients go through k_sgemm_small
@@ -845,6 +845,8 @@ class _LinearBias(torch.autograd.Function):
         ctx.cd = cd
         if cd is None or cd == torch.float32:
             ctx.save_for_backward(x, W)
+            if HIDDEN_SLICES[0] and W.shape[1] <= 256 and sgemm_nt_slices_ok(x, W) and b.dtype == torch.float32:
+                return sgemm_nt_slices(x, W.detach(), b.detach().contiguous())        # (SVGP_fc: 512 x 64 -> 20, one small launch)
             return torch.addmm(b, x, W.t())
         # compute-dtype operands, fp32 accumulate AND fp32 result (no rounding of the output to the compute dtype,
         # no cast launch after the GEMM); the images are kept for the backward pass.  Small dependent launches cost
