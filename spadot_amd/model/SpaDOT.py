@@ -117,6 +117,21 @@ class SpaDOT(nn.Module):
         bc = svgp.batch_constants(x[:b], key=batch_key)
         return svgp.elbo_finish(bc, svgp.elbo_start(bc, z_enc))
 
+    def branch_svgp_head(self, x, y, tp, batch_size, batch_key=None, y_seed32=None):
+        """First part of branch_svgp: encoder, batch constants and everything of the ELBO in front of the batched inverse
+        (the branch's ~8 short launches).  Returns the state branch_svgp_rest() continues from."""
+        b = batch_size
+        svgp = self.svgp_dict[str(tp)]
+        z_enc = self.SVGPEncoder.pre_head(y_seed32 if y_seed32 is not None else y[:b],
+                                          x_bf16=y[:b] if (y_seed32 is not None and y.dtype == torch.bfloat16) else None)
+        bc = svgp.batch_constants(x[:b], key=batch_key)
+        return svgp, bc, z_enc, svgp.elbo_start_pre(bc, z_enc)
+
+    def branch_svgp_rest(self, state):
+        svgp, bc, z_enc, pre = state
+        started = svgp.elbo_start_sweep(bc, pre) if pre is not None else svgp.elbo_start(bc, z_enc)
+        return svgp.elbo_finish(bc, started)
+
     def tail(self, zg, p_m, p_v, y, batch_size, noise=None, y_seed32=None):
         """Latent head + decoder + reconstruction: (recon, GAT_KL, alignment, final_latent).  y_seed32: the seeds' rows
         of y already in fp32 (cached batches keep them: no cast launch per step)."""

@@ -84,10 +84,22 @@ class _SVGPCore(torch.autograd.Function):
         dw = c diag(K_nm dSigma K_mn) + mu (K_nm dt),   dmu = w (K_nm dt),   dvar = -dw w^2  (+ the direct terms)."""
 
     @staticmethod
-    def start(z, bc, rc):
+    def start(z, bc, rc, stop_before_sweep=False):
         """First half of forward, from z = (mu | logvar) [b, 2L] fp32: Sigma_l for every latent dim, the sweep launch
         (the long pole of the branch, ~0.2 ms on 2L compute units) and t.  Separate so that the caller can issue
-        it early."""
+        it early.  stop_before_sweep: everything in front of the sweep launch only; finish_start() launches the sweep
+        (GraphedStepper's `svgp_head_first`: the short launches of this half as a graph of their own, in front of the GAT
+        branch's first GEMM instead of beside it)."""
+        if isinstance(z, dict):                    # the state a stop_before_sweep call returned: launch the sweep now
+            st = z
+            lib = model_lib()
+            with torch.no_grad():
+                m, L = rc.m, st["L"]
+                X = torch.empty((2 * L, m, m), dtype=F64, device=st["G"].device)
+                ld = torch.empty(2 * L, dtype=F64, device=st["G"].device)
+                _check(lib.spadot_spd_inverse_logdet2(_p(st["G"]), L, 2 * L, m, _p(rc.KjI), _p(rc.K2j), _p(X), _p(ld), _stream()),
+                       "spadot_spd_inverse_logdet2")
+            return st["mu"], st["var"], st["w"], X, ld, st["t"]
         with torch.no_grad():
             z = z.contiguous().float()
             b, L = z.shape[0], z.shape[1] // 2
@@ -114,6 +126,8 @@ class _SVGPCore(torch.autograd.Function):
                     # the inverse: timeline, round 4) -- one small launch of its own
                     t = torch.empty((L, m), dtype=F64, device=z.device)
                     _check(lib.spadot_svgp_tvec(_p(z), _p(Kn), b, L, m, _p(t), _stream()), "spadot_svgp_tvec")
+                if stop_before_sweep:
+                    return dict(mu=mu, var=var, w=w, G=G, t=t, L=L)
                 X = torch.empty((2 * L, m, m), dtype=F64, device=z.device)
                 ld = torch.empty(2 * L, dtype=F64, device=z.device)
                 _check(lib.spadot_spd_inverse_logdet2(_p(G), L, 2 * L, m, _p(rc.KjI), _p(rc.K2j), _p(X), _p(ld), _stream()),
@@ -309,6 +323,17 @@ class SVGP(nn.Module):
         """z = SVGP_fc output (mu | logvar) [b, 2L].  Builds Sigma_l and launches the batched inverse; elbo_finish()
         does the rest.  Two calls so that the composite model can issue the GAT kernels in between."""
         return z, _SVGPCore.start(z.detach(), bc, self._rc())
+
+    def elbo_start_pre(self, bc, z):
+        """elbo_start() up to, not including, the sweep launch (None when this shape takes the split inverse: then nothing is
+        deferred); elbo_start_sweep() completes it."""
+        if self._rc().m > SWEEP_DIRECT_M:
+            return None
+        return z, _SVGPCore.start(z.detach(), bc, self._rc(), stop_before_sweep=True)
+
+    def elbo_start_sweep(self, bc, pre):
+        z, st = pre
+        return z, _SVGPCore.start(st, bc, self._rc())
 
     def _finish(self, bc, started):
         z, pre = started

@@ -470,6 +470,14 @@ class GraphedStepper:
         # update in two graphs around an event (see update(), chained()); needs FlatAdamW(first=...)
         self.split_update = bool(model_config.get("split_update", os.environ.get("SPADOT_SPLIT_UPDATE", "1") == "1"))
         self._head_event, self._head_ready, self._chain = None, False, False
+        # svgp_head_first (round 4): the SVGP branch's ~8 short launches in front of its inverse (encoder, Sigma build) run
+        # 180-240 us beside the GAT branch's first GEMM -- each of them waits for a compute-unit slot that a GEMM workgroup
+        # vacates (timeline) -- against ~100 us alone, and the inverse behind them ends the forward pair ~100 us after the GAT
+        # branch (stage stamps).  With this switch they are a graph of their own and the GAT branch's graph is launched behind
+        # them (the main stream waits for an event recorded between the two SVGP graphs): the GAT branch starts later, the
+        # inverse much earlier.
+        self.svgp_head_first = bool(self.staged and model_config.get("svgp_head_first", os.environ.get("SPADOT_SVGP_HEAD", "0") == "1"))
+        self._enc_event = None
         self.stamps = (torch.zeros(32, dtype=torch.int64, device=next(model.parameters()).device)
                        if os.environ.get("SPADOT_STAMPS") == "1" else None)
         # the model knows its steppers (weakly): its public entries that touch the encoder between steps break the chain
@@ -536,14 +544,14 @@ class GraphedStepper:
                     from ..ops import stamp
 
                     def head():
-                        stamp(self.stamps, 12)
+                        stamp(self.stamps, 24)
                         self.opt.step_head()
-                        stamp(self.stamps, 13)
+                        stamp(self.stamps, 25)
 
                     def rest():
-                        stamp(self.stamps, 14)
+                        stamp(self.stamps, 26)
                         self.opt.step_rest()
-                        stamp(self.stamps, 15)
+                        stamp(self.stamps, 27)
                 ga, _ = self._capture(head)
                 gb, _ = self._capture(rest)
                 self.opt_graph = (ga, gb)
@@ -630,6 +638,15 @@ class GraphedStepper:
             st["pm"], st["pv"], st["skl"] = model.branch_svgp(st["xs"], st["ys"], tp, b, batch_key=(tp, bi),
                                                               y_seed32=getattr(batch, "y_seed32", None) if cached else None)
 
+        def svgp_fwd_head():
+            st["xs"] = batch.x[:b] if cached else loc[seeds]
+            st["ys"] = batch.y[:b] if cached else Y[seeds]
+            st["svgp_state"] = model.branch_svgp_head(st["xs"], st["ys"], tp, b, batch_key=(tp, bi),
+                                                      y_seed32=getattr(batch, "y_seed32", None) if cached else None)
+
+        def svgp_fwd_rest():
+            st["pm"], st["pv"], st["skl"] = model.branch_svgp_rest(st["svgp_state"])
+
         def tail():
             leaves = [st[k].detach().requires_grad_(True) for k in ("zg", "pm", "pv", "skl")]
             recon, gkl, align, z = model.tail(leaves[0], leaves[1], leaves[2], st["ys"], b,
@@ -666,6 +683,9 @@ class GraphedStepper:
             fns = (gat_fwd, svgp_fwd, tail, svgp_bwd, gat_bwd_top, gat_bwd_rest)
         else:
             fns = (gat_fwd, svgp_fwd, tail, svgp_bwd, gat_bwd)
+        if self.svgp_head_first:
+            # a SEVENTH stage: the SVGP branch's short launches in front of its inverse as a graph of their own (see __init__)
+            fns = fns + (svgp_fwd_head, svgp_fwd_rest)
         if self.stamps is not None:
             # measurement aid (SPADOT_STAMPS=1): a device timestamp at the head and the end of every stage graph
             # (slots 2 k, 2 k + 1), read back by tools/stage_stamps.py -- when each stage really starts with no profiler attached
@@ -717,7 +737,25 @@ class GraphedStepper:
             else:
                 side.wait_stream(main)
             self._head_ready = False
-        if self.issue_order[0] == "m" and two_streams:
+        head_first = self.svgp_head_first and len(fns) >= 7
+        if head_first:
+            head, rest = fns[-2], fns[-1]
+            fns = fns[:-2]
+            if two_streams:
+                if self._enc_event is None:
+                    self._enc_event = torch.cuda.Event()
+                with torch.cuda.stream(side):
+                    head()
+                    self._enc_event.record(side)
+                main.wait_event(self._enc_event)
+                fns[0]()
+                with torch.cuda.stream(side):
+                    rest()
+            else:
+                head()
+                rest()
+                fns[0]()
+        elif self.issue_order[0] == "m" and two_streams:
             fns[0]()
             with torch.cuda.stream(side):
                 fns[1]()
@@ -773,7 +811,7 @@ class GraphedStepper:
         key = (tp, bi, epoch >= 1, epoch >= self.cfg["ot_epoch"] and tp_i != 0, "staged")
         if key in self.graphs:
             graphs, out = self.graphs[key]
-            self._issue_staged([g.replay for g in graphs])
+            self._issue_staged([(g.replay if g is not None else None) for g in graphs])
             res = out.clone() if self.clone_output else out
         elif key not in self.seen:                                          # warm-up visit: eager, same stages
             self.seen.add(key)
@@ -785,16 +823,21 @@ class GraphedStepper:
             torch.cuda.synchronize()
             graphs = []
             out = None
+            nf = len(fns)
             for k, fn in enumerate(fns):
+                if self.svgp_head_first and k == 1:
+                    graphs.append(None)                                      # (replaced by the two graphs at the end of the list)
+                    continue
                 g = torch.cuda.CUDAGraph()
-                pool = self.pool_side if k in (1, 3) else self.pool          # the SVGP stages run beside the GAT ones
+                side_stage = k in (1, 3) or (self.svgp_head_first and k >= nf - 2)
+                pool = self.pool_side if side_stage else self.pool           # the SVGP stages run beside the GAT ones
                 with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
                     r = fn()
                 if k == 2:
                     out = r
                 graphs.append(g)
             self.graphs[key] = (graphs, out)
-            self._issue_staged([g.replay for g in graphs])
+            self._issue_staged([(g.replay if g is not None else None) for g in graphs])
             res = out.clone() if self.clone_output else out
         if with_update:
             self.update()

@@ -22,7 +22,7 @@ from spadot_amd.ops import FlatAdamW  # noqa: E402
 from spadot_amd.synthetic import make_dataset  # noqa: E402
 from spadot_amd.utils import _train_utils as tu, _utils  # noqa: E402
 
-NAMES = ["gat_fwd", "svgp_fwd", "tail", "svgp_bwd", "gat_bwd", "gat_bwd_2", "upd_head", "upd_rest"]
+NAMES = {0: "gat_fwd", 1: "svgp_fwd", 2: "tail", 3: "svgp_bwd", 4: "gat_bwd", 5: "stage5", 6: "stage6", 7: "stage7", 12: "upd_head", 13: "upd_rest"}
 
 
 def main():
@@ -65,13 +65,18 @@ def main():
     rel = a - t0
     med = np.median(rel, axis=0)
     print(f"median over {len(rows)} replayed steps (us, relative to the start of the GAT forward graph):")
-    for k, name in enumerate(NAMES):
+    head_first = os.environ.get("SPADOT_SVGP_HEAD") == "1"
+    if head_first:
+        NAMES[5], NAMES[6] = "svgp_head", "svgp_rest"
+    for k, name in sorted(NAMES.items()):
         s, e = med[2 * k], med[2 * k + 1]
         if a[:, 2 * k].max() == 0:
             continue
         print(f"  {name:10s} start {s:9.1f}  end {e:9.1f}  ({e - s:7.1f})")
+    sv_start, sv_end = (med[12], med[13]) if head_first else (med[2], med[3])          # the SVGP forward's last graph
     print(f"  svgp_bwd starts {med[6] - med[5]:.1f} us after the tail ends; gat_bwd starts {med[8] - med[5]:.1f} us after the tail ends")
-    print(f"  svgp_fwd ends {med[3] - med[1]:+.1f} us relative to gat_fwd's end; svgp_bwd ends {med[7] - med[9]:+.1f} us relative to gat_bwd's end")
+    print(f"  svgp_fwd ends {sv_end - med[1]:+.1f} us relative to gat_fwd's end; svgp_bwd ends {med[7] - med[9]:+.1f} us relative to gat_bwd's end")
+    print(f"  step period (upd_rest end of this step - upd_rest end of the previous one is not stamped): gat_fwd start -> upd_rest end {med[27]:.1f} us")
 
 
 if __name__ == "__main__":
