@@ -678,12 +678,15 @@ def _small_weight_grad(g, x):
     return g.t() @ x
 
 
-# The MLP stages' forward maps y = x W^T on csrc/gemm_f32.hip.  History (round 4, same box, tools/ab_step.sh): the first, stepped
-# form (16 dependent contraction steps per workgroup) took 65 + 8 us for the first map where the library takes 47-57 us beside
-# the GAT branch's first GEMM; the one-shot form (the whole slice of the contraction staged in LDS by loads that are all in
-# flight together) is what these switches select now.
-SGEMM_SLICES = [__import__("os").environ.get("SPADOT_SGEMM_SLICES", "1") == "1"]    # [False]: the library for the first map's forward
-HIDDEN_SLICES = [__import__("os").environ.get("SPADOT_HIDDEN_SLICES", "1") == "1"]  # the hidden map's forward and SVGP_fc on it too
+# The MLP stages' forward maps y = x W^T on csrc/gemm_f32.hip -- OFF by default: both forms lost to the library inside the
+# step (round 4, same-box A/B with tools/ab_step.sh).  The stepped form (16 dependent contraction steps per workgroup): 65 + 8 us
+# for the first map where the library takes 47-57 us beside the GAT branch's first GEMM.  The one-shot form (a workgroup's whole
+# slice staged in 136 KB of LDS by loads that are all in flight): neutral for the first map (564.8 against 566.8 steps/s) and
+# -6 % under the hidden map and SVGP_fc (532.6) -- a workgroup that needs most of a compute unit's LDS waits for a whole unit
+# to drain beside a GEMM, the same effect as the 1024-thread workgroups of DESIGN section 4.  What this branch needs is few
+# dependent steps AND a small footprint at once.
+SGEMM_SLICES = [__import__("os").environ.get("SPADOT_SGEMM_SLICES", "0") == "1"]    # [True]: csrc/gemm_f32.hip for the first map's forward
+HIDDEN_SLICES = [__import__("os").environ.get("SPADOT_HIDDEN_SLICES", "0") == "1"]  # ... and for the hidden map's forward and SVGP_fc
 
 
 def sgemm_nt_slices_ok(x, W):
@@ -700,7 +703,7 @@ def sgemm_nt_slices(x, W, bias=None, slices=None):
         tiles = ((M + 63) // 64) * ((N + 63) // 64)         # them for ~1.5 rounds of the chip's 256 compute units
         slices = 1 if K <= 256 else max((K + 251) // 252, min((384 + tiles - 1) // tiles, 64))
     lib = model_lib()
-    ws = torch.empty(int(lib.spadot_sgemm_nt_slices_workspace(M, N, slices)), dtype=torch.float32, device=x.device) if slices > 1 else None
+    ws = torch.empty(int(lib.spadot_sgemm_nt_slices_workspace(M, N, slices)), dtype=torch.float32, device=x.device)
     out = torch.empty((M, N), dtype=torch.float32, device=x.device)
     _check(lib.spadot_sgemm_nt_slices(_p(x), x.stride(0), _p(W), K, _p(out), N, _p(bias) if bias is not None else None, M, N, K, slices,
                                       _p(ws), _stream()), "spadot_sgemm_nt_slices")

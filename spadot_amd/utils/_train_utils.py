@@ -824,10 +824,14 @@ class GraphedStepper:
             graphs = []
             out = None
             nf = len(fns)
-            for k, fn in enumerate(fns):
-                if self.svgp_head_first and k == 1:
-                    graphs.append(None)                                      # (replaced by the two graphs at the end of the list)
-                    continue
+            graphs = [None] * nf
+            # capture order = data order: with svgp_head_first the SVGP forward is the two graphs at the END of the list (the
+            # one-graph form at index 1 is not captured), and they must exist before the tail reads their outputs
+            order = list(range(nf))
+            if self.svgp_head_first:
+                order = [0, nf - 2, nf - 1] + list(range(2, nf - 2))
+            for k in order:
+                fn = fns[k]
                 g = torch.cuda.CUDAGraph()
                 side_stage = k in (1, 3) or (self.svgp_head_first and k >= nf - 2)
                 pool = self.pool_side if side_stage else self.pool           # the SVGP stages run beside the GAT ones
@@ -835,7 +839,7 @@ class GraphedStepper:
                     r = fn()
                 if k == 2:
                     out = r
-                graphs.append(g)
+                graphs[k] = g
             self.graphs[key] = (graphs, out)
             self._issue_staged([(g.replay if g is not None else None) for g in graphs])
             res = out.clone() if self.clone_output else out
