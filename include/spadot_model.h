@@ -174,8 +174,6 @@ int spadot_svgp_pre(const float *z, int b, int L, double *mu, double *var, doubl
 /* ... and A[l, i, :] = K_nm[i, :] / var[i, l]  ([L, b, m] fp64) in the same launch */
 int spadot_svgp_pre2(const float *z, const double *Kn, int b, int L, int m, double *mu, double *var, double *w, double *muw,
                      double *A, void *stream);
-/* t [L, m] = (mu / var)^T K_nm straight from z (svgp.py:76: K_mn (y / noise) for every latent dimension), one small launch */
-int spadot_svgp_tvec(const float *z, const double *Kn, int b, int L, int m, double *t, void *stream);
 /* The small products behind the inverse for all L latent dimensions in two launches: r_l = S_l t_l, Mr_l = M r_l,
  * raw[:, l] = X2 r_l (X2 [rows2, m]) and sm_l = <S_l, M>; smpart: scratch of >= L * 4 * ceil(m / 4) doubles. */
 int spadot_svgp_mid(const double *S, const double *t, const double *M, const double *X2, int L, int m, int rows2,

@@ -216,7 +216,6 @@ def model_lib():
         "spadot_svgp_grad_tail": [vp] * 11 + [ci, ci, cd] + [vp] * 4,
         "spadot_svgp_pre": [vp, ci, ci, vp, vp, vp, vp, vp],
         "spadot_svgp_pre2": [vp, vp, ci, ci, ci, vp, vp, vp, vp, vp, vp],
-        "spadot_svgp_tvec": [vp, vp, ci, ci, ci, vp, vp],
         "spadot_svgp_mid": [vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp],
         "spadot_spd_inverse_logdet2": [vp, ci, ci, ci, vp, vp, vp, vp, vp],
         "spadot_latent_head_forward": [vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, vp, vp],

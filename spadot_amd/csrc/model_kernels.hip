@@ -842,28 +842,6 @@ __global__ __launch_bounds__(256) void k_svgp_pre2(const float *__restrict__ z, 
     for (int k = lane; k < m; k += 64) ar[k] = kr[k] * wi;
 }
 
-// t[l][j] = sum_i (mu[i][l] / var[i][l]) K_nm[i][j]  ([L, m] fp64) straight from z: block = 64 columns x 4 row groups of one
-// latent dimension, fixed summation order.  (The library ran this 2.4 MFLOP product on one or two workgroups: 13-32 us in front
-// of the inverse, the long pole of the step's forward chain.)
-__global__ __launch_bounds__(256) void k_svgp_tvec(const float *__restrict__ z, const double *__restrict__ Kn, int b, int L, int m,
-                                                   double *__restrict__ t) {
-    __shared__ double red[4][64];
-    const int l = blockIdx.y, cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int j = blockIdx.x * 64 + cl;
-    double acc = 0.0;
-    if (j < m) {
-#pragma unroll 8
-        for (int i = rg; i < b; i += 4) {
-            const double m_ = (double)z[(size_t)i * 2 * L + l];
-            const double v = (double)expf(z[(size_t)i * 2 * L + L + l]);
-            acc = fma(m_ / v, Kn[(size_t)i * m + j], acc);
-        }
-    }
-    red[rg][cl] = acc;
-    __syncthreads();
-    if (rg == 0 && j < m) t[(size_t)l * m + j] = ((red[0][cl] + red[1][cl]) + red[2][cl]) + red[3][cl];
-}
-
 // The small products after the inverse, all latent dimensions at once (they were five library launches):
 //   mid1: r_l = S_l t_l and the row parts of <S_l, M>            (one wave per row of S_l)
 //   mid2: Mr_l = M r_l, raw[:, l] = X2 r_l, sm_l = <S_l, M>       (one wave per row of M / X2)
@@ -2308,11 +2286,6 @@ int spadot_svgp_pre2(const float *z, const double *Kn, int b, int L, int m, doub
                      double *A, void *stream) {
     if (b <= 0 || L <= 0 || m <= 0 || !Kn || !A) return -22;
     hipLaunchKernelGGL(k_svgp_pre2, dim3((b * L + 3) / 4), dim3(256), 0, (hipStream_t)stream, z, Kn, b, L, m, mu, var, w, muw, A);
-    return hipGetLastError() == hipSuccess ? 0 : -5;
-}
-int spadot_svgp_tvec(const float *z, const double *Kn, int b, int L, int m, double *t, void *stream) {
-    if (b <= 0 || L <= 0 || m <= 0 || !z || !Kn || !t) return -22;
-    hipLaunchKernelGGL(k_svgp_tvec, dim3((m + 63) / 64, L), dim3(256), 0, (hipStream_t)stream, z, Kn, b, L, m, t);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 int spadot_svgp_mid(const double *S, const double *t, const double *M, const double *X2, int L, int m, int rows2,

@@ -122,10 +122,7 @@ class _SVGPCore(torch.autograd.Function):
                     t = dgemm_small(2, muw, Kn)                              # [L, m]
                 else:
                     torch.baddbmm(G, A.transpose(1, 2), Kn.unsqueeze(0).expand(L, b, m), beta=0.0, alpha=c, out=G)
-                    # t = (mu w)^T K_nm [L, m]: 2.4 MFLOP that the library ran on one or two workgroups (13-32 us in front of
-                    # the inverse: timeline, round 4) -- one small launch of its own
-                    t = torch.empty((L, m), dtype=F64, device=z.device)
-                    _check(lib.spadot_svgp_tvec(_p(z), _p(Kn), b, L, m, _p(t), _stream()), "spadot_svgp_tvec")
+                    t = muw.T @ Kn                                           # [L, m]
                 if stop_before_sweep:
                     return dict(mu=mu, var=var, w=w, G=G, t=t, L=L)
                 X = torch.empty((2 * L, m, m), dtype=F64, device=z.device)

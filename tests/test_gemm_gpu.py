@@ -268,10 +268,13 @@ def test_dgemm_small_matches_torch_fp64(mode, batch, M, N, K, shareA, shareB):
 
 @pytest.mark.parametrize("M,N,K,ldx,slices", [(512, 256, 3000, 3072, None), (512, 64, 256, 256, 4), (235, 33, 70, 70, 3), (1, 1, 1, 1, 1),
                                               (64, 20, 64, 64, None), (300, 130, 1001, 1001, 7)])
-def test_sgemm_nt_slices_matches_fp64(M, N, K, ldx, slices):
-    """csrc k_sgemm_nt_slices + k_slices_sum (y = x W^T + b with the contraction in slices) against fp64: the SVGP encoder's
-    first map shape with its zero-padded rows, ragged sizes, unaligned leading dimensions; bit-repeatable."""
+def test_sgemm_nt_slices_matches_fp64(M, N, K, ldx, slices, monkeypatch):
+    """csrc k_sgemm_nt_slices / k_sgemm_nt_oneshot + k_slices_sum (y = x W^T + b with the contraction in slices) against fp64: the
+    SVGP encoder's first map shape with its zero-padded rows (one-shot form: aligned rows, K % 4 == 0), ragged sizes and
+    unaligned leading dimensions (stepped form); bit-repeatable.  (Off by default in the step -- DESIGN section 4, round 4 --
+    so the switch is set here.)"""
     from spadot_amd import ops
+    monkeypatch.setitem(ops.SGEMM_SLICES, 0, True)
     rng = np.random.default_rng(M + N + K)
     x = torch.zeros((M, ldx), dtype=torch.float32, device=DEV)
     x[:, :K] = torch.as_tensor(rng.normal(size=(M, K)), dtype=torch.float32)
