@@ -156,7 +156,8 @@ def roofline_train(dd, unit, cfg, G, compute_dtype, n_params, live_ms_per_step):
           (all n_sub rows) and layer 3 (seeds + hop 1 rows): forward, input gradient, weight gradient; the two G-sized
           MLP maps on the b seeds -- against the dense bf16 MFMA peak;
       gat edge: SURVEY 8(d)'s minimum per layer, 2 n H C s + E (8 + 2 H s) bytes, once forward and twice backward (target
-          side and source side each read and write one n x H C image) -- against the 8 TB/s HBM peak;
+          side and source side each read and write one n x H C image) -- against the 8 TB/s HBM peak (the family's
+          microseconds include the aggregate-first last layer's own kernels, csrc/gat_tail.hip);
       optimizer: 8 fp32 streams over the flat buffers (p, g, m, v read; p, m, v written; g read once more for the norm);
       everything else is latency (20 workgroups of fp64 sweep, ~90 launches of a few microseconds)."""
     b0 = dd["dataloaders"][unit[0]][unit[1]]
@@ -170,14 +171,20 @@ def roofline_train(dd, unit, cfg, G, compute_dtype, n_params, live_ms_per_step):
     layers = [(n, n, g1.E)] + ([(lg[0].n, lg[0].n_tgt, lg[0].E), (lg[1].n, lg[1].n_tgt, lg[1].E)] if lg is not None
                               else [(n, n, g1.E), (n, n, g1.E)])
     hid_s, hid_d = cfg["svgp_encoder_layers"][0], cfg["decoder_layers"][-1]
+    # layer 3: round 3 mapped all n1 = seeds + hop-1 rows; the aggregate-first form (csrc/gat_tail.hip, default since round 4)
+    # maps the b aggregated seed rows -- the flops actually executed are what is priced, not the ones avoided
+    from spadot_amd import ops as _ops
+    tail_form = bool(_ops.GAT_TAIL[0] and lg is not None and lg[1].n_tgt * 4 <= lg[1].n and HC <= 2048)
+    rows3 = b if tail_form else n1
     gemm_flops = (2 * 2.0 * n * G * HC            # layer 1: forward, weight gradient
                   + 3 * 2.0 * n * HC * HC          # layer 2
-                  + 3 * 2.0 * n1 * HC * HC         # layer 3 (rows: seeds + hop 1)
+                  + 3 * 2.0 * rows3 * HC * HC      # layer 3
                   + 2 * 2.0 * b * G * hid_s        # SVGP encoder's G-sized map: forward, weight gradient
                   + 3 * 2.0 * b * hid_d * G)       # decoder's G-sized map
     gat_bytes = sum(3 * ((ns + nt) * HC * s_el + E * (8 + 2 * H * s_el)) for ns, nt, E in layers)
     opt_bytes = 8.0 * 4 * n_params
-    out = {"workload": f"one step: n_sub={n}, seeds+hop1={n1}, b={b}, E={g1.E}, G={G}, H={H}, C={C}, {compute_dtype}",
+    out = {"workload": f"one step: n_sub={n}, seeds+hop1={n1}, b={b}, E={g1.E}, G={G}, H={H}, C={C}, {compute_dtype}, "
+                       f"layer 3 {'aggregate-first (b rows mapped)' if tail_form else 'map-first (n1 rows mapped)'}",
            "live_ms_per_step": live_ms_per_step,
            "algorithmic": {"gemm_flops_per_step": gemm_flops, "gat_edge_bytes_per_step": gat_bytes, "optimizer_bytes_per_step": opt_bytes}}
     fam_path = newest_profile(f"train_cfg3_{compute_dtype}_families.json")

@@ -14,9 +14,11 @@ import sys
 def family(name):
     """Kernel family of one launch, by name (Tensile names: BBS/BSS/_B_ = bf16 inputs, _DB_ = fp64, _S_/SB = fp32)."""
     n = name
-    if "k_gat_" in n:
+    if "k_gat_" in n or "k_tail_" in n:          # csrc/gat_mfma.hip, model_kernels.hip and the aggregate-first last layer (gat_tail.hip)
         return "gat_edge"
-    if "k_gemm_bf16" in n or "k_gemm_wgrad_bf16" in n or "k_wgrad_reduce" in n or "k_gemm_tn_bf16" in n:
+    if "k_dgemm_small" in n:
+        return "gemm_f64_library"       # (the same family as the library's fp64 products it stands in for when switched on)
+    if "k_gemm_bf16" in n or "k_gemm_wgrad_bf16" in n or "k_wgrad_reduce" in n or "k_gemm_tn_bf16" in n or "k_gemm_tail_reduce" in n:
         return "gemm_bf16_own"          # csrc/gemm_bf16.hip, csrc/gemm_wgrad_bf16.hip (with its partial-sum launch)
     if n.startswith("Cijk_") or n.startswith("Custom_Cijk") or "rocblas_gem" in n or "gemv" in n.lower():
         if "_DB_" in n or "double" in n:
