@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..ops import BatchGraph, latent_head, sqerr_sum
+from ..ops import stamp_if, BatchGraph, latent_head, sqerr_sum
 from .decoder import Decoder
 from .encoder import GATEncoder, SVGPEncoder
 from .svgp import SVGP
@@ -114,8 +114,11 @@ class SpaDOT(nn.Module):
         svgp = self.svgp_dict[str(tp)]
         z_enc = self.SVGPEncoder.pre_head(y_seed32 if y_seed32 is not None else y[:b],
                                           x_bf16=y[:b] if (y_seed32 is not None and y.dtype == torch.bfloat16) else None)
+        stamp_if(16)                                            # (SPADOT_STAMPS=1 only: encoder done)
         bc = svgp.batch_constants(x[:b], key=batch_key)
-        return svgp.elbo_finish(bc, svgp.elbo_start(bc, z_enc))
+        started = svgp.elbo_start(bc, z_enc)
+        stamp_if(18)                                            # (inverse done; slot 17 = in front of it, set in svgp.py)
+        return svgp.elbo_finish(bc, started)
 
     def branch_svgp_head(self, x, y, tp, batch_size, batch_key=None, y_seed32=None):
         """First part of branch_svgp: encoder, batch constants and everything of the ELBO in front of the batched inverse

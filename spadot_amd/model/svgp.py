@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from .._lib import model_lib
-from ..ops import DGEMM_SMALL, _SPLIT, _check, _p, _stream, dgemm_small, elbo_reduce, kernel_matrix, rowdot, spd_inverse_logdet
+from ..ops import DGEMM_SMALL, stamp_if, _SPLIT, _check, _p, _stream, dgemm_small, elbo_reduce, kernel_matrix, rowdot, spd_inverse_logdet
 
 SWEEP_DIRECT_M = _SPLIT[0]      # up to here one sweep launch takes the matrices as they are (ops._spd_inverse_logdet_nograd)
 
@@ -125,6 +125,7 @@ class _SVGPCore(torch.autograd.Function):
                     t = muw.T @ Kn                                           # [L, m]
                 if stop_before_sweep:
                     return dict(mu=mu, var=var, w=w, G=G, t=t, L=L)
+                stamp_if(17)                                                 # (SPADOT_STAMPS=1 only: Sigma built, in front of the inverse)
                 X = torch.empty((2 * L, m, m), dtype=F64, device=z.device)
                 ld = torch.empty(2 * L, dtype=F64, device=z.device)
                 _check(lib.spadot_spd_inverse_logdet2(_p(G), L, 2 * L, m, _p(rc.KjI), _p(rc.K2j), _p(X), _p(ld), _stream()),

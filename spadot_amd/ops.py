@@ -1568,6 +1568,16 @@ def knn(coords, kk):
     return out
 
 
+STAMP_BUF = [None]      # measurement aid: the int64 stamp buffer of a GraphedStepper built with SPADOT_STAMPS=1 (else None)
+
+
+def stamp_if(slot):
+    """A device timestamp into slot `slot` of the active stamp buffer, if there is one (tools/stage_stamps.py: where the time
+    inside a captured stage goes, with no profiler attached)."""
+    if STAMP_BUF[0] is not None:
+        stamp(STAMP_BUF[0], slot)
+
+
 def stamp(buf, slot):
     """buf[slot] (int64 device tensor) = the device timestamp counter (10 ns units) at this point of the current stream
     (include/spadot_model.h: spadot_stamp); capturable."""

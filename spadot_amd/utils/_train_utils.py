@@ -480,6 +480,9 @@ class GraphedStepper:
         self._enc_event = None
         self.stamps = (torch.zeros(32, dtype=torch.int64, device=next(model.parameters()).device)
                        if os.environ.get("SPADOT_STAMPS") == "1" else None)
+        if self.stamps is not None:
+            from .. import ops as _ops
+            _ops.STAMP_BUF[0] = self.stamps
         # the model knows its steppers (weakly): its public entries that touch the encoder between steps break the chain
         import weakref
         reg = getattr(model, "_steppers", None)

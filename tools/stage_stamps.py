@@ -74,6 +74,9 @@ def main():
             continue
         print(f"  {name:10s} start {s:9.1f}  end {e:9.1f}  ({e - s:7.1f})")
     sv_start, sv_end = (med[12], med[13]) if head_first else (med[2], med[3])          # the SVGP forward's last graph
+    if a[:, 16].max() > 0:
+        print(f"  inside svgp_fwd: encoder {med[16] - med[2]:.1f} us, Sigma build {med[17] - med[16]:.1f}, inverse {med[18] - med[17]:.1f}, "
+              f"behind the inverse {med[3] - med[18]:.1f}")
     print(f"  svgp_bwd starts {med[6] - med[5]:.1f} us after the tail ends; gat_bwd starts {med[8] - med[5]:.1f} us after the tail ends")
     print(f"  svgp_fwd ends {sv_end - med[1]:+.1f} us relative to gat_fwd's end; svgp_bwd ends {med[7] - med[9]:+.1f} us relative to gat_bwd's end")
     print(f"  step period (upd_rest end of this step - upd_rest end of the previous one is not stamped): gat_fwd start -> upd_rest end {med[27]:.1f} us")
