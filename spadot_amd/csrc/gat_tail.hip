@@ -64,6 +64,31 @@ template <> __device__ __forceinline__ void store8<__bf16>(__bf16 *p, const floa
                                                bf16_pack2(o[6], o[7]));
 }
 
+// the same eight elements kept PACKED until they are used (bf16: 4 registers instead of 8)
+template <typename T> struct Raw8;
+template <> struct Raw8<float> { float4 a, b; };
+template <> struct Raw8<__bf16> { uint4 v; };
+template <typename T> __device__ __forceinline__ Raw8<T> load8_raw(const T *p);
+template <> __device__ __forceinline__ Raw8<float> load8_raw<float>(const float *p) {
+    Raw8<float> r;
+    r.a = *reinterpret_cast<const float4 *>(p); r.b = *reinterpret_cast<const float4 *>(p + 4);
+    return r;
+}
+template <> __device__ __forceinline__ Raw8<__bf16> load8_raw<__bf16>(const __bf16 *p) {
+    Raw8<__bf16> r;
+    r.v = *reinterpret_cast<const uint4 *>(p);
+    return r;
+}
+__device__ __forceinline__ void unpack8(const Raw8<float> &r, float *o) {
+    o[0] = r.a.x; o[1] = r.a.y; o[2] = r.a.z; o[3] = r.a.w; o[4] = r.b.x; o[5] = r.b.y; o[6] = r.b.z; o[7] = r.b.w;
+}
+__device__ __forceinline__ void unpack8(const Raw8<__bf16> &r, float *o) {
+    o[0] = __uint_as_float(r.v.x << 16); o[1] = __uint_as_float(r.v.x & 0xffff0000u);
+    o[2] = __uint_as_float(r.v.y << 16); o[3] = __uint_as_float(r.v.y & 0xffff0000u);
+    o[4] = __uint_as_float(r.v.z << 16); o[5] = __uint_as_float(r.v.z & 0xffff0000u);
+    o[6] = __uint_as_float(r.v.w << 16); o[7] = __uint_as_float(r.v.w & 0xffff0000u);
+}
+
 __device__ __forceinline__ float wave_sum_f(float x) {
 #pragma unroll
     for (int off = WAVE / 2; off > 0; off >>= 1) x += __shfl_xor(x, off, WAVE);
@@ -551,6 +576,63 @@ __global__ __launch_bounds__(NT) void k_tail_src_bwd(const T *__restrict__ dA, c
         }
         __syncthreads();
     }
+    if (staged) {
+        // ONE flat loop over the block's edges (they are sorted by source row), four edges' dA rows in flight at a time; a row
+        // is finished (logit terms added, stored) when the edge pointer passes its end -- rows without edges included.  The
+        // per-row loop below pays one memory latency per edge group of every row in turn (8 rows x ~2 groups); this pays one
+        // per four edges of the whole block.
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float dss[H];
+#pragma unroll
+        for (int h = 0; h < H; h++) dss[h] = 0.f;
+        int r = 0;                                                    // current row of the block
+        auto flush = [&](int rr) {
+            const int j = j0 + rr;
+            if (j < n) {
+#pragma unroll
+                for (int h = 0; h < H; h++) {
+                    const float dsd = j < n_tgt ? ds_dst[(size_t)j * H + h] : 0.f;
+#pragma unroll
+                    for (int q = 0; q < 8; q++) acc[q] = fmaf(dss[h], w[2 * h][q], fmaf(dsd, w[2 * h + 1][q], acc[q]));
+                    if (t == h) ds_src[(size_t)j * H + h] = dss[h];
+                }
+            }
+            if (j < rows_out && live) store8<T>(dx + (size_t)j * lddx + k, acc);
+#pragma unroll
+            for (int q = 0; q < 8; q++) acc[q] = 0.f;
+#pragma unroll
+            for (int h = 0; h < H; h++) dss[h] = 0.f;
+        };
+        for (int u0 = 0; u0 < nE; u0 += 4) {
+            Raw8<T> gv[4][H];
+            const int kk = live ? k : 0;                              // (threads past K read column 0 again and store nothing)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int u = min(u0 + e, nE - 1);                    // (past the end: the last edge again, not accumulated)
+                const int i = tg[u];
+#pragma unroll
+                for (int h = 0; h < H; h++) gv[e][h] = load8_raw<T>(dA + ((size_t)h * n_tgt + i) * K + kk);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int u = u0 + e;
+                if (u < nE) {                                         // (block-uniform)
+                    while (base + u >= rp[r + 1]) { flush(r); r++; }
+#pragma unroll
+                    for (int h = 0; h < H; h++) {
+                        const float a = al[u][h];
+                        dss[h] += dl[u][h];
+                        float g8[8];
+                        unpack8(gv[e][h], g8);
+#pragma unroll
+                        for (int q = 0; q < 8; q++) acc[q] = fmaf(a, g8[q], acc[q]);
+                    }
+                }
+            }
+        }
+        for (; r < j1 - j0; r++) flush(r);
+        return;
+    }
     for (int j = j0; j < j1; j++) {
         float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (j < n) {
@@ -559,18 +641,10 @@ __global__ __launch_bounds__(NT) void k_tail_src_bwd(const T *__restrict__ dA, c
             for (int h = 0; h < H; h++) { dss[h] = 0.f; dsd[h] = j < n_tgt ? ds_dst[(size_t)j * H + h] : 0.f; }
             const int q0 = rp[j - j0], q1 = rp[j - j0 + 1];
             for (int p = q0; p < q1; p++) {
-                int i;
+                const int e = eid_t[p], i = col_t[p];
                 float a[H];
-                if (staged) {
-                    i = tg[p - base];
 #pragma unroll
-                    for (int h = 0; h < H; h++) { a[h] = al[p - base][h]; dss[h] += dl[p - base][h]; }
-                } else {
-                    const int e = eid_t[p];
-                    i = col_t[p];
-#pragma unroll
-                    for (int h = 0; h < H; h++) { a[h] = alpha[(size_t)e * H + h]; dss[h] += dz[(size_t)e * H + h]; }
-                }
+                for (int h = 0; h < H; h++) { a[h] = alpha[(size_t)e * H + h]; dss[h] += dz[(size_t)e * H + h]; }
                 if (live) {
                     float gv[H][8];
 #pragma unroll
