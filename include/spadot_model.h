@@ -350,6 +350,8 @@ int spadot_gat_tail_aggregate(const void *x, int dtype, int ldx, const float *s,
                               int K, void *A, float *alpha, void *stream);
 int spadot_gat_tail_headmean(const void *O, int dtype, const float *bias, int n_tgt, int H, int C, void *out, void *stream);
 int spadot_gat_tail_colsum_rows(const void *g, int dtype, int rows, int C, float *out, void *stream);
+/* ... and gs = scale * g (same dtype) in the same pass: the backward's d O_h = g / H and the bias gradient in one launch */
+int spadot_gat_tail_scale_colsum(const void *g, int dtype, int rows, int C, double scale, void *gs, float *out, void *stream);
 int spadot_gat_tail_edge_backward(const void *x, int dtype, int ldx, const void *dA, const float *s, const float *alpha, const int *rowptr,
                                   const int *col, int n_tgt, int H, int K, float *dz, float *ds_dst, void *stream);
 int spadot_gat_tail_source_backward(const void *dA, int dtype, const float *alpha, const float *dz, const float *ds_dst, const float *wv,

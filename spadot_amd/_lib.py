@@ -181,6 +181,7 @@ def model_lib():
         "spadot_gat_tail_aggregate": [vp, ci, ci, vp, vp, vp, ci, ci, ci, vp, vp, vp],
         "spadot_gat_tail_headmean": [vp, ci, vp, ci, ci, ci, vp, vp],
         "spadot_gat_tail_colsum_rows": [vp, ci, ci, ci, vp, vp],
+        "spadot_gat_tail_scale_colsum": [vp, ci, ci, ci, cd, vp, vp, vp],
         "spadot_gat_tail_edge_backward": [vp, ci, ci, vp, vp, vp, vp, vp, ci, ci, ci, vp, vp, vp],
         "spadot_gat_tail_source_backward": [vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, ci, vp, vp],
         "spadot_gat_tail_dwvec_rows": [ci],

@@ -389,6 +389,31 @@ __global__ __launch_bounds__(NT) void k_tail_colsum_rows(const T *__restrict__ g
     }
 }
 
+// The same column sums AND gs = scale * g in the storage type, in one pass over g (the backward's first two launches)
+template <typename T>
+__global__ __launch_bounds__(NT) void k_tail_scale_colsum(const T *__restrict__ g, int rows, int C, float scale, T *__restrict__ gs,
+                                                          float *__restrict__ out) {
+    __shared__ float red[16][17];
+    const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int c = (int)blockIdx.x * 16 + cl;
+    float a = 0.f;
+    if (c < C)
+#pragma unroll 8
+        for (int r = rg; r < rows; r += 16) {
+            const float v = (float)g[(size_t)r * C + c];
+            a += v;
+            gs[(size_t)r * C + c] = (T)(v * scale);
+        }
+    red[rg][cl] = a;
+    __syncthreads();
+    if (rg == 0 && c < C) {
+        float tot = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; k++) tot += red[k][cl];
+        out[c] = tot;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // Seed i, backward through aggregation and softmax: d alpha[e][h] = <dA[h][i], x_{col[e]}> (EG edges at a time: EG H partial
 // dots per lane, one butterfly, one LDS exchange), parked in dz; then per head (wave = head)
@@ -826,6 +851,15 @@ int spadot_gat_tail_colsum_rows(const void *g, int dtype, int rows, int C, float
     const unsigned grid = (unsigned)((C + 15) / 16);
     if (dtype == DT_BF16) hipLaunchKernelGGL(k_tail_colsum_rows<__bf16>, dim3(grid), dim3(NT), 0, st, (const __bf16 *)g, rows, C, out);
     else hipLaunchKernelGGL(k_tail_colsum_rows<float>, dim3(grid), dim3(NT), 0, st, (const float *)g, rows, C, out);
+    return rc_last();
+}
+
+int spadot_gat_tail_scale_colsum(const void *g, int dtype, int rows, int C, double scale, void *gs, float *out, void *stream) {
+    if (!g || !gs || !out || rows <= 0 || C <= 0 || (dtype != DT_F32 && dtype != DT_BF16)) return -22;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = (unsigned)((C + 15) / 16);
+    if (dtype == DT_BF16) hipLaunchKernelGGL(k_tail_scale_colsum<__bf16>, dim3(grid), dim3(NT), 0, st, (const __bf16 *)g, rows, C, (float)scale, (__bf16 *)gs, out);
+    else hipLaunchKernelGGL(k_tail_scale_colsum<float>, dim3(grid), dim3(NT), 0, st, (const float *)g, rows, C, (float)scale, (float *)gs, out);
     return rc_last();
 }
 

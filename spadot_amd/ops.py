@@ -364,8 +364,12 @@ class _GATTail(torch.autograd.Function):
         dev = x.device
         g = g.contiguous()
         dbias = torch.empty(C, dtype=torch.float32, device=dev)
-        _check(lib.spadot_gat_tail_colsum_rows(_p(g), _DT[g.dtype], nt, C, _p(dbias), _stream()), "spadot_gat_tail_colsum_rows")
-        gs = (g * (1.0 / H)).to(x.dtype)                                   # d O_h = g / H for every head
+        if g.dtype == x.dtype:             # bias gradient (column sums of g) and d O_h = g / H for every head: one pass over g
+            gs = torch.empty_like(g)
+            _check(lib.spadot_gat_tail_scale_colsum(_p(g), dt, nt, C, 1.0 / H, _p(gs), _p(dbias), _stream()), "spadot_gat_tail_scale_colsum")
+        else:
+            _check(lib.spadot_gat_tail_colsum_rows(_p(g), _DT[g.dtype], nt, C, _p(dbias), _stream()), "spadot_gat_tail_colsum_rows")
+            gs = (g * (1.0 / H)).to(x.dtype)
         dA = torch.bmm(gs.unsqueeze(0).expand(H, nt, C), Wg)              # [H, nt, K]
         direct = ctx.wgrad is not None and _DIRECT_GRAD[0]
         dW = ctx.wgrad if direct else torch.empty((H * C, K), dtype=torch.float32, device=dev)
