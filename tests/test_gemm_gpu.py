@@ -274,7 +274,7 @@ def test_sgemm_nt_slices_matches_fp64(M, N, K, ldx, slices, monkeypatch):
     unaligned leading dimensions (stepped form); bit-repeatable.  (Off by default in the step -- DESIGN section 4, round 4 --
     so the switch is set here.)"""
     from spadot_amd import ops
-    monkeypatch.setitem(ops.SGEMM_SLICES, 0, True)
+    monkeypatch.setattr(ops, "SGEMM_SLICES", [True])
     rng = np.random.default_rng(M + N + K)
     x = torch.zeros((M, ldx), dtype=torch.float32, device=DEV)
     x[:, :K] = torch.as_tensor(rng.normal(size=(M, K)), dtype=torch.float32)
