@@ -154,6 +154,154 @@ __global__ __launch_bounds__(256) void k_cost_write(const double *__restrict__ x
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The x.y term on the fp64 matrix cores (round 4).  v_mfma_f64_16x16x4_f64 with its accumulator fed back is, on this
+// hardware, bit for bit the sequential fma chain over k = 0, 1, 2, ... that dist_row() runs (tools/mfma_f64_chain_probe.hip:
+// 1 048 576 random 20-term chains, 0 differences; profiles/r04/mfma_f64_chain_probe.txt), so the distances -- and with them
+// the exact median -- do not change by a bit; latent dimensions that are not a multiple of 4 are padded with zeros
+// (fma(0, 0, acc) = acc).  The fp64 matrix rate equals the vector rate on this chip; what the matrix cores buy is the
+// vector ALU: the per-entry epilogue (scale, clamp, compare or convert, ~8 fp64 operations) no longer queues behind 20 FMAs.
+//   wave = 64 columns (four 16-column tiles, the B operands y and |y|^2 in registers for the whole launch) x `rows_per_block`
+//   rows in blocks of 16 (A: x rows, 5 loads of one double per lane); C/D: col = lane & 15, row = (lane >> 4) + 4 reg.
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+template <int STEPS>
+struct MfmaCols {
+    double b[4][STEPS];
+    double yy[4];
+    bool live[4];
+};
+template <int STEPS>
+__device__ __forceinline__ void mfma_load_cols(const double *__restrict__ y, const double *__restrict__ yyv, int d, int J, int j0, int lane,
+                                               MfmaCols<STEPS> &c) {
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const int j = j0 + 16 * t + (lane & 15);
+        c.live[t] = j < J;
+        c.yy[t] = c.live[t] ? yyv[j] : 0.0;
+#pragma unroll
+        for (int s = 0; s < STEPS; s++) {
+            const int k = 4 * s + (lane >> 4);
+            c.b[t][s] = (c.live[t] && k < d) ? y[(size_t)j * d + k] : 0.0;
+        }
+    }
+}
+// distances of rows i0 .. i0 + 15 against the wave's 64 columns: out[t][r] for row i0 + (lane >> 4) + 4 r, col tile t
+template <int STEPS>
+__device__ __forceinline__ void mfma_dist_block(const double *__restrict__ x, const double *__restrict__ xx, int d, int I, int i0, int lane,
+                                                const MfmaCols<STEPS> &c, double (*out)[4]) {
+    double a[STEPS];
+    const int ia = min(i0 + (lane & 15), I - 1);
+#pragma unroll
+    for (int s = 0; s < STEPS; s++) {
+        const int k = 4 * s + (lane >> 4);
+        a[s] = k < d ? x[(size_t)ia * d + k] : 0.0;
+    }
+    double xr[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) xr[r] = xx[min(i0 + (lane >> 4) + 4 * r, I - 1)];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < STEPS; s++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], c.b[t][s], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            double v = -2.0 * acc[r];           // sklearn's chain: v = -2 dot; v += |x|^2; v += |y|^2; clip at 0
+            v += xr[r];
+            v += c.yy[t];
+            out[t][r] = v > 0.0 ? v : 0.0;
+        }
+    }
+}
+
+template <typename T, int STEPS>
+__global__ __launch_bounds__(256) void k_cost_write_mfma(const double *__restrict__ x, const double *__restrict__ y,
+                                                         const double *__restrict__ xx, const double *__restrict__ yyv, int d, int I, int J,
+                                                         int ld, int rows_per_block, double denom, int use_recip, T *__restrict__ C) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j0 = ((int)blockIdx.x * 4 + wave) * 64;
+    if (j0 >= ld) return;
+    MfmaCols<STEPS> c;
+    mfma_load_cols<STEPS>(y, yyv, d, J, j0, lane, c);
+    const double inv = 1.0 / denom;
+    const int i_beg = blockIdx.y * rows_per_block, i_end = min(I, i_beg + rows_per_block);
+    for (int i0 = i_beg; i0 < i_end; i0 += 16) {
+        double v[4][4];
+        mfma_dist_block<STEPS>(x, xx, d, I, i0, lane, c, v);
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int j = j0 + 16 * t + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int i = i0 + (lane >> 4) + 4 * r;
+                if (i < i_end && j < ld) {
+                    // fp64 storage: the division of the reference (bit-identical); fp32 storage: the product with the reciprocal
+                    // (its error, one fp64 ulp, vanishes in the rounding to fp32 that follows)
+                    const double q = c.live[t] ? (use_recip ? v[t][r] * inv : v[t][r] / denom) : 0.0;
+                    C[(size_t)i * ld + j] = (T)q;
+                }
+            }
+        }
+    }
+}
+
+template <int STEPS>
+__global__ __launch_bounds__(256) void k_cost_bracket_mfma(const double *__restrict__ x, const double *__restrict__ y,
+                                                           const double *__restrict__ xx, const double *__restrict__ yyv, int d, int I, int J,
+                                                           int rows_per_block, u64 lo, u64 hi, u64 *__restrict__ counts,
+                                                           u64 *__restrict__ cand, u64 cap) {
+    constexpr unsigned LCAP = 2048;
+    __shared__ u64 sh_below[4];
+    __shared__ u64 lbuf[LCAP];
+    __shared__ unsigned lcnt;
+    __shared__ u64 gbase;
+    if (threadIdx.x == 0) lcnt = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j0 = ((int)blockIdx.x * 4 + wave) * 64;
+    u64 below = 0;
+    if (j0 < J) {
+        MfmaCols<STEPS> c;
+        mfma_load_cols<STEPS>(y, yyv, d, J, j0, lane, c);
+        const int i_beg = blockIdx.y * rows_per_block, i_end = min(I, i_beg + rows_per_block);
+        for (int i0 = i_beg; i0 < i_end; i0 += 16) {
+            double v[4][4];
+            mfma_dist_block<STEPS>(x, xx, d, I, i0, lane, c, v);
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int i = i0 + (lane >> 4) + 4 * r;
+                    if (c.live[t] && i < i_end) {
+                        const u64 key = (u64)__double_as_longlong(v[t][r]);
+                        if (key < lo) below++;
+                        else if (key <= hi) {
+                            const unsigned p = atomicAdd(&lcnt, 1u);
+                            if (p < LCAP) lbuf[p] = key;
+                            else {
+                                const u64 pos = atomicAdd(&counts[1], 1ull);
+                                if (pos < cap) cand[pos] = key;
+                            }
+                        }
+                    }
+                }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) below += __shfl_xor(below, off, 64);
+    if (lane == 0) sh_below[wave] = below;
+    __syncthreads();
+    const unsigned nl = min(lcnt, LCAP);
+    if (threadIdx.x == 0) {
+        atomicAdd(&counts[0], sh_below[0] + sh_below[1] + sh_below[2] + sh_below[3]);
+        gbase = nl ? atomicAdd(&counts[1], (u64)nl) : 0ull;
+    }
+    __syncthreads();
+    for (unsigned t = threadIdx.x; t < nl; t += 256)
+        if (gbase + t < cap) cand[gbase + t] = lbuf[t];
+}
+
 struct Workspace {           // device scratch kept by the solver between calls (hipMalloc costs more than the passes)
     void *ptr = nullptr;
     size_t bytes = 0;
@@ -190,12 +338,17 @@ int run(const double *x, const double *y, int d, int I, int J, int ld, int stora
     const int S = 1 << 18, DELTA = 2048;
     const size_t cap = sampled ? n / 25 + 65536 : n;                      // 4 % of the entries: the bracket holds ~1.6 %
     const size_t tmp_b = sort_tmp_bytes(cap > (size_t)S ? cap : (size_t)S);
-    const size_t xx_b = ((size_t)I * 8 + 255) / 256 * 256;
-    const size_t need = xx_b + 256 + 2 * (size_t)S * 8 + 2 * cap * 8 + tmp_b;
+    const size_t xx_b = ((size_t)I * 8 + 255) / 256 * 256, yy_b = ((size_t)J * 8 + 255) / 256 * 256;
+    const size_t need = xx_b + yy_b + 256 + 2 * (size_t)S * 8 + 2 * cap * 8 + tmp_b;
     int rc = reserve(ws, need);
     if (rc) return rc;
     unsigned char *base = (unsigned char *)ws->ptr;
     double *xx = (double *)base;                 base += xx_b;
+    double *yyv = (double *)base;                base += yy_b;
+    // the two passes over all I x J distances on the fp64 matrix cores (SPADOT_OT_COST_MFMA=0: the vector kernels)
+    constexpr int STEPS = DD == 20 ? 5 : (MAX_D + 3) / 4;
+    static const bool use_mfma = [] { const char *e = getenv("SPADOT_OT_COST_MFMA"); return !(e && e[0] == '0'); }();
+    const dim3 grid_mj((J + 255) / 256, (I + rpb - 1) / rpb), grid_mld((ld + 255) / 256, (I + rpb - 1) / rpb);
     u64 *counts = (u64 *)base;                   base += 256;
     u64 *skeys = (u64 *)base;                    base += (size_t)S * 8;
     u64 *ssort = (u64 *)base;                    base += (size_t)S * 8;
@@ -204,6 +357,7 @@ int run(const double *x, const double *y, int d, int I, int J, int ld, int stora
     void *tmp = base;
     size_t tb = tmp_b;
     hipLaunchKernelGGL(k_cost_norms, dim3((I + 255) / 256), dim3(256), 0, st, x, d, I, xx);
+    if (use_mfma) hipLaunchKernelGGL(k_cost_norms, dim3((J + 255) / 256), dim3(256), 0, st, y, d, J, yyv);     // (the chain load_col() runs)
     double denom = 1.0;
     long long path = 0, ncand = 0;
     if (divide_by_median) {
@@ -219,7 +373,10 @@ int run(const double *x, const double *y, int d, int I, int J, int ld, int stora
             if (r2 < S) COST_CHECK(hipMemcpyAsync(&hi, ssort + r2, sizeof(u64), hipMemcpyDeviceToHost, st));
             COST_CHECK(hipMemsetAsync(counts, 0, sizeof(u64) * 2, st));
             COST_CHECK(hipStreamSynchronize(st));
-            hipLaunchKernelGGL(k_cost_bracket<DD>, grid_j, dim3(256), 0, st, x, y, xx, d, I, J, rpb, lo, hi, counts, cand, (u64)cap);
+            if (use_mfma)
+                hipLaunchKernelGGL(k_cost_bracket_mfma<STEPS>, grid_mj, dim3(256), 0, st, x, y, xx, yyv, d, I, J, rpb, lo, hi, counts, cand, (u64)cap);
+            else
+                hipLaunchKernelGGL(k_cost_bracket<DD>, grid_j, dim3(256), 0, st, x, y, xx, d, I, J, rpb, lo, hi, counts, cand, (u64)cap);
             u64 hc[2] = {0, 0};
             COST_CHECK(hipMemcpyAsync(hc, counts, sizeof(u64) * 2, hipMemcpyDeviceToHost, st));
             COST_CHECK(hipStreamSynchronize(st));
@@ -255,7 +412,11 @@ int run(const double *x, const double *y, int d, int I, int J, int ld, int stora
         }
         denom = (n & 1) ? key_to_double(m[0]) : (key_to_double(m[0]) + key_to_double(m[1])) / 2.0;
     }
-    if (storage_f32)
+    if (use_mfma && storage_f32)
+        hipLaunchKernelGGL((k_cost_write_mfma<float, STEPS>), grid_mld, dim3(256), 0, st, x, y, xx, yyv, d, I, J, ld, rpb, denom, 1, (float *)C);
+    else if (use_mfma)
+        hipLaunchKernelGGL((k_cost_write_mfma<double, STEPS>), grid_mld, dim3(256), 0, st, x, y, xx, yyv, d, I, J, ld, rpb, denom, 0, (double *)C);
+    else if (storage_f32)
         hipLaunchKernelGGL((k_cost_write<float, DD>), grid_ld, dim3(256), 0, st, x, y, xx, d, I, J, ld, rpb, denom, (float *)C);
     else
         hipLaunchKernelGGL((k_cost_write<double, DD>), grid_ld, dim3(256), 0, st, x, y, xx, d, I, J, ld, rpb, denom, (double *)C);
