@@ -99,7 +99,9 @@ class GATConv(nn.Module):
         nn.init.uniform_(self.att_src, -bound, bound)
         nn.init.uniform_(self.att_dst, -bound, bound)
 
-    def forward(self, x, graph, act=False, fresh=False):
+    def forward(self, x, graph, act=False, fresh=False, taps=None, tap=None):
+        """taps / tap (optional): the dense map's output is stored as taps[tap] -- where a backward pass issued in pieces cuts
+        between this layer's edge phase and its dense map (GraphedStepper `defer_wgrad`)."""
         # head mean over few targets (the encoder's last layer for the seeds): aggregate first, map the n_tgt aggregated
         # rows instead of all source rows (ops.gat_tail; the same function, ~15x fewer flops at the benchmarked shape)
         if (not act and isinstance(graph, BatchGraph) and x.dtype == self.compute_dtype
@@ -110,7 +112,10 @@ class GATConv(nn.Module):
                 if not fresh:
                     wimg[:, :self.in_channels].copy_(self.lin.weight.detach())
             return gat_tail(x, self.lin.weight, wimg, self.att_src, self.att_dst, self.bias, graph, self.heads, self.out_channels)
-        return self.edge(self.dense(x, fresh), graph, act)
+        d = self.dense(x, fresh)
+        if taps is not None and tap is not None:
+            taps[tap] = d
+        return self.edge(d, graph, act)
 
     def dense(self, x, fresh=False):
         """h = x W^T  [n, H*C] (MFMA GEMM in the compute dtype; x may be K-padded).  fresh: the compute-dtype image
@@ -118,7 +123,7 @@ class GATConv(nn.Module):
         cd = self.compute_dtype
         if cd == torch.float32:
             return F.linear(x[:, :self.in_channels].float(), self.lin.weight)
-        return dense_cd(x.to(cd), self.lin.weight, self, fresh=fresh)
+        return dense_cd(x.to(cd), self.lin.weight, self, fresh=fresh, defer=getattr(self, "defer_wgrad", False))
 
     def edge(self, h, graph, act=False):
         """Everything after the dense map (ops.gat_edge)."""
@@ -141,6 +146,12 @@ class GATEncoder(nn.Module):
     def top_parameters(self):
         """The parameters above the second layer's output: layer 3 and the head (what a backward pass reaches first)."""
         return list(self.gat3.parameters()) + list(self.GAT_fc.parameters())
+
+    def above_second_dense(self):
+        """The parameters whose gradients a backward pass has produced when it reaches the second layer's dense map: the head,
+        layer 3 and the second layer's edge-phase parameters (everything but gat2.lin.weight and layer 1)."""
+        return (list(self.GAT_fc.parameters()) + list(self.gat3.parameters())
+                + [self.gat2.att_src, self.gat2.att_dst, self.gat2.bias])
 
     def first_layer_parameters(self):
         """The parameters whose gradients a backward pass produces last (ops.FlatAdamW `last`)."""
@@ -189,17 +200,17 @@ class GATEncoder(nn.Module):
             taps["h1"] = h
         if lg is not None and lg[1].n_tgt == rows:
             # only what the seeds' rows of layer 3 depend on: layer 2 for seeds + hop 1, layer 3 for the seeds
-            h = self.gat2(h, lg[0], act=True, fresh=fresh)
+            h = self.gat2(h, lg[0], act=True, fresh=fresh, taps=taps, tap="d2")
             if taps is not None:
                 taps["h2"] = h
             h = self.gat3(h, lg[1], act=False, fresh=fresh)
         elif g3 is not None and g3.n_tgt == rows:
-            h = self.gat2(h, edge_index, act=True, fresh=fresh)
+            h = self.gat2(h, edge_index, act=True, fresh=fresh, taps=taps, tap="d2")
             if taps is not None:
                 taps["h2"] = h
             h = self.gat3(h, g3, act=False, fresh=fresh)          # edge phase for the seeds only: same rows, ~n/rows less work
         else:
-            h = self.gat2(h, edge_index, act=True, fresh=fresh)
+            h = self.gat2(h, edge_index, act=True, fresh=fresh, taps=taps, tap="d2")
             if taps is not None:
                 taps["h2"] = h
             h = self.gat3(h, edge_index, act=False, fresh=fresh)

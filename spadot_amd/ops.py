@@ -351,7 +351,9 @@ class _GATTail(torch.autograd.Function):
         ctx.graph, ctx.H, ctx.C = graph, H, C
         ctx.bias_dtype, ctx.att_shape, ctx.att_dtype = bias.dtype, att_src.shape, att_src.dtype
         g = W.grad
-        ctx.wgrad = g if (g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.shape == W.shape) else None
+        okv = lambda g_, p_: g_ if (g_ is not None and g_.dtype == torch.float32 and g_.is_contiguous() and g_.shape == p_.shape) else None
+        ctx.wgrad = okv(g, W)
+        ctx.agrad = (okv(att_src.grad, att_src), okv(att_dst.grad, att_dst))     # flat-gradient views (FlatAdamW)
         return out
 
     @staticmethod
@@ -373,7 +375,11 @@ class _GATTail(torch.autograd.Function):
         dA = torch.bmm(gs.unsqueeze(0).expand(H, nt, C), Wg)              # [H, nt, K]
         direct = ctx.wgrad is not None and _DIRECT_GRAD[0]
         dW = ctx.wgrad if direct else torch.empty((H * C, K), dtype=torch.float32, device=dev)
-        _bmm_f32(gs.t().unsqueeze(0).expand(H, C, nt), A, out=dW.view(H, C, K))
+        # what only the optimizer reads -- dW_h = (g/H)^T A_h, d w = dS^T x, the chain through w = W_h^T att -- may be queued
+        # (ops.DEFERRED) and written into the flat gradient later; the chain to dx runs now
+        defer = direct and _deferring() and ctx.agrad[0] is not None and ctx.agrad[1] is not None
+        if not defer:
+            _bmm_f32(gs.t().unsqueeze(0).expand(H, C, nt), A, out=dW.view(H, C, K))
         dz = torch.empty((graph.E, H), dtype=torch.float32, device=dev)
         ds_dst = torch.empty((nt, H), dtype=torch.float32, device=dev)
         _check(lib.spadot_gat_tail_edge_backward(_p(x), dt, Kp, _p(dA), _p(s), _p(alpha), _p(graph.rowptr), _p(graph.col), nt, H, K,
@@ -384,13 +390,23 @@ class _GATTail(torch.autograd.Function):
                                                    _p(graph.eid_t), n, nt, x.shape[0], H, K, _p(dx), Kp, _p(ds_src), _stream()),
                "spadot_gat_tail_source_backward")
         R = int(lib.spadot_gat_tail_dwvec_rows(n))
-        part = torch.empty((R, 2 * H * K), dtype=torch.float32, device=dev)
-        _check(lib.spadot_gat_tail_dwvec(_p(x), dt, Kp, _p(ds_src), _p(ds_dst), n, nt, H, K, _p(part), _stream()), "spadot_gat_tail_dwvec")
-        dwv = torch.empty(2 * H * K, dtype=torch.float32, device=dev)
-        _check(lib.spadot_colsum(_p(part), R, 2 * H * K, _p(dwv), _stream()), "spadot_colsum")
+
+        def weight_side(datt_src_ptr, datt_dst_ptr, with_dw):
+            if with_dw:
+                _bmm_f32(gs.t().unsqueeze(0).expand(H, C, nt), A, out=dW.view(H, C, K))
+            part = torch.empty((R, 2 * H * K), dtype=torch.float32, device=dev)
+            _check(lib.spadot_gat_tail_dwvec(_p(x), dt, Kp, _p(ds_src), _p(ds_dst), n, nt, H, K, _p(part), _stream()), "spadot_gat_tail_dwvec")
+            dwv = torch.empty(2 * H * K, dtype=torch.float32, device=dev)
+            _check(lib.spadot_colsum(_p(part), R, 2 * H * K, _p(dwv), _stream()), "spadot_colsum")
+            _check(lib.spadot_gat_tail_wvec_backward(_p(Wd), K, _p(a_s), _p(a_d), _p(dwv), H, C, K, _p(dW), K, 1, datt_src_ptr, datt_dst_ptr,
+                                                     _stream()), "spadot_gat_tail_wvec_backward")
+
+        if defer:
+            ga_s, ga_d = ctx.agrad
+            DEFERRED[0].append(lambda: weight_side(_p(ga_s), _p(ga_d), True))
+            return dx, dW, None, ga_s, ga_d, dbias.to(ctx.bias_dtype), None, None, None
         datt = torch.empty((2, H * C), dtype=torch.float32, device=dev)
-        _check(lib.spadot_gat_tail_wvec_backward(_p(Wd), K, _p(a_s), _p(a_d), _p(dwv), H, C, K, _p(dW), K, 1, _p(datt),
-                                                 ctypes.c_void_p(datt.data_ptr() + 4 * H * C), _stream()), "spadot_gat_tail_wvec_backward")
+        weight_side(_p(datt), ctypes.c_void_p(datt.data_ptr() + 4 * H * C), False)
         return (dx, dW, None, datt[0].view(ctx.att_shape).to(ctx.att_dtype), datt[1].view(ctx.att_shape).to(ctx.att_dtype),
                 dbias.to(ctx.bias_dtype), None, None, None)
 
@@ -403,6 +419,17 @@ def gat_tail(x, W, wimg, att_src, att_dst, bias, graph, heads, channels):
 # ----------------------------------------------------------------------------- dense maps in the compute dtype
 
 _DIRECT_GRAD = [False]     # True only inside FlatAdamW.backward (a plain .backward() would ADD the returned view to itself)
+
+# Off-chain gradient work (round 4).  A weight gradient -- dW of a dense map, the attention-vector chain of the last GAT layer --
+# feeds nothing in the backward pass: only the optimizer reads it.  While DEFERRED[0] is a list, the backward functions below
+# append that work as closures instead of launching it (and return the flat-gradient VIEW it will be written to); the caller
+# (GraphedStepper, `defer_wgrad`) runs the closures later, on the side stream, beside the rest of the GAT backward -- whose
+# dependency chain they would otherwise lengthen by their own duration.
+DEFERRED = [None]
+
+
+def _deferring():
+    return DEFERRED[0] is not None and _DIRECT_GRAD[0]
 
 
 def cast_rows(pairs):
@@ -577,9 +604,10 @@ class _DenseCD(torch.autograd.Function):
     gradient in fp32 straight out of the GEMM (no bf16 round trip)."""
 
     @staticmethod
-    def forward(ctx, x, W, wbuf, fresh):
+    def forward(ctx, x, W, wbuf, fresh, defer=False):
         N, K = W.shape
         Kp = x.shape[1]
+        ctx.defer = bool(defer)
         assert Kp >= K and wbuf.shape == (N, Kp) and wbuf.dtype == x.dtype
         if not fresh:                              # (fresh: the caller has just cast W into wbuf, e.g. ops.cast_rows)
             wbuf[:, :K].copy_(W)                   # cast into the persistent padded image (pad columns stay zero)
@@ -614,8 +642,13 @@ class _DenseCD(torch.autograd.Function):
         # (x[:, :K] is a strided view: the GEMM takes its row stride, the result is a dense [N, K])
         dW = None
         if ctx.needs_input_grad[1]:
-            dW = wgrad_bf16(g, x, ctx.K, ctx.wgrad if (ctx.wgrad is not None and _DIRECT_GRAD[0]) else None)
-        return dx, dW, None, None
+            if ctx.defer and ctx.wgrad is not None and _deferring():
+                # nothing downstream reads dW: queued (the closure keeps g and x alive), written into the flat gradient later
+                DEFERRED[0].append(lambda g=g, x=x, K=ctx.K, out=ctx.wgrad: wgrad_bf16(g, x, K, out))
+                dW = ctx.wgrad
+            else:
+                dW = wgrad_bf16(g, x, ctx.K, ctx.wgrad if (ctx.wgrad is not None and _DIRECT_GRAD[0]) else None)
+        return dx, dW, None, None, None
 
 
 class _FirstMapSeeds(torch.autograd.Function):
@@ -902,10 +935,11 @@ def weight_image(W, width, dtype, holder, tag="_wpad"):
     return buf
 
 
-def dense_cd(x, W, holder, tag="_wpad", fresh=False):
+def dense_cd(x, W, holder, tag="_wpad", fresh=False, defer=False):
     """x [n, Kp >= K] in the compute dtype, W fp32 [N, K]; `holder` (a module) keeps the padded compute-dtype
-    image of W between calls.  fresh=True: the image already holds the current W (cast by the caller)."""
-    return _DenseCD.apply(x, W, weight_image(W, x.shape[1], x.dtype, holder, tag), fresh)
+    image of W between calls.  fresh=True: the image already holds the current W (cast by the caller).  defer=True: this
+    map's weight gradient may be queued (ops.DEFERRED) instead of launched inside the backward pass."""
+    return _DenseCD.apply(x, W, weight_image(W, x.shape[1], x.dtype, holder, tag), fresh, defer)
 
 
 # ----------------------------------------------------------------------------- small-MLP stages
@@ -1506,7 +1540,10 @@ class _LinearSqErr(torch.autograd.Function):
         _check(model_lib().spadot_bias_sqerr_backward(_p(g1), _p(o), _p(bias), _p(y), b, G, ctx.inv_scale, _p(gc), _p(db),
                                                       _stream()), "spadot_bias_sqerr_backward")
         dh = torch.mm(gc, Wc, out_dtype=torch.float32) if ctx.needs_input_grad[0] else None
-        if direct and ctx.wgrad is not None:
+        if direct and ctx.wgrad is not None and _deferring():
+            DEFERRED[0].append(lambda gc=gc, hc=hc, out=ctx.wgrad: torch.mm(gc.t(), hc, out_dtype=torch.float32, out=out))
+            dW = ctx.wgrad
+        elif direct and ctx.wgrad is not None:
             dW = torch.mm(gc.t(), hc, out_dtype=torch.float32, out=ctx.wgrad)
         else:
             dW = torch.mm(gc.t(), hc, out_dtype=torch.float32)

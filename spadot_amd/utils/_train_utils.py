@@ -477,6 +477,19 @@ class GraphedStepper:
         # them (the main stream waits for an event recorded between the two SVGP graphs): the GAT branch starts later, the
         # inverse much earlier.
         self.svgp_head_first = bool(self.staged and model_config.get("svgp_head_first", os.environ.get("SPADOT_SVGP_HEAD", "0") == "1"))
+        # defer_wgrad (round 4): gradient work that only the optimizer reads -- the second GAT layer's weight gradient (87 + 37 us
+        # with its slice sum), the last layer's weight / attention-vector chain (~48 us), the decoder output map's weight gradient
+        # (18 us) -- is taken OFF the GAT backward's dependency chain: the backward functions queue it (ops.DEFERRED), the GAT
+        # backward becomes two graphs cut behind the second layer's edge phase with an event between them, and the queue runs
+        # as a graph of its own on the SIDE stream behind the SVGP backward, which ends ~360 us before the GAT backward (stage
+        # stamps).  Same kernels, same operands, same results; only where and when they run changes.
+        self.defer_wgrad = bool(self.staged and not self.overlap and not self.split_bwd
+                                and model_config.get("defer_wgrad", os.environ.get("SPADOT_DEFER_WGRAD", "1") == "1")
+                                and hasattr(model.GATEncoder, "above_second_dense"))
+        if self.defer_wgrad:
+            self.svgp_head_first = False
+            object.__setattr__(model.GATEncoder.gat2, "defer_wgrad", True)
+        self._late_event = None
         self._enc_event = None
         self.stamps = (torch.zeros(32, dtype=torch.int64, device=next(model.parameters()).device)
                        if os.environ.get("SPADOT_STAMPS") == "1" else None)
@@ -633,7 +646,7 @@ class GraphedStepper:
         # its own stream: the GAT branch all n_sub rows, the SVGP branch (and the tail after it) the seeds' rows.
         def gat_fwd():
             y_all = batch.y if cached else Y[batch.n_id]
-            st["zg"] = model.branch_gat(y_all, batch.graph, b, taps=st if (self.overlap or self.split_bwd) else None)
+            st["zg"] = model.branch_gat(y_all, batch.graph, b, taps=st if (self.overlap or self.split_bwd or self.defer_wgrad) else None)
 
         def svgp_fwd():
             st["xs"] = batch.x[:b] if cached else loc[seeds]
@@ -674,6 +687,28 @@ class GraphedStepper:
         def gat_bwd_lo():           # the first layer: its edge backward and the largest weight gradient
             opt.backward_partial([st["h1"]], [st["gh1"]], P["gat_lo"])
 
+        from .. import ops as _ops
+
+        def queued(fn):             # off-chain gradient work of `fn` goes to st["late"] instead of being launched
+            def run():
+                _ops.DEFERRED[0] = st.setdefault("late", [])
+                try:
+                    return fn()
+                finally:
+                    _ops.DEFERRED[0] = None
+            return run
+
+        def gat_bwd_a():            # head, layer 3, the second layer's edge phase; stops at the second layer's dense output
+            st["gd2"] = opt.backward_partial([st["zg"]], [st["g"][0]], P["gat_above_d2"], extra_inputs=[st["d2"]])[0]
+
+        def gat_bwd_b():            # the second layer's dense map (its weight gradient queued) and layer 1
+            opt.backward_partial([st["d2"]], [st["gd2"]], P["gat_below_d2"])
+
+        def late():                 # what the three stages above queued: side stream, behind the SVGP backward
+            jobs = st.pop("late", [])
+            for job in jobs:
+                job()
+
         def gat_bwd_top():          # the head and layer 3; stops at the second layer's output
             st["gh2"] = opt.backward_partial([st["zg"]], [st["g"][0]], P["gat_top"], extra_inputs=[st["h2"]])[0]
 
@@ -686,6 +721,8 @@ class GraphedStepper:
             fns = (gat_fwd, svgp_fwd, tail, svgp_bwd, gat_bwd_top, gat_bwd_rest)
         else:
             fns = (gat_fwd, svgp_fwd, tail, svgp_bwd, gat_bwd)
+        if self.defer_wgrad:
+            fns = (gat_fwd, svgp_fwd, queued(tail), svgp_bwd, queued(gat_bwd_a), queued(gat_bwd_b), late)
         if self.svgp_head_first:
             # a SEVENTH stage: the SVGP branch's short launches in front of its inverse as a graph of their own (see __init__)
             fns = fns + (svgp_fwd_head, svgp_fwd_rest)
@@ -715,6 +752,10 @@ class GraphedStepper:
             self._groups = {"gat": gat, "svgp": svgp, "tail": [p for p in self.opt.params if id(p) not in taken],
                             "gat_lo": [p for p in gat if id(p) in lo], "gat_hi": [p for p in gat if id(p) not in lo],
                             "gat_top": [p for p in gat if id(p) in top], "gat_rest": [p for p in gat if id(p) not in top]}
+            if hasattr(self.model.GATEncoder, "above_second_dense"):
+                above = {id(p) for p in self.model.GATEncoder.above_second_dense()}
+                self._groups["gat_above_d2"] = [p for p in gat if id(p) in above]
+                self._groups["gat_below_d2"] = [p for p in gat if id(p) not in above]
         return self._groups
 
     def _issue_staged(self, fns, two_streams=True):
@@ -740,6 +781,32 @@ class GraphedStepper:
             else:
                 side.wait_stream(main)
             self._head_ready = False
+        if self.defer_wgrad and len(fns) == 7:
+            # (gat_fwd, svgp_fwd, tail, svgp_bwd, gat_bwd_a, gat_bwd_b, late)
+            if not two_streams:
+                for k in (0, 1, 2, 3, 4, 5, 6):
+                    r = fns[k]()
+                    if k == 2:
+                        res = r
+                return res
+            fns[0]()
+            with torch.cuda.stream(side):
+                fns[1]()
+            main.wait_stream(side)
+            res = fns[2]()
+            side.wait_stream(main)
+            fns[4]()
+            if self._late_event is None:
+                self._late_event = torch.cuda.Event()
+            self._late_event.record(main)
+            with torch.cuda.stream(side):
+                fns[3]()
+            fns[5]()
+            with torch.cuda.stream(side):
+                side.wait_event(self._late_event)
+                fns[6]()
+            main.wait_stream(side)
+            return res
         head_first = self.svgp_head_first and len(fns) >= 7
         if head_first:
             head, rest = fns[-2], fns[-1]
@@ -836,7 +903,7 @@ class GraphedStepper:
             for k in order:
                 fn = fns[k]
                 g = torch.cuda.CUDAGraph()
-                side_stage = k in (1, 3) or (self.svgp_head_first and k >= nf - 2)
+                side_stage = k in (1, 3) or (self.svgp_head_first and k >= nf - 2) or (self.defer_wgrad and nf == 7 and k == 6)
                 pool = self.pool_side if side_stage else self.pool           # the SVGP stages run beside the GAT ones
                 with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
                     r = fn()
