@@ -2154,7 +2154,13 @@ int spadot_spd_inverse_logdet2(const double *A, int Lsrc, int L, int m, const do
     const int T = (m + TS - 1) / TS;
     const int RS = TS < SWEEP_RS ? TS : SWEEP_RS;   // register core per tile edge; the rest of a tile lives in LDS
     const int CS = TS + ((TS & 1) ? 0 : 1);         // k_spd_sweep's column-buffer stride
-    const size_t lds = sizeof(double) * (2 * ((size_t)T * CS + 1) + (size_t)m + 16 + (size_t)(TS * TS - RS * RS) * SWEEP_NT);
+    size_t lds = sizeof(double) * (2 * ((size_t)T * CS + 1) + (size_t)m + 16 + (size_t)(TS * TS - RS * RS) * SWEEP_NT);
+    // SPADOT_SWEEP_LDS_KB=n (n <= 160): the launch ASKS for n KB of LDS although it uses a few -- with most of a compute unit's
+    // 160 KB taken, no GEMM or GAT workgroup (they all stage tiles in LDS) can be placed beside a sweep workgroup, which is
+    // bound by its unit's fp64 vector rate: beside the GAT branch's kernels the inverse takes 308 us in the step against
+    // 202 us alone (stage stamps, round 4).  The price: a workgroup that needs a whole unit's LDS waits until one drains.
+    static const long pad_kb = [] { const char *e = getenv("SPADOT_SWEEP_LDS_KB"); return e ? atol(e) : 0L; }();
+    if (pad_kb > 0 && pad_kb <= 160 && (size_t)pad_kb * 1024 > lds) lds = (size_t)pad_kb * 1024;
 #define SWEEP_CASE(N)                                                                                         \
     case N: {                                                                                                 \
         static PerDeviceFlag attr_set;                                                                              \

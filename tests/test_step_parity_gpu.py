@@ -289,14 +289,18 @@ def test_cfg4_width_step_staged_equals_eager_and_the_oracle_forward():
     assert b0.graph.n > 9000 and b0.y is not None and b0.y.shape[1] == 9344 and b0.y.dtype == torch.bfloat16
     model.fixed_noise = (torch.zeros((512, 10), device=DEV), torch.zeros((512, 10), device=DEV))
     staged = tu.GraphedStepper(model, opt, dict(cfg, staged_graphs=True), dd)
+    # (9 281 is not a multiple of 4: the flat buffers hold alignment slots between parameters that no gradient is ever
+    # written to -- they are zero in a run and would keep the poison value here -- so the comparison goes parameter by parameter)
+    pgrad = lambda: torch.cat([p.grad.reshape(-1) for p in opt.params])
     for rep in range(3):
         for bi in (0, 19):                                        # first and last (partial) batch
             staged.beta1_t[1].fill_(-beta1)
             la = tu.forward_backward(model, cfg, dd, 1, tp, bi, epoch, staged.beta1_t, optimizer=opt)
-            ga = opt.flat_grad.clone()
-            opt.flat_grad.fill_(7.0)
+            ga = pgrad().clone()
+            for p in opt.params:
+                p.grad.fill_(7.0)
             lb = staged.fb(1, tp, bi, epoch, beta1)
-            gb = opt.flat_grad
+            gb = pgrad()
             assert torch.isfinite(lb).all() and torch.isfinite(gb).all()
             np.testing.assert_allclose(lb.cpu().numpy(), la.cpu().numpy(), rtol=1e-4, atol=1e-5)
             scale = float(ga.abs().max())
