@@ -690,3 +690,44 @@ def test_weight_images_follow_every_writer_of_the_weights():
     # a maintain_image() on the optimizer that lost the parameters is refused
     from spadot_amd.ops import weight_image
     assert not opt.maintain_image(enc.gat1.lin.weight, weight_image(enc.gat1.lin.weight, 256, torch.bfloat16, enc.gat1))
+
+
+def test_deferred_weight_gradients_leave_the_same_bits():
+    """GraphedStepper(defer_wgrad): the second GAT layer's weight gradient, the last layer's weight / attention-vector chain and
+    the decoder output map's weight gradient are queued by the backward functions and run later on the side stream (round 4).
+    Same kernels on the same operands: the flat gradient of a replayed step must equal, bit for bit, the one the same stepper
+    leaves with the switch off (bf16, 4000 spots x 1200 genes: the matrix-core paths and the aggregate-first last layer)."""
+    from spadot_amd.model import SpaDOT
+    from spadot_amd.ops import FlatAdamW
+    from spadot_amd.synthetic import make_dataset
+    from spadot_amd.utils import _train_utils as tu, _utils
+    data = make_dataset(2, 4000, 1200, seed=9)
+    cfg = _utils.load_model_config(types.SimpleNamespace(config=None))
+    cfg.update(input_dim=1200, timepoints=[0, 1], device=torch.device(DEV), compute_dtype=torch.bfloat16,
+               inducing_point_nums=300, n_clusters=6)
+    _utils.set_seed(3)
+    dd = tu.prepare_dataloader(data, cfg)
+    model = SpaDOT.SpaDOT(cfg, dd).to(DEV)
+    opt = FlatAdamW(model.parameters(), lr=cfg["lr"], first=model.SVGPEncoder.parameters())
+    tu._update_Kmeans(model, cfg, dd)
+    tu._update_OT_matrix(model, cfg)
+    model.train()
+    model.fixed_noise = (torch.zeros((512, 10), device=DEV), torch.zeros((512, 10), device=DEV))
+    on = tu.GraphedStepper(model, opt, dict(cfg, staged_graphs=True, defer_wgrad=True), dd)
+    off = tu.GraphedStepper(model, opt, dict(cfg, staged_graphs=True, defer_wgrad=False), dd)
+    assert on.defer_wgrad and not off.defer_wgrad
+    object.__setattr__(model.GATEncoder.gat2, "defer_wgrad", True)      # (the flag on the layer only permits queueing)
+    ep = cfg["ot_epoch"]
+    for rep in range(3):                                   # eager, capture + replay, replay
+        for bi in (0, 2):
+            la = off.fb(1, 1, bi, ep, 0.5).clone()
+            ga = opt.flat_grad.clone()
+            opt.flat_grad.zero_()
+            lb = on.fb(1, 1, bi, ep, 0.5)
+            torch.cuda.synchronize()
+            assert torch.equal(la, lb)
+            assert torch.equal(ga, opt.flat_grad), float((ga - opt.flat_grad).abs().max())
+    # the last-layer gradients that travel through the queue are really there
+    g3 = model.GATEncoder.gat3
+    assert float(g3.att_src.grad.abs().max()) > 0 and float(g3.lin.weight.grad.abs().max()) > 0
+    assert float(model.GATEncoder.gat2.lin.weight.grad.abs().max()) > 0
