@@ -426,6 +426,7 @@ _DIRECT_GRAD = [False]     # True only inside FlatAdamW.backward (a plain .backw
 # (GraphedStepper, `defer_wgrad`) runs the closures later, on the side stream, beside the rest of the GAT backward -- whose
 # dependency chain they would otherwise lengthen by their own duration.
 DEFERRED = [None]
+_UNIT_SEEDS = set()        # addresses of the constant-one tensors FlatAdamW.backward_partial seeds a scalar loss with
 
 
 def _deferring():
@@ -1293,8 +1294,17 @@ class _MixLosses(torch.autograd.Function):
         terms = [t.reshape(()).float() if t.dtype != torch.float32 else t for t in terms]
         _need_cuda(w6, *terms)
         out8 = torch.empty(8, dtype=torch.float32, device=w6.device)
-        arr = (ctypes.c_void_p * 6)(*(t.data_ptr() for t in terms))
-        _check(model_lib().spadot_mix_losses_forward(arr, _p(w6), _p(out8), _stream()), "spadot_mix_losses_forward")
+
+        def run(terms=terms, w6=w6, out8=out8):
+            arr = (ctypes.c_void_p * 6)(*(t.data_ptr() for t in terms))
+            _check(model_lib().spadot_mix_losses_forward(arr, _p(w6), _p(out8), _stream()), "spadot_mix_losses_forward")
+
+        # the loss VALUES feed nothing in the backward pass (its seed is a constant): with a queue open they are computed
+        # later, off the step's dependency chain (ops.DEFERRED); out8 is filled then
+        if DEFERRED[0] is not None:
+            DEFERRED[0].append(run)
+        else:
+            run()
         ctx.save_for_backward(w6)
         log7 = out8[:7]
         ctx.mark_non_differentiable(log7)
@@ -1306,6 +1316,8 @@ class _MixLosses(torch.autograd.Function):
         (w6,) = ctx.saved_tensors
         if g is None:
             return (None,) * 7
+        if g.data_ptr() in _UNIT_SEEDS:            # d elbo / d term_k = w6[k] for the constant-one seed: no launch
+            return (None, *(w6[k] if ctx.needs_input_grad[k + 1] else None for k in range(6)))
         g6 = torch.empty(6, dtype=torch.float32, device=w6.device)
         _check(model_lib().spadot_mix_losses_backward(_p(g.contiguous().float()), _p(w6), _p(g6), _stream()),
                "spadot_mix_losses_backward")
@@ -1521,8 +1533,18 @@ class _LinearSqErr(torch.autograd.Function):
         cast_rows([(h, hc), (W.detach().contiguous(), Wc)])
         o = torch.mm(hc, Wc.t(), out_dtype=torch.float32)
         out = torch.empty(1, dtype=torch.float32, device=h.device)
-        _check(model_lib().spadot_bias_sqerr_forward(_p(o), _p(bias), _p(y), b, G, float(inv_scale), _p(_get_scratch(h.device)),
-                                                     _p(out), _stream()), "spadot_bias_sqerr_forward")
+
+        # (a queued launch gets its own partial-sum scratch: it must not share the per-device one with what runs meanwhile)
+        scratch = _get_scratch(h.device) if DEFERRED[0] is None else torch.empty_like(_get_scratch(h.device))
+
+        def value(o=o, bias=bias, y=y, out=out, scratch=scratch):
+            _check(model_lib().spadot_bias_sqerr_forward(_p(o), _p(bias), _p(y), b, G, float(inv_scale), _p(scratch), _p(out), _stream()),
+                   "spadot_bias_sqerr_forward")
+
+        if DEFERRED[0] is not None:            # the VALUE of the reconstruction term feeds only the logging vector: queued
+            DEFERRED[0].append(value)
+        else:
+            value()
         ctx.save_for_backward(hc, Wc, o, bias, y)
         ctx.inv_scale = float(inv_scale)
         ok = lambda g_, p_: g_ if (g_ is not None and g_.dtype == torch.float32 and g_.is_contiguous() and g_.shape == p_.shape) else None
@@ -1783,6 +1805,7 @@ class FlatAdamW:
             one = getattr(self, "_one", None)
             if one is None or one.device != outputs.device:
                 one = self._one = torch.ones((), dtype=torch.float32, device=outputs.device)
+                _UNIT_SEEDS.add(one.data_ptr())
             grad_outputs = one
         _DIRECT_GRAD[0] = True
         try:
