@@ -19,7 +19,10 @@ problem (r mod 4, r mod 4 + 1); every step all-reduces the flat gradient buffer 
 beside the end of the backward pass); pair solves need no collective.  `value` = steps of all ranks / max-over-ranks
 wall time.
 
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0 -- at most LINE_LIMIT (6000) characters: the contract's keys, `roofline`, `cpu_baseline` and
+one-number summaries; the full record (texts, per-repeat timings, kernel tables) goes to gpurun_out/bench_detail_<N>gpu.json,
+named in the line as `detail_file` (tests/test_bench_line_cpu.py).  `python bench.py --gpus N` with N > 1 and no WORLD_SIZE
+starts the N ranks itself (children, `python -m torch.distributed.run`), before anything touches the GPU.
 """
 import contextlib
 import argparse
