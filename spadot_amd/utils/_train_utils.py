@@ -488,7 +488,9 @@ class GraphedStepper:
                                 and hasattr(model.GATEncoder, "above_second_dense"))
         if self.defer_wgrad:
             self.svgp_head_first = False
-            object.__setattr__(model.GATEncoder.gat2, "defer_wgrad", True)
+            # (SPADOT_DEFER_L2=0: the second layer's weight gradient stays on the main stream, only the small jobs are queued)
+            object.__setattr__(model.GATEncoder.gat2, "defer_wgrad",
+                               bool(model_config.get("defer_layer2_wgrad", os.environ.get("SPADOT_DEFER_L2", "1") == "1")))
         self._late_event = None
         self._enc_event = None
         self.stamps = (torch.zeros(32, dtype=torch.int64, device=next(model.parameters()).device)
