@@ -161,7 +161,10 @@ class SpaDOT(nn.Module):
     def _side_stream(self):
         st = getattr(self, "_svgp_stream", None)
         if st is None:
-            st = torch.cuda.Stream(device=self.device)
+            # default -1 (SPADOT_SIDE_PRIORITY=0 for the old form): a high-priority HIP stream (hipStreamCreateWithPriority): when both queues have
+            # workgroups waiting, the dispatcher hands free compute-unit slots to this stream's short launches first
+            prio = int(__import__("os").environ.get("SPADOT_SIDE_PRIORITY", "-1"))
+            st = torch.cuda.Stream(device=self.device, priority=prio)
             self._svgp_stream = st
         return st
 

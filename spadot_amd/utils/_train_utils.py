@@ -493,6 +493,10 @@ class GraphedStepper:
                                bool(model_config.get("defer_layer2_wgrad", os.environ.get("SPADOT_DEFER_L2", "1") == "1")))
         self._late_event = None
         self._enc_event = None
+        # late_stream (round 4, opt-in): the deferred gradient work on a third stream and memory pool of its own
+        self.late_stream = bool(self.defer_wgrad and model_config.get("late_stream", os.environ.get("SPADOT_LATE_STREAM", "0") == "1"))
+        self._late_stream = None
+        self.pool_late = None
         self.stamps = (torch.zeros(32, dtype=torch.int64, device=next(model.parameters()).device)
                        if os.environ.get("SPADOT_STAMPS") == "1" else None)
         if self.stamps is not None:
@@ -743,6 +747,12 @@ class GraphedStepper:
             fns = tuple(stamped(k, fn) for k, fn in enumerate(fns))
         return fns
 
+    def _late_stream_obj(self):
+        if self._late_stream is None:
+            self._late_stream = torch.cuda.Stream(device=torch.device(self.cfg["device"]),
+                                                  priority=int(os.environ.get("SPADOT_LATE_PRIORITY", "0")))
+        return self._late_stream
+
     def _param_groups(self):
         if self._groups is None:
             own = {id(p) for p in self.opt.params}
@@ -804,9 +814,18 @@ class GraphedStepper:
             with torch.cuda.stream(side):
                 fns[3]()
             fns[5]()
-            with torch.cuda.stream(side):
-                side.wait_event(self._late_event)
-                fns[6]()
+            if self.late_stream:
+                # the queued gradient work on a THIRD stream: it starts when its inputs exist (the event behind the first
+                # GAT backward graph), not behind the SVGP backward
+                late = self._late_stream_obj()
+                late.wait_event(self._late_event)
+                with torch.cuda.stream(late):
+                    fns[6]()
+                main.wait_stream(late)
+            else:
+                with torch.cuda.stream(side):
+                    side.wait_event(self._late_event)
+                    fns[6]()
             main.wait_stream(side)
             return res
         head_first = self.svgp_head_first and len(fns) >= 7
@@ -907,6 +926,10 @@ class GraphedStepper:
                 g = torch.cuda.CUDAGraph()
                 side_stage = k in (1, 3) or (self.svgp_head_first and k >= nf - 2) or (self.defer_wgrad and nf == 7 and k == 6)
                 pool = self.pool_side if side_stage else self.pool           # the SVGP stages run beside the GAT ones
+                if self.late_stream and self.defer_wgrad and nf == 7 and k == 6:
+                    if self.pool_late is None:
+                        self.pool_late = torch.cuda.graph_pool_handle()
+                    pool = self.pool_late                                     # (runs beside BOTH other streams' graphs)
                 with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
                     r = fn()
                 if k == 2:
