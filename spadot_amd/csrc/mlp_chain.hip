@@ -615,6 +615,7 @@ int spadot_mlp_chain_backward(const float *dy, const float *x, int b, int n_laye
     }
     hipLaunchKernelGGL(k_mlp_chain_bwd, dim3(rows), dim3(256), LDS_BWD, (hipStream_t)stream, dy, x, b, ch, dx, workspace, width);
     if (hipGetLastError() != hipSuccess) return -5;
+    if (!grads) return 0;                                            // (the caller sums the partials later: spadot_colsum)
     return spadot_colsum(workspace, rows, width, grads, stream);     // grads: one workspace row = [dW | dbias | dgamma | dbeta] per stage
 }
 
@@ -648,11 +649,12 @@ int spadot_headfc_forward(const void *h_bf16, const float *W, const float *bias,
 
 int spadot_headfc_backward(const float *g, const void *h_bf16, const float *W, int b, int K, int N, void *dh_bf16,
                            float *workspace, float *grads, void *stream) {
-    if (b <= 0 || K <= 0 || K % 8 || N <= 0 || N > FC_MAXN || !workspace || !grads) return -22;
+    if (b <= 0 || K <= 0 || K % 8 || N <= 0 || N > FC_MAXN || !workspace) return -22;
     const int blocks = (b + 7) / 8;
     hipLaunchKernelGGL(k_headfc_bwd, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, (const __bf16 *)h_bf16, W, b, K, N,
                        (__bf16 *)dh_bf16, workspace);
     if (hipGetLastError() != hipSuccess) return -5;
+    if (!grads) return 0;                                                  // (the caller sums the partials later: spadot_colsum)
     return spadot_colsum(workspace, blocks, N * K + N, grads, stream);     // grads = [dW (N x K) | db (N)]
 }
 

@@ -724,6 +724,35 @@ __global__ __launch_bounds__(256) void k_rowdot_bwd(const T *__restrict__ g, con
     gA[idx] = (T)((double)g[r] * (double)B[(size_t)i * m + k]);
 }
 
+// q1[l, i] = sum_n G2T[l, n] T[l, n, i]^2 + 1/2 g_kl m0[l, i]      (T [L, n2, b], G2T [L, n2], m0 and q1 [L, b]; fp64)
+// = diag(K_nm S_l D_l S_l K_mn) of _SVGPCore.backward with D_l = X2^T diag(G2_l) X2 + g_kl/2 M, T_l = X2 S_l K_mn and
+// m0_l = diag(K_nm S_l M S_l K_mn) formed ahead of the backward pass (they do not depend on the incoming gradients).
+// Workgroup = 16 columns x 16 row slices; a slice walks its rows n = s, s + 16, ... in order, the slices are added in order.
+__global__ __launch_bounds__(256) void k_svgp_q1t(const double *__restrict__ T, const double *__restrict__ G2T,
+                                                  const double *__restrict__ m0, const double *__restrict__ g_kl, int n2,
+                                                  int b, double *__restrict__ q1) {
+    __shared__ double part[16][17];
+    const int l = blockIdx.y, c = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + c;
+    const double *Tl = T + (size_t)l * n2 * b, *gl = G2T + (size_t)l * n2;
+    double acc = 0.0;
+    if (i < b) {
+#pragma unroll 8
+        for (int n = sl; n < n2; n += 16) {
+            const double t = Tl[(size_t)n * b + i];
+            acc = fma(gl[n] * t, t, acc);
+        }
+    }
+    part[sl][c] = acc;
+    __syncthreads();
+    if (sl == 0 && i < b) {
+        double a = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) a += part[k][c];
+        q1[(size_t)l * b + i] = a + 0.5 * g_kl[0] * m0[(size_t)l * b + i];
+    }
+}
+
 constexpr double LOG_2PI = 1.8378770664093453;   // SpaDOT.py:138
 
 template <typename T>
@@ -2303,6 +2332,13 @@ int spadot_svgp_mid(const double *S, const double *t, const double *M, const dou
     hipLaunchKernelGGL(k_svgp_mid1, dim3(gx, L), dim3(256), 0, st_, S, t, M, m, r, smpart);
     hipLaunchKernelGGL(k_svgp_mid2, dim3((m + rows2 + 3) / 4, L), dim3(256), 0, st_, M, X2, (const double *)r,
                        (const double *)smpart, nparts, m, rows2, L, Mr, raw, sm);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+int spadot_svgp_q1t(const double *T, const double *G2T, const double *m0, const double *g_kl, int L, int n2, int b,
+                    double *q1, void *stream) {
+    if (L <= 0 || n2 <= 0 || b <= 0 || !T || !G2T || !m0 || !g_kl || !q1) return -22;
+    hipLaunchKernelGGL(k_svgp_q1t, dim3((b + 15) / 16, L), dim3(256), 0, (hipStream_t)stream, T, G2T, m0, g_kl, n2, b, q1);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 

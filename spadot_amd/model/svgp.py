@@ -168,6 +168,12 @@ class _SVGPCore(torch.autograd.Function):
                                             _p(out4), _p(skl32), _stream()), "spadot_svgp_post_forward")
         ctx.save_for_backward(mu, var, w, X, r, Mr, X2S, p_m, p_v, mv, tr, out4)
         ctx.bc, ctx.rc, ctx.bN = bc, rc, b_over_N
+        # what backward() needs that does NOT depend on the incoming gradients (q2 = diag(K_nm S2 K_mn), the contiguous
+        # K_nm S_l): precompute_backward() may fill this holder between forward and backward -- GraphedStepper does, on the
+        # side stream while the loss tail runs on the main stream and the side stream would idle; backward() computes
+        # whatever the holder lacks
+        ctx.holder = {"_inputs": (bc.K_nm, X[L:], X2S, b), "M": rc.M}
+        _LAST_HOLDER[0] = ctx.holder
         ctx.mark_non_differentiable(out4)
         ctx.set_materialize_grads(False)          # no zero-filled gradient tensors for outputs the loss does not use
         return p_m, p_v, skl32[0], out4
@@ -209,16 +215,61 @@ class _SVGPCore(torch.autograd.Function):
             Kdt = dgemm_small(1, Kn, dt)                                                         # [b, L]
         else:
             dr = gMr.addmm_(G1.T, X2, alpha=c)                               # [L, m] (in place: no copy of gMr in front of the GEMM)
-            dt = torch.bmm(S, dr.unsqueeze(2)).squeeze(2)                    # [L, m]
-            A2 = X2.unsqueeze(0) * G2T.unsqueeze(2)                          # [L, 2b, m]
-            D = torch.baddbmm(gM.expand(L, m, m), A2.transpose(1, 2), X2.unsqueeze(0).expand(L, 2 * b, m))
-            KS = X2S[:, :b].contiguous()                                     # [L, b, m] = K_nm S_l
-            q1 = rowdot(torch.bmm(KS, D).reshape(1, L * b, m), KS.reshape(L * b, m)).reshape(L, b)
-            q2 = rowdot(torch.matmul(Kn, S2), Kn)                            # diag(K_nm S2 K_mn)  [L, b]
-            Kdt = Kn @ dt.T                                                  # [b, L]
+            Kdt = None
+            if MID_BWD[0]:
+                # dt_l = S_l dr_l and K_nm dt^T are the forward's r = S t / raw = X2 r with other operands: the same two
+                # wave-per-row launches (spadot_svgp_mid) instead of a batched library GEMM with ONE output column
+                # (MT64x128x16: 41 us in the step) and a [b, m] x [m, L] product (27 us)
+                dt = torch.empty((L, m), dtype=F64, device=dev)
+                Kdt = torch.empty((b, L), dtype=F64, device=dev)
+                nparts = (m + 3) // 4 * 4
+                junk = torch.empty(L * m + L + L * nparts, dtype=F64, device=dev)
+                _check(lib.spadot_svgp_mid(_p(S), _p(dr), _p(rc.M), _p(Kn), L, m, b, _p(dt), _p(junk), _p(Kdt), _p(junk[L * m:]),
+                                           _p(junk[L * m + L:]), L * nparts, _stream()), "spadot_svgp_mid")
+            else:
+                dt = torch.bmm(S, dr.unsqueeze(2)).squeeze(2)                # [L, m]
+            pre = getattr(ctx, "holder", None) or {}
+            if "T" in pre:
+                q1 = torch.empty((L, b), dtype=F64, device=dev)
+                _check(lib.spadot_svgp_q1t(_p(pre["T"]), _p(G2T), _p(pre["m0"]), _p(g_kl), L, 2 * b, b, _p(q1), _stream()),
+                       "spadot_svgp_q1t")
+            else:
+                A2 = X2.unsqueeze(0) * G2T.unsqueeze(2)                      # [L, 2b, m]
+                D = torch.baddbmm(gM.expand(L, m, m), A2.transpose(1, 2), X2.unsqueeze(0).expand(L, 2 * b, m))
+                KS = pre["KS"] if "KS" in pre else X2S[:, :b].contiguous()   # [L, b, m] = K_nm S_l
+                q1 = rowdot(torch.bmm(KS, D).reshape(1, L * b, m), KS.reshape(L * b, m)).reshape(L, b)
+            q2 = pre["q2"] if "q2" in pre else rowdot(torch.matmul(Kn, S2), Kn)     # diag(K_nm S2 K_mn)  [L, b]
+            if Kdt is None:
+                Kdt = Kn @ dt.T                                              # [b, L]
         _check(lib.spadot_svgp_grad_tail(_p(q1), _p(q2), _p(Kdt), _p(p_v), _p(bc.ktilde), _p(p_m), _p(mu), _p(w), _p(g_kl),
                                          _p(g_mu), _p(g_var), b, L, c, None, None, _p(dz), _stream()), "spadot_svgp_grad_tail")
         return dz, None, None, None, None
+
+
+Q1T = [__import__("os").environ.get("SPADOT_SVGP_Q1T", "0") == "1"]
+MID_BWD = [__import__("os").environ.get("SPADOT_SVGP_MIDBWD", "1") == "1"]
+_LAST_HOLDER = [None]          # the holder of the most recent _SVGPCore.forward (see precompute_backward)
+
+
+def precompute_backward(holder=None):
+    """The gradient-independent products of _SVGPCore.backward -- q2 = diag(K_nm S2 K_mn) (a [b, m] x [L, m, m] product + a
+    row dot: 94 + 32 us inside the backward pair of a cfg3 step) and the contiguous copy of K_nm S_l (15 us) -- computed ahead
+    of the backward pass into the holder of the most recent forward (or `holder`).  No-op when already done."""
+    h = holder if holder is not None else _LAST_HOLDER[0]
+    if h is None or "q2" in h or DGEMM_SMALL[0]:
+        return h
+    Kn, S2, X2S, b = h["_inputs"]
+    with torch.no_grad():
+        h["q2"] = rowdot(torch.matmul(Kn, S2), Kn)
+        h["KS"] = KS = X2S[:, :b].contiguous()
+        if Q1T[0] and "M" in h:
+            # q1 = diag(K_nm S D S K_mn) with D = X2^T diag(G2) X2 + g/2 M needs the gradients only as WEIGHTS of squares:
+            # q1[l, i] = sum_n G2[l, n] T_l[n, i]^2 + g/2 m0[l, i],  T_l = X2 S_l K_mn [2b, b],  m0_l = diag(K_nm S_l M S_l K_mn).
+            # T and m0 are formed here (2.5 + 0.6 GFLOP, beside the loss tail); the backward pass then needs one reduction
+            # launch in place of a scaled copy of X2, the D product, K_nm S_l D_l and a row dot (~140 us in the step)
+            h["T"] = torch.matmul(X2S, Kn.t())                               # [L, 2b, b]
+            h["m0"] = rowdot(torch.matmul(KS, h["M"]), KS)                   # [L, b]
+    return h
 
 
 class SVGP(nn.Module):

@@ -1099,10 +1099,14 @@ class _MLPChain(torch.autograd.Function):
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         mean, inv = [stats[2 * l] for l in range(n)], [stats[2 * l + 1] for l in range(n)]
         cs = (ctypes.c_double * n)(*ctx.slope)
+        late = direct and _deferring()          # the parameter gradients feed only the optimizer: their column sum is queued
         _check(lib.spadot_mlp_chain_backward(_p(dy.contiguous().float()), _p(x), b, n, cd, _ptr_array(Ws), _ptr_array(gs), cs,
                                              _ptr_array(a), _ptr_array(y), _ptr_array(mean), _ptr_array(inv),
-                                             None if dx is None else _p(dx), _p(ws), _p(grads), _stream()),
+                                             None if dx is None else _p(dx), _p(ws), None if late else _p(grads), _stream()),
                "spadot_mlp_chain_backward")
+        if late:
+            DEFERRED[0].append(lambda ws=ws, grads=grads: _check(
+                lib.spadot_colsum(_p(ws), ws.shape[0], ws.shape[1], _p(grads), _stream()), "spadot_colsum"))
         out = []
         off = 0
         for l in range(n):
@@ -1167,8 +1171,12 @@ class _HeadFC(torch.autograd.Function):
         ws = torch.empty(((b + 7) // 8, N * K + N), dtype=torch.float32, device=dev)
         direct = ctx.flat_out is not None and _DIRECT_GRAD[0] and ctx.flat_out.numel() == N * K + N
         grads = ctx.flat_out if direct else torch.empty(N * K + N, dtype=torch.float32, device=dev)
-        _check(model_lib().spadot_headfc_backward(_p(g.contiguous().float()), _p(h), _p(W), b, K, N, _p(dh), _p(ws), _p(grads),
-                                                  _stream()), "spadot_headfc_backward")
+        late = direct and _deferring()
+        _check(model_lib().spadot_headfc_backward(_p(g.contiguous().float()), _p(h), _p(W), b, K, N, _p(dh), _p(ws),
+                                                  None if late else _p(grads), _stream()), "spadot_headfc_backward")
+        if late:
+            DEFERRED[0].append(lambda ws=ws, grads=grads: _check(
+                model_lib().spadot_colsum(_p(ws), ws.shape[0], ws.shape[1], _p(grads), _stream()), "spadot_colsum"))
         return dh, grads[:N * K].view(N, K), grads[N * K:]
 
 

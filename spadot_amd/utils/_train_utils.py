@@ -493,6 +493,10 @@ class GraphedStepper:
                                bool(model_config.get("defer_layer2_wgrad", os.environ.get("SPADOT_DEFER_L2", "1") == "1")))
         self._late_event = None
         self._enc_event = None
+        # svgp_pre (round 4): the gradient-independent products of the SVGP backward (svgp.precompute_backward: ~140 us of its
+        # ~500 us chain inside the backward pair) as a graph of their own on the side stream, launched right behind the SVGP
+        # forward: they run while the loss tail occupies the main stream and the side stream would otherwise idle
+        self.svgp_pre = bool(self.defer_wgrad and model_config.get("svgp_precompute", os.environ.get("SPADOT_SVGP_PRE", "1") == "1"))
         # late_stream (round 4, opt-in): the deferred gradient work on a third stream and memory pool of its own
         self.late_stream = bool(self.defer_wgrad and model_config.get("late_stream", os.environ.get("SPADOT_LATE_STREAM", "0") == "1"))
         self._late_stream = None
@@ -659,6 +663,8 @@ class GraphedStepper:
             st["ys"] = batch.y[:b] if cached else Y[seeds]
             st["pm"], st["pv"], st["skl"] = model.branch_svgp(st["xs"], st["ys"], tp, b, batch_key=(tp, bi),
                                                               y_seed32=getattr(batch, "y_seed32", None) if cached else None)
+            from ..model import svgp as _svgp
+            st["svgp_holder"] = _svgp._LAST_HOLDER[0]
 
         def svgp_fwd_head():
             st["xs"] = batch.x[:b] if cached else loc[seeds]
@@ -668,6 +674,10 @@ class GraphedStepper:
 
         def svgp_fwd_rest():
             st["pm"], st["pv"], st["skl"] = model.branch_svgp_rest(st["svgp_state"])
+
+        def svgp_pre():             # gradient-independent part of the SVGP backward (side stream, beside the tail)
+            from ..model import svgp as _svgp
+            _svgp.precompute_backward(st["svgp_holder"])
 
         def tail():
             leaves = [st[k].detach().requires_grad_(True) for k in ("zg", "pm", "pv", "skl")]
@@ -729,6 +739,8 @@ class GraphedStepper:
             fns = (gat_fwd, svgp_fwd, tail, svgp_bwd, gat_bwd)
         if self.defer_wgrad:
             fns = (gat_fwd, svgp_fwd, queued(tail), svgp_bwd, queued(gat_bwd_a), queued(gat_bwd_b), late)
+            if self.svgp_pre:
+                fns = fns + (svgp_pre,)
         if self.svgp_head_first:
             # a SEVENTH stage: the SVGP branch's short launches in front of its inverse as a graph of their own (see __init__)
             fns = fns + (svgp_fwd_head, svgp_fwd_rest)
@@ -793,10 +805,10 @@ class GraphedStepper:
             else:
                 side.wait_stream(main)
             self._head_ready = False
-        if self.defer_wgrad and len(fns) == 7:
-            # (gat_fwd, svgp_fwd, tail, svgp_bwd, gat_bwd_a, gat_bwd_b, late)
+        if self.defer_wgrad and len(fns) in (7, 8):
+            # (gat_fwd, svgp_fwd, tail, svgp_bwd, gat_bwd_a, gat_bwd_b, late[, svgp_pre])
             if not two_streams:
-                for k in (0, 1, 2, 3, 4, 5, 6):
+                for k in ((0, 1, 7, 2, 3, 4, 5, 6) if len(fns) == 8 else (0, 1, 2, 3, 4, 5, 6)):
                     r = fns[k]()
                     if k == 2:
                         res = r
@@ -804,8 +816,11 @@ class GraphedStepper:
             fns[0]()
             with torch.cuda.stream(side):
                 fns[1]()
-            main.wait_stream(side)
+            main.wait_stream(side)                       # (an event behind the SVGP forward: what follows on `side` is not waited for)
             res = fns[2]()
+            if len(fns) == 8:                            # (launched behind the tail: the host hands the critical graph over first)
+                with torch.cuda.stream(side):
+                    fns[7]()
             side.wait_stream(main)
             fns[4]()
             if self._late_event is None:
@@ -921,12 +936,15 @@ class GraphedStepper:
             order = list(range(nf))
             if self.svgp_head_first:
                 order = [0, nf - 2, nf - 1] + list(range(2, nf - 2))
+            if self.defer_wgrad and nf == 8:             # svgp_pre fills the holder the SVGP backward's capture reads
+                order = [0, 1, 7, 2, 3, 4, 5, 6]
             for k in order:
                 fn = fns[k]
                 g = torch.cuda.CUDAGraph()
-                side_stage = k in (1, 3) or (self.svgp_head_first and k >= nf - 2) or (self.defer_wgrad and nf == 7 and k == 6)
+                side_stage = (k in (1, 3) or (self.svgp_head_first and k >= nf - 2)
+                              or (self.defer_wgrad and nf in (7, 8) and k in (6, 7)))
                 pool = self.pool_side if side_stage else self.pool           # the SVGP stages run beside the GAT ones
-                if self.late_stream and self.defer_wgrad and nf == 7 and k == 6:
+                if self.late_stream and self.defer_wgrad and nf in (7, 8) and k == 6:
                     if self.pool_late is None:
                         self.pool_late = torch.cuda.graph_pool_handle()
                     pool = self.pool_late                                     # (runs beside BOTH other streams' graphs)

@@ -179,6 +179,42 @@ def test_kernel_matrix_and_svgp_match_reference(ops, tag):
     np.testing.assert_allclose(B_t.cpu().numpy(), g[f"{tag}_B_t"], rtol=1e-6, atol=1e-9)
 
 
+@pytest.mark.parametrize("b,m,L", [(64, 17, 3), (512, 236, 10), (200, 261, 4)])
+def test_svgp_backward_precomputed_and_restructured_forms_agree(ops, b, m, L):
+    """_SVGPCore.backward three ways: plain (library products for dt, K dt, D, K S D), with dt / K dt on the wave-per-row
+    kernels (MID_BWD), and with its gradient-independent products formed ahead of the backward pass (precompute_backward:
+    q2, K S, and -- Q1T -- T = X2 S K_mn, m0, after which q1 is one reduction launch).  Same algebra, fp64: the encoder
+    gradients agree to rounding."""
+    from spadot_amd.model import svgp as sv
+    rng = np.random.default_rng(7)
+    cfg = dict(device=DEV, kernel_type="Gaussian", kernel_scale=0.1)
+    mod = sv.SVGP(cfg, rng.uniform(0, 1, (m, 2)), 5000.0)
+    x = T(rng.uniform(0, 1, (b, 2))).to(DEV)
+    z0 = torch.as_tensor(np.concatenate([rng.normal(0, 1, (b, L)), rng.normal(-1, 0.3, (b, L))], 1), dtype=torch.float32).to(DEV)
+    gpm, gpv = T(rng.normal(0, 1, (b, L))).to(DEV), T(rng.normal(0, 1, (b, L))).to(DEV)
+
+    def run(mid, pre, q1t):
+        old = sv.MID_BWD[0], sv.Q1T[0]
+        sv.MID_BWD[0], sv.Q1T[0] = mid, q1t
+        try:
+            z = z0.clone().requires_grad_(True)
+            bc = mod.batch_constants(x)
+            p_m, p_v, skl = mod.elbo_finish(bc, mod.elbo_start(bc, z))
+            if pre:
+                h = sv.precompute_backward()
+                assert "q2" in h and "KS" in h and (("T" in h) == q1t)
+            (dz,) = torch.autograd.grad([p_m, p_v, skl], [z], [gpm, gpv, torch.tensor(0.7, device=DEV)])
+            return dz.double().cpu().numpy()
+        finally:
+            sv.MID_BWD[0], sv.Q1T[0] = old
+
+    ref = run(False, False, False)
+    scale = np.abs(ref).max()
+    for mid, pre, q1t in ((True, False, False), (True, True, False), (True, True, True), (False, True, True)):
+        got = run(mid, pre, q1t)
+        assert np.abs(got - ref).max() <= 2e-6 * scale, (mid, pre, q1t, np.abs(got - ref).max(), scale)
+
+
 def test_reduction_kernels_gradients_vs_torch(ops):
     """rowdot / elbo_reduce / sqerr_sum: values and gradients against the same formulas in plain torch fp64."""
     rng = np.random.default_rng(4)
