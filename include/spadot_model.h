@@ -164,9 +164,14 @@ int spadot_svgp_post_backward(const float *g_skl, const double *out4, const doub
                               int m, double c, double b_over_N, double *g_mu, double *g_var, double *G1, double *G2T,
                               double *g_kl, double *gMr, double *gM, void *stream);
 /* q1[l, i] = sum_n G2T[l, n] T[l, n, i]^2 + g_kl / 2 * m0[l, i]: the diag(K_nm dSigma K_mn) term of _SVGPCore.backward
- * (svgp.py:62-104 differentiated) from T_l = X2 S_l K_mn [L, n2, b] and m0 [L, b] formed ahead of the backward pass. */
-int spadot_svgp_q1t(const double *T, const double *G2T, const double *m0, const double *g_kl, int L, int n2, int b,
-                    double *q1, void *stream);
+ * (svgp.py:62-104 differentiated) from T_l = X2 S_l K_mn, given as its two halves Ta = K_nm S_l K_mn and Tb = P S_l K_mn
+ * (each [L, nh, b]; G2T [L, 2 nh]), and m0 [L, b], all formed ahead of the backward pass. */
+int spadot_svgp_q1t(const double *Ta, const double *Tb, const double *G2T, const double *m0, const double *g_kl, int L, int nh,
+                    int b, double *q1, void *stream);
+/* p_m = c raw[:b] and p_v = k~ + rd_a^T (rd_a [L, b] = diag(K_nm S_l K_mn)): what the loss tail needs of
+ * spadot_svgp_post_forward (svgp.py:62-84), which may then run later. */
+int spadot_svgp_post_pm_pv(const double *raw, const double *rd_a, const double *ktilde, int b, int L, double c, double *p_m,
+                           double *p_v, void *stream);
 int spadot_svgp_grad_tail(const double *q1, const double *q2, const double *Kdt, const double *p_v, const double *ktilde,
                           const double *p_m, const double *mu, const double *w, const double *g_kl, const double *g_mu,
                           const double *g_var, int b, int L, double c, double *dmu, double *dvar, float *dz,

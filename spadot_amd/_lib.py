@@ -215,7 +215,8 @@ def model_lib():
         "spadot_svgp_post_forward": [vp] * 9 + [ci, ci, ci, cd, cd, cd] + [vp] * 7,
         "spadot_svgp_post_backward": [vp] * 13 + [ci, ci, ci, cd, cd] + [vp] * 8,
         "spadot_svgp_grad_tail": [vp] * 11 + [ci, ci, cd] + [vp] * 4,
-        "spadot_svgp_q1t": [vp, vp, vp, vp, ci, ci, ci, vp, vp],
+        "spadot_svgp_q1t": [vp, vp, vp, vp, vp, ci, ci, ci, vp, vp],
+        "spadot_svgp_post_pm_pv": [vp, vp, vp, ci, ci, cd, vp, vp, vp],
         "spadot_svgp_pre": [vp, ci, ci, vp, vp, vp, vp, vp],
         "spadot_svgp_pre2": [vp, vp, ci, ci, ci, vp, vp, vp, vp, vp, vp],
         "spadot_svgp_mid": [vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp],

@@ -724,23 +724,29 @@ __global__ __launch_bounds__(256) void k_rowdot_bwd(const T *__restrict__ g, con
     gA[idx] = (T)((double)g[r] * (double)B[(size_t)i * m + k]);
 }
 
-// q1[l, i] = sum_n G2T[l, n] T[l, n, i]^2 + 1/2 g_kl m0[l, i]      (T [L, n2, b], G2T [L, n2], m0 and q1 [L, b]; fp64)
+// q1[l, i] = sum_n G2T[l, n] T[l, n, i]^2 + 1/2 g_kl m0[l, i]      (T [L, 2 nh, b] in two halves, G2T [L, 2 nh], m0 and q1 [L, b]; fp64)
 // = diag(K_nm S_l D_l S_l K_mn) of _SVGPCore.backward with D_l = X2^T diag(G2_l) X2 + g_kl/2 M, T_l = X2 S_l K_mn and
 // m0_l = diag(K_nm S_l M S_l K_mn) formed ahead of the backward pass (they do not depend on the incoming gradients).
 // Workgroup = 16 columns x 16 row slices; a slice walks its rows n = s, s + 16, ... in order, the slices are added in order.
-__global__ __launch_bounds__(256) void k_svgp_q1t(const double *__restrict__ T, const double *__restrict__ G2T,
-                                                  const double *__restrict__ m0, const double *__restrict__ g_kl, int n2,
-                                                  int b, double *__restrict__ q1) {
+__global__ __launch_bounds__(256) void k_svgp_q1t(const double *__restrict__ Ta, const double *__restrict__ Tb,
+                                                  const double *__restrict__ G2T, const double *__restrict__ m0,
+                                                  const double *__restrict__ g_kl, int nh, int b, double *__restrict__ q1) {
     __shared__ double part[16][17];
     const int l = blockIdx.y, c = threadIdx.x & 15, sl = threadIdx.x >> 4;
     const int i = blockIdx.x * 16 + c;
-    const double *Tl = T + (size_t)l * n2 * b, *gl = G2T + (size_t)l * n2;
+    // rows 0 .. nh-1 of T_l live in Ta [L, nh, b], rows nh .. 2 nh - 1 in Tb [L, nh, b]
+    const double *Tal = Ta + (size_t)l * nh * b, *Tbl = Tb + (size_t)l * nh * b, *gl = G2T + (size_t)l * 2 * nh;
     double acc = 0.0;
     if (i < b) {
 #pragma unroll 8
-        for (int n = sl; n < n2; n += 16) {
-            const double t = Tl[(size_t)n * b + i];
+        for (int n = sl; n < nh; n += 16) {
+            const double t = Tal[(size_t)n * b + i];
             acc = fma(gl[n] * t, t, acc);
+        }
+#pragma unroll 8
+        for (int n = sl; n < nh; n += 16) {
+            const double t = Tbl[(size_t)n * b + i];
+            acc = fma(gl[nh + n] * t, t, acc);
         }
     }
     part[sl][c] = acc;
@@ -814,6 +820,18 @@ __global__ __launch_bounds__(1024) void k_svgp_post_fwd(const double *__restrict
         out4[3] = -fabs(ce - (l3 - b_over_N * kl)) / L;
         if (skl32) skl32[0] = (float)out4[3];
     }
+}
+
+// The part of k_svgp_post_fwd the loss tail waits for: p_m = c raw[:b], p_v = k~ + diag(K_nm S_l K_mn) (rd_a [L, b]); the ELBO
+// scalars (l3, ce, kl, SVGP_KL) and mv / tr follow later, off the step's critical chain (svgp.py: ELBO_LATE).
+__global__ __launch_bounds__(256) void k_svgp_post_pmpv(const double *__restrict__ raw, const double *__restrict__ rd_a,
+                                                        const double *__restrict__ kt, int b, int L, double c,
+                                                        double *__restrict__ p_m, double *__restrict__ p_v) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= b * L) return;
+    const int i = e / L, l = e - i * L;
+    p_m[e] = c * raw[e];
+    p_v[e] = kt[i] + rd_a[(size_t)l * b + i];
 }
 
 // Backward of the above: g_skl = d loss / d SVGP_KL (fp32 device scalar), G_pm / G_pv = upstream gradients of the
@@ -2335,10 +2353,18 @@ int spadot_svgp_mid(const double *S, const double *t, const double *M, const dou
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
-int spadot_svgp_q1t(const double *T, const double *G2T, const double *m0, const double *g_kl, int L, int n2, int b,
-                    double *q1, void *stream) {
-    if (L <= 0 || n2 <= 0 || b <= 0 || !T || !G2T || !m0 || !g_kl || !q1) return -22;
-    hipLaunchKernelGGL(k_svgp_q1t, dim3((b + 15) / 16, L), dim3(256), 0, (hipStream_t)stream, T, G2T, m0, g_kl, n2, b, q1);
+int spadot_svgp_post_pm_pv(const double *raw, const double *rd_a, const double *ktilde, int b, int L, double c, double *p_m,
+                           double *p_v, void *stream) {
+    if (b <= 0 || L <= 0 || !raw || !rd_a || !ktilde || !p_m || !p_v) return -22;
+    hipLaunchKernelGGL(k_svgp_post_pmpv, dim3((b * L + 255) / 256), dim3(256), 0, (hipStream_t)stream, raw, rd_a, ktilde, b, L, c,
+                       p_m, p_v);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+int spadot_svgp_q1t(const double *Ta, const double *Tb, const double *G2T, const double *m0, const double *g_kl, int L, int nh,
+                    int b, double *q1, void *stream) {
+    if (L <= 0 || nh <= 0 || b <= 0 || !Ta || !Tb || !G2T || !m0 || !g_kl || !q1) return -22;
+    hipLaunchKernelGGL(k_svgp_q1t, dim3((b + 15) / 16, L), dim3(256), 0, (hipStream_t)stream, Ta, Tb, G2T, m0, g_kl, nh, b, q1);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 

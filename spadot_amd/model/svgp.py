@@ -158,30 +158,54 @@ class _SVGPCore(torch.autograd.Function):
         smpart = torch.empty(L * nparts, dtype=F64, device=dev)
         _check(lib.spadot_svgp_mid(_p(S), _p(t.contiguous()), _p(rc.M), _p(X2), L, m, 2 * b, _p(r), _p(Mr), _p(raw), _p(sm),
                                    _p(smpart), L * nparts, _stream()), "spadot_svgp_mid")
-        X2S = dgemm_small(0, X2, S) if DGEMM_SMALL[0] else torch.matmul(X2, S)     # [L, 2b, m]
-        rd = rowdot(X2S, X2)                                                 # [L, 2b]
         p_m, mv, p_v, tr = (torch.empty((b, L), dtype=F64, device=dev) for _ in range(4))
         out4 = torch.empty(4, dtype=F64, device=dev)
         skl32 = torch.empty(1, dtype=torch.float32, device=dev)
-        _check(lib.spadot_svgp_post_forward(_p(raw), _p(rd), _p(r), _p(Mr), _p(ld), _p(sm), _p(mu), _p(var), _p(bc.ktilde),
-                                            b, L, m, c, rc.logdet_K_f - rc.mlogj - m, b_over_N, _p(p_m), _p(mv), _p(p_v), _p(tr),
-                                            _p(out4), _p(skl32), _stream()), "spadot_svgp_post_forward")
-        ctx.save_for_backward(mu, var, w, X, r, Mr, X2S, p_m, p_v, mv, tr, out4)
+        kl_const = rc.logdet_K_f - rc.mlogj - m
+        holder = {"M": rc.M, "Kn": bc.K_nm, "S2": X[L:], "b": b}
+        if ELBO_LATE[0] is not None and not DGEMM_SMALL[0]:
+            # The loss tail waits for p_m and p_v only: K_nm S_l (half of X2 S_l), its row dot and a small kernel.  The other
+            # half (P S_l), mv / tr and the ELBO scalars (l3, ce, kl, SVGP_KL: read by backward() and, as VALUES, by the
+            # logging vector, which is queued too) are appended to the open queue and run off the critical chain.
+            KS = torch.matmul(bc.K_nm, S)                                    # [L, b, m]
+            rd_a = rowdot(KS, bc.K_nm)                                       # [L, b]
+            _check(lib.spadot_svgp_post_pm_pv(_p(raw), _p(rd_a), _p(bc.ktilde), b, L, c, _p(p_m), _p(p_v), _stream()),
+                   "spadot_svgp_post_pm_pv")
+            holder["KS"] = KS
+
+            def rest(KS=KS, rd_a=rd_a, holder=holder):
+                PS = torch.matmul(bc.P, S)                                   # [L, b, m]
+                rd = torch.cat([rd_a, rowdot(PS, bc.P)], dim=1)              # [L, 2b]
+                scratch = torch.empty((2, b, L), dtype=F64, device=dev)      # (p_m, p_v again: the tail may be reading the real ones)
+                _check(lib.spadot_svgp_post_forward(_p(raw), _p(rd), _p(r), _p(Mr), _p(ld), _p(sm), _p(mu), _p(var), _p(bc.ktilde),
+                                                    b, L, m, c, kl_const, b_over_N, _p(scratch[0]), _p(mv), _p(scratch[1]), _p(tr),
+                                                    _p(out4), _p(skl32), _stream()), "spadot_svgp_post_forward")
+                holder["PS"] = PS
+            ELBO_LATE[0].append(rest)
+        else:
+            X2S = dgemm_small(0, X2, S) if DGEMM_SMALL[0] else torch.matmul(X2, S)     # [L, 2b, m]
+            rd = rowdot(X2S, X2)                                             # [L, 2b]
+            _check(lib.spadot_svgp_post_forward(_p(raw), _p(rd), _p(r), _p(Mr), _p(ld), _p(sm), _p(mu), _p(var), _p(bc.ktilde),
+                                                b, L, m, c, kl_const, b_over_N, _p(p_m), _p(mv), _p(p_v), _p(tr),
+                                                _p(out4), _p(skl32), _stream()), "spadot_svgp_post_forward")
+            holder["X2S"] = X2S
+        ctx.save_for_backward(mu, var, w, X, r, Mr, p_m, p_v, mv, tr, out4)
         ctx.bc, ctx.rc, ctx.bN = bc, rc, b_over_N
-        # what backward() needs that does NOT depend on the incoming gradients (q2 = diag(K_nm S2 K_mn), the contiguous
-        # K_nm S_l): precompute_backward() may fill this holder between forward and backward -- GraphedStepper does, on the
+        # what backward() needs that does NOT depend on the incoming gradients (q2 = diag(K_nm S2 K_mn), K_nm S_l, T = X2 S_l
+        # K_mn, m0): precompute_backward() may fill this holder between forward and backward -- GraphedStepper does, on the
         # side stream while the loss tail runs on the main stream and the side stream would idle; backward() computes
         # whatever the holder lacks
-        ctx.holder = {"_inputs": (bc.K_nm, X[L:], X2S, b), "M": rc.M}
-        _LAST_HOLDER[0] = ctx.holder
+        ctx.holder = holder
+        _LAST_HOLDER[0] = holder
         ctx.mark_non_differentiable(out4)
         ctx.set_materialize_grads(False)          # no zero-filled gradient tensors for outputs the loss does not use
         return p_m, p_v, skl32[0], out4
 
     @staticmethod
     def backward(ctx, G_pm, G_pv, g_skl, _unused):
-        mu, var, w, X, r, Mr, X2S, p_m, p_v, mv, tr, out4 = ctx.saved_tensors
+        mu, var, w, X, r, Mr, p_m, p_v, mv, tr, out4 = ctx.saved_tensors
         bc, rc = ctx.bc, ctx.rc
+        pre = ctx.holder
         b, L = mu.shape
         m, c = rc.m, bc.c
         Kn, X2 = bc.K_nm, bc.X2
@@ -208,7 +232,7 @@ class _SVGPCore(torch.autograd.Function):
             dr = dgemm_small(2, G1, X2, C0=gMr, alpha=c, beta=1.0)                               # [L, m]
             dt = dgemm_small(0, S, dr.unsqueeze(2)).squeeze(2)                                   # [L, m]
             D = dgemm_small(2, X2, X2, C0=gM, rowscale=G2T, out=torch.empty((L, m, m), dtype=F64, device=dev))
-            KS = X2S[:, :b]                                                                      # [L, b, m] = K_nm S_l (a view)
+            KS = pre["X2S"][:, :b]                                                               # [L, b, m] = K_nm S_l (a view)
             KSD = dgemm_small(0, KS, D)
             q1 = rowdot(KSD.reshape(1, L * b, m), KS.contiguous().reshape(L * b, m)).reshape(L, b)
             q2 = rowdot(dgemm_small(0, Kn, S2), Kn)                                              # diag(K_nm S2 K_mn)  [L, b]
@@ -228,15 +252,14 @@ class _SVGPCore(torch.autograd.Function):
                                            _p(junk[L * m + L:]), L * nparts, _stream()), "spadot_svgp_mid")
             else:
                 dt = torch.bmm(S, dr.unsqueeze(2)).squeeze(2)                # [L, m]
-            pre = getattr(ctx, "holder", None) or {}
-            if "T" in pre:
+            if "Ta" in pre:
                 q1 = torch.empty((L, b), dtype=F64, device=dev)
-                _check(lib.spadot_svgp_q1t(_p(pre["T"]), _p(G2T), _p(pre["m0"]), _p(g_kl), L, 2 * b, b, _p(q1), _stream()),
-                       "spadot_svgp_q1t")
+                _check(lib.spadot_svgp_q1t(_p(pre["Ta"]), _p(pre["Tb"]), _p(G2T), _p(pre["m0"]), _p(g_kl), L, b, b, _p(q1),
+                                           _stream()), "spadot_svgp_q1t")
             else:
                 A2 = X2.unsqueeze(0) * G2T.unsqueeze(2)                      # [L, 2b, m]
                 D = torch.baddbmm(gM.expand(L, m, m), A2.transpose(1, 2), X2.unsqueeze(0).expand(L, 2 * b, m))
-                KS = pre["KS"] if "KS" in pre else X2S[:, :b].contiguous()   # [L, b, m] = K_nm S_l
+                KS = _holder_KS(pre)                                         # [L, b, m] = K_nm S_l, contiguous
                 q1 = rowdot(torch.bmm(KS, D).reshape(1, L * b, m), KS.reshape(L * b, m)).reshape(L, b)
             q2 = pre["q2"] if "q2" in pre else rowdot(torch.matmul(Kn, S2), Kn)     # diag(K_nm S2 K_mn)  [L, b]
             if Kdt is None:
@@ -246,29 +269,42 @@ class _SVGPCore(torch.autograd.Function):
         return dz, None, None, None, None
 
 
-Q1T = [__import__("os").environ.get("SPADOT_SVGP_Q1T", "0") == "1"]
+Q1T = [__import__("os").environ.get("SPADOT_SVGP_Q1T", "1") == "1"]
 MID_BWD = [__import__("os").environ.get("SPADOT_SVGP_MIDBWD", "1") == "1"]
+# a list while a caller wants the part of forward() the loss tail does not wait for queued instead of run (GraphedStepper's
+# svgp_pre stage runs the queue right behind the SVGP forward graph, beside the tail); None: forward() runs everything
+ELBO_LATE = [None]
 _LAST_HOLDER = [None]          # the holder of the most recent _SVGPCore.forward (see precompute_backward)
 
 
+def _holder_KS(h):
+    if "KS" not in h:
+        h["KS"] = h["X2S"][:, :h["b"]].contiguous()
+    return h["KS"]
+
+
 def precompute_backward(holder=None):
-    """The gradient-independent products of _SVGPCore.backward -- q2 = diag(K_nm S2 K_mn) (a [b, m] x [L, m, m] product + a
-    row dot: 94 + 32 us inside the backward pair of a cfg3 step) and the contiguous copy of K_nm S_l (15 us) -- computed ahead
-    of the backward pass into the holder of the most recent forward (or `holder`).  No-op when already done."""
+    """The gradient-independent products of _SVGPCore.backward, computed ahead of the backward pass into the holder of the
+    most recent forward (or `holder`): q2 = diag(K_nm S2 K_mn) (a [b, m] x [L, m, m] product + a row dot: 94 + 32 us inside
+    the backward pair of a cfg3 step), the contiguous K_nm S_l, and -- Q1T -- T = X2 S_l K_mn and m0 (below).  A forward
+    that queued the rest of its ELBO (ELBO_LATE) must have had that queue run before.  No-op when already done."""
     h = holder if holder is not None else _LAST_HOLDER[0]
     if h is None or "q2" in h or DGEMM_SMALL[0]:
         return h
-    Kn, S2, X2S, b = h["_inputs"]
+    Kn, S2, b = h["Kn"], h["S2"], h["b"]
     with torch.no_grad():
         h["q2"] = rowdot(torch.matmul(Kn, S2), Kn)
-        h["KS"] = KS = X2S[:, :b].contiguous()
-        if Q1T[0] and "M" in h:
+        KS = _holder_KS(h)
+        if Q1T[0]:
             # q1 = diag(K_nm S D S K_mn) with D = X2^T diag(G2) X2 + g/2 M needs the gradients only as WEIGHTS of squares:
             # q1[l, i] = sum_n G2[l, n] T_l[n, i]^2 + g/2 m0[l, i],  T_l = X2 S_l K_mn [2b, b],  m0_l = diag(K_nm S_l M S_l K_mn).
             # T and m0 are formed here (2.5 + 0.6 GFLOP, beside the loss tail); the backward pass then needs one reduction
             # launch in place of a scaled copy of X2, the D product, K_nm S_l D_l and a row dot (~140 us in the step)
-            h["T"] = torch.matmul(X2S, Kn.t())                               # [L, 2b, b]
-            h["m0"] = rowdot(torch.matmul(KS, h["M"]), KS)                   # [L, b]
+            PS = h["PS"] if "PS" in h else h["X2S"][:, b:]
+            h["Ta"] = torch.matmul(KS, Kn.t())                               # [L, b, b]
+            h["Tb"] = torch.matmul(PS, Kn.t())                               # [L, b, b]
+            Lb = KS.shape[0] * KS.shape[1]                                   # (rowdot's second operand is ONE [rows, m] matrix)
+            h["m0"] = rowdot(torch.matmul(KS, h["M"]).reshape(1, Lb, -1), KS.reshape(Lb, -1)).reshape(KS.shape[0], KS.shape[1])
     return h
 
 

@@ -1358,6 +1358,7 @@ class _RowDot(torch.autograd.Function):
         _need_cuda(A, B)
         A, B = A.contiguous(), B.contiguous()
         L, n, m = A.shape
+        assert B.shape == (n, m) and B.dtype == A.dtype, (A.shape, B.shape)     # (ONE [n, m] matrix under every l)
         out = torch.empty((L, n), dtype=A.dtype, device=A.device)
         _check(model_lib().spadot_rowdot_forward(_p(A), _p(B), L, n, m, _DT[A.dtype], _p(out), _stream()),
                "spadot_rowdot_forward")

@@ -497,6 +497,11 @@ class GraphedStepper:
         # ~500 us chain inside the backward pair) as a graph of their own on the side stream, launched right behind the SVGP
         # forward: they run while the loss tail occupies the main stream and the side stream would otherwise idle
         self.svgp_pre = bool(self.defer_wgrad and model_config.get("svgp_precompute", os.environ.get("SPADOT_SVGP_PRE", "1") == "1"))
+        # svgp_elbo_late: the SVGP forward hands p_m / p_v to the tail and leaves the rest of its ELBO (P S_l, mv, tr, the scalars)
+        # to the svgp_pre stage (svgp.ELBO_LATE)
+        self.svgp_elbo_late = bool(self.svgp_pre and os.environ.get("SPADOT_LATE_STREAM", "0") != "1"
+                                   and model_config.get("svgp_elbo_late", os.environ.get("SPADOT_SVGP_ELBO_LATE", "1") == "1"))
+        self.pre_stream = bool(self.svgp_pre and os.environ.get("SPADOT_PRE_STREAM", "0") == "1")
         # late_stream (round 4, opt-in): the deferred gradient work on a third stream and memory pool of its own
         self.late_stream = bool(self.defer_wgrad and model_config.get("late_stream", os.environ.get("SPADOT_LATE_STREAM", "0") == "1"))
         self._late_stream = None
@@ -659,11 +664,16 @@ class GraphedStepper:
             st["zg"] = model.branch_gat(y_all, batch.graph, b, taps=st if (self.overlap or self.split_bwd or self.defer_wgrad) else None)
 
         def svgp_fwd():
+            from ..model import svgp as _svgp
             st["xs"] = batch.x[:b] if cached else loc[seeds]
             st["ys"] = batch.y[:b] if cached else Y[seeds]
-            st["pm"], st["pv"], st["skl"] = model.branch_svgp(st["xs"], st["ys"], tp, b, batch_key=(tp, bi),
-                                                              y_seed32=getattr(batch, "y_seed32", None) if cached else None)
-            from ..model import svgp as _svgp
+            if self.svgp_elbo_late:             # the part of the ELBO the tail does not wait for goes to the svgp_pre stage
+                _svgp.ELBO_LATE[0] = st.setdefault("svgp_late", [])
+            try:
+                st["pm"], st["pv"], st["skl"] = model.branch_svgp(st["xs"], st["ys"], tp, b, batch_key=(tp, bi),
+                                                                  y_seed32=getattr(batch, "y_seed32", None) if cached else None)
+            finally:
+                _svgp.ELBO_LATE[0] = None
             st["svgp_holder"] = _svgp._LAST_HOLDER[0]
 
         def svgp_fwd_head():
@@ -675,8 +685,11 @@ class GraphedStepper:
         def svgp_fwd_rest():
             st["pm"], st["pv"], st["skl"] = model.branch_svgp_rest(st["svgp_state"])
 
-        def svgp_pre():             # gradient-independent part of the SVGP backward (side stream, beside the tail)
+        def svgp_pre():             # rest of the ELBO + gradient-independent part of the SVGP backward (side stream, beside the tail)
             from ..model import svgp as _svgp
+            with torch.no_grad():
+                for job in st.pop("svgp_late", []):
+                    job()
             _svgp.precompute_backward(st["svgp_holder"])
 
         def tail():
@@ -759,6 +772,11 @@ class GraphedStepper:
             fns = tuple(stamped(k, fn) for k, fn in enumerate(fns))
         return fns
 
+    def _pre_stream_obj(self):
+        if getattr(self, "_pre_stream", None) is None:
+            self._pre_stream = torch.cuda.Stream(device=torch.device(self.cfg["device"]), priority=0)
+        return self._pre_stream
+
     def _late_stream_obj(self):
         if self._late_stream is None:
             self._late_stream = torch.cuda.Stream(device=torch.device(self.cfg["device"]),
@@ -819,8 +837,17 @@ class GraphedStepper:
             main.wait_stream(side)                       # (an event behind the SVGP forward: what follows on `side` is not waited for)
             res = fns[2]()
             if len(fns) == 8:                            # (launched behind the tail: the host hands the critical graph over first)
-                with torch.cuda.stream(side):
-                    fns[7]()
+                if self.pre_stream:
+                    # (opt-in: a third stream at NORMAL priority -- the side stream's high priority puts these GEMMs in
+                    # front of the loss tail's short launches)
+                    pre = self._pre_stream_obj()
+                    pre.wait_stream(side)
+                    with torch.cuda.stream(pre):
+                        fns[7]()
+                    side.wait_stream(pre)
+                else:
+                    with torch.cuda.stream(side):
+                        fns[7]()
             side.wait_stream(main)
             fns[4]()
             if self._late_event is None:
