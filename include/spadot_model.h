@@ -219,6 +219,13 @@ int spadot_cluster_losses_backward(const float *z, const float *centres, const f
                                    const long long *cluster_list, const float *work, const float *g_km,
                                    const float *g_ot, int b, int D, int K, int Kp, int Kl, int do_km, int do_ot,
                                    float *dz, void *stream);
+/* forward AND dz = d(g_km[0] * km + g_ot[0] * ot) / dz in ONE launch, for gradient seeds known when the forward runs (the loss
+ * weights of _train_utils.py:205-212, device scalars).  Same arithmetic as forward + backward.  Returns -95 when the shape
+ * does not take the kernel's one-chunk fast path (K <= 16, b * D <= 10240): call forward / backward then. */
+int spadot_cluster_losses_fb(const float *z, const long long *labels_all, const long long *seed_ids, const float *centres,
+                             const float *prev_centres, const float *gamma, const long long *cluster_list, int b, int D, int K,
+                             int Kp, int Kl, int do_km, int do_ot, const float *g_km, const float *g_ot, float *out2,
+                             float *work, float *dz, void *stream);
 /* elbo = sum_k w6[k] * *terms6[k] (_train_utils.py:205-212); out7 [8 floats] = (elbo, the six terms, elbo again).
  * terms6 is a HOST array of six device pointers.  backward: g6[k] = g_elbo[0] * w6[k]. */
 int spadot_mix_losses_forward(const float *const *terms6, const float *w6, float *out7, void *stream);
@@ -437,9 +444,22 @@ int spadot_mlp_chain_forward(const float *x, int b, int n_layers, const int *dim
                              const float *const *bias, const float *const *gamma, const float *const *beta, const double *eps,
                              const double *slope, float *const *a, float *const *y, float *const *mean, float *const *invstd,
                              void *stream);
+/* ... the same launch, also leaving a bf16 copy of the LAST stage's output [b, dims[n_layers]] in y_last_bf16 (may be NULL):
+ * the operand of the output map's matrix-core GEMM (decoder.py:20), so that no cast launch sits between them. */
+int spadot_mlp_chain_forward_bf16(const float *x, int b, int n_layers, const int *dims, const float *const *W,
+                                  const float *const *bias, const float *const *gamma, const float *const *beta,
+                                  const double *eps, const double *slope, float *const *a, float *const *y, float *const *mean,
+                                  float *const *invstd, void *y_last_bf16, void *stream);
+/* grads may be NULL: the per-workgroup partials stay in `workspace` and the caller adds them later (spadot_colsum).
+ * spadot_mlp_chain_backward_add: dx = (the chain's input gradient) + dx_add [b, dims[0]] (may be NULL) -- a gradient that
+ * reaches the chain's input by another path, added here instead of by a launch of its own. */
 int spadot_mlp_chain_backward(const float *dy, const float *x, int b, int n_layers, const int *dims, const float *const *W,
                               const float *const *gamma, const double *slope, float *const *a, float *const *y,
                               float *const *mean, float *const *invstd, float *dx, float *workspace, float *grads, void *stream);
+int spadot_mlp_chain_backward_add(const float *dy, const float *x, int b, int n_layers, const int *dims, const float *const *W,
+                                  const float *const *gamma, const double *slope, float *const *a, float *const *y,
+                                  float *const *mean, float *const *invstd, float *dx, const float *dx_add, float *workspace,
+                                  float *grads, void *stream);
 
 /* ---- reconstruction term on the output map's GEMM result (csrc/mlp_chain.hip) -------------------------------------------
  * out[0] = inv_scale * sum_{r,c} (y[r,c] - (o[r,c] + bias[c]))^2   (/root/reference/SpaDOT/model/SpaDOT.py:89 on the

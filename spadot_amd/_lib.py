@@ -201,7 +201,9 @@ def model_lib():
         "spadot_bias_sqerr_backward": [vp, vp, vp, vp, ci, ci, cd, vp, vp, vp],
         "spadot_mlp_chain_workspace": [ci, ci, vp, vp, vp],
         "spadot_mlp_chain_forward": [vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+        "spadot_mlp_chain_forward_bf16": [vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
         "spadot_mlp_chain_backward": [vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+        "spadot_mlp_chain_backward_add": [vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
         "spadot_kernel_matrix": [vp, vp, ci, ci, ci, cd, ci, ci, vp, vp],
         "spadot_spd_inverse_logdet": [vp, ci, ci, vp, vp, vp],
         "spadot_rowdot_forward": [vp, vp, ci, ci, ci, ci, vp, vp],
@@ -225,6 +227,7 @@ def model_lib():
         "spadot_latent_head_backward": [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp],
         "spadot_cluster_losses_forward": [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp],
         "spadot_cluster_losses_backward": [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp],
+        "spadot_cluster_losses_fb": [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp],
         "spadot_mix_losses_forward": [vp, vp, vp, vp],
         "spadot_mix_losses_backward": [vp, vp, vp, vp],
         "spadot_sqerr_forward": [vp, vp, ll, cd, ci, vp, vp, vp],

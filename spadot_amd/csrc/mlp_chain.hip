@@ -37,6 +37,7 @@ struct Stage {
 struct Chain {
     Stage s[MAXL];
     int n;
+    __bf16 *ybf;                        // forward: optional bf16 copy of the last stage's output (the output map's GEMM operand)
 };
 
 __device__ __forceinline__ float wave_sum(float x) {
@@ -104,7 +105,10 @@ __global__ __launch_bounds__(256) void k_mlp_chain_fwd(const float *__restrict__
                 const float v = (av - mean) * invstd * par[1][j] + par[2][j];
                 const float yv = v > 0.f ? v : s.slope * v;
                 ar[j] = yv;
-                if (row < b) { s.a[(size_t)row * dout + j] = av; s.y[(size_t)row * dout + j] = yv; }
+                if (row < b) {
+                    s.a[(size_t)row * dout + j] = av; s.y[(size_t)row * dout + j] = yv;
+                    if (ch.ybf && l == ch.n - 1) ch.ybf[(size_t)row * dout + j] = (__bf16)yv;
+                }
             }
             if (lane == 0 && row < b) { s.mean[row] = mean; s.invstd[row] = invstd; }
         }
@@ -122,7 +126,7 @@ constexpr int LPR = 256 / RBB;                              // lanes per row in 
 constexpr int LDS_BWD_FLOATS = 4 * RBB * LDW + 2 * RBB + MAXD + WST;
 __global__ __launch_bounds__(256) void k_mlp_chain_bwd(const float *__restrict__ dy_last, const float *__restrict__ x, int b,
                                                        Chain ch, float *__restrict__ dx_out, float *__restrict__ ws,
-                                                       int ws_width) {
+                                                       int ws_width, const float *__restrict__ dx_add) {
     extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
     float (*gz)[LDW] = reinterpret_cast<float (*)[LDW]>(lds_dyn);
     float (*da)[LDW] = reinterpret_cast<float (*)[LDW]>(lds_dyn + RBB * LDW);
@@ -318,7 +322,14 @@ __global__ __launch_bounds__(256) void k_mlp_chain_bwd(const float *__restrict__
                     const float4 o = *reinterpret_cast<const float4 *>(&xh[0][0] + 4 * e);
                     const float4 a4 = make_float4(acc[u].x + o.x, acc[u].y + o.y, acc[u].z + o.z, acc[u].w + o.w);
                     if (l > 0) *reinterpret_cast<float4 *>(&gz[r][k0]) = a4;
-                    else if (r0 + r < b) *reinterpret_cast<float4 *>(dx_out + (size_t)(r0 + r) * din + k0) = a4;
+                    else if (r0 + r < b) {
+                        float4 o4 = a4;
+                        if (dx_add) {       // a gradient that reaches the chain's input by another path (the cluster terms' dz)
+                            const float4 e4 = *reinterpret_cast<const float4 *>(dx_add + (size_t)(r0 + r) * din + k0);
+                            o4 = make_float4(a4.x + e4.x, a4.y + e4.y, a4.z + e4.z, a4.w + e4.w);
+                        }
+                        *reinterpret_cast<float4 *>(dx_out + (size_t)(r0 + r) * din + k0) = o4;
+                    }
                 }
             }
         }
@@ -567,6 +578,7 @@ bool fill_chain(Chain &ch, int n_layers, const int *dims, const float *const *W,
         off += dout * din + 3 * dout;
     }
     ch.n = n_layers;
+    ch.ybf = nullptr;
     return true;
 }
 
@@ -590,21 +602,31 @@ int spadot_mlp_chain_workspace(int b, int n_layers, const int *dims, int *n_rows
     return 0;
 }
 
-int spadot_mlp_chain_forward(const float *x, int b, int n_layers, const int *dims, const float *const *W,
-                             const float *const *bias, const float *const *gamma, const float *const *beta, const double *eps,
-                             const double *slope, float *const *a, float *const *y, float *const *mean, float *const *invstd,
-                             void *stream) {
+int spadot_mlp_chain_forward_bf16(const float *x, int b, int n_layers, const int *dims, const float *const *W,
+                                  const float *const *bias, const float *const *gamma, const float *const *beta,
+                                  const double *eps, const double *slope, float *const *a, float *const *y, float *const *mean,
+                                  float *const *invstd, void *y_last_bf16, void *stream) {
     Chain ch;
     if (b <= 0 || !fill_chain(ch, n_layers, dims, W, bias, gamma, beta, eps, slope, a, y, mean, invstd)) return -22;
+    ch.ybf = (__bf16 *)y_last_bf16;                      // may be null
     hipLaunchKernelGGL(k_mlp_chain_fwd, dim3((b + RBF - 1) / RBF), dim3(256), 0, (hipStream_t)stream, x, b, ch);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
-int spadot_mlp_chain_backward(const float *dy, const float *x, int b, int n_layers, const int *dims, const float *const *W,
-                              const float *const *gamma, const double *slope, float *const *a, float *const *y,
-                              float *const *mean, float *const *invstd, float *dx, float *workspace, float *grads, void *stream) {
+int spadot_mlp_chain_forward(const float *x, int b, int n_layers, const int *dims, const float *const *W,
+                             const float *const *bias, const float *const *gamma, const float *const *beta, const double *eps,
+                             const double *slope, float *const *a, float *const *y, float *const *mean, float *const *invstd,
+                             void *stream) {
+    return spadot_mlp_chain_forward_bf16(x, b, n_layers, dims, W, bias, gamma, beta, eps, slope, a, y, mean, invstd, nullptr, stream);
+}
+
+int spadot_mlp_chain_backward_add(const float *dy, const float *x, int b, int n_layers, const int *dims, const float *const *W,
+                                  const float *const *gamma, const double *slope, float *const *a, float *const *y,
+                                  float *const *mean, float *const *invstd, float *dx, const float *dx_add, float *workspace,
+                                  float *grads, void *stream) {
     Chain ch;
     if (b <= 0 || !fill_chain(ch, n_layers, dims, W, nullptr, gamma, nullptr, nullptr, slope, a, y, mean, invstd)) return -22;
+    if (dx_add && !dx) return -22;
     int rows, width;
     if (spadot_mlp_chain_workspace(b, n_layers, dims, &rows, &width)) return -22;
     constexpr int LDS_BWD = LDS_BWD_FLOATS * (int)sizeof(float);
@@ -613,10 +635,17 @@ int spadot_mlp_chain_backward(const float *dy, const float *x, int b, int n_laye
         if (hipFuncSetAttribute((const void *)k_mlp_chain_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BWD) != hipSuccess) return -5;
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_mlp_chain_bwd, dim3(rows), dim3(256), LDS_BWD, (hipStream_t)stream, dy, x, b, ch, dx, workspace, width);
+    hipLaunchKernelGGL(k_mlp_chain_bwd, dim3(rows), dim3(256), LDS_BWD, (hipStream_t)stream, dy, x, b, ch, dx, workspace, width, dx_add);
     if (hipGetLastError() != hipSuccess) return -5;
     if (!grads) return 0;                                            // (the caller sums the partials later: spadot_colsum)
     return spadot_colsum(workspace, rows, width, grads, stream);     // grads: one workspace row = [dW | dbias | dgamma | dbeta] per stage
+}
+
+int spadot_mlp_chain_backward(const float *dy, const float *x, int b, int n_layers, const int *dims, const float *const *W,
+                              const float *const *gamma, const double *slope, float *const *a, float *const *y,
+                              float *const *mean, float *const *invstd, float *dx, float *workspace, float *grads, void *stream) {
+    return spadot_mlp_chain_backward_add(dy, x, b, n_layers, dims, W, gamma, slope, a, y, mean, invstd, dx, nullptr, workspace, grads,
+                                         stream);
 }
 
 int spadot_bias_sqerr_forward(const float *o, const float *bias, const float *y, int b, int G, double inv_scale, double *scratch,

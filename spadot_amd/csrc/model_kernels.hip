@@ -1809,12 +1809,19 @@ __global__ __launch_bounds__(256) void k_latent_head_bwd(const float *__restrict
 //   prev [Kp, D] centres of the previous time point; gamma [Kp, Kl] row-normalised plan; cluster_list [Kl].
 //   work (saved for the backward): means [K*D] | cnt [K] | n_distinct | lab [b] (as floats).
 constexpr int CL_MAXK = 64, CL_MAXD = 64, CL_KREG = 16;
+// FB: the same launch also writes dz = d(g_km km + g_ot ot) / dz for gradient seeds that are known when the forward runs (the
+// loss weights, device scalars): k_cluster_losses_bwd's arithmetic on the state this kernel has in LDS anyway.  Host-side
+// conditions (spadot_cluster_losses_fb): the fast path (K <= CL_KREG), the whole batch in ONE chunk, and room for
+// [centres | d means | distances] in the segment-partial buffer.
+template <bool FB>
 __global__ __launch_bounds__(512) void k_cluster_losses_fwd(const float *__restrict__ z, const long long *__restrict__ labels_all,
                                                             const long long *__restrict__ seed_ids, const float *__restrict__ centres,
                                                             const float *__restrict__ prev, const float *__restrict__ gamma,
                                                             const long long *__restrict__ cluster_list, int b, int D, int K, int Kp,
                                                             int Kl, int do_km, int do_ot, float *__restrict__ out2,
-                                                            float *__restrict__ work, int chunk_rows) {
+                                                            float *__restrict__ work, int chunk_rows,
+                                                            const float *__restrict__ g_km = nullptr,
+                                                            const float *__restrict__ g_ot = nullptr, float *__restrict__ dz = nullptr) {
     // Latency-bound single workgroup: everything that is scanned repeatedly sits in LDS and the scans are
     // branch-free and unrolled, so the LDS reads of successive rows are in flight together.
     __shared__ double sh[16];
@@ -1942,6 +1949,41 @@ __global__ __launch_bounds__(512) void k_cluster_losses_fwd(const float *__restr
     if (t == 0) {
         out2[0] = do_km ? (float)(km / D / (nd > 0 ? nd : 1)) : 0.f;
         out2[1] = do_ot ? (float)(ot / ((double)Kp * Kl)) : 0.f;
+    }
+    if constexpr (FB) {
+        // s_means = batch means, s_cnt = counts, s_z[0 .. Kp D) = previous centres, s_lab = the batch's labels (one chunk)
+        float *s_cen = s_part, *s_dm = s_part + (size_t)K * D, *s_dist = s_part + 2 * (size_t)K * D;
+        const float gk = (do_km && g_km) ? g_km[0] : 0.f, go = (do_ot && g_ot) ? g_ot[0] : 0.f;
+        __syncthreads();                                  // (block_sum_d's scratch and s_part are free now)
+        for (int pq = t; pq < K * D; pq += blockDim.x) { s_dm[pq] = 0.f; s_cen[pq] = centres[pq]; }
+        if (do_ot)
+            for (int pq = t; pq < Kp * Kl; pq += blockDim.x) {
+                const int p = pq / Kl, q = pq - p * Kl, k = (int)cluster_list[q];
+                float a = 0.f;
+#pragma unroll 4
+                for (int e = 0; e < D; e++) { const float df = s_means[k * D + e] - s_z[p * D + e]; a += df * df; }
+                s_dist[pq] = sqrtf(a);
+            }
+        __syncthreads();
+        if (do_ot)
+            for (int qd = t; qd < Kl * D; qd += blockDim.x) {
+                const int q = qd / D, d = qd - q * D, k = (int)cluster_list[q];
+                if (s_cnt[k] <= 0) continue;
+                float acc = 0.f;
+                for (int p = 0; p < Kp; p++) {
+                    const float dist = s_dist[p * Kl + q];
+                    if (dist > 0.f) acc += gamma[p * Kl + q] * (s_means[k * D + d] - s_z[p * D + d]) / dist;
+                }
+                s_dm[k * D + d] = go * acc / ((float)Kp * Kl) / (float)s_cnt[k];
+            }
+        __syncthreads();
+        const float ndf = nd > 0 ? (float)nd : 1.f;
+        const float ck = gk * 2.f / ((float)D * ndf);
+#pragma unroll 4
+        for (int e = t; e < b * D; e += blockDim.x) {
+            const int i = e / D, d = e - i * D, k = s_lab[i];
+            dz[e] = ck * (z[e] - s_cen[k * D + d]) + s_dm[k * D + d];
+        }
     }
 }
 
@@ -2433,9 +2475,31 @@ int spadot_cluster_losses_forward(const float *z, const long long *labels_all, c
     size_t lds = sizeof(float) * (size_t)chunk * D + sizeof(int) * (size_t)chunk;
     if (K <= CL_KREG && D <= 512) lds += sizeof(float) * (size_t)(512 / D) * K * (D + 1);
     static PerDeviceFlag attr_set;     
-    if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_cluster_losses_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); attr_set = true; }
-    hipLaunchKernelGGL(k_cluster_losses_fwd, dim3(1), dim3(512), lds, (hipStream_t)stream, z, labels_all, seed_ids, centres,
+    if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_cluster_losses_fwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); attr_set = true; }
+    hipLaunchKernelGGL(k_cluster_losses_fwd<false>, dim3(1), dim3(512), lds, (hipStream_t)stream, z, labels_all, seed_ids, centres,
                        prev_centres, gamma, cluster_list, b, D, K, Kp, Kl, do_km, do_ot, out2, work, chunk);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+// Forward AND the gradient for given seeds in one launch; -95 (not supported: use forward + backward) unless the batch takes
+// the kernel's fast path in one chunk.
+int spadot_cluster_losses_fb(const float *z, const long long *labels_all, const long long *seed_ids, const float *centres,
+                             const float *prev_centres, const float *gamma, const long long *cluster_list, int b, int D, int K,
+                             int Kp, int Kl, int do_km, int do_ot, const float *g_km, const float *g_ot, float *out2,
+                             float *work, float *dz, void *stream) {
+    if (b <= 0 || D <= 0 || K <= 0 || K > CL_MAXK || D > CL_MAXD || !dz) return -22;
+    if (do_ot && (Kp <= 0 || Kp > CL_MAXK || Kl <= 0 || Kl > K || !prev_centres || !gamma || !cluster_list)) return -22;
+    int chunk = 10240 / D;
+    if (chunk > b) chunk = b;
+    if (chunk < CL_MAXK) chunk = CL_MAXK;
+    chunk = (chunk + 7) / 8 * 8;
+    const size_t part = (size_t)(512 / D) * K * (D + 1);
+    if (K > CL_KREG || chunk < b || part < 2 * (size_t)K * D + (do_ot ? (size_t)Kp * Kl : 0)) return -95;
+    const size_t lds = sizeof(float) * (size_t)chunk * D + sizeof(int) * (size_t)chunk + sizeof(float) * part;
+    static PerDeviceFlag attr_set;     
+    if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_cluster_losses_fwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); attr_set = true; }
+    hipLaunchKernelGGL(k_cluster_losses_fwd<true>, dim3(1), dim3(512), lds, (hipStream_t)stream, z, labels_all, seed_ids, centres,
+                       prev_centres, gamma, cluster_list, b, D, K, Kp, Kl, do_km, do_ot, out2, work, chunk, g_km, g_ot, dz);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 

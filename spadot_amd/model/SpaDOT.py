@@ -135,16 +135,19 @@ class SpaDOT(nn.Module):
         started = svgp.elbo_start_sweep(bc, pre) if pre is not None else svgp.elbo_start(bc, z_enc)
         return svgp.elbo_finish(bc, started)
 
-    def tail(self, zg, p_m, p_v, y, batch_size, noise=None, y_seed32=None):
+    def tail(self, zg, p_m, p_v, y, batch_size, noise=None, y_seed32=None, z_hook=None):
         """Latent head + decoder + reconstruction: (recon, GAT_KL, alignment, final_latent).  y_seed32: the seeds' rows
-        of y already in fp32 (cached batches keep them: no cast launch per step)."""
+        of y already in fp32 (cached batches keep them: no cast launch per step).  z_hook(final_latent): called between the
+        latent head and the decoder; may return a gradient for final_latent that no backward path of its own delivers (the
+        cluster terms' dz, formed by their forward launch): the decoder's backward adds it."""
         b = batch_size
         Ls, Lg = self.SVGP_z_dim, self.GAT_z_dim
         noise = noise if noise is not None else getattr(self, "fixed_noise", None)
         eps = None if noise is None else torch.cat([noise[0][:b].float(), noise[1][:b].float()], dim=1)
         final_latent, GAT_KL, alignment_loss = latent_head(zg, p_m, p_v, eps, Ls, Lg, self._rng_state())
         yb32 = y_seed32 if y_seed32 is not None else y[:b, :self.input_dim].float()
-        recon_loss = self.decoder.recon_loss(final_latent, yb32, 1.0 / self.input_dim)
+        dz_extra = z_hook(final_latent) if z_hook is not None else None
+        recon_loss = self.decoder.recon_loss(final_latent, yb32, 1.0 / self.input_dim, dz_extra=dz_extra)
         return recon_loss, GAT_KL, alignment_loss, final_latent
 
     def _rng_state(self):

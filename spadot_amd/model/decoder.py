@@ -9,7 +9,10 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..ops import linear_bias, ln_act, mlp_chain, mlp_chain_ok, recon_sqerr, recon_sqerr_ok, sqerr_sum
+from ..ops import grad_bias, linear_bias, ln_act, mlp_chain, mlp_chain_ok, recon_sqerr, recon_sqerr_ok, sqerr_sum, weight_image
+
+
+NOCAST = [__import__("os").environ.get("SPADOT_DEC_NOCAST", "1") == "1"]      # [False]: cast launch in front of the output map (A/B)
 
 
 def _hidden_stage(fan_in, fan_out):
@@ -30,25 +33,51 @@ class Decoder(nn.Module):
         self.decoder_net = nn.Sequential(*stages)
 
     def forward(self, latent_sample):
-        h, last = self._hidden(latent_sample)
+        h, last, _ = self._hidden(latent_sample)
         # hidden -> G is the only large GEMM here: compute dtype on MFMA (fp32 accumulate), fp32 result
         return linear_bias(h, last.weight, last.bias, self.compute_dtype)
 
-    def recon_loss(self, latent_sample, y, inv_scale):
+    def recon_loss(self, latent_sample, y, inv_scale, dz_extra=None):
         """inv_scale * sum (y - decoder(latent))^2 (SpaDOT.py:89) without materialising the reconstruction separately: in the
         bf16 compute dtype the bias add, the squared error and its sum are one launch behind the output map's GEMM."""
-        h, last = self._hidden(latent_sample)
-        if self.compute_dtype == torch.bfloat16 and recon_sqerr_ok(h, last.weight, last.bias, y):
-            return recon_sqerr(h, last.weight, last.bias, y, inv_scale)
+        bf = self.compute_dtype == torch.bfloat16
+        nocast = bf and NOCAST[0]
+        # dz_extra: a gradient for latent_sample that arrives by no backward path of its own (ops.cluster_losses_fb); the hidden
+        # stages' backward launch adds it
+        h, last, hb = self._hidden(latent_sample, bf16_out=nocast, dx_add=dz_extra)
+        if bf and recon_sqerr_ok(h, last.weight, last.bias, y):
+            # no cast launch between the hidden stages and the output map: the chain's launch leaves a bf16 copy of its result,
+            # and under an optimizer that keeps bf16 weight images current the map's weight needs none either
+            return recon_sqerr(h, last.weight, last.bias, y, inv_scale, hb, self._output_image(last.weight) if nocast else None)
         return sqerr_sum(y, linear_bias(h, last.weight, last.bias, self.compute_dtype), inv_scale)
 
-    def _hidden(self, latent_sample):
+    def _output_image(self, W):
+        """The bf16 image of the output map's weight that a FlatAdamW pinned by GraphedStepper keeps current (its update kernel
+        writes it), or None: not training, no such optimizer, or one that no longer owns W (same rules as GATEncoder)."""
+        opt = getattr(self, "_image_optimizer", None)
+        if opt is None or not self.training or not W.is_cuda:
+            return None
+        if not opt.owns(W):
+            object.__setattr__(self, "_image_optimizer", None)
+            return None
+        im = weight_image(W, W.shape[1], torch.bfloat16, self, tag="_wout")
+        if not opt.maintain_image(W, im):
+            return None
+        opt.sync_images()
+        return im
+
+    def _hidden(self, latent_sample, bf16_out=False, dx_add=None):
         stages = list(self.decoder_net)
-        h = latent_sample
+        h, hb = latent_sample, None
         hidden = [(stages[i], stages[i + 1], stages[i + 2].negative_slope) for i in range(0, len(stages) - 1, 3)]
         if hidden and mlp_chain_ok(h, hidden):
-            h = mlp_chain(h, hidden)                    # all hidden stages: one launch forward, two backward
+            if bf16_out:
+                h, hb = mlp_chain(h, hidden, bf16_out=True, dx_add=dx_add)     # all hidden stages: one launch forward, two backward
+            else:
+                h = mlp_chain(h, hidden, dx_add=dx_add)
         else:
+            if dx_add is not None:
+                h = grad_bias(h, dx_add)
             for dense, norm, slope in hidden:
                 h = ln_act(linear_bias(h, dense.weight, dense.bias), norm, slope)     # LN + LeakyReLU: one launch
-        return h, stages[-1]
+        return h, stages[-1], hb

@@ -252,6 +252,8 @@ class _SVGPCore(torch.autograd.Function):
                                            _p(junk[L * m + L:]), L * nparts, _stream()), "spadot_svgp_mid")
             else:
                 dt = torch.bmm(S, dr.unsqueeze(2)).squeeze(2)                # [L, m]
+            if Q1T[0] and T_IN_BACKWARD[0] and "Ta" not in pre and "q2" in pre:
+                _form_T(pre)                                                 # (A/B: T at the head of the backward instead of beside the tail)
             if "Ta" in pre:
                 q1 = torch.empty((L, b), dtype=F64, device=dev)
                 _check(lib.spadot_svgp_q1t(_p(pre["Ta"]), _p(pre["Tb"]), _p(G2T), _p(pre["m0"]), _p(g_kl), L, b, b, _p(q1),
@@ -270,6 +272,7 @@ class _SVGPCore(torch.autograd.Function):
 
 
 Q1T = [__import__("os").environ.get("SPADOT_SVGP_Q1T", "1") == "1"]
+T_IN_BACKWARD = [__import__("os").environ.get("SPADOT_SVGP_T_LATE", "0") == "1"]
 MID_BWD = [__import__("os").environ.get("SPADOT_SVGP_MIDBWD", "1") == "1"]
 # a list while a caller wants the part of forward() the loss tail does not wait for queued instead of run (GraphedStepper's
 # svgp_pre stage runs the queue right behind the SVGP forward graph, beside the tail); None: forward() runs everything
@@ -294,17 +297,26 @@ def precompute_backward(holder=None):
     Kn, S2, b = h["Kn"], h["S2"], h["b"]
     with torch.no_grad():
         h["q2"] = rowdot(torch.matmul(Kn, S2), Kn)
-        KS = _holder_KS(h)
-        if Q1T[0]:
-            # q1 = diag(K_nm S D S K_mn) with D = X2^T diag(G2) X2 + g/2 M needs the gradients only as WEIGHTS of squares:
-            # q1[l, i] = sum_n G2[l, n] T_l[n, i]^2 + g/2 m0[l, i],  T_l = X2 S_l K_mn [2b, b],  m0_l = diag(K_nm S_l M S_l K_mn).
-            # T and m0 are formed here (2.5 + 0.6 GFLOP, beside the loss tail); the backward pass then needs one reduction
-            # launch in place of a scaled copy of X2, the D product, K_nm S_l D_l and a row dot (~140 us in the step)
-            PS = h["PS"] if "PS" in h else h["X2S"][:, b:]
-            h["Ta"] = torch.matmul(KS, Kn.t())                               # [L, b, b]
-            h["Tb"] = torch.matmul(PS, Kn.t())                               # [L, b, b]
-            Lb = KS.shape[0] * KS.shape[1]                                   # (rowdot's second operand is ONE [rows, m] matrix)
-            h["m0"] = rowdot(torch.matmul(KS, h["M"]).reshape(1, Lb, -1), KS.reshape(Lb, -1)).reshape(KS.shape[0], KS.shape[1])
+        _holder_KS(h)
+        if Q1T[0] and not T_IN_BACKWARD[0]:
+            _form_T(h)
+    return h
+
+
+def _form_T(h):
+    """q1 = diag(K_nm S D S K_mn) with D = X2^T diag(G2) X2 + g/2 M needs the gradients only as WEIGHTS of squares:
+        q1[l, i] = sum_n G2[l, n] T_l[n, i]^2 + g/2 m0[l, i],   T_l = X2 S_l K_mn [2b, b],   m0_l = diag(K_nm S_l M S_l K_mn).
+    T (as its halves Ta = K_nm S_l K_mn, Tb = P S_l K_mn) and m0 are formed here: 2.5 + 0.6 GFLOP, beside the loss tail; the
+    backward pass then needs ONE reduction launch (spadot_svgp_q1t) in place of a scaled copy of X2, the D product, K_nm S_l D_l
+    and a row dot (~140 us in the step)."""
+    Kn, b = h["Kn"], h["b"]
+    KS = _holder_KS(h)
+    with torch.no_grad():
+        PS = h["PS"] if "PS" in h else h["X2S"][:, b:]
+        h["Ta"] = torch.matmul(KS, Kn.t())                                   # [L, b, b]
+        h["Tb"] = torch.matmul(PS, Kn.t())                                   # [L, b, b]
+        Lb = KS.shape[0] * KS.shape[1]                                       # (rowdot's second operand is ONE [rows, m] matrix)
+        h["m0"] = rowdot(torch.matmul(KS, h["M"]).reshape(1, Lb, -1), KS.reshape(Lb, -1)).reshape(KS.shape[0], KS.shape[1])
     return h
 
 

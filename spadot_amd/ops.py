@@ -1054,6 +1054,11 @@ def _contiguous_grad_block(params):
     return torch.empty(0, dtype=torch.float32, device=gs_[0].device).set_(st0, off, (pos - off,))
 
 
+CHAIN_BF16_OUT = [False]
+CHAIN_DX_ADD = [None]
+_LAST_CHAIN_BF16 = []
+
+
 class _MLPChain(torch.autograd.Function):
     """[Linear, LayerNorm, LeakyReLU] x n on a 2-D fp32 input: one launch forward, one + a column sum backward."""
 
@@ -1071,9 +1076,15 @@ class _MLPChain(torch.autograd.Function):
         cd = (ctypes.c_int * (n + 1))(*dims)
         ce = (ctypes.c_double * n)(*[float(e) for e in eps])
         cs = (ctypes.c_double * n)(*[float(v) for v in slope])
-        _check(model_lib().spadot_mlp_chain_forward(_p(x), b, n, cd, _ptr_array(Ws), _ptr_array(bs), _ptr_array(gs),
-                                                    _ptr_array(betas), ce, cs, _ptr_array(a), _ptr_array(y), _ptr_array(mean),
-                                                    _ptr_array(inv), _stream()), "spadot_mlp_chain_forward")
+        # (bf16 copy of the result for a matrix-core consumer: decoder's output map reads it instead of casting)
+        ybf = torch.empty((b, dims[-1]), dtype=torch.bfloat16, device=dev) if CHAIN_BF16_OUT[0] else None
+        _check(model_lib().spadot_mlp_chain_forward_bf16(_p(x), b, n, cd, _ptr_array(Ws), _ptr_array(bs), _ptr_array(gs),
+                                                         _ptr_array(betas), ce, cs, _ptr_array(a), _ptr_array(y), _ptr_array(mean),
+                                                         _ptr_array(inv), None if ybf is None else _p(ybf), _stream()),
+               "spadot_mlp_chain_forward_bf16")
+        if ybf is not None:
+            _LAST_CHAIN_BF16.append(ybf)
+        ctx.dx_add = CHAIN_DX_ADD[0]             # (set by mlp_chain(dx_add=...) around this call)
         ctx.save_for_backward(x, stats, *Ws, *gs, *a, *y)
         ctx.n, ctx.dims, ctx.slope = n, dims, [float(v) for v in slope]
         # FlatAdamW keeps every .grad as a view of its flat buffer; when this chain's parameters sit there back to back in
@@ -1100,10 +1111,13 @@ class _MLPChain(torch.autograd.Function):
         mean, inv = [stats[2 * l] for l in range(n)], [stats[2 * l + 1] for l in range(n)]
         cs = (ctypes.c_double * n)(*ctx.slope)
         late = direct and _deferring()          # the parameter gradients feed only the optimizer: their column sum is queued
-        _check(lib.spadot_mlp_chain_backward(_p(dy.contiguous().float()), _p(x), b, n, cd, _ptr_array(Ws), _ptr_array(gs), cs,
-                                             _ptr_array(a), _ptr_array(y), _ptr_array(mean), _ptr_array(inv),
-                                             None if dx is None else _p(dx), _p(ws), None if late else _p(grads), _stream()),
-               "spadot_mlp_chain_backward")
+        add = ctx.dx_add
+        assert add is None or (dx is not None and add.shape == x.shape and add.dtype == torch.float32 and add.is_contiguous())
+        _check(lib.spadot_mlp_chain_backward_add(_p(dy.contiguous().float()), _p(x), b, n, cd, _ptr_array(Ws), _ptr_array(gs), cs,
+                                                 _ptr_array(a), _ptr_array(y), _ptr_array(mean), _ptr_array(inv),
+                                                 None if dx is None else _p(dx), None if add is None else _p(add), _p(ws),
+                                                 None if late else _p(grads), _stream()),
+               "spadot_mlp_chain_backward_add")
         if late:
             DEFERRED[0].append(lambda ws=ws, grads=grads: _check(
                 lib.spadot_colsum(_p(ws), ws.shape[0], ws.shape[1], _p(grads), _stream()), "spadot_colsum"))
@@ -1131,10 +1145,36 @@ def mlp_chain_ok(x, stages):
     return bool(model_lib().spadot_mlp_chain_supported(len(stages), (ctypes.c_int * len(dims))(*dims)))
 
 
-def mlp_chain(x, stages):
-    """leaky_relu(LayerNorm(Linear(.))) applied stage after stage (decoder.py:3-20's hidden part)."""
+def mlp_chain(x, stages, bf16_out=False, dx_add=None):
+    """leaky_relu(LayerNorm(Linear(.))) applied stage after stage (decoder.py:3-20's hidden part).  bf16_out: also return a
+    bf16 copy of the result (written by the same launch; detached: a GEMM operand, not a differentiable output).
+    dx_add [like x, fp32]: a gradient that reaches x by another path and is NOT returned by that path's own backward (see
+    cluster_losses_fb); the chain's backward launch adds it to the input gradient it returns."""
     params = [t_ for lin, ln, _ in stages for t_ in (lin.weight, lin.bias, ln.weight, ln.bias)]
-    return _MLPChain.apply(x.contiguous(), [ln.eps for _, ln, _ in stages], [sl for _, _, sl in stages], *params)
+    CHAIN_BF16_OUT[0], CHAIN_DX_ADD[0] = bool(bf16_out), dx_add
+    try:
+        out = _MLPChain.apply(x.contiguous(), [ln.eps for _, ln, _ in stages], [sl for _, _, sl in stages], *params)
+    finally:
+        CHAIN_BF16_OUT[0], CHAIN_DX_ADD[0] = False, None
+    return (out, _LAST_CHAIN_BF16.pop()) if bf16_out else out
+
+
+class _GradBias(torch.autograd.Function):
+    """Identity whose backward adds a constant `extra` to the gradient (the fallback of mlp_chain(dx_add=...) for consumers
+    that cannot fold the addition into a launch of their own)."""
+
+    @staticmethod
+    def forward(ctx, x, extra):
+        ctx.extra = extra
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (ctx.extra if g is None else g + ctx.extra), None
+
+
+def grad_bias(x, extra):
+    return _GradBias.apply(x, extra)
 
 
 HEAD_FC_FWD = [__import__("os").environ.get("SPADOT_HEAD_FC_FWD", "0") == "1"]
@@ -1287,6 +1327,60 @@ class _ClusterLosses(torch.autograd.Function):
                                                           ptr(keep[0]), ptr(keep[1]), b, D, K, Kp, Kl, do_km, do_ot, _p(dz),
                                                           _stream()), "spadot_cluster_losses_backward")
         return dz, None, None, None, None, None, None, None, None
+
+
+class _ClusterLossesFB(torch.autograd.Function):
+    """cluster_losses whose gradient w.r.t. z is formed by the FORWARD launch for gradient seeds known then (w_km, w_ot: device
+    scalars, e.g. views of the loss-weight vector) and handed to the caller (`dz`), who routes it to z's other consumer
+    (mlp_chain(dx_add=dz)).  backward() returns NO gradient for z -- and refuses seeds other than the promised ones."""
+
+    @staticmethod
+    def forward(ctx, z, labels_all, seed_ids, centres, prev, gamma, cluster_list, do_km, do_ot, w_km, w_ot, box):
+        b, D = z.shape
+        K = centres.shape[0]
+        Kp, Kl = (prev.shape[0], cluster_list.shape[0]) if do_ot else (0, 0)
+        out = torch.empty(2, dtype=torch.float32, device=z.device)
+        work = torch.empty(K * D + K + 1 + b, dtype=torch.float32, device=z.device)
+        dz = torch.empty_like(z)
+        ptr = lambda t: None if t is None else _p(t)
+        rc = model_lib().spadot_cluster_losses_fb(_p(z), _p(labels_all), _p(seed_ids), _p(centres), ptr(prev), ptr(gamma),
+                                                  ptr(cluster_list), b, D, K, Kp, Kl, int(do_km), int(do_ot), _p(w_km), _p(w_ot),
+                                                  _p(out), _p(work), _p(dz), _stream())
+        if rc == -95:
+            box["dz"] = None
+            return None, None
+        _check(rc, "spadot_cluster_losses_fb")
+        box["dz"] = dz
+        ctx.seeds = (w_km.data_ptr() if do_km else None, w_ot.data_ptr() if do_ot else None)
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, g_km, g_ot):
+        for g, want in zip((g_km, g_ot), ctx.seeds):
+            if want is not None and (g is None or g.data_ptr() != want):
+                raise RuntimeError("cluster_losses_fb: backward seeded with something other than the weights its gradient was "
+                                   "formed with (use ops.cluster_losses outside GraphedStepper's staged tail)")
+        return (None,) * 12
+
+
+def cluster_losses_fb(z, labels_all, seed_ids, centres, prev_centres, gamma, cluster_list, do_km, do_ot, w_km, w_ot):
+    """(km, ot, dz) in ONE launch: the two losses (autograd outputs without a gradient path to z) and dz = d(w_km km + w_ot ot)
+    / dz, or None when the shape is outside the fused kernel's range.  The caller must (a) route dz to z's gradient itself and
+    (b) seed km / ot's backward with exactly w_km / w_ot (a backward seeded otherwise raises)."""
+    z = z.contiguous()
+    if not (z.is_cuda and z.dtype == torch.float32 and centres.dtype == torch.float32 and centres.is_contiguous()
+            and labels_all.dtype == seed_ids.dtype == torch.int64 and seed_ids.numel() == z.shape[0]
+            and w_km.dtype == w_ot.dtype == torch.float32):
+        return None
+    if do_ot and not (gamma.is_contiguous() and prev_centres.is_contiguous() and gamma.dtype == prev_centres.dtype == torch.float32
+                      and gamma.shape == (prev_centres.shape[0], cluster_list.shape[0]) and prev_centres.shape[1] == z.shape[1]):
+        return None
+    box = {}
+    km, ot = _ClusterLossesFB.apply(z, labels_all, seed_ids.contiguous(), centres, prev_centres, gamma, cluster_list, do_km, do_ot,
+                                    w_km, w_ot, box)
+    if box.get("dz") is None:
+        return None
+    return km, ot, box["dz"]
 
 
 def cluster_losses(z, labels_all, seed_ids, centres, prev_centres=None, gamma=None, cluster_list=None, do_km=True, do_ot=False):
@@ -1535,11 +1629,19 @@ class _LinearSqErr(torch.autograd.Function):
     launches where linear_bias + sqerr_sum take 5 + 5."""
 
     @staticmethod
-    def forward(ctx, h, W, bias, y, inv_scale):
+    def forward(ctx, h, W, bias, y, inv_scale, hc=None, Wc=None):
+        """hc: a bf16 copy of h that already exists (ops.mlp_chain(bf16_out=True)); Wc: a current bf16 image of W
+        (FlatAdamW.maintain_image).  Whatever is missing is cast here (one launch)."""
         b, G = y.shape
-        hc = torch.empty(h.shape, dtype=torch.bfloat16, device=h.device)
-        Wc = torch.empty(W.shape, dtype=torch.bfloat16, device=W.device)
-        cast_rows([(h, hc), (W.detach().contiguous(), Wc)])
+        pairs = []
+        if hc is None:
+            hc = torch.empty(h.shape, dtype=torch.bfloat16, device=h.device)
+            pairs.append((h, hc))
+        if Wc is None:
+            Wc = torch.empty(W.shape, dtype=torch.bfloat16, device=W.device)
+            pairs.append((W.detach().contiguous(), Wc))
+        if pairs:
+            cast_rows(pairs)
         o = torch.mm(hc, Wc.t(), out_dtype=torch.float32)
         out = torch.empty(1, dtype=torch.float32, device=h.device)
 
@@ -1578,7 +1680,7 @@ class _LinearSqErr(torch.autograd.Function):
             dW = torch.mm(gc.t(), hc, out_dtype=torch.float32, out=ctx.wgrad)
         else:
             dW = torch.mm(gc.t(), hc, out_dtype=torch.float32)
-        return dh, dW, db, None, None
+        return dh, dW, db, None, None, None, None
 
 
 def recon_sqerr_ok(h, W, bias, y):
@@ -1588,9 +1690,11 @@ def recon_sqerr_ok(h, W, bias, y):
                 and bias is not None)
 
 
-def recon_sqerr(h, W, bias, y, inv_scale):
+def recon_sqerr(h, W, bias, y, inv_scale, h_bf16=None, W_image=None):
     """inv_scale * sum (y - linear(h, W, bias))^2, the output map computed in bf16 (see _LinearSqErr)."""
-    return _LinearSqErr.apply(h.contiguous(), W, bias, y.contiguous(), inv_scale)
+    ok = lambda t_, like: (t_ is not None and t_.dtype == torch.bfloat16 and t_.is_contiguous() and t_.shape == like.shape)
+    return _LinearSqErr.apply(h.contiguous(), W, bias, y.contiguous(), inv_scale, h_bf16 if ok(h_bf16, h) else None,
+                              W_image if ok(W_image, W) else None)
 
 
 def kmeans_assign(x, centers):

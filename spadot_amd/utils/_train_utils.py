@@ -23,7 +23,7 @@ import torch
 
 from ..graph import build_batch_graph, knn_graph, precompute_batches
 from ..model import SpaDOT
-from ..ops import FlatAdamW, cluster_losses, mix_losses
+from ..ops import FlatAdamW, cluster_losses, cluster_losses_fb, mix_losses
 from .OT_loss.ot_solvers import compute_transport_map, compute_transport_maps
 
 LOSS_NAMES = ["elbo", "Recon", "SVGP_KL", "GAT_KL", "alignment", "KMeans", "OT"]
@@ -321,9 +321,12 @@ def _update_OT_matrix(model, model_config):
 
 # ------------------------------------------------------------------------------ the step
 
-def _cluster_terms(model, model_config, tp, tp_i, seed_ids, z, do_km, do_ot):
+def _cluster_terms(model, model_config, tp, tp_i, seed_ids, z, do_km, do_ot, weights=None):
     """(K-means loss, OT loss) of one batch through ops.cluster_losses (one launch each way); zeros for the
-    terms that are not active yet (_train_utils.py:198-204)."""
+    terms that are not active yet (_train_utils.py:198-204).
+    weights (the device vector of _loss_weights): (km, ot, dz) through ops.cluster_losses_fb instead -- the gradient
+    dz = d(omiga2 km + omiga3 ot)/dz comes out of the forward launch and the caller routes it -- or None when that kernel does
+    not take the shape."""
     if not (do_km or do_ot):
         zero = torch.zeros((), dtype=torch.float32, device=z.device)
         return zero, zero
@@ -333,6 +336,9 @@ def _cluster_terms(model, model_config, tp, tp_i, seed_ids, z, do_km, do_ot):
         prev_tp = model_config["timepoints"][tp_i - 1]
         prev = _device_state(model, prev_tp)["centers"]
         gamma = model._gamma_dev[f"{prev_tp}_{tp}"]
+    if weights is not None:
+        return cluster_losses_fb(z, st["labels"], seed_ids, st["centers"], prev, gamma, st["cluster_list"], do_km, do_ot,
+                                 weights[4], weights[5])
     return cluster_losses(z, st["labels"], seed_ids, st["centers"], prev, gamma, st["cluster_list"], do_km, do_ot)
 
 
@@ -458,6 +464,7 @@ class GraphedStepper:
         if model_config.get("optimizer_weight_images", os.environ.get("SPADOT_OPT_IMAGES", "1") == "1") \
                 and hasattr(optimizer, "maintain_image"):
             object.__setattr__(model.GATEncoder, "_image_optimizer", optimizer)
+            object.__setattr__(model.decoder, "_image_optimizer", optimizer)       # (the output map's weight: decoder.py)
             if not getattr(model, "_image_refresh_hook", False):
                 # (whichever optimizer is pinned WHEN a state_dict is loaded, not the one that was pinned first)
                 def _refresh(mod, incompatible):
@@ -501,6 +508,10 @@ class GraphedStepper:
         # to the svgp_pre stage (svgp.ELBO_LATE)
         self.svgp_elbo_late = bool(self.svgp_pre and os.environ.get("SPADOT_LATE_STREAM", "0") != "1"
                                    and model_config.get("svgp_elbo_late", os.environ.get("SPADOT_SVGP_ELBO_LATE", "1") == "1"))
+        # cluster_fb: the K-means / OT terms and their gradient in one launch, the gradient added by the decoder's backward
+        # launch (ops.cluster_losses_fb): two launches fewer on the loss tail's chain.  Only where the backward seed is certain:
+        # the staged tail's backward_partial.
+        self.cluster_fb = bool(self.defer_wgrad and model_config.get("cluster_fb", os.environ.get("SPADOT_CLUSTER_FB", "1") == "1"))
         self.pre_stream = bool(self.svgp_pre and os.environ.get("SPADOT_PRE_STREAM", "0") == "1")
         # late_stream (round 4, opt-in): the deferred gradient work on a third stream and memory pool of its own
         self.late_stream = bool(self.defer_wgrad and model_config.get("late_stream", os.environ.get("SPADOT_LATE_STREAM", "0") == "1"))
@@ -694,9 +705,22 @@ class GraphedStepper:
 
         def tail():
             leaves = [st[k].detach().requires_grad_(True) for k in ("zg", "pm", "pv", "skl")]
+            box = {}
+
+            def hook(z):
+                # K-means / OT terms AND their gradient w.r.t. z in one launch (the seeds of this stage's backward are the
+                # loss weights: backward_partial's constant-one seed through mix_losses); the decoder's backward adds it
+                if not (self.cluster_fb and (do_km or do_ot)):
+                    return None
+                res = _cluster_terms(model, cfg, tp, tp_i, seeds, z, do_km, do_ot, weights=self.beta1_t)
+                if res is None:
+                    return None
+                box["km"], box["ot"] = res[0], res[1]
+                return res[2]
+
             recon, gkl, align, z = model.tail(leaves[0], leaves[1], leaves[2], st["ys"], b,
-                                              y_seed32=getattr(batch, "y_seed32", None) if cached else None)
-            km, ot = _cluster_terms(model, cfg, tp, tp_i, seeds, z, do_km, do_ot)
+                                              y_seed32=getattr(batch, "y_seed32", None) if cached else None, z_hook=hook)
+            km, ot = (box["km"], box["ot"]) if "km" in box else _cluster_terms(model, cfg, tp, tp_i, seeds, z, do_km, do_ot)
             elbo, losses = mix_losses(self.beta1_t, (recon, leaves[3], gkl, align, km, ot))
             st["g"] = opt.backward_partial(elbo, None, P["tail"], extra_inputs=leaves)
             if self.keep_latents:
@@ -774,7 +798,8 @@ class GraphedStepper:
 
     def _pre_stream_obj(self):
         if getattr(self, "_pre_stream", None) is None:
-            self._pre_stream = torch.cuda.Stream(device=torch.device(self.cfg["device"]), priority=0)
+            self._pre_stream = torch.cuda.Stream(device=torch.device(self.cfg["device"]),
+                                                 priority=int(os.environ.get("SPADOT_PRE_PRIORITY", "0")))
         return self._pre_stream
 
     def _late_stream_obj(self):

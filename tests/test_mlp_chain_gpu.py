@@ -191,3 +191,53 @@ def test_head_fc_from_bf16_rows_matches_float_linear(b, K, N):
     hh = h.clone().requires_grad_(True)
     out2 = ops.head_fc(hh, WW.detach().requires_grad_(True), bb.detach().requires_grad_(True))
     np.testing.assert_allclose(out2.detach().cpu().numpy(), res[0][0].cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("b,dims", [(512, [20, 64, 256]), (37, [12, 24, 8, 256])])
+def test_chain_bf16_copy_and_added_input_gradient(b, dims):
+    """mlp_chain(bf16_out=True): the same launch leaves the bf16 rounding of its result; mlp_chain(dx_add=e): the backward launch
+    returns dx + e -- both without touching any other output (bit-identical values and parameter gradients)."""
+    from spadot_amd import ops
+    stages = _stages(dims, 11)
+    g = torch.Generator(device=DEV).manual_seed(b)
+    x = torch.randn((b, dims[0]), device=DEV, generator=g)
+    w = torch.randn((b, dims[-1]), device=DEV, generator=g)
+    extra = torch.randn((b, dims[0]), device=DEV, generator=g)
+    h0, dx0, g0 = _run(ops, x, stages, w, True)
+    for lin, ln, _ in stages:
+        for p in (*lin.parameters(), *ln.parameters()):
+            p.grad = None
+    xin = x.clone().requires_grad_(True)
+    h, hb = ops.mlp_chain(xin, stages, bf16_out=True, dx_add=extra)
+    (h * w).sum().backward()
+    assert torch.equal(h.detach(), h0) and hb.dtype == torch.bfloat16 and torch.equal(hb, h0.bfloat16())
+    assert torch.equal(xin.grad, dx0 + extra)
+    for a, u in zip([p.grad for lin, ln, _ in stages for p in (lin.weight, lin.bias, ln.weight, ln.bias)], g0):
+        assert torch.equal(a, u)
+    # the fallback for consumers without such a launch: an identity whose backward adds the constant
+    xin = x.clone().requires_grad_(True)
+    (ops.grad_bias(xin, extra) * 2.0).sum().backward()
+    assert torch.equal(xin.grad, torch.full_like(x, 2.0) + extra)
+
+
+def test_reconstruction_term_from_ready_bf16_operands():
+    """recon_sqerr with the bf16 copy of h (mlp_chain's) and a current bf16 image of W handed in: no cast launch, same bits."""
+    from spadot_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(5)
+    b, G, K = 512, 3000, 256
+    h = torch.randn((b, K), device=DEV, generator=g)
+    W = torch.randn((G, K), device=DEV, generator=g) * 0.1
+    bias = torch.randn(G, device=DEV, generator=g) * 0.1
+    y = torch.randn((b, G), device=DEV, generator=g)
+    res = []
+    for ready in (False, True):
+        hh, WW, bb = (t.clone().requires_grad_(True) for t in (h, W, bias))
+        loss = ops.recon_sqerr(hh, WW, bb, y, 1.0 / G, h.bfloat16() if ready else None, W.bfloat16() if ready else None)
+        loss.backward()
+        res.append((loss.detach().clone(), hh.grad, WW.grad, bb.grad))
+    for a, u in zip(res[0], res[1]):
+        assert torch.equal(a, u)
+    # operands of the wrong shape or dtype are ignored (cast path), not trusted
+    hh, WW, bb = (t.clone().requires_grad_(True) for t in (h, W, bias))
+    loss = ops.recon_sqerr(hh, WW, bb, y, 1.0 / G, h[:, :8].bfloat16().contiguous(), W.half())
+    assert torch.equal(loss.detach(), res[0][0])

@@ -193,26 +193,40 @@ def test_svgp_backward_precomputed_and_restructured_forms_agree(ops, b, m, L):
     z0 = torch.as_tensor(np.concatenate([rng.normal(0, 1, (b, L)), rng.normal(-1, 0.3, (b, L))], 1), dtype=torch.float32).to(DEV)
     gpm, gpv = T(rng.normal(0, 1, (b, L))).to(DEV), T(rng.normal(0, 1, (b, L))).to(DEV)
 
-    def run(mid, pre, q1t):
+    def run(mid, pre, q1t, late=False):
         old = sv.MID_BWD[0], sv.Q1T[0]
         sv.MID_BWD[0], sv.Q1T[0] = mid, q1t
         try:
             z = z0.clone().requires_grad_(True)
             bc = mod.batch_constants(x)
-            p_m, p_v, skl = mod.elbo_finish(bc, mod.elbo_start(bc, z))
+            queue = [] if late else None
+            sv.ELBO_LATE[0] = queue          # (late: forward hands p_m / p_v over first and queues the rest of its ELBO)
+            try:
+                p_m, p_v, skl = mod.elbo_finish(bc, mod.elbo_start(bc, z))
+            finally:
+                sv.ELBO_LATE[0] = None
+            head = (p_m.detach().clone(), p_v.detach().clone())
+            if late:
+                assert len(queue) == 1
+                with torch.no_grad():
+                    queue[0]()
             if pre:
                 h = sv.precompute_backward()
-                assert "q2" in h and "KS" in h and (("T" in h) == q1t)
+                assert "q2" in h and "KS" in h and (("Ta" in h) == q1t)
             (dz,) = torch.autograd.grad([p_m, p_v, skl], [z], [gpm, gpv, torch.tensor(0.7, device=DEV)])
-            return dz.double().cpu().numpy()
+            return dz.double().cpu().numpy(), head[0].cpu().numpy(), head[1].cpu().numpy(), float(skl)
         finally:
             sv.MID_BWD[0], sv.Q1T[0] = old
 
-    ref = run(False, False, False)
+    ref, pm0, pv0, skl0 = run(False, False, False)
     scale = np.abs(ref).max()
-    for mid, pre, q1t in ((True, False, False), (True, True, False), (True, True, True), (False, True, True)):
-        got = run(mid, pre, q1t)
-        assert np.abs(got - ref).max() <= 2e-6 * scale, (mid, pre, q1t, np.abs(got - ref).max(), scale)
+    for mid, pre, q1t, late in ((True, False, False, False), (True, True, False, False), (True, True, True, False),
+                                (False, True, True, False), (True, True, True, True), (True, False, False, True)):
+        got, pm, pv, skl = run(mid, pre, q1t, late)
+        assert np.abs(got - ref).max() <= 2e-6 * scale, (mid, pre, q1t, late, np.abs(got - ref).max(), scale)
+        np.testing.assert_allclose(pm, pm0, rtol=1e-9, atol=1e-12)           # (K_nm S_l as a product of its own: other tiles)
+        np.testing.assert_allclose(pv, pv0, rtol=1e-9, atol=1e-12)
+        assert skl == pytest.approx(skl0, rel=1e-6)
 
 
 def test_reduction_kernels_gradients_vs_torch(ops):
@@ -656,6 +670,29 @@ def test_cluster_losses_vs_oracle_and_torch_gradient(ops, b, K, absent):
     km1, ot1 = ops.cluster_losses(zd.detach(), torch.as_tensor(all_labels, dtype=torch.int64, device=DEV),
                                   torch.as_tensor(seeds, dtype=torch.int64, device=DEV), f32(centres), do_km=True, do_ot=False)
     assert float(km1) == float(km) and float(ot1) == 0.0
+    # forward + gradient in ONE launch for seeds known in advance (cluster_losses_fb): the same bits as the two launches, no
+    # gradient path of its own to z, and a backward seeded with anything but the promised weights refuses
+    wv = torch.tensor([0.0, 0.0, 0.0, 0.0, 0.7, -1.9], dtype=torch.float32, device=DEV)
+    args = (torch.as_tensor(all_labels, dtype=torch.int64, device=DEV), torch.as_tensor(seeds, dtype=torch.int64, device=DEV),
+            f32(centres), f32(prev), f32(g_norm), torch.as_tensor(clusters, dtype=torch.int64, device=DEV))
+    for do_km, do_ot in ((True, True), (True, False)):
+        zp = f32(z).requires_grad_(True)
+        kmp, otp = ops.cluster_losses(zp, *args, do_km, do_ot)
+        torch.autograd.backward([kmp, otp], [wv[4], wv[5]])
+        zq = f32(z).requires_grad_(True)
+        res = ops.cluster_losses_fb(zq, *args, do_km, do_ot, wv[4], wv[5])
+        if b * D > 10240:                    # more than one chunk: outside the fused kernel's range, the caller falls back
+            assert res is None
+            return
+        kmq, otq, dzq = res
+        assert float(kmq) == float(kmp) and float(otq) == float(otp)
+        assert torch.equal(dzq, zp.grad)
+        torch.autograd.backward([kmq, otq], [wv[4], wv[5]])
+        assert zq.grad is None
+    zq = f32(z).requires_grad_(True)
+    kmq, otq, _ = ops.cluster_losses_fb(zq, *args, True, True, wv[4], wv[5])
+    with pytest.raises(RuntimeError, match="cluster_losses_fb"):
+        torch.autograd.backward([kmq, otq], [wv[4].clone(), wv[5]])
 
 
 def test_mix_losses(ops):

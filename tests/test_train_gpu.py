@@ -653,8 +653,23 @@ def test_weight_images_follow_every_writer_of_the_weights():
     for _ in range(3):                                    # eager, capture, replay: the optimizer now maintains the images
         for bi in range(2):
             st.step(1, 1, bi, ep, 0.5)
-    assert enc._image_optimizer is opt and len(opt._images) == 3
+    # (the three GAT layers' weights and the decoder's output map: decoder.py _output_image)
+    assert enc._image_optimizer is opt and model.decoder._image_optimizer is opt and len(opt._images) == 4
     assert images_current() == 0.0
+
+    def output_image_error():
+        from spadot_amd.ops import weight_image
+        torch.cuda.synchronize()
+        W = list(model.decoder.decoder_net)[-1].weight
+        im = weight_image(W, W.shape[1], torch.bfloat16, model.decoder, tag="_wout")
+        return float((im.float() - W.detach().to(torch.bfloat16).float()).abs().max())
+
+    assert output_image_error() == 0.0
+    with torch.no_grad():
+        list(model.decoder.decoder_net)[-1].weight.mul_(1.04)      # a write the optimizer did not make: caught by step()'s sync
+    assert output_image_error() > 0.0
+    st.step(1, 1, 0, ep, 0.5)
+    assert output_image_error() == 0.0
 
     # (2a) load_state_dict between two replayed steps
     sd = {k: (v.clone() * 1.03 if k.endswith("lin.weight") else v.clone()) for k, v in model.state_dict().items()}
@@ -678,7 +693,7 @@ def test_weight_images_follow_every_writer_of_the_weights():
     for bi in range(2):
         tu.training_step(model, opt2, cfg, dd, 1, 1, bi, ep, 0.5)
     torch.cuda.synchronize()
-    assert enc._image_optimizer is None                    # the stale pin is gone
+    assert enc._image_optimizer is None and model.decoder._image_optimizer is None      # the stale pins are gone
     assert float((enc.gat1.lin.weight.detach() - before).abs().max()) > 0.0
     # the eager path casts the images at the head of every forward (nobody maintains them now): behind the last update
     # they lag, the next forward brings them up to date
