@@ -512,7 +512,6 @@ class GraphedStepper:
         # launch (ops.cluster_losses_fb): two launches fewer on the loss tail's chain.  Only where the backward seed is certain:
         # the staged tail's backward_partial.
         self.cluster_fb = bool(self.defer_wgrad and model_config.get("cluster_fb", os.environ.get("SPADOT_CLUSTER_FB", "1") == "1"))
-        self.pre_stream = bool(self.svgp_pre and os.environ.get("SPADOT_PRE_STREAM", "0") == "1")
         # late_stream (round 4, opt-in): the deferred gradient work on a third stream and memory pool of its own
         self.late_stream = bool(self.defer_wgrad and model_config.get("late_stream", os.environ.get("SPADOT_LATE_STREAM", "0") == "1"))
         self._late_stream = None
@@ -796,12 +795,6 @@ class GraphedStepper:
             fns = tuple(stamped(k, fn) for k, fn in enumerate(fns))
         return fns
 
-    def _pre_stream_obj(self):
-        if getattr(self, "_pre_stream", None) is None:
-            self._pre_stream = torch.cuda.Stream(device=torch.device(self.cfg["device"]),
-                                                 priority=int(os.environ.get("SPADOT_PRE_PRIORITY", "0")))
-        return self._pre_stream
-
     def _late_stream_obj(self):
         if self._late_stream is None:
             self._late_stream = torch.cuda.Stream(device=torch.device(self.cfg["device"]),
@@ -862,17 +855,8 @@ class GraphedStepper:
             main.wait_stream(side)                       # (an event behind the SVGP forward: what follows on `side` is not waited for)
             res = fns[2]()
             if len(fns) == 8:                            # (launched behind the tail: the host hands the critical graph over first)
-                if self.pre_stream:
-                    # (opt-in: a third stream at NORMAL priority -- the side stream's high priority puts these GEMMs in
-                    # front of the loss tail's short launches)
-                    pre = self._pre_stream_obj()
-                    pre.wait_stream(side)
-                    with torch.cuda.stream(pre):
-                        fns[7]()
-                    side.wait_stream(pre)
-                else:
-                    with torch.cuda.stream(side):
-                        fns[7]()
+                with torch.cuda.stream(side):
+                    fns[7]()
             side.wait_stream(main)
             fns[4]()
             if self._late_event is None:
