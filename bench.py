@@ -700,14 +700,18 @@ def _main(real_stdout, args):
         plan_first = solver.plan("numpy") if want_parity else None     # (before the timed iterations move a, b on)
         for _ in range(args.warmup):
             solver.run_iterations(OT_CFG, OT_CFG["epsilon"], ITERS_PER_STEP, timed=False)
+        # the timed region: EXACTLY `steps` steps of ITERS_PER_STEP iterations, barrier + synchronize on both sides and nothing
+        # that waits for the device in between (until round 4 every step read its own HIP events back: a host
+        # synchronisation per 10 iterations, 9 us per iteration of drained queue that no solve pays -- the solver's own loop
+        # reads one 16-byte record per 15 iterations, `iters_per_s_with_convergence_checks` below)
         barrier()
         t0 = time.perf_counter()
-        ev_ms = 0.0
         for _ in range(args.steps):
-            ev_ms += solver.run_iterations(OT_CFG, OT_CFG["epsilon"], ITERS_PER_STEP, timed=True)
+            solver.run_iterations(OT_CFG, OT_CFG["epsilon"], ITERS_PER_STEP, timed=False)
         barrier()
         el = max_over_ranks(time.perf_counter() - t0)
         iters = args.steps * ITERS_PER_STEP
+        ev_ms = solver.run_iterations(OT_CFG, OT_CFG["epsilon"], iters, timed=True)      # the same iterations between two HIP events
         # the same iterations inside the solver's real loop: + snapshot, duality-gap measure and one
         # host sync every batch_size (5) iterations
         ck_it, ck_ms = solver.run_checked(OT_CFG, OT_CFG["epsilon"], nbatches=max(4, args.steps), last_stage=True)

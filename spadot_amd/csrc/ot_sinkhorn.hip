@@ -2055,7 +2055,7 @@ int spadot_ot_run_iterations(spadot_ot_solver *s, const spadot_ot_config *cfg, d
     // `batch_size` fast iterations per batch; a raised tau flag makes the run unusable (return 2)
     const int bs = std::max(1, std::min(cfg->batch_size, MAX_BATCH));
     HIP_CHECK(hipMemsetAsync(s->flags + MAX_BATCH - 1, 0, sizeof(int), s->stream));
-    HIP_CHECK(hipEventRecord(s->ev0, s->stream));
+    if (ms_out) HIP_CHECK(hipEventRecord(s->ev0, s->stream));      // (untimed calls stay capturable: no event nodes)
     for (int left = iters; left > 0; left -= bs) {
         const int nb = std::min(left, bs);
         snapshot(s);
@@ -2064,8 +2064,8 @@ int spadot_ot_run_iterations(spadot_ot_solver *s, const spadot_ot_config *cfg, d
             else one_iteration_T<double>(s, P, s->flags + MAX_BATCH - 1, false);
         }
     }
-    HIP_CHECK(hipEventRecord(s->ev1, s->stream));
     if (ms_out) {
+        HIP_CHECK(hipEventRecord(s->ev1, s->stream));
         HIP_CHECK(hipMemcpyAsync(s->h_flags, s->flags + MAX_BATCH - 1, sizeof(int), hipMemcpyDeviceToHost, s->stream));
         HIP_CHECK(hipEventSynchronize(s->ev1));
         HIP_CHECK(hipStreamSynchronize(s->stream));
