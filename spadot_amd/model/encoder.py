@@ -11,7 +11,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..graph import build_batch_graph
-from ..ops import (BatchGraph, bn_act, cast_rows, dense_cd, first_map_seeds, first_map_seeds_ok, gat_edge, gat_tail, gat_tail_ok,
+from ..ops import (stamp_if, BatchGraph, bn_act, cast_rows, dense_cd, first_map_seeds, first_map_seeds_ok, gat_edge, gat_tail, gat_tail_ok,
                    head_fc, head_fc_ok, hidden_map, linear_bias, weight_image)
 
 
@@ -68,7 +68,9 @@ class SVGPEncoder(nn.Module):
                 h = hidden_map(h, lin.weight)              # (same product; its backward dodges a library tile that stalls)
             else:
                 h = F.linear(h[:, :lin.in_features].float(), lin.weight)
+            stamp_if(19 + i // 3 * 2)                      # (SPADOT_STAMPS=1 only: slots 19 / 21 behind the maps, 20 / 22 behind BN)
             h = bn_act(h, lin.bias, bn, act.negative_slope)
+            stamp_if(20 + i // 3 * 2)
         return linear_bias(h, self.SVGP_fc.weight, self.SVGP_fc.bias)
 
 

@@ -114,6 +114,7 @@ class _SVGPCore(torch.autograd.Function):
                 A = torch.empty((L, b, m), dtype=F64, device=z.device)       # diag(w_l) K_nm, written by the pre kernel
                 _check(lib.spadot_svgp_pre2(_p(z), _p(Kn), b, L, m, _p(mu), _p(var), _p(w), _p(muw), _p(A), _stream()),
                        "spadot_svgp_pre2")
+                stamp_if(23)                                                 # (SPADOT_STAMPS=1 only: pre2 done)
                 G = torch.empty((L, m, m), dtype=F64, device=z.device)
                 if DGEMM_SMALL[0]:
                     # G_l = c K_mn diag(w_l) K_nm and t = (mu w)^T K_nm on the fp64 matrix cores (csrc/gemm_f64.hip: 64 x 64 tiles
@@ -122,6 +123,7 @@ class _SVGPCore(torch.autograd.Function):
                     t = dgemm_small(2, muw, Kn)                              # [L, m]
                 else:
                     torch.baddbmm(G, A.transpose(1, 2), Kn.unsqueeze(0).expand(L, b, m), beta=0.0, alpha=c, out=G)
+                    stamp_if(28)                                             # (SPADOT_STAMPS=1 only: G done)
                     t = muw.T @ Kn                                           # [L, m]
                 if stop_before_sweep:
                     return dict(mu=mu, var=var, w=w, G=G, t=t, L=L)

@@ -77,6 +77,10 @@ def main():
     if a[:, 16].max() > 0:
         print(f"  inside svgp_fwd: encoder {med[16] - med[2]:.1f} us, Sigma build {med[17] - med[16]:.1f}, inverse {med[18] - med[17]:.1f}, "
               f"behind the inverse {med[3] - med[18]:.1f}")
+    if a[:, 19].max() > 0 and a[:, 28].max() > 0:
+        print(f"  inside the encoder: first map {med[19] - med[2]:.1f} us, BN {med[20] - med[19]:.1f}, hidden map {med[21] - med[20]:.1f}, "
+              f"BN {med[22] - med[21]:.1f}, SVGP_fc {med[16] - med[22]:.1f}; Sigma build: pre2 {med[23] - med[16]:.1f}, G {med[28] - med[23]:.1f}, "
+              f"t {med[17] - med[28]:.1f}")
     print(f"  svgp_bwd starts {med[6] - med[5]:.1f} us after the tail ends; gat_bwd starts {med[8] - med[5]:.1f} us after the tail ends")
     print(f"  svgp_fwd ends {sv_end - med[1]:+.1f} us relative to gat_fwd's end; svgp_bwd ends {med[7] - med[9]:+.1f} us relative to gat_bwd's end")
     print(f"  step period (upd_rest end of this step - upd_rest end of the previous one is not stamped): gat_fwd start -> upd_rest end {med[27]:.1f} us")
