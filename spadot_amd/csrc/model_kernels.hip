@@ -2729,8 +2729,13 @@ int spadot_adamw_range_dev(float *param, const float *grad, float *exp_avg, floa
             return -22;
     }
     hipStream_t st_ = (hipStream_t)stream;
+    // SPADOT_ADAMW_MAX_WGS (default 512; 4096 until round 4): workgroups of the streaming update.  Two 256-thread workgroups per
+    // compute unit stream as fast as sixteen (80 us for the 483 MB of cfg3 either way) and leave the wave slots to what runs
+    // beside the update -- the next step's SVGP encoder, chained to the update's first part: 619.6 / 620.5 -> 624.5 / 627.3
+    // steps/s (same box; 256 workgroups: 617)
+    static const long long max_wgs = [] { const char *e = getenv("SPADOT_ADAMW_MAX_WGS"); long long v = e ? atoll(e) : 512; return v < 1 ? 1 : v; }();
     const long long want4 = (count / 4 + 255) / 256;
-    const int nb = (int)(want4 < 4096 ? want4 : 4096);
+    const int nb = (int)(want4 < max_wgs ? want4 : max_wgs);
     hipLaunchKernelGGL(k_adamw_img, dim3(nb), dim3(256), 0, st_, param + offset, grad + offset, exp_avg + offset, exp_avg_sq + offset,
                        sumsq, count, (float)lr, (float)beta1, (float)beta2, (float)eps, (float)weight_decay, (float)max_norm,
                        step_dev, grad_scale_dev, *tab, offset);
