@@ -1462,8 +1462,14 @@ __global__ __launch_bounds__(256) void k_adamw_img(float *__restrict__ p, const 
 // Small-MLP stages: BatchNorm1d (training) + LeakyReLU, LayerNorm + LeakyReLU, each ONE launch forward and one
 // (LayerNorm: two) backward instead of the library's 4-5 and 3-4.  b rows <= a few thousand, F features <= 1024.
 // ------------------------------------------------------------------------------------------
-constexpr int BN_RPT = 32;                                           // rows a thread keeps in registers on the one-load path
-constexpr int BN_COLS = 16, BN_RG = 16, BN_NT = BN_COLS * BN_RG;      // 16 columns x 16 row lanes: 256-thread workgroups.  These
+#ifndef BN_RG_DEF
+#define BN_RG_DEF 16                                                 // (build define for A/B runs: 16 / 8 / 4 row lanes = 256 / 128 / 64 threads)
+#endif
+constexpr int BN_RPT = 512 / BN_RG_DEF;                              // rows a thread keeps in registers on the one-load path (b <= 512)
+#ifndef BN_COLS_DEF
+#define BN_COLS_DEF 16
+#endif
+constexpr int BN_COLS = BN_COLS_DEF, BN_RG = BN_RG_DEF, BN_NT = BN_COLS * BN_RG;      // 16 columns x 16 row lanes: 256-thread workgroups.  These
 // launches run on the side stream beside the GAT branch's GEMMs, whose waves fill the register files: a new workgroup
 // starts when a GEMM workgroup retires, and a 1024-thread one (64 row lanes, 30 % faster on an idle GPU) needs a whole
 // compute unit to drain first -- it sat ~100 us in the queue (rocprofv3 timeline, profiles/r02).  Same box, same run
