@@ -503,7 +503,12 @@ class GraphedStepper:
         # svgp_pre (round 4): the gradient-independent products of the SVGP backward (svgp.precompute_backward: ~140 us of its
         # ~500 us chain inside the backward pair) as a graph of their own on the side stream, launched right behind the SVGP
         # forward: they run while the loss tail occupies the main stream and the side stream would otherwise idle
-        self.svgp_pre = bool(self.defer_wgrad and model_config.get("svgp_precompute", os.environ.get("SPADOT_SVGP_PRE", "1") == "1"))
+        want_pre = bool(model_config.get("svgp_precompute", os.environ.get("SPADOT_SVGP_PRE", "1") == "1"))
+        self.svgp_pre = bool(self.defer_wgrad and want_pre)
+        # ... and in the stepper's other staged forms (the five graphs without a queue, the six of the bucketed gradient exchange:
+        # what data-parallel ranks replay) as one more graph behind the tail's, without the late ELBO (their loss values are
+        # computed inside the tail)
+        self.svgp_pre_generic = bool(self.staged and not self.defer_wgrad and not self.split_bwd and not self.svgp_head_first and want_pre)
         # svgp_elbo_late: the SVGP forward hands p_m / p_v to the tail and leaves the rest of its ELBO (P S_l, mv, tr, the scalars)
         # to the svgp_pre stage (svgp.ELBO_LATE)
         self.svgp_elbo_late = bool(self.svgp_pre and os.environ.get("SPADOT_LATE_STREAM", "0") != "1"
@@ -511,7 +516,8 @@ class GraphedStepper:
         # cluster_fb: the K-means / OT terms and their gradient in one launch, the gradient added by the decoder's backward
         # launch (ops.cluster_losses_fb): two launches fewer on the loss tail's chain.  Only where the backward seed is certain:
         # the staged tail's backward_partial.
-        self.cluster_fb = bool(self.defer_wgrad and model_config.get("cluster_fb", os.environ.get("SPADOT_CLUSTER_FB", "1") == "1"))
+        self.cluster_fb = bool((self.defer_wgrad or self.svgp_pre_generic)
+                               and model_config.get("cluster_fb", os.environ.get("SPADOT_CLUSTER_FB", "1") == "1"))
         # late_stream (round 4, opt-in): the deferred gradient work on a third stream and memory pool of its own
         self.late_stream = bool(self.defer_wgrad and model_config.get("late_stream", os.environ.get("SPADOT_LATE_STREAM", "0") == "1"))
         self._late_stream = None
@@ -777,6 +783,8 @@ class GraphedStepper:
             fns = (gat_fwd, svgp_fwd, queued(tail), svgp_bwd, queued(gat_bwd_a), queued(gat_bwd_b), late)
             if self.svgp_pre:
                 fns = fns + (svgp_pre,)
+        if self.svgp_pre_generic:
+            fns = fns + (svgp_pre,)         # (last: _issue_staged launches it on the side stream behind the tail's graph)
         if self.svgp_head_first:
             # a SEVENTH stage: the SVGP branch's short launches in front of its inverse as a graph of their own (see __init__)
             fns = fns + (svgp_fwd_head, svgp_fwd_rest)
@@ -879,6 +887,10 @@ class GraphedStepper:
                     fns[6]()
             main.wait_stream(side)
             return res
+        pre = None
+        if self.svgp_pre_generic:
+            pre, fns = fns[-1], fns[:-1]
+            assert len(fns) == (6 if self.overlap else 5)
         head_first = self.svgp_head_first and len(fns) >= 7
         if head_first:
             head, rest = fns[-2], fns[-1]
@@ -908,6 +920,12 @@ class GraphedStepper:
         if two_streams:
             main.wait_stream(side)
         res = fns[2]()
+        if pre is not None:                  # gradient-independent half of the SVGP backward: side stream, beside the tail
+            if two_streams:
+                with torch.cuda.stream(side):
+                    pre()
+            else:
+                pre()
         if two_streams:
             side.wait_stream(main)
         if len(fns) == 6 and self.split_bwd:
@@ -932,7 +950,7 @@ class GraphedStepper:
             fns[4]()
         if two_streams:
             main.wait_stream(side)
-        if len(fns) == 6:
+        if self.overlap:
             cut = self.opt.tail_offset
             w1 = self.grad_sync_async(self.opt.flat_grad[:cut])
             fns[5]()
@@ -974,11 +992,14 @@ class GraphedStepper:
                 order = [0, nf - 2, nf - 1] + list(range(2, nf - 2))
             if self.defer_wgrad and nf == 8:             # svgp_pre fills the holder the SVGP backward's capture reads
                 order = [0, 1, 7, 2, 3, 4, 5, 6]
+            if self.svgp_pre_generic:
+                order = [0, 1, nf - 1] + list(range(2, nf - 1))
             for k in order:
                 fn = fns[k]
                 g = torch.cuda.CUDAGraph()
                 side_stage = (k in (1, 3) or (self.svgp_head_first and k >= nf - 2)
-                              or (self.defer_wgrad and nf in (7, 8) and k in (6, 7)))
+                              or (self.defer_wgrad and nf in (7, 8) and k in (6, 7))
+                              or (self.svgp_pre_generic and k == nf - 1))
                 pool = self.pool_side if side_stage else self.pool           # the SVGP stages run beside the GAT ones
                 if self.late_stream and self.defer_wgrad and nf in (7, 8) and k == 6:
                     if self.pool_late is None:

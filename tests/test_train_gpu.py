@@ -414,13 +414,14 @@ def test_bucketed_exchange_splits_the_backward_without_changing_the_gradient():
         seen.append((view.data_ptr() - opt.flat_grad.data_ptr(), view.numel(), view.clone()))
         return Handle()
 
-    # (the unsplit five-graph form WITHOUT the single-GPU reorderings of round 4 -- queued gradient work, the SVGP backward's
-    # precomputed half, the fused cluster launch: the bucketed form does not take them, and "bit for bit" is about where the
-    # backward is cut, not about two routes through the same algebra; those are compared, to rounding, in
-    # test_deferred_weight_gradients_leave_the_same_gradient)
+    # (the unsplit five-graph form WITHOUT the queue of round 4 -- deferred gradient work and the late ELBO need it, the bucketed
+    # form cannot take them: "bit for bit" is about where the backward is cut, not about two routes through the same algebra;
+    # those are compared, to rounding, in test_deferred_weight_gradients_leave_the_same_gradient.  Both forms here DO take the
+    # SVGP backward's precomputed half and the fused cluster launch: svgp_pre_generic)
     plain = tu.GraphedStepper(model, opt, dict(cfg, staged_graphs=True, defer_wgrad=False), dd)
     split = tu.GraphedStepper(model, opt, dict(cfg, staged_graphs=True), dd, grad_sync=lambda f: f, grad_sync_async=fake_async)
-    assert split.overlap and not plain.overlap and not plain.defer_wgrad and not plain.svgp_pre and not plain.cluster_fb
+    assert split.overlap and not plain.overlap and not plain.defer_wgrad and not plain.svgp_pre
+    assert plain.svgp_pre_generic and split.svgp_pre_generic and plain.cluster_fb and split.cluster_fb
     for rep in range(4):                                   # eager, capture + replay, replay, replay
         for bi in range(2):
             la = plain.fb(1, 1, bi, cfg["ot_epoch"], 0.5)
@@ -740,7 +741,8 @@ def test_deferred_weight_gradients_leave_the_same_gradient():
     on = tu.GraphedStepper(model, opt, dict(cfg, staged_graphs=True, defer_wgrad=True), dd)
     off = tu.GraphedStepper(model, opt, dict(cfg, staged_graphs=True, defer_wgrad=False), dd)
     assert on.defer_wgrad and not off.defer_wgrad
-    assert on.svgp_pre and on.svgp_elbo_late and on.cluster_fb and not (off.svgp_pre or off.svgp_elbo_late or off.cluster_fb)
+    assert on.svgp_pre and on.svgp_elbo_late and on.cluster_fb and not (off.svgp_pre or off.svgp_elbo_late)
+    assert off.svgp_pre_generic and off.cluster_fb          # (the five-graph form keeps the precomputed half and the fused launch)
     object.__setattr__(model.GATEncoder.gat2, "defer_wgrad", True)      # (the flag on the layer only permits queueing)
     ep = cfg["ot_epoch"]
     for rep in range(3):                                   # eager, capture + replay, replay
