@@ -153,9 +153,15 @@ int spadot_ot_plan_rowsums_host(spadot_ot_solver *s, double *rowsums_host);
 /* Benchmark hook: run `iters` scaling iterations (one iteration = one update_a_b, ot_func.cpp:586-687)
  * at the solver's current state with the given stage epsilon, no convergence checks, no host syncs.
  * ms_out (may be NULL) receives the HIP-event time of the timed region in milliseconds.  Returns 2 if a
- * scaling exceeded tau during the run (the fast schedule is then not what a solve would execute). */
+ * scaling exceeded tau during the run (the fast schedule is then not what a solve would execute).
+ * With ms_out == NULL nothing is read back and the tau flag is NOT cleared either: it accumulates over consecutive
+ * untimed calls and spadot_ot_run_tau_flag() reads it once behind them. */
 int spadot_ot_run_iterations(spadot_ot_solver *s, const spadot_ot_config *cfg, double eps_stage,
                              int iters, float *ms_out);
+
+/* The tau flag spadot_ot_run_iterations raises (synchronises the solver's stream): 1 if a scaling exceeded tau since the
+ * flag was last cleared, 0 if not, negative on error.  reset != 0 clears it afterwards. */
+int spadot_ot_run_tau_flag(spadot_ot_solver *s, int reset);
 
 /* The solver's real inner loop `nbatches` times (snapshot, batch_size or 5 iterations, convergence measure,
  * read-back + stream sync), ignoring the threshold: what "iterations per second" costs inside a solve.

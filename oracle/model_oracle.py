@@ -213,23 +213,28 @@ def gauss_cross_entropy(mu1, var1, mu2, var2):
     return -0.5 * (1.8378770664093453 + torch.log(var2) + (var1 + mu1 ** 2 - 2 * mu1 * mu2 + mu2 ** 2) / var2)
 
 
-def spadot_forward(P, svgp, x, y, edge_index, batch_size, heads, noise_svgp, noise_gat, train=True):
+def spadot_forward(P, svgp, x, y, edge_index, batch_size, heads, noise_svgp, noise_gat, train=True, svgp_no_grad=False):
     """SpaDOT.py:52-94 with the two reparameterisation noises supplied by the caller.
-    Returns (recon, SVGP_KL, GAT_KL, alignment, final_latent) and a dict of intermediates."""
+    Returns (recon, SVGP_KL, GAT_KL, alignment, final_latent) and a dict of intermediates.
+    svgp_no_grad: the SVGP branch (encoder, posterior, ELBO) is evaluated without a tape -- same VALUES; a backward pass then
+    yields the exact gradients of the GAT encoder's and the decoder's parameters (no path from them runs through that branch)
+    and none for the SVGP encoder's.  For shapes whose taped (b, m, m) ELBO tensors do not fit the host (m ~ 600: 1.5 GB per
+    latent dimension, ten of them alive until the backward pass)."""
     b = batch_size
     L = noise_svgp.shape[1]
     G = y.shape[1]
-    q_mu, q_var = svgp_encoder(P, y[:b], train)
-    rec, kl, pm, pv = [], [], [], []
-    for l in range(L):
-        m_l, v_l, mu_hat, A_hat = svgp.approximate_posterior_params(x[:b], x[:b], q_mu[:, l], q_var[:, l])
-        r_l, k_l = svgp.variational_loss(x[:b], q_mu[:, l], q_var[:, l], mu_hat, A_hat)
-        rec.append(r_l); kl.append(k_l); pm.append(m_l); pv.append(v_l)
-    elbo = torch.stack(rec).sum() - (b / svgp.N_train) * torch.stack(kl).sum()
-    p_m, p_v = torch.stack(pm, dim=1), torch.stack(pv, dim=1)
-    ce = gauss_cross_entropy(p_m, p_v, q_mu, q_var).sum()
-    diff = ce - elbo
-    svgp_kl = (-diff if ce.item() > elbo.item() else diff) / L      # SpaDOT.py:76-77 sign trick
+    with (torch.no_grad() if svgp_no_grad else torch.enable_grad()):
+        q_mu, q_var = svgp_encoder(P, y[:b], train)
+        rec, kl, pm, pv = [], [], [], []
+        for l in range(L):
+            m_l, v_l, mu_hat, A_hat = svgp.approximate_posterior_params(x[:b], x[:b], q_mu[:, l], q_var[:, l])
+            r_l, k_l = svgp.variational_loss(x[:b], q_mu[:, l], q_var[:, l], mu_hat, A_hat)
+            rec.append(r_l); kl.append(k_l); pm.append(m_l); pv.append(v_l)
+        elbo = torch.stack(rec).sum() - (b / svgp.N_train) * torch.stack(kl).sum()
+        p_m, p_v = torch.stack(pm, dim=1), torch.stack(pv, dim=1)
+        ce = gauss_cross_entropy(p_m, p_v, q_mu, q_var).sum()
+        diff = ce - elbo
+        svgp_kl = (-diff if ce.item() > elbo.item() else diff) / L      # SpaDOT.py:76-77 sign trick
     z_svgp = p_m + noise_svgp * torch.sqrt(p_v)
     g_mu, g_var = gat_encoder(P, y, edge_index, heads)
     g_mu, g_var = g_mu[:b], g_var[:b]
@@ -347,11 +352,11 @@ def induced_batch(edge_index, n_nodes, seeds, hops=2):
 
 # ----------------------------------------------------------------------------- one optimizer step
 
-def step_loss(P, svgp, x, y, edge_index, batch_size, heads, noise_svgp, noise_gat, weights, km=None, ot=None):
+def step_loss(P, svgp, x, y, edge_index, batch_size, heads, noise_svgp, noise_gat, weights, km=None, ot=None, svgp_no_grad=False):
     """Forward + composite loss of one batch (_train_utils.py:193-212).  Returns (loss, terms dict of 0-dim
     tensors, final_latent)."""
     (recon, skl, gkl, align, z), _ = spadot_forward(P, svgp, x, y, edge_index, batch_size, heads, noise_svgp,
-                                                    noise_gat, train=True)
+                                                    noise_gat, train=True, svgp_no_grad=svgp_no_grad)
     l1, b1, b2, o1, o2, o3 = weights
     kml = kmeans_loss(z, km[0], km[1]) if km is not None else torch.zeros((), dtype=z.dtype)
     otl = ot_loss(z, *ot) if ot is not None else torch.zeros((), dtype=z.dtype)

@@ -70,6 +70,24 @@ def oracle_step(inp, cfg, beta1, noise, n_steps=1):
                 grads={k: v.numpy() for k, v in detail["grads"].items()}, seconds=secs)
 
 
+def oracle_step_without_svgp_tape(inp, cfg, beta1, noise):
+    """oracle_step's loss terms and latent, and the gradients of the GAT encoder's and the decoder's parameters ONLY: the SVGP
+    branch is evaluated without a tape (model_oracle.spadot_forward svgp_no_grad), so the ten (b, m, m) ELBO tensors are never
+    alive together -- affordable at cfg2's m ~ 600.  Those gradients are exact: no path from these parameters to the loss
+    runs through the SVGP branch.  Returns dict(losses [7], latent, grads {name: ndarray}, seconds)."""
+    w = (cfg["lambda1"], float(beta1), cfg["beta2"], cfg["omiga1"], cfg["omiga2"], cfg["omiga3"])
+    t0 = time.perf_counter()
+    for v in inp["P"].values():
+        v.grad = None
+    loss, terms, z = mo.step_loss(inp["P"], inp["svgp"], inp["x"], inp["y"], inp["ei"], inp["b"], cfg["gat_attention_heads"],
+                                  noise[0], noise[1], w, km=inp["km"], ot=inp["ot"], svgp_no_grad=True)
+    loss.backward()
+    grads = {k: v.grad.detach().numpy().copy() for k, v in inp["P"].items() if v.requires_grad and v.grad is not None}
+    assert grads and not any(k.startswith("SVGPEncoder.") for k in grads)
+    return dict(losses=np.array([float(terms[n].detach()) for n in LOSS_NAMES]), latent=z.detach().numpy(), grads=grads,
+                seconds=[time.perf_counter() - t0])
+
+
 def compare(dev_losses, dev_latent, dev_grads, ref):
     """Agreement of a device step with the oracle's.  dev_losses [7], dev_latent [b, z], dev_grads {name: array}.
     Per parameter: relative L2 error ||g_dev - g_ref|| / ||g_ref|| and cosine; parameters whose reference gradient

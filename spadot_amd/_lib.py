@@ -145,6 +145,8 @@ def ot_lib():
     lib.spadot_ot_plan_rowsums_host.restype = ci
     lib.spadot_ot_run_iterations.argtypes = [vp, ctypes.POINTER(OTConfig), cd, ci, ctypes.POINTER(ctypes.c_float)]
     lib.spadot_ot_run_iterations.restype = ci
+    lib.spadot_ot_run_tau_flag.argtypes = [vp, ci]
+    lib.spadot_ot_run_tau_flag.restype = ci
     lib.spadot_ot_run_checked.argtypes = [vp, ctypes.POINTER(OTConfig), cd, ci, ci, ctypes.POINTER(ci), ctypes.POINTER(ctypes.c_float)]
     lib.spadot_ot_run_checked.restype = ci
     lib.spadot_ot_time_kernels.argtypes = [vp, ctypes.POINTER(OTConfig), cd, ci, ctypes.POINTER(ctypes.c_float)]

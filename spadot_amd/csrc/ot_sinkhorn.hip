@@ -2054,7 +2054,8 @@ int spadot_ot_run_iterations(spadot_ot_solver *s, const spadot_ot_config *cfg, d
     // same schedule as the solver's batches minus the convergence measure and its sync: snapshot +
     // `batch_size` fast iterations per batch; a raised tau flag makes the run unusable (return 2)
     const int bs = std::max(1, std::min(cfg->batch_size, MAX_BATCH));
-    HIP_CHECK(hipMemsetAsync(s->flags + MAX_BATCH - 1, 0, sizeof(int), s->stream));
+    // (untimed calls leave the flag alone: it accumulates until spadot_ot_run_tau_flag reads it)
+    if (ms_out) HIP_CHECK(hipMemsetAsync(s->flags + MAX_BATCH - 1, 0, sizeof(int), s->stream));
     if (ms_out) HIP_CHECK(hipEventRecord(s->ev0, s->stream));      // (untimed calls stay capturable: no event nodes)
     for (int left = iters; left > 0; left -= bs) {
         const int nb = std::min(left, bs);
@@ -2073,6 +2074,16 @@ int spadot_ot_run_iterations(spadot_ot_solver *s, const spadot_ot_config *cfg, d
         if (s->h_flags[0] != 0) return 2;
     }
     return 0;
+    SPADOT_LEAVE(SPADOT_EHIP)
+}
+
+int spadot_ot_run_tau_flag(spadot_ot_solver *s, int reset) {
+    SPADOT_ENTER
+    if (!s) return -22;
+    HIP_CHECK(hipMemcpyAsync(s->h_flags, s->flags + MAX_BATCH - 1, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    if (reset) HIP_CHECK(hipMemsetAsync(s->flags + MAX_BATCH - 1, 0, sizeof(int), s->stream));
+    HIP_CHECK(hipStreamSynchronize(s->stream));
+    return s->h_flags[0] != 0 ? 1 : 0;
     SPADOT_LEAVE(SPADOT_EHIP)
 }
 

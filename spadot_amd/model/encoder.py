@@ -131,7 +131,8 @@ class GATConv(nn.Module):
         """Everything after the dense map (ops.gat_edge)."""
         if not isinstance(graph, BatchGraph):
             graph = build_batch_graph(graph, h.shape[0], h.device)
-        return gat_edge(h, self.att_src, self.att_dst, self.bias, graph, self.heads, self.out_channels, self.concat, act)
+        return gat_edge(h, self.att_src, self.att_dst, self.bias, graph, self.heads, self.out_channels, self.concat, act,
+                        defer=getattr(self, "defer_wgrad", False))
 
 
 class GATEncoder(nn.Module):

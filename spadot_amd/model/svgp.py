@@ -197,8 +197,7 @@ class _SVGPCore(torch.autograd.Function):
         # K_mn, m0): precompute_backward() may fill this holder between forward and backward -- GraphedStepper does, on the
         # side stream while the loss tail runs on the main stream and the side stream would idle; backward() computes
         # whatever the holder lacks
-        ctx.holder = holder
-        _LAST_HOLDER[0] = holder
+        ctx.holder = holder                       # (reachable from the outputs: holder_of(p_m))
         ctx.mark_non_differentiable(out4)
         ctx.set_materialize_grads(False)          # no zero-filled gradient tensors for outputs the loss does not use
         return p_m, p_v, skl32[0], out4
@@ -279,7 +278,17 @@ MID_BWD = [__import__("os").environ.get("SPADOT_SVGP_MIDBWD", "1") == "1"]
 # a list while a caller wants the part of forward() the loss tail does not wait for queued instead of run (GraphedStepper's
 # svgp_pre stage runs the queue right behind the SVGP forward graph, beside the tail); None: forward() runs everything
 ELBO_LATE = [None]
-_LAST_HOLDER = [None]          # the holder of the most recent _SVGPCore.forward (see precompute_backward)
+
+
+def holder_of(out):
+    """The precompute holder of the _SVGPCore.forward that produced `out` (its p_m, p_v or SVGP_KL): the backward node of a
+    custom Function IS its ctx, so the holder travels with the outputs -- no module-level "most recent forward" that would
+    pin one model's fp64 [L, m, m] tensors and couple concurrent models."""
+    node = getattr(out, "grad_fn", None)
+    h = getattr(node, "holder", None)
+    if h is None:
+        raise ValueError("not an output of _SVGPCore.forward (or detached): no precompute holder")
+    return h
 
 
 def _holder_KS(h):
@@ -288,12 +297,12 @@ def _holder_KS(h):
     return h["KS"]
 
 
-def precompute_backward(holder=None):
-    """The gradient-independent products of _SVGPCore.backward, computed ahead of the backward pass into the holder of the
-    most recent forward (or `holder`): q2 = diag(K_nm S2 K_mn) (a [b, m] x [L, m, m] product + a row dot: 94 + 32 us inside
+def precompute_backward(holder):
+    """The gradient-independent products of _SVGPCore.backward, computed ahead of the backward pass into `holder` (holder_of
+    an output of that forward): q2 = diag(K_nm S2 K_mn) (a [b, m] x [L, m, m] product + a row dot: 94 + 32 us inside
     the backward pair of a cfg3 step), the contiguous K_nm S_l, and -- Q1T -- T = X2 S_l K_mn and m0 (below).  A forward
     that queued the rest of its ELBO (ELBO_LATE) must have had that queue run before.  No-op when already done."""
-    h = holder if holder is not None else _LAST_HOLDER[0]
+    h = holder
     if h is None or "q2" in h or DGEMM_SMALL[0]:
         return h
     Kn, S2, b = h["Kn"], h["S2"], h["b"]

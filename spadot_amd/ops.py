@@ -102,7 +102,7 @@ class _GATEdgeMFMA(torch.autograd.Function):
     the transposed plan."""
 
     @staticmethod
-    def forward(ctx, h, att_src, att_dst, bias, graph, H, C, act, plans):
+    def forward(ctx, h, att_src, att_dst, bias, graph, H, C, act, plans, defer=False):
         _need_cuda(h, att_src, att_dst, bias)
         lib = model_lib()
         pt, ps = plans
@@ -131,6 +131,7 @@ class _GATEdgeMFMA(torch.autograd.Function):
         ctx.save_for_backward(h, s_src, s_dst, out, alpha, a_s, a_d)
         ctx.graph, ctx.H, ctx.C, ctx.act, ctx.plans = graph, H, C, act, plans
         ctx.bias_dtype, ctx.att_shape, ctx.att_dtype = bias.dtype, att_src.shape, att_src.dtype
+        ctx.flat3, ctx.defer = _adjacent_flat_grads((att_src, att_dst, bias), H * C), bool(defer)
         return out
 
     @staticmethod
@@ -180,6 +181,23 @@ class _GATEdgeMFMA(torch.autograd.Function):
                                         _p(part) if fold else None, W3, n, h.shape[0] if pad_ok else n,
                                         _p(dz) if fold else None, _p(graph.rowptr_t) if fold else None,
                                         _p(graph.eid_t) if fold else None, None, _stream()), "spadot_gat_aggregate")
+        if fold and ctx.flat3 is not None and _DIRECT_GRAD[0]:
+            # the three gradients lie back to back in the optimizer's flat gradient buffer: the column sum over the blocks
+            # writes them THERE (no copy launch behind it), and -- nothing in the backward pass reads them -- not HERE, on the
+            # chain in front of this layer's dense map (in the profiled step the first layer's column sum waited 79 us for a
+            # compute unit beside the side stream's weight-gradient GEMM, with the step's last GEMM queued behind it): queued
+            # for the side stream where the layer's inputs are final when that queue runs (`defer`, ops.DEFERRED), else run
+            # at the END of this backward stage (ops.POST_CHAIN: behind the last GEMM, same stream)
+            fa, fd, fb_ = ctx.flat3
+            nrow = part.shape[0]
+            job = lambda: _check(lib.spadot_colsum(_p(part), nrow, W3, _p(fa), _stream()), "spadot_colsum")
+            if ctx.defer and _deferring():
+                DEFERRED[0].append(job)
+            elif POST_CHAIN[0] is not None:
+                POST_CHAIN[0].append(job)
+            else:
+                job()
+            return dh, fa, fd, fb_, None, None, None, None, None, None
         datt = torch.empty((3, H * C), dtype=torch.float32, device=dev)
         if fold:
             _check(lib.spadot_colsum(_p(part), part.shape[0], W3, _p(datt), _stream()), "spadot_colsum")
@@ -190,7 +208,20 @@ class _GATEdgeMFMA(torch.autograd.Function):
                                            _p(datt), ctypes.c_void_p(datt.data_ptr() + 4 * H * C), _p(g_pre), nt, _stream()),
                    "spadot_gat_att_grad")
         return (dh, datt[0].view(ctx.att_shape).to(ctx.att_dtype), datt[1].view(ctx.att_shape).to(ctx.att_dtype),
-                datt[2].to(ctx.bias_dtype), None, None, None, None, None)
+                datt[2].to(ctx.bias_dtype), None, None, None, None, None, None)
+
+
+def _adjacent_flat_grads(params, width):
+    """The .grad views of `params` (each `width` fp32 numbers) if they lie back to back in memory -- consecutive segments of
+    a FlatAdamW gradient buffer -- so that ONE kernel can write all of them through the first one's address; else None."""
+    gs = [getattr(p, "grad", None) for p in params]
+    if any(g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.numel() != width or g.shape != p.shape
+           for g, p in zip(gs, params)):
+        return None
+    base = gs[0].data_ptr()
+    if any(g.data_ptr() != base + 4 * width * k for k, g in enumerate(gs)):
+        return None
+    return tuple(gs)
 
 
 class _GATEdge(torch.autograd.Function):
@@ -263,12 +294,14 @@ class _GATEdge(torch.autograd.Function):
                 dbias.to(ctx.bias_dtype), None, None, None, None, None)
 
 
-def gat_edge(h, att_src, att_dst, bias, graph, heads, channels, concat=True, act=False):
+def gat_edge(h, att_src, att_dst, bias, graph, heads, channels, concat=True, act=False, defer=False):
     """Everything of one GATConv layer after the dense map h = x W^T: attention logits, edge softmax,
-    aggregation, bias, optional leaky_relu(0.01), head concat/mean.  att_src / att_dst: [1, H, C] parameters."""
+    aggregation, bias, optional leaky_relu(0.01), head concat/mean.  att_src / att_dst: [1, H, C] parameters.
+    defer: the layer's attention-vector / bias gradient sum may be queued in ops.DEFERRED (the caller runs that queue only
+    when this layer's backward kernels have finished: GraphedStepper, the second layer)."""
     plans = _mfma_plans(h, graph, heads, channels, concat) if h.is_cuda else None
     if plans is not None:
-        return _GATEdgeMFMA.apply(h, att_src, att_dst, bias, graph, heads, channels, act, plans)
+        return _GATEdgeMFMA.apply(h, att_src, att_dst, bias, graph, heads, channels, act, plans, defer)
     return _GATEdge.apply(h, att_src, att_dst, bias, graph, heads, channels, concat, act)
 
 
@@ -426,7 +459,23 @@ _DIRECT_GRAD = [False]     # True only inside FlatAdamW.backward (a plain .backw
 # (GraphedStepper, `defer_wgrad`) runs the closures later, on the side stream, beside the rest of the GAT backward -- whose
 # dependency chain they would otherwise lengthen by their own duration.
 DEFERRED = [None]
+# Gradient work that feeds nothing in the backward pass and whose inputs are final only when its stage ends: run at the END of
+# the stage that queued it, on the same stream (FlatAdamW.backward / backward_partial drain it behind autograd.grad).
+POST_CHAIN = [None]
 _UNIT_SEEDS = set()        # addresses of the constant-one tensors FlatAdamW.backward_partial seeds a scalar loss with
+_UNIT_ONES = {}            # (device type, index) -> THE constant one of that device: never freed, so its address in
+                           # _UNIT_SEEDS can never come to belong to another tensor
+
+
+def unit_seed(device):
+    """The process-wide constant-one fp32 scalar of `device`: the seed of every scalar-loss backward of FlatAdamW.  The loss
+    kernels recognise it by address (no launch for d loss / d term); it lives as long as the process."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    one = _UNIT_ONES.get(key)
+    if one is None:
+        one = _UNIT_ONES[key] = torch.ones((), dtype=torch.float32, device=device)
+        _UNIT_SEEDS.add(one.data_ptr())
+    return one
 
 
 def _deferring():
@@ -623,6 +672,9 @@ class _DenseCD(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, wbuf = ctx.saved_tensors
+        # a queued weight gradient reads g LATER, on another stream, ordered only behind what was enqueued before this stage
+        # (GraphedStepper._late_event): it may be queued only if g needs no copy or cast launched here
+        g_final = g.is_contiguous() and g.dtype == x.dtype
         g = g.contiguous()
         dx = None
         if ctx.needs_input_grad[0]:
@@ -643,7 +695,7 @@ class _DenseCD(torch.autograd.Function):
         # (x[:, :K] is a strided view: the GEMM takes its row stride, the result is a dense [N, K])
         dW = None
         if ctx.needs_input_grad[1]:
-            if ctx.defer and ctx.wgrad is not None and _deferring():
+            if ctx.defer and ctx.wgrad is not None and _deferring() and g_final:
                 # nothing downstream reads dW: queued (the closure keeps g and x alive), written into the flat gradient later
                 DEFERRED[0].append(lambda g=g, x=x, K=ctx.K, out=ctx.wgrad: wgrad_bf16(g, x, K, out))
                 dW = ctx.wgrad
@@ -1897,10 +1949,14 @@ class FlatAdamW:
         copy instead of one AccumulateGrad add per parameter (~45 launches a step).  Parameters the loss
         does not reach get zeros, like a backward() after zero_grad()."""
         _DIRECT_GRAD[0] = True
+        post = POST_CHAIN[0] = []
         try:
             grads = torch.autograd.grad(loss, self.params, allow_unused=True)
         finally:
             _DIRECT_GRAD[0] = False
+            POST_CHAIN[0] = None
+        for job in post:
+            job()
         # (a gradient that already IS the flat view -- written in place by ops.dense_cd -- needs no copy)
         pairs = [(p.grad, g) for p, g in zip(self.params, grads) if g is not None and g.data_ptr() != p.grad.data_ptr()]
         dst = [d for d, _ in pairs]
@@ -1915,16 +1971,16 @@ class FlatAdamW:
         ins = list(params) + list(extra_inputs)
         if grad_outputs is None and torch.is_tensor(outputs) and outputs.dim() == 0 and outputs.dtype == torch.float32:
             # the seed of a scalar loss from a constant instead of a ones_like fill launch per step
-            one = getattr(self, "_one", None)
-            if one is None or one.device != outputs.device:
-                one = self._one = torch.ones((), dtype=torch.float32, device=outputs.device)
-                _UNIT_SEEDS.add(one.data_ptr())
-            grad_outputs = one
+            grad_outputs = unit_seed(outputs.device)
         _DIRECT_GRAD[0] = True
+        post = POST_CHAIN[0] = []
         try:
             grads = torch.autograd.grad(outputs, ins, grad_outputs=grad_outputs, allow_unused=True)
         finally:
             _DIRECT_GRAD[0] = False
+            POST_CHAIN[0] = None
+        for job in post:            # what the stage's backward functions left for its end (ops.POST_CHAIN)
+            job()
         pg = grads[:len(params)]
         pairs = [(p.grad, g) for p, g in zip(params, pg) if g is not None and g.data_ptr() != p.grad.data_ptr()]
         self._zero_unreached(params, pg)

@@ -184,6 +184,14 @@ class OTSolver:
             raise RuntimeError(f"run_iterations failed with {rc}")
         return ms.value if timed else None
 
+    def tau_flag(self, reset=True):
+        """Whether a scaling exceeded tau in the untimed run_iterations calls since the flag was last cleared (one 4-byte
+        read-back + stream sync)."""
+        rc = self.lib.spadot_ot_run_tau_flag(self.h, 1 if reset else 0)
+        if rc < 0:
+            raise RuntimeError(f"run_tau_flag failed with {rc}")
+        return bool(rc)
+
     def run_checked(self, cfg, eps_stage, nbatches, last_stage=True):
         """The solver's real inner loop (with convergence measure + sync) `nbatches` times.
         Returns (iterations run, milliseconds)."""

@@ -632,6 +632,11 @@ class GraphedStepper:
         self._head_ready = False
 
     def _run(self, tp_i, tp, bi, epoch, beta1, with_update):
+        # (a replayed graph holds no weight-cast launch: anything torch saw writing the GAT weights since their bf16 images
+        # were cast -- load_state_dict, a broadcast, flat_param.copy_ -- is caught here, on EVERY path into a step: step()
+        # and the data-parallel fb(); three integer compares otherwise)
+        if getattr(self.model.GATEncoder, "_image_optimizer", None) is self.opt:
+            self.opt.sync_images()
         if getattr(self.model, "_state_version", 0) != self.version:      # a state tensor was re-allocated
             self.graphs.clear()
             self.version = getattr(self.model, "_state_version", 0)
@@ -690,7 +695,7 @@ class GraphedStepper:
                                                                   y_seed32=getattr(batch, "y_seed32", None) if cached else None)
             finally:
                 _svgp.ELBO_LATE[0] = None
-            st["svgp_holder"] = _svgp._LAST_HOLDER[0]
+            st["svgp_holder"] = _svgp.holder_of(st["pm"])
 
         def svgp_fwd_head():
             st["xs"] = batch.x[:b] if cached else loc[seeds]
@@ -1023,10 +1028,6 @@ class GraphedStepper:
         return self._run(tp_i, tp, bi, epoch, beta1, False)
 
     def step(self, tp_i, tp, bi, epoch, beta1):
-        # (a replayed graph holds no weight-cast launch: anything torch saw writing the GAT weights since their bf16 images
-        # were cast -- load_state_dict, a broadcast, flat_param.copy_ -- is caught here; three integer compares otherwise)
-        if getattr(self.model.GATEncoder, "_image_optimizer", None) is self.opt:
-            self.opt.sync_images()
         if self.grad_sync is None:                  # single replica: the optimizer step is part of the step graph
             return self._run(tp_i, tp, bi, epoch, beta1, True)
         res = self.fb(tp_i, tp, bi, epoch, beta1)

@@ -211,7 +211,7 @@ def test_svgp_backward_precomputed_and_restructured_forms_agree(ops, b, m, L):
                 with torch.no_grad():
                     queue[0]()
             if pre:
-                h = sv.precompute_backward()
+                h = sv.precompute_backward(sv.holder_of(p_m))
                 assert "q2" in h and "KS" in h and (("Ta" in h) == q1t)
             (dz,) = torch.autograd.grad([p_m, p_v, skl], [z], [gpm, gpv, torch.tensor(0.7, device=DEV)])
             return dz.double().cpu().numpy(), head[0].cpu().numpy(), head[1].cpu().numpy(), float(skl)

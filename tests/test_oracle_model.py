@@ -71,6 +71,36 @@ def test_composite_forward_matches_reference():
     np.testing.assert_allclose(z.numpy(), g["final_latent"], rtol=1e-6, atol=1e-8)
 
 
+def test_svgp_branch_without_a_tape_leaves_the_other_gradients_exact():
+    """spadot_forward(svgp_no_grad=True) (the cfg2-size gradient check of tests/test_step_parity_gpu.py): same values, and the
+    gradients of every GAT-encoder / decoder parameter equal the fully taped ones -- no path from them runs through the SVGP
+    branch; the SVGP encoder's parameters get none."""
+    g = load_golden("model_composite.npz")
+    b, heads = int(g["batch_size"]), int(g["heads"])
+    n_id = torch.as_tensor(g["n_id"])
+    xb, yb = T(g["X"])[n_id], T(g["Y"])[n_id]
+    sv = mo.SVGPOracle(g["ind0"], float(g["N_train0"]))
+    w = (0.1, 0.5, 1e-4, 0.1, 0.1, 1.0)
+    out = {}
+    for flag in (False, True):
+        P = {k: (v.double().clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v)
+             for k, v in _params(g).items()}
+        loss, terms, z = mo.step_loss(P, sv, xb, yb, torch.as_tensor(g["sub_edge_index"]), b, heads, T(g["noise_svgp"]),
+                                      T(g["noise_gat"]), w, svgp_no_grad=flag)
+        loss.backward()
+        out[flag] = (float(loss.detach()), z.detach().numpy(), {k: v.grad for k, v in P.items() if torch.is_tensor(v) and v.requires_grad})
+    assert out[True][0] == pytest.approx(out[False][0], rel=1e-13)
+    np.testing.assert_allclose(out[True][1], out[False][1], rtol=1e-13)
+    n_checked = 0
+    for k, gr in out[False][2].items():
+        if k.startswith("SVGPEncoder."):
+            assert out[True][2][k] is None and gr is not None
+        else:
+            np.testing.assert_allclose(out[True][2][k].numpy(), gr.numpy(), rtol=1e-12, atol=1e-300)
+            n_checked += 1
+    assert n_checked >= 20
+
+
 def test_all_latent_samples_matches_reference():
     g = load_golden("model_composite.npz")
     P = _params(g)

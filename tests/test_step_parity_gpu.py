@@ -7,9 +7,10 @@
     _train_utils.py:187-217 -> SpaDOT.py:52-94, (b, m, m) ELBO tensor and all) on the same weights, batch, graph,
     noise, K-means state and OT plan.
   * cfg2 (2 x 5 000 spots x 2 000 genes, fp32, 1 200 inducing points -> m ~ 600): graphed steps == eager steps and
-    one oracle-checked forward.
+    one oracle-checked step: loss terms, latent, and the gradients of every GAT-encoder / decoder parameter (the SVGP
+    branch without a tape on the host: its taped (b, m, m) tensors would need 15 GB).
   * cfg5 shape (20 000 spots x 5 000 genes per time point, 256 inducing points over 10 time points -> m ~ 26, k = 30):
-    the step runs, staged replay == eager, everything finite.
+    staged replay == eager, and one WHOLE oracle step (m ~ 26 makes it affordable) at cfg3's bf16 thresholds.
 
   * cfg1 shape (ChickenHeart-like ragged pair: 747 + 1 966 spots, k = 6 / 12, G = 500, last batches of 235 and 430
     seeds): one oracle-checked fp32 step per time point on its PARTIAL last batch (N_train / b with the partial b,
@@ -135,7 +136,7 @@ def _assert_step_parity(rep, dtype, ref):
     assert len(rep["zero_grad_params"]) >= 2 and rep["zero_grad_dev_rel_norm_max"] <= 1e-6
 
 
-def test_cfg2_fp32_graphed_steps_match_eager_and_the_oracle_forward():
+def test_cfg2_fp32_graphed_steps_match_eager_and_the_oracle_step():
     """BASELINE.json configs[1]: 2 time points x 5 000 spots x 2 000 genes, fp32 compute, the default 1 200 inducing
     points (m ~ 600 per time point: the blocked SPD inverse), k = 30."""
     from oracle import model_oracle as mo, step_parity as sp
@@ -146,18 +147,25 @@ def test_cfg2_fp32_graphed_steps_match_eager_and_the_oracle_forward():
     b0 = dd["dataloaders"][tp][0]
     assert b0.graph.n > 4500
 
-    # (a) one forward against the oracle (no gradient on the host: its (b, m, m) tensor is 1.5 GB per latent dim)
+    # (a) one step against the oracle: the seven loss terms, the latent, and the gradient of every GAT-encoder and decoder
+    # parameter (round 5).  The SVGP branch is evaluated without a tape on the host -- its (b, m, m) tensor is 1.5 GB per
+    # latent dimension at m ~ 600, ten of them alive under autograd -- which leaves the other parameters' gradients exact
+    # (oracle/step_parity.oracle_step_without_svgp_tape); the SVGP encoder's gradients are checked at cfg3 / cfg1 / cfg5 sizes.
     noise = sp.make_noise(b0.batch_size, seed=3)
     inp = sp.oracle_inputs(model, dd, cfg, tp, 0, tp - 1)
-    w = (cfg["lambda1"], beta1, cfg["beta2"], cfg["omiga1"], cfg["omiga2"], cfg["omiga3"])
-    with torch.no_grad():
-        _, terms, z_ref = mo.step_loss(inp["P"], inp["svgp"], inp["x"], inp["y"], inp["ei"], inp["b"],
-                                       cfg["gat_attention_heads"], noise[0], noise[1], w, km=inp["km"], ot=inp["ot"])
-    want = np.array([float(terms[n]) for n in sp.LOSS_NAMES])
+    ref = sp.oracle_step_without_svgp_tape(inp, cfg, beta1, noise)
     dl, dz, dg = sp.device_step(model, opt, cfg, dd, tu, 1, tp, 0, epoch, beta1, noise)
-    np.testing.assert_allclose(dl, want, rtol=1e-4, err_msg=str(sp.LOSS_NAMES))
-    np.testing.assert_allclose(dz, z_ref.numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(dl, ref["losses"], rtol=1e-4, err_msg=str(sp.LOSS_NAMES))
+    np.testing.assert_allclose(dz, ref["latent"], rtol=1e-4, atol=1e-4)
     assert all(np.isfinite(v).all() for v in dg.values())
+    rep = sp.compare(dl, dz, dg, ref)
+    rep["oracle_seconds"] = ref["seconds"]
+    _report("cfg2_f32", rep)
+    print(json.dumps({k: v for k, v in rep.items() if k != "per_param"}))
+    assert any(k.startswith("GATEncoder.gat1") for k in rep["per_param"]) and any(k.startswith("decoder.") for k in rep["per_param"])
+    assert rep["max_rel_loss_err"] <= 1e-5, rep["loss_rel_err"]
+    assert rep["grad_cos_min"] >= 0.999999, (rep["grad_cos_min_param"], rep["grad_cos_min"])
+    assert rep["grad_rel_l2_max"] <= 2e-4, (rep["grad_rel_l2_max_param"], rep["grad_rel_l2_max"])
 
     # (b) replayed graphs == eager steps on the same batches (noise silenced in both)
     model.fixed_noise = (torch.zeros((512, 10), device=DEV), torch.zeros((512, 10), device=DEV))
@@ -212,6 +220,20 @@ def test_cfg5_shape_step_runs_staged_equals_eager():
             np.testing.assert_allclose(gb.cpu().numpy(), ga.cpu().numpy(), rtol=2e-3, atol=2e-4 * scale)
     la = la.cpu().numpy()
     assert (la[[1, 3, 4, 5, 6]] > 0).all()                      # Recon, GAT_KL, alignment, K-means, OT are live
+    # one WHOLE oracle step at this shape (round 5; m ~ 26: the (b, m, m) ELBO tensor is 2.8 MB, the cost is the fp64 GAT
+    # over 20 000 x 5 000): 7 loss terms, latent, every gradient, at cfg3's bf16 thresholds
+    from oracle import step_parity as sp
+    model.fixed_noise = None
+    noise = sp.make_noise(b0.batch_size, seed=11)
+    inp = sp.oracle_inputs(model, dd, cfg, tp, 0, tp - 1)
+    ref = sp.oracle_step(inp, cfg, beta1, noise)
+    dl, dz, dg = sp.device_step(model, opt, cfg, dd, tu, 1, tp, 0, epoch, beta1, noise)
+    rep = sp.compare(dl, dz, dg, ref)
+    rep["oracle_seconds"] = ref["seconds"]
+    _report("cfg5shape_bf16", rep)
+    print(json.dumps({k: v for k, v in rep.items() if k != "per_param"}))
+    _assert_step_parity(rep, "bf16", ref)
+    model.fixed_noise = (torch.zeros((512, 10), device=DEV), torch.zeros((512, 10), device=DEV))
     for k in range(3):
         out = staged.step(1, tp, 0, epoch, beta1)
     torch.cuda.synchronize()
