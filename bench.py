@@ -117,6 +117,7 @@ def cpu_train_steps(model, opt, dd, cfg, tu, tp, bi, tp_prev, epoch, beta1, n_st
 # ------------------------------------------------------------------------------ training-leg roofline, epoch block
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak (spec; the guide measures ~1.25-1.5 PF on random data)
+MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 matrix (v_mfma_f32_32x32x2_f32 class) peak -- what the fp32 compute dtype is priced on
 
 
 def source_fingerprint():
@@ -148,7 +149,7 @@ def newest_profile(name):
     return None
 
 
-def roofline_train(dd, unit, cfg, G, compute_dtype, n_params, live_ms_per_step):
+def roofline_train(dd, unit, cfg, G, compute_dtype, n_params, live_ms_per_step, tag="cfg3"):
     """Where the training step stands against the machine, per kernel family.
 
     ALGORITHMIC work per step comes from the shapes of the batch actually run (computed here, live); the MICROSECONDS
@@ -190,14 +191,15 @@ def roofline_train(dd, unit, cfg, G, compute_dtype, n_params, live_ms_per_step):
                        f"layer 3 {'aggregate-first (b rows mapped)' if tail_form else 'map-first (n1 rows mapped)'}",
            "live_ms_per_step": live_ms_per_step,
            "algorithmic": {"gemm_flops_per_step": gemm_flops, "gat_edge_bytes_per_step": gat_bytes, "optimizer_bytes_per_step": opt_bytes}}
-    fam_path = newest_profile(f"train_cfg3_{compute_dtype}_families.json")
+    fam_path = newest_profile(f"train_{tag}_{compute_dtype}_families.json")
     if fam_path is None:
         out["source"] = "no committed rocprofv3 family summary for this dtype: only the algorithmic work is reported"
         return out
     prof = json.load(open(fam_path))
     fam = prof["families"]
     us = lambda *names: sum(fam.get(k, {}).get("us_per_step", 0.0) for k in names)
-    gemm_us = us("gemm_bf16_library", "gemm_bf16_own") if compute_dtype == "bf16" else us("gemm_f32_library")
+    gemm_us = us("gemm_bf16_library", "gemm_bf16_own") if compute_dtype == "bf16" else us("gemm_f32_library", "gemm_f32_own")
+    gemm_peak = MFMA_BF16_PEAK_TFLOPS if compute_dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
     gat_us, opt_us = us("gat_edge"), us("optimizer")
     out["source"] = (f"kernel microseconds REPLAYED from {os.path.relpath(fam_path, ROOT)} (rocprofv3 --kernel-trace of "
                      f"`bench.py --leg train`, {prof['steps']} steps, {prof.get('wall_us_per_step_without_profiler_stalls', prof['wall_us_per_step']):.0f} us/step under the profiler); "
@@ -209,8 +211,8 @@ def roofline_train(dd, unit, cfg, G, compute_dtype, n_params, live_ms_per_step):
         out["mfma_busy_top"] = mfma_top(prof["mfma"])
     out["families"] = {
         "gemm_" + compute_dtype: {"bound": "mfma", "us_per_step": gemm_us, "achieved": gemm_flops / max(gemm_us, 1e-9) / 1e6,
-                                  "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                  "frac": gemm_flops / max(gemm_us, 1e-9) / 1e6 / MFMA_BF16_PEAK_TFLOPS},
+                                  "peak": gemm_peak, "unit": "TFLOP/s",
+                                  "frac": gemm_flops / max(gemm_us, 1e-9) / 1e6 / gemm_peak},
         "gat_edge": {"bound": "hbm", "us_per_step": gat_us, "achieved": gat_bytes / max(gat_us, 1e-9) / 1e3, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": gat_bytes / max(gat_us, 1e-9) / 1e3 / HBM_PEAK_GBS},
         "optimizer": {"bound": "hbm", "us_per_step": opt_us, "achieved": opt_bytes / max(opt_us, 1e-9) / 1e3, "peak": HBM_PEAK_GBS,
@@ -403,15 +405,24 @@ def write_detail(full, n_gpus):
 
 # ------------------------------------------------------------------------------ main
 
+# BASELINE.json's single-GPU shapes (cfg2 = configs[1], cfg3 = configs[2], cfg5shape = configs[4]'s per-GPU
+# shape: two of its ten time points, the 256 inducing points scaled to them).  The driver's default command is cfg3.
+PRESETS = {
+    "cfg3": dict(spots=10000, genes=3000, timepoints=5, compute_dtype="bf16", inducing=1200),
+    "cfg2": dict(spots=5000, genes=2000, timepoints=2, compute_dtype="f32", inducing=1200),
+    "cfg5shape": dict(spots=20000, genes=5000, timepoints=2, compute_dtype="bf16", inducing=52),
+}
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--spots", type=int, default=10000, help="spots per time point (N_t)")
-    ap.add_argument("--genes", type=int, default=3000)
-    ap.add_argument("--timepoints", type=int, default=5)
-    ap.add_argument("--compute-dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--spots", type=int, default=None, help="spots per time point (N_t)")
+    ap.add_argument("--genes", type=int, default=None)
+    ap.add_argument("--timepoints", type=int, default=None)
+    ap.add_argument("--compute-dtype", default=None, choices=["bf16", "f32"])
     ap.add_argument("--ot-storage", default="f32", choices=["f32", "f64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; value = their median")
@@ -420,10 +431,23 @@ def parse_args(argv=None):
     ap.add_argument("--leg", default="both", choices=["both", "train", "sinkhorn"])
     ap.add_argument("--no-sinkhorn-parity", action="store_true",
                     help="skip the whole-solve oracle check of the Sinkhorn leg (about a minute of one host thread)")
+    ap.add_argument("--preset", default="cfg3", choices=sorted(PRESETS),
+                    help="BASELINE.json shape: cfg3 (default; the one `metric` is quoted on), cfg2 (configs[1]: 2 x 5000 x 2000, fp32, "
+                         "m ~ 600) or cfg5shape (configs[4] per GPU: 20000 x 5000 per time point, m ~ 26, bf16).  Explicit "
+                         "--spots / --genes / --timepoints / --compute-dtype / --inducing override the preset's values")
+    ap.add_argument("--inducing", type=int, default=None, help="inducing_point_nums over all time points (config.yaml: 1200)")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="launcher rehearsal: start the ranks, run the all-reduce-of-ones proof on the chosen backend, print the "
                          "line's header and exit -- no GPU is touched (tests/test_bench_line_cpu.py, SPADOT_BENCH_BACKEND=gloo)")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    pre = PRESETS[args.preset]
+    args.custom = False
+    for k in ("spots", "genes", "timepoints", "compute_dtype", "inducing"):
+        if getattr(args, k) is None:
+            setattr(args, k, pre[k])
+        elif getattr(args, k) != pre[k]:
+            args.custom = True
+    return args
 
 
 def launch_ranks(args, argv):
@@ -562,7 +586,8 @@ def _main(real_stdout, args):
         # run); every rank holds every time point's rows (0.3 GB) and K-means state, builds and caches only ITS batches;
         # the model is replicated, gradients are all-reduced.
         data = make_dataset(T, N, G, seed=1993)
-        cfg.update(input_dim=G, timepoints=list(range(T)), device=torch.device(dev), compute_dtype=cdt)
+        cfg.update(input_dim=G, timepoints=list(range(T)), device=torch.device(dev), compute_dtype=cdt,
+                   inducing_point_nums=int(args.inducing))
         plan = None
         if world == 1:
             own = list(range(T))
@@ -659,7 +684,7 @@ def _main(real_stdout, args):
                      "bucketed_grad_exchange": bool(state["stepper"] is not None and state["stepper"].overlap)}
         train_res["units_in_schedule"] = len(sched)
         train_res["roofline_train"] = roofline_train(dd, sched[0], cfg, G, args.compute_dtype, int(opt.count),
-                                                     train_res["ms_per_step"])
+                                                     train_res["ms_per_step"], tag="custom" if args.custom else args.preset)
         if world == 1 and not args.no_epoch:
             train_res["epoch"] = epoch_block(tu, model, opt, cfg, dd, state["stepper"], T, beta1, torch)
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -785,8 +810,8 @@ def _main(real_stdout, args):
         out["dtype"] = args.compute_dtype
         out["dtype_detail"] = (f"{args.compute_dtype} GAT branch + linears, f32 parameters/optimizer, f64 SVGP algebra; "
                                f"Sinkhorn {args.ot_storage} kernel matrix with f64 scalings")
-        name = "cfg3" if (T, N, G) == (5, 10000, 3000) else "custom shape"
-        out["config"] = {"workload": f"{name}: {T} time points x {N} spots x {G} genes, batch 512, k=30, 1200 inducing points; "
+        name = "custom shape" if args.custom else args.preset
+        out["config"] = {"workload": f"{name}: {T} time points x {N} spots x {G} genes, batch 512, k=30, {args.inducing} inducing points; "
                                      f"Sinkhorn pair problem {N}x{N}",
                          "train": {k: v for k, v in (train_res or {}).items()
                                    if k not in ("cpu_baseline", "parity_check", "roofline_train", "epoch")},

@@ -60,7 +60,8 @@ def train(args):
     _utils._save_inducing_points(args, dataloader_dict["inducing_points"])
 
     print("Training model...")
-    model, loss_df = _train_utils.train_SpaDOT(dataloader_dict, model_config)
+    # (args.epoch_seconds, optional list: wall time per epoch -- tools/e2e_chickenheart.py)
+    model, loss_df = _train_utils.train_SpaDOT(dataloader_dict, model_config, epoch_seconds=getattr(args, "epoch_seconds", None))
     loss_df.T.to_csv(args.output_dir + os.sep + "loss.csv")
     if getattr(args, "save_model", False):
         torch.save(model.state_dict(), args.output_dir + os.sep + "SpaDOT_model.pth")

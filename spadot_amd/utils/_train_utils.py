@@ -1048,9 +1048,11 @@ def training_step(model, optimizer, model_config, dataloader_dict, tp_i, tp, bi,
     return losses
 
 
-def train_SpaDOT(dataloader_dict, model_config, verbose=True):
+def train_SpaDOT(dataloader_dict, model_config, verbose=True, epoch_seconds=None):
     """_train_utils.py:155-236.  Returns (model, loss_df) with loss_df indexed like the reference's
     (columns = epochs, rows = loss names; train.py:38 writes its transpose).
+    epoch_seconds (optional list): receives the host wall time of every epoch, K-means / OT refresh included (each epoch ends
+    with a device synchronisation of its own: the loss read-back and the refit).
     The steps of an epoch run inside GraphedStepper.chained(): anything a caller adds BETWEEN two steps that touches the
     SVGP encoder (weights, BatchNorm statistics) belongs outside the chain or must call stepper.barrier()."""
     import pandas as pd
@@ -1097,6 +1099,9 @@ def train_SpaDOT(dataloader_dict, model_config, verbose=True):
         _update_Kmeans(model, model_config, dataloader_dict)
         if (epoch + 1) % model_config["ot_config"]["ot_epochs"] == 0:
             _update_OT_matrix(model, model_config)
+        if epoch_seconds is not None:
+            torch.cuda.synchronize(device)
+            epoch_seconds.append(time() - ep_start)
     if verbose:
         print("Training finished...")
         print("Training time: %d seconds." % int(time() - t_start))
