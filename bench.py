@@ -177,8 +177,7 @@ def roofline_train(dd, unit, cfg, G, compute_dtype, n_params, live_ms_per_step, 
     hid_s, hid_d = cfg["svgp_encoder_layers"][0], cfg["decoder_layers"][-1]
     # layer 3: round 3 mapped all n1 = seeds + hop-1 rows; the aggregate-first form (csrc/gat_tail.hip, default since round 4)
     # maps the b aggregated seed rows -- the flops actually executed are what is priced, not the ones avoided
-    from spadot_amd import ops as _ops
-    tail_form = bool(_ops.GAT_TAIL[0] and lg is not None and lg[1].n_tgt * 4 <= lg[1].n and HC <= 2048)
+    tail_form = bool(lg is not None and lg[1].n_tgt * 4 <= lg[1].n and HC <= 2048)
     rows3 = b if tail_form else n1
     gemm_flops = (2 * 2.0 * n * G * HC            # layer 1: forward, weight gradient
                   + 3 * 2.0 * n * HC * HC          # layer 2
@@ -634,7 +633,7 @@ def _main(real_stdout, args):
                    if use_graphs else None)
 
         if stepper is not None:
-            stepper.clone_output = os.environ.get("SPADOT_STEP_CLONE") == "1"      # like train_SpaDOT: losses consumed in-stream
+            stepper.clone_output = False          # like train_SpaDOT: the losses are consumed in-stream
         state = {"stepper": stepper}
 
         def step(i):

@@ -258,25 +258,6 @@ int spadot_kmeans_assign(const void *x, const void *centers, int n, int k, int d
 int spadot_sgemm_small(int mode, const float *A, int lda, const float *B, int ldb, float *C, int ldc, int M, int N, int K,
                        const float *bias, int batch, long long strideA, long long strideB, long long strideC, void *stream);
 
-/* out [M, N] = A [M, K] B [N, K]^T (+ bias[n]) in fp32 with the contraction cut into `slices` slices (csrc/gemm_f32.hip: the
- * forward maps of the small MLP stages, y = x W^T, encoder.py:7-34 -- a short output over a long contraction: 512 x 256 from
- * K = 3000): one launch computes the slices' partial products (workspace: spadot_sgemm_nt_slices_workspace(M, N, slices)
- * floats), a second adds them in slice order.  Bit-repeatable. */
-long long spadot_sgemm_nt_slices_workspace(int M, int N, int slices);
-int spadot_sgemm_nt_slices(const float *A, int lda, const float *B, int ldb, float *out, int ldo, const float *bias, int M, int N,
-                           int K, int slices, float *workspace, void *stream);
-
-/* Small batched fp64 products on the fp64 matrix cores (csrc/gemm_f64.hip; the m x m / b x m algebra of svgp.py:62-104):
- *   C[z] = alpha op(A[z]) op(B[z]) + beta C0[z]          z < batch, operands advance by their batch strides (elements; 0 = shared)
- *   mode 0: a(i, k) = A[i lda + k], b(k, j) = B[k ldb + j];  mode 1: b(k, j) = B[j ldb + k];  mode 2: a(i, k) = A[k lda + i], b as mode 0
- * C0 may be NULL (no addend) and may alias nothing that is written; rowscale (mode 2 only, may be NULL): the rows of A are
- * scaled along the contraction, a(i, k) = A[k lda + i] rowscale[z stride_rs + k ldrs]  (K_mn diag(w_l) K_nm without the
- * scaled copy).  64 x 64 tiles, 256 threads, 35 KB of LDS; sums in ascending k: repeated calls are bit-identical. */
-int spadot_dgemm_small(int mode, const double *A, int lda, long long strideA, const double *B, int ldb, long long strideB,
-                       double *C, int ldc, long long strideC, const double *C0, int ldc0, long long strideC0,
-                       const double *rowscale, int ldrs, long long stride_rs, double alpha, double beta, int M, int N, int K,
-                       int batch, void *stream);
-
 /* Measurement aid: buf[slot] = the device's constant-rate timestamp counter (100 MHz: 10 ns units) when the launch runs.
  * Launched at the head and the end of a captured stage it dates the stage on the GPU with no profiler attached. */
 int spadot_stamp(unsigned long long *buf, int slot, void *stream);
@@ -314,7 +295,9 @@ int spadot_knn(const double *x, int n, int d, int kk, int *out, void *stream);
  * which the per-node kernels fill through cellq[e] = chunk * 512 + position of edge e.  The image must be ZERO before
  * its first use and may then be reused: edges always overwrite the same cells.
  *   spadot_gat_alpha             alpha[e, hd] = softmax over the incoming edges of each of the n_tgt targets, written as
- *                                fp32 [E, H] and into the by-target plan's image (cellq = plan's cellq)
+ *                                fp32 [E, H] and into the by-target plan's image (cellq = plan's cellq) and, optionally, into
+ *                                the by-SOURCE plan's image (cellq_s indexed by by-target edge position): round 5, the
+ *                                backward product's weights are gradient-independent and are written by the forward pass
  *   spadot_gat_aggregate         mode 0: out[row] = act?(sum_cols w x[col] + vec_a (bias));              plan by target
  *                                mode 1: out[row] = sum_cols w x[col] + ds_src[row] vec_a + ds_dst[row] vec_b  (att_src,
  *                                att_dst: the logits' own gradient path);                                plan by source
@@ -330,8 +313,8 @@ int spadot_knn(const double *x, int n, int d, int kk, int *out, void *stream);
  *                                plan_cell [chunk][32 rows][16] -> edge position or -1; with bias_part block b leaves the
  *                                column sums of its 32 rows of g_pre at bias_part[b * part_width + part_col ..] (the bias
  *                                gradient up to a column sum over the blocks: spadot_colsum, fixed order)
- *   spadot_gat_softmax_backward  dz (raw d alpha) -> d logits in place, ds_dst[i] = sum over incoming edges; alpha also
- *                                written into the by-SOURCE plan's image (cellq_s indexed by by-target edge position)
+ *   spadot_gat_softmax_backward  dz (raw d alpha) -> d logits in place, ds_dst[i] = sum over incoming edges; with cellq_s /
+ *                                acell_s (both or neither) alpha is also written into the by-SOURCE plan's image
  *   spadot_gat_ds_src            ds_src[j] = sum of dz over the outgoing edges of j (transposed CSR)
  * spadot_gat_mfma_supported(dtype, H, C, max_cols) tells whether a plan whose longest column list is max_cols can run. */
 int spadot_gat_mfma_supported(int dtype, int H, int C, int max_cols);
@@ -378,8 +361,10 @@ int spadot_gat_tail_dwvec(const void *x, int dtype, int ldx, const float *ds_src
                           float *part, void *stream);
 int spadot_gat_tail_wvec_backward(const float *W, int ldw, const float *att_src, const float *att_dst, const float *dwv, int H, int C, int K,
                                   float *dW, int lddw, int accumulate, float *datt_src, float *datt_dst, void *stream);
+/* (cellq_s / acell_s, both or neither: the by-SOURCE plan's cell map and image -- the same weights once more, for the backward
+ * product; a layer that will not be differentiated passes NULL) */
 int spadot_gat_alpha(const float *s_src, const float *s_dst, const int *rowptr, const int *col, const int *cellq, int n_tgt,
-                     int H, float *alpha, void *acell, void *stream);
+                     int H, float *alpha, void *acell, const int *cellq_s, void *acell_s, void *stream);
 int spadot_gat_aggregate(const void *x, int dtype, const void *acell, const int *plan_rows, const int *plan_sptr,
                          const int *plan_cols, int nb, int max_cols, int H, int C, int mode, const float *vec_a,
                          const float *vec_b, int act, const float *ds_src, const float *ds_dst, void *out,
@@ -472,9 +457,8 @@ int spadot_bias_sqerr_backward(const float *g1, const float *o, const float *bia
 
 /* ---- GAT_fc on the bf16 rows of the last GAT layer (csrc/mlp_chain.hip) -------------------------------------------------
  * out [b x N] (fp32) = h [b x K] (bf16) . W^T [N x K] (fp32) + bias, N <= 32, K % 8 == 0: the (mu | logvar) head of
- * /root/reference/SpaDOT/model/encoder.py:59-61 without an fp32 copy of h.  backward (fixed order): dh (bf16) and per-8-row partials of dW, db in
- * one launch, summed by a second. */
-int spadot_headfc_forward(const void *h_bf16, const float *W, const float *bias, int b, int K, int N, float *out, void *stream);
+ * /root/reference/SpaDOT/model/encoder.py:59-61.  The forward is a cast + library GEMM; backward (fixed order): dh (bf16) and
+ * per-8-row partials of dW, db in one launch, summed by a second. */
 int spadot_headfc_backward(const float *g, const void *h_bf16, const float *W, int b, int K, int N, void *dh_bf16,
                            float *workspace /* ceil(b / 8) x (N K + N) floats */, float *grads /* [dW (N x K) | db (N)] */,
                            void *stream);

@@ -173,7 +173,7 @@ def model_lib():
         "spadot_gat_backward_source": [vp, ci, vp, vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, vp, vp],
         "spadot_gat_logits": [vp, ci, vp, vp, ci, ci, ci, vp, vp, vp],
         "spadot_gat_att_grad": [vp, ci, vp, vp, ci, ci, ci, vp, ci, vp, vp, vp, ci, vp],
-        "spadot_gat_alpha": [vp, vp, vp, vp, vp, ci, ci, vp, vp, vp],
+        "spadot_gat_alpha": [vp, vp, vp, vp, vp, ci, ci, vp, vp, vp, vp, vp],
         "spadot_gat_softmax_backward": [vp, vp, vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp],
         "spadot_gat_ds_src": [vp, vp, vp, ci, ci, vp, vp],
         "spadot_gat_mfma_supported": [ci, ci, ci, ci],
@@ -197,7 +197,6 @@ def model_lib():
         "spadot_gemm_wgrad_bf16": [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, vp, vp, vp],
         "spadot_gemm_wgrad_bf16_tiled": [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp],
         "spadot_mlp_chain_supported": [ci, vp],
-        "spadot_headfc_forward": [vp, vp, vp, ci, ci, ci, vp, vp],
         "spadot_headfc_backward": [vp, vp, vp, ci, ci, ci, vp, vp, vp, vp],
         "spadot_bias_sqerr_forward": [vp, vp, vp, ci, ci, cd, vp, vp, vp],
         "spadot_bias_sqerr_backward": [vp, vp, vp, vp, ci, ci, cd, vp, vp, vp],
@@ -242,8 +241,6 @@ def model_lib():
         "spadot_cast_rows_multi": [vp, vp, vp, vp, vp, ci, vp],
         "spadot_knn": [vp, ci, ci, ci, vp, vp],
         "spadot_stamp": [vp, ci, vp],
-        "spadot_sgemm_nt_slices": [vp, ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, vp, vp],
-        "spadot_dgemm_small": [ci, vp, ci, ll, vp, ci, ll, vp, ci, ll, vp, ci, ll, vp, ci, ll, cd, cd, ci, ci, ci, ci, vp],
         "spadot_grad_sumsq": [vp, ll, vp, vp, vp],
         "spadot_clip_adamw_dev": [vp, vp, vp, vp, ll, cd, cd, cd, cd, cd, cd, vp, vp, vp, vp, vp, vp],
         "spadot_clip_adamw_images_dev": [vp, vp, vp, vp, ll, cd, cd, cd, cd, cd, cd, vp, vp, vp, vp, ctypes.POINTER(WeightImages), vp],
@@ -262,8 +259,6 @@ def model_lib():
     lib.spadot_gemm_wgrad_bf16_workspace.restype = ll
     lib.spadot_gemm_wgrad_bf16_workspace_tiled.argtypes = [ci, ci, ci, ci, ci]
     lib.spadot_gemm_wgrad_bf16_workspace_tiled.restype = ll
-    lib.spadot_sgemm_nt_slices_workspace.argtypes = [ci, ci, ci]
-    lib.spadot_sgemm_nt_slices_workspace.restype = ll
     _seal(lib)
     lib._spadot_ready = True
     return lib

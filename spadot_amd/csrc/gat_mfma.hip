@@ -82,12 +82,17 @@ __device__ __forceinline__ void acell_put(__bf16 *__restrict__ acell, size_t off
 }
 
 // alpha[e, hd] = softmax over the incoming edges e of target i of LeakyReLU_0.2(s_src[j] + s_dst[i])
-// (exp(e - max) / (sum + 1e-16): SURVEY App. A), also scattered as bf16 hi + lo into the plan's dense weight image.
+// (exp(e - max) / (sum + 1e-16): SURVEY App. A), also scattered as bf16 hi + lo into the plan's dense weight image --
+// and, when the layer will be differentiated (cellq_s / acell_s given), into the SOURCE-side plan's image as well: the
+// backward product alpha^T g_pre reads the same weights, so that scatter (until round 4 part of k_gat_softmax_bwd, ~20 MB of
+// 2-byte writes on the backward pass's critical chain) is gradient-independent and belongs to the forward pass, whose GAT
+// branch ends ~80 us before the SVGP branch it runs beside.
 template <int H>
 __global__ __launch_bounds__(256) void k_gat_alpha(const float *__restrict__ s_src, const float *__restrict__ s_dst,
                                                    const int *__restrict__ rowptr, const int *__restrict__ col,
                                                    const int *__restrict__ cellq, int n_tgt, float *__restrict__ alpha,
-                                                   __bf16 *__restrict__ acell) {
+                                                   __bf16 *__restrict__ acell, const int *__restrict__ cellq_s,
+                                                   __bf16 *__restrict__ acell_s) {
     constexpr int EP = 64 / H;
     const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= n_tgt) return;
@@ -124,6 +129,7 @@ __global__ __launch_bounds__(256) void k_gat_alpha(const float *__restrict__ s_s
             const float a = __expf(ev[t] - m) * inv;
             alpha[(size_t)p * H + hd] = a;
             acell_put(acell, acell_off(cellq[p], H, hd), a);
+            if (acell_s) acell_put(acell_s, acell_off(cellq_s[p], H, hd), a);
         }
     }
     for (int t = 4; t < npass; t++) {
@@ -132,13 +138,14 @@ __global__ __launch_bounds__(256) void k_gat_alpha(const float *__restrict__ s_s
             const float a = __expf(leaky(s_src[(size_t)col[p] * H + hd] + sd, ATT_SLOPE) - m) * inv;
             alpha[(size_t)p * H + hd] = a;
             acell_put(acell, acell_off(cellq[p], H, hd), a);
+            if (acell_s) acell_put(acell_s, acell_off(cellq_s[p], H, hd), a);
         }
     }
 }
 
 // dz[e] holds the raw d(alpha[e]) on entry; on exit dz[e] = d(logit[e]) = alpha (d(alpha) - sum_k alpha_k d(alpha_k)) *
-// LeakyReLU'(z) and ds_dst[i] = sum_e dz[e].  alpha is also scattered into the SOURCE-side plan's weight image (what the
-// backward product alpha^T g_pre reads).
+// LeakyReLU'(z) and ds_dst[i] = sum_e dz[e].  With acell_s given, alpha is also scattered into the SOURCE-side plan's weight
+// image (what the backward product alpha^T g_pre reads) -- callers that had k_gat_alpha write that image pass NULL.
 template <int H>
 __global__ __launch_bounds__(256) void k_gat_softmax_bwd(const float *__restrict__ alpha, const float *__restrict__ s_src,
                                                          const float *__restrict__ s_dst, const int *__restrict__ rowptr,
@@ -175,7 +182,7 @@ __global__ __launch_bounds__(256) void k_gat_softmax_bwd(const float *__restrict
         const float d = a * (da - dsum) * (z > 0.f ? 1.f : ATT_SLOPE);
         dz[(size_t)p * H + hd] = d;
         dsd += d;
-        acell_put(acell_s, acell_off(cellq_s[p], H, hd), a);
+        if (acell_s) acell_put(acell_s, acell_off(cellq_s[p], H, hd), a);
     };
 #pragma unroll
     for (int t = 0; t < 4; t++) {
@@ -239,6 +246,9 @@ constexpr int ATILEB = 2048;                        // hi (1 KiB) | lo (1 KiB)
 #ifndef EDOT_WGS
 #define EDOT_WGS 4
 #endif
+#ifndef EDOT_PROBE
+#define EDOT_PROBE 0                                // measurement builds only (tools/gat_probe.sh): bit 0 no `out` read / g_pre write,
+#endif                                              // bit 1 every X row = the block's first column, bit 2 no dz scatter, bit 3 prologue only
 #ifndef EDOT_PAD
 #define EDOT_PAD 1                                  // 0 (with -DEDOT_WGS=5): unpadded, XOR-swizzled G tile, five workgroups per CU
 #endif
@@ -528,7 +538,7 @@ __global__ __launch_bounds__(NT, EDOT_WGS) void k_gat_edot(const __bf16 *__restr
         if (node >= 0) {
             const size_t off = (size_t)node * HC + hoff + (size_t)pc * 8;
             g = *reinterpret_cast<const uint4 *>(g_out + off);
-            if (act) {
+            if (act && !(EDOT_PROBE & 1)) {
                 const uint4 o = *reinterpret_cast<const uint4 *>(outp + off);
                 unsigned gw[4] = {g.x, g.y, g.z, g.w};
                 const unsigned ow[4] = {o.x, o.y, o.z, o.w};
@@ -541,7 +551,7 @@ __global__ __launch_bounds__(NT, EDOT_WGS) void k_gat_edot(const __bf16 *__restr
                 }
                 g = make_uint4(gw[0], gw[1], gw[2], gw[3]);
             }
-            *reinterpret_cast<uint4 *>(g_pre + off) = g;
+            if (!(EDOT_PROBE & 1)) *reinterpret_cast<uint4 *>(g_pre + off) = g;
         }
         *reinterpret_cast<uint4 *>(gt + (size_t)r * GS + (size_t)((pc ^ (r & XM)) * 16)) = g;
     }
@@ -559,10 +569,10 @@ __global__ __launch_bounds__(NT, EDOT_WGS) void k_gat_edot(const __bf16 *__restr
         *reinterpret_cast<float2 *>(bias_part + (size_t)b * part_width + part_col + hoff + 2 * tid) = make_float2(b0, b1);
     }
 
-    const int s0 = sptr[b], ntile = (sptr[b + 1] - s0) / 32;
+    const int s0 = sptr[b], ntile = (EDOT_PROBE & 8) ? 0 : (sptr[b + 1] - s0) / 32;
     const int sl = lane & 31, hh = lane >> 5;
     for (int nt = wave; nt < ntile; nt += 4) {
-        const int sid = pcol[s0 + nt * 32 + sl];
+        const int sid = (EDOT_PROBE & 2) ? pcol[s0] : pcol[s0 + nt * 32 + sl];
         const __bf16 *xrow = Xh + (size_t)sid * HC + hoff + 16 * hh;
         const unsigned char *grow = gt + (size_t)sl * GS;
         const int gx = sl & XM;                                       // this row's chunk XOR
@@ -584,7 +594,7 @@ __global__ __launch_bounds__(NT, EDOT_WGS) void k_gat_edot(const __bf16 *__restr
         for (int i = 0; i < 16; i++) {
             const int r = (i & 3) + 8 * (i >> 2) + 4 * hh;
             const int e = cq[r * KSTEP];
-            if (e >= 0) dz[(size_t)e * H + hd] = acc[i];
+            if (e >= 0 && (!(EDOT_PROBE & 4) || acc[i] == 123.f)) dz[(size_t)e * H + hd] = acc[i];
         }
     }
 }
@@ -607,17 +617,18 @@ int spadot_gat_mfma_supported(int dtype, int H, int C, int max_cols) {
 }
 
 int spadot_gat_alpha(const float *s_src, const float *s_dst, const int *rowptr, const int *col, const int *cellq, int n_tgt,
-                     int H, float *alpha, void *acell, void *stream) {
+                     int H, float *alpha, void *acell, const int *cellq_s, void *acell_s, void *stream) {
     if (n_tgt <= 0 || !(H == 1 || H == 2 || H == 4 || H == 8) || !cellq || !alpha || !acell) return -22;
+    if ((cellq_s == nullptr) != (acell_s == nullptr)) return -22;
     H_DISPATCH(k_gat_alpha, dim3((unsigned)((n_tgt + 3) / 4)), dim3(256), 0, (hipStream_t)stream, s_src, s_dst, rowptr, col, cellq,
-               n_tgt, alpha, (__bf16 *)acell);
+               n_tgt, alpha, (__bf16 *)acell, cellq_s, (__bf16 *)acell_s);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
 int spadot_gat_softmax_backward(const float *alpha, const float *s_src, const float *s_dst, const int *rowptr,
                                 const int *col, const int *cellq_s, int n_tgt, int n_all, int H, float *dz, float *ds_dst,
                                 void *acell_s, void *stream) {
-    if (n_tgt <= 0 || n_all < n_tgt || !(H == 1 || H == 2 || H == 4 || H == 8) || !cellq_s || !acell_s) return -22;
+    if (n_tgt <= 0 || n_all < n_tgt || !(H == 1 || H == 2 || H == 4 || H == 8) || ((cellq_s == nullptr) != (acell_s == nullptr))) return -22;
     H_DISPATCH(k_gat_softmax_bwd, dim3((unsigned)((n_all + 3) / 4)), dim3(256), 0, (hipStream_t)stream, alpha, s_src, s_dst, rowptr,
                col, cellq_s, n_tgt, n_all, dz, ds_dst, (__bf16 *)acell_s);
     return hipGetLastError() == hipSuccess ? 0 : -5;

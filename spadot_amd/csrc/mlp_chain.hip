@@ -426,78 +426,13 @@ __global__ __launch_bounds__(SB_COLS * SB_GY) void k_bias_sqerr_bwd(const float 
 }
 
 // ---- GAT_fc: the [b x K] bf16 output of the last GAT layer -> (mu | logvar) [b x N] fp32, N <= 32 (encoder.py:59-61) ----------
-// forward: four rows per wave (every weight load serves them all), the lanes split K (16-byte bf16 loads), the N dot products
-// reduced by shuffles -- no fp32 copy of h.
+// forward: cast + library GEMM (a one-launch forward from the bf16 rows measured 18-35 us at the end of the forward pair
+// against 5 + 7 us, round 2; removed in round 5).
 // backward: 8 rows per block -- dh = g W written in bf16 (what the GAT layer's backward reads) and the block's partials of dW and
 // db -- then one k_colsum_parts launch adds the blocks in order (a thread-per-column form without partials was a chain of 64
 // dependent memory round trips).
 constexpr int FC_MAXN = 32;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-constexpr int FC_RW = 4;                    // rows per wave, forward: every weight load serves four rows
-__global__ __launch_bounds__(256) void k_headfc_fwd(const __bf16 *__restrict__ h, const float *__restrict__ W,
-                                                    const float *__restrict__ bias, int b, int K, int N, float *__restrict__ out) {
-    // W (N x K fp32, <= 64 KiB) goes to LDS first: every thread issues its 16-byte loads together (read straight from global,
-    // row by row, the kernel was a chain of ~60 dependent L2 round trips: 18-35 us)
-    extern __shared__ __attribute__((aligned(16))) float wl[];
-    {
-        constexpr int NWL = 16;                                       // 256 threads x 16 x 16 B = 64 KiB
-        const int n4 = N * K / 4;
-        float4 v[NWL];
-#pragma unroll
-        for (int u = 0; u < NWL; u++) {
-            const int e = threadIdx.x + u * 256;
-            v[u] = e < n4 ? reinterpret_cast<const float4 *>(W)[e] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int u = 0; u < NWL; u++) {
-            const int e = threadIdx.x + u * 256;
-            if (e < n4) reinterpret_cast<float4 *>(wl)[e] = v[u];
-        }
-    }
-    __syncthreads();
-    const int lane = threadIdx.x & 63, row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * FC_RW;
-    if (row0 >= b) return;
-    float acc[FC_MAXN][FC_RW];
-#pragma unroll
-    for (int j = 0; j < FC_MAXN; j++)
-#pragma unroll
-        for (int r = 0; r < FC_RW; r++) acc[j][r] = 0.f;
-    for (int k0 = lane * 8; k0 < K; k0 += 64 * 8) {
-        float hf[FC_RW][8];
-#pragma unroll
-        for (int r = 0; r < FC_RW; r++) {
-            bf16x8 hv;
-#pragma unroll
-            for (int e = 0; e < 8; e++) hv[e] = (__bf16)0.f;
-            if (row0 + r < b) hv = *reinterpret_cast<const bf16x8 *>(h + (size_t)(row0 + r) * K + k0);
-#pragma unroll
-            for (int e = 0; e < 8; e++) hf[r][e] = (float)hv[e];
-        }
-#pragma unroll
-        for (int j = 0; j < FC_MAXN; j++) {
-            if (j < N) {
-                const float4 w0 = *reinterpret_cast<const float4 *>(wl + (size_t)j * K + k0);
-                const float4 w1 = *reinterpret_cast<const float4 *>(wl + (size_t)j * K + k0 + 4);
-#pragma unroll
-                for (int r = 0; r < FC_RW; r++)
-                    acc[j][r] += hf[r][0] * w0.x + hf[r][1] * w0.y + hf[r][2] * w0.z + hf[r][3] * w0.w + hf[r][4] * w1.x +
-                                 hf[r][5] * w1.y + hf[r][6] * w1.z + hf[r][7] * w1.w;
-            }
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < FC_MAXN; j++) {
-        if (j < N) {
-            const float bj = bias[j];
-#pragma unroll
-            for (int r = 0; r < FC_RW; r++) {
-                const float t = wave_sum(acc[j][r]);
-                if (lane == 0 && row0 + r < b) out[(size_t)(row0 + r) * N + j] = t + bj;
-            }
-        }
-    }
-}
 
 __global__ __launch_bounds__(256) void k_headfc_bwd(const float *__restrict__ g, const __bf16 *__restrict__ h,
                                                     const float *__restrict__ W, int b, int K, int N,
@@ -662,17 +597,6 @@ int spadot_bias_sqerr_backward(const float *g1, const float *o, const float *bia
     if (b <= 0 || G <= 0) return -22;
     hipLaunchKernelGGL(k_bias_sqerr_bwd, dim3((G + SB_COLS - 1) / SB_COLS), dim3(SB_COLS * SB_GY), 0, (hipStream_t)stream, g1, o,
                        bias, y, b, G, inv_scale, (__bf16 *)g_bf16, dbias);
-    return hipGetLastError() == hipSuccess ? 0 : -5;
-}
-
-int spadot_headfc_forward(const void *h_bf16, const float *W, const float *bias, int b, int K, int N, float *out, void *stream) {
-    if (b <= 0 || K <= 0 || K % 8 || N <= 0 || N > FC_MAXN || (size_t)N * K * 4 > 65536) return -22;
-    static PerDeviceFlag attr_set;     
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)k_headfc_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, 65536) != hipSuccess) return -5;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(k_headfc_fwd, dim3((b + 4 * FC_RW - 1) / (4 * FC_RW)), dim3(256), (size_t)N * K * 4, (hipStream_t)stream, (const __bf16 *)h_bf16, W, bias, b, K, N, out);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 

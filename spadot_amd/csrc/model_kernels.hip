@@ -2250,12 +2250,9 @@ int spadot_spd_inverse_logdet2(const double *A, int Lsrc, int L, int m, const do
     const int RS = TS < SWEEP_RS ? TS : SWEEP_RS;   // register core per tile edge; the rest of a tile lives in LDS
     const int CS = TS + ((TS & 1) ? 0 : 1);         // k_spd_sweep's column-buffer stride
     size_t lds = sizeof(double) * (2 * ((size_t)T * CS + 1) + (size_t)m + 16 + (size_t)(TS * TS - RS * RS) * SWEEP_NT);
-    // SPADOT_SWEEP_LDS_KB=n (n <= 160): the launch ASKS for n KB of LDS although it uses a few -- with most of a compute unit's
-    // 160 KB taken, no GEMM or GAT workgroup (they all stage tiles in LDS) can be placed beside a sweep workgroup, which is
-    // bound by its unit's fp64 vector rate: beside the GAT branch's kernels the inverse takes 308 us in the step against
-    // 202 us alone (stage stamps, round 4).  The price: a workgroup that needs a whole unit's LDS waits until one drains.
-    static const long pad_kb = [] { const char *e = getenv("SPADOT_SWEEP_LDS_KB"); return e ? atol(e) : 0L; }();
-    if (pad_kb > 0 && pad_kb <= 160 && (size_t)pad_kb * 1024 > lds) lds = (size_t)pad_kb * 1024;
+    // (Asking for most of a compute unit's 160 KB of LDS, so that no GEMM or GAT workgroup is placed beside a sweep workgroup,
+    // changed nothing -- 313 us in the step, 591.5 against 592.5 steps/s, round 4: the slow-down beside the GAT branch is the
+    // chip's clock under matrix-core load, not a neighbour on the unit.)
 #define SWEEP_CASE(N)                                                                                         \
     case N: {                                                                                                 \
         static PerDeviceFlag attr_set;                                                                              \
@@ -2665,7 +2662,7 @@ int spadot_clip_adamw_dev(float *param, const float *grad, float *exp_avg, float
     const int nbs = (int)(want4 < 1 ? 1 : (want4 < 512 ? want4 : 512));
     // 0: the one-launch form (same-box A/B: 1.972 -> 1.941 ms per step with 2048); clamped to the scratch buffer's
     // capacity (FlatAdamW.scratch: 4096 doubles, one partial per workgroup)
-    static const int split = [] { const char *e = getenv("SPADOT_SUMSQ_SPLIT"); const int v = e ? atoi(e) : 2048; return v > 4096 ? 4096 : v; }();
+    constexpr int split = 2048;
     if (split > 0) {
         const int nb2 = (int)(want4 < 1 ? 1 : (want4 < split ? want4 : split));
         hipLaunchKernelGGL(k_sumsq_part_u<4>, dim3(nb2), dim3(256), 0, st_, grad, count, scratch);
@@ -2739,7 +2736,7 @@ int spadot_adamw_range_dev(float *param, const float *grad, float *exp_avg, floa
     // compute unit stream as fast as sixteen (80 us for the 483 MB of cfg3 either way) and leave the wave slots to what runs
     // beside the update -- the next step's SVGP encoder, chained to the update's first part: 619.6 / 620.5 -> 624.5 / 627.3
     // steps/s (same box; 256 workgroups: 617)
-    static const long long max_wgs = [] { const char *e = getenv("SPADOT_ADAMW_MAX_WGS"); long long v = e ? atoll(e) : 512; return v < 1 ? 1 : v; }();
+    constexpr long long max_wgs = 512;
     const long long want4 = (count / 4 + 255) / 256;
     const int nb = (int)(want4 < max_wgs ? want4 : max_wgs);
     hipLaunchKernelGGL(k_adamw_img, dim3(nb), dim3(256), 0, st_, param + offset, grad + offset, exp_avg + offset, exp_avg_sq + offset,

@@ -345,9 +345,9 @@ int run(const double *x, const double *y, int d, int I, int J, int ld, int stora
     unsigned char *base = (unsigned char *)ws->ptr;
     double *xx = (double *)base;                 base += xx_b;
     double *yyv = (double *)base;                base += yy_b;
-    // the two passes over all I x J distances on the fp64 matrix cores (SPADOT_OT_COST_MFMA=0: the vector kernels)
+    // the two passes over all I x J distances on the fp64 matrix cores (bit-identical to the vector kernels' fma chain)
     constexpr int STEPS = DD == 20 ? 5 : (MAX_D + 3) / 4;
-    static const bool use_mfma = [] { const char *e = getenv("SPADOT_OT_COST_MFMA"); return !(e && e[0] == '0'); }();
+    constexpr bool use_mfma = true;
     const dim3 grid_mj((J + 255) / 256, (I + rpb - 1) / rpb), grid_mld((ld + 255) / 256, (I + rpb - 1) / rpb);
     u64 *counts = (u64 *)base;                   base += 256;
     u64 *skeys = (u64 *)base;                    base += (size_t)S * 8;

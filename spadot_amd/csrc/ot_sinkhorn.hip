@@ -1455,7 +1455,7 @@ void gap_measure(spadot_ot_solver *s, const IterParams &P, void *Rout) {
 }
 
 int spec_batches() { static const int v = [] { const char *e = getenv("SPADOT_OT_SPEC_BATCHES"); return e ? atoi(e) : 3; }(); return v; }
-bool pipe_gap() { static const bool v = [] { const char *e = getenv("SPADOT_OT_PIPE_GAP"); return !(e && e[0] == '0'); }(); return v; }
+constexpr bool pipe_gap() { return true; }      // (the last stage's loop pipelined by one pass: round 3; its switch went in round 5)
 
 // The pipelined last-stage loop (see process_stage): groups of SPEC batches until the gap is at or below `threshold`
 // (or max_groups groups have run; < 0: no limit).  Updates gap, cur_iter, done (iterations) and nchecks.
@@ -1888,35 +1888,13 @@ extern "C" int spadot_ot_set_cost_from_latents_dev(spadot_ot_solver *s, const do
                                                    const double *y_dev, int d, int divide_by_median) {
     SPADOT_ENTER
     if (!s || !x_dev || !y_dev || d < 1 || d > MAX_LATENT_DIM) return -22;
-    const char *legacy = getenv("SPADOT_OT_COST_LEGACY");       // round-1 path (materialised fp64 matrix + radix select): A/B runs
-    if (!(legacy && legacy[0] == '1')) {
-        const int rc = spadot_cost_from_latents_impl(x_dev, y_dev, d, s->I, s->J, s->ld, s->storage == SPADOT_F32, s->C,
-                                                     divide_by_median, s->stream, &s->cost_ws, &s->cost_ws_bytes, nullptr,
-                                                     s->cost_info);
-        if (rc >= 1000) throw hip_failure{(hipError_t)(rc - 1000), __FILE__, __LINE__, "spadot_cost_from_latents_impl"};
-        if (rc != 0) return rc;
-        s->sum_kbar_eps = -1.0;
-        return 0;
-    }
-    const int I = s->I, J = s->J;
-    const size_t n = (size_t)I * J;
-    DevBuf dbuf(sizeof(double) * n);
-    double *D = dbuf.as<double>();
-    const int rpb = 32;
-    hipLaunchKernelGGL(k_sqeuclid, dim3((J + 255) / 256, (I + rpb - 1) / rpb), dim3(256), 0, s->stream, x_dev,
-                       y_dev, d, I, J, D, rpb);
-    double denom = 1.0;
-    if (divide_by_median) {
-        // np.median: middle element, or the mean of the two middle elements
-        if (n & 1) denom = select_kth(s, D, n, n / 2);
-        else denom = (select_kth(s, D, n, n / 2 - 1) + select_kth(s, D, n, n / 2)) / 2.0;
-    }
-    dim3 g((s->ld + 255) / 256, (unsigned)std::min(I, 8192));
-    if (s->storage == SPADOT_F32)
-        hipLaunchKernelGGL(k_scale_to_cost<float>, g, dim3(256), 0, s->stream, D, denom, (float *)s->C, I, J, s->ld);
-    else
-        hipLaunchKernelGGL(k_scale_to_cost<double>, g, dim3(256), 0, s->stream, D, denom, (double *)s->C, I, J, s->ld);
-    HIP_CHECK(hipStreamSynchronize(s->stream));
+    // (round 1's path -- the fp64 distance matrix materialised, radix select, a scaling pass: 3.3 ms at 10k x 10k against
+    // 0.85 -- went with its switch in round 5)
+    const int rc = spadot_cost_from_latents_impl(x_dev, y_dev, d, s->I, s->J, s->ld, s->storage == SPADOT_F32, s->C,
+                                                 divide_by_median, s->stream, &s->cost_ws, &s->cost_ws_bytes, nullptr,
+                                                 s->cost_info);
+    if (rc >= 1000) throw hip_failure{(hipError_t)(rc - 1000), __FILE__, __LINE__, "spadot_cost_from_latents_impl"};
+    if (rc != 0) return rc;
     s->sum_kbar_eps = -1.0;
     return 0;
     SPADOT_LEAVE(SPADOT_EHIP)
@@ -1948,10 +1926,8 @@ int spadot_ot_solve(spadot_ot_solver *s, const double *G_host, const spadot_ot_c
     hipLaunchKernelGGL(k_fill, dim3((J + 255) / 256), dim3(256), 0, s->stream, s->b, 1.0, J);
     HIP_CHECK(hipMemsetAsync(s->flags, 0, sizeof(int) * (MAX_BATCH + 1), s->stream));
 
-    // speculative batches (skip the idle tau-absorb launches, vector-only gap); SPADOT_OT_NO_SPEC=1 keeps
-    // the always-safe schedule for A/B runs
-    const char *nospec = getenv("SPADOT_OT_NO_SPEC");
-    const bool spec = !(nospec && nospec[0] == '1');
+    // speculative batches (skip the idle tau-absorb launches, vector-only gap)
+    const bool spec = true;
     const double f = exp(-log(cfg->epsilon) / S);
     double eps_i = cfg->epsilon0 * f;
     double gap = INFINITY;

@@ -212,13 +212,17 @@ class BlockPlan:
         p._acell = {}
         return p
 
-    def weight_image(self, H):
+    def weight_image(self, H, owner=None):
         """The plan's dense weight image [chunks][H][hi | lo][512] (bf16), zero where a tile has no edge.  Allocated once
-        per head count and reused by every call on this plan: edges always overwrite the same cells, the rest stays 0."""
-        img = self._acell.get(H)
+        per head count (and `owner`) and reused by every call on this plan: edges always overwrite the same cells, the rest
+        stays 0.  owner: any hashable that tells apart the users whose images must stay alive side by side -- the
+        source-side image is written by a layer's FORWARD pass and read by its backward pass, so two layers that share a
+        graph (no per-layer tiers) each keep their own."""
+        key = H if owner is None else (H, owner)
+        img = self._acell.get(key)
         if img is None:
             img = torch.zeros(int(self.cols.numel()) // 16 * H * 1024, dtype=torch.bfloat16, device=self.cols.device)
-            self._acell[H] = img
+            self._acell[key] = img
         return img
 
 

@@ -25,7 +25,7 @@ class SpaDOT(nn.Module):
         self.dtype = torch.float32
         from ..utils._utils import resolve_compute_dtype
         self.compute_dtype = resolve_compute_dtype(model_config.get("compute_dtype"))
-        self.svgp_issue = model_config.get("svgp_issue", __import__("os").environ.get("SPADOT_SVGP_ISSUE", "first"))
+        self.svgp_issue = model_config.get("svgp_issue", "first")
         self.device = torch.device(model_config["device"])
 
         self.SVGPEncoder = SVGPEncoder(input_dim=self.input_dim, SVGP_z_dim=self.SVGP_z_dim,
@@ -64,10 +64,9 @@ class SpaDOT(nn.Module):
         # The SVGP branch is issued in two halves -- encoder + Sigma + the batched inverse (its long pole) first, the
         # rest after the GAT branch has been issued -- so that the inverse runs beside the GAT kernels
         # (model_config['svgp_issue'] = 'first' | 'after_dense' moves the first half behind the first GAT GEMM;
-        # SPADOT_NO_SIDE=1 puts everything on one stream: 2.82 ms instead of 2.46 ms per cfg3 step).
+        # everything on one stream measured 2.82 ms instead of 2.46 ms per cfg3 step, round 1).
         main = torch.cuda.current_stream()
-        env = __import__("os").environ
-        side = self._side_stream() if env.get("SPADOT_NO_SIDE") != "1" else main
+        side = self._side_stream()
         s_gat, s_svgp = main, side
         side.wait_stream(main)
         state = {}
@@ -120,21 +119,6 @@ class SpaDOT(nn.Module):
         stamp_if(18)                                            # (inverse done; slot 17 = in front of it, set in svgp.py)
         return svgp.elbo_finish(bc, started)
 
-    def branch_svgp_head(self, x, y, tp, batch_size, batch_key=None, y_seed32=None):
-        """First part of branch_svgp: encoder, batch constants and everything of the ELBO in front of the batched inverse
-        (the branch's ~8 short launches).  Returns the state branch_svgp_rest() continues from."""
-        b = batch_size
-        svgp = self.svgp_dict[str(tp)]
-        z_enc = self.SVGPEncoder.pre_head(y_seed32 if y_seed32 is not None else y[:b],
-                                          x_bf16=y[:b] if (y_seed32 is not None and y.dtype == torch.bfloat16) else None)
-        bc = svgp.batch_constants(x[:b], key=batch_key)
-        return svgp, bc, z_enc, svgp.elbo_start_pre(bc, z_enc)
-
-    def branch_svgp_rest(self, state):
-        svgp, bc, z_enc, pre = state
-        started = svgp.elbo_start_sweep(bc, pre) if pre is not None else svgp.elbo_start(bc, z_enc)
-        return svgp.elbo_finish(bc, started)
-
     def tail(self, zg, p_m, p_v, y, batch_size, noise=None, y_seed32=None, z_hook=None):
         """Latent head + decoder + reconstruction: (recon, GAT_KL, alignment, final_latent).  y_seed32: the seeds' rows
         of y already in fp32 (cached batches keep them: no cast launch per step).  z_hook(final_latent): called between the
@@ -164,10 +148,10 @@ class SpaDOT(nn.Module):
     def _side_stream(self):
         st = getattr(self, "_svgp_stream", None)
         if st is None:
-            # default -1 (SPADOT_SIDE_PRIORITY=0 for the old form): a high-priority HIP stream (hipStreamCreateWithPriority): when both queues have
-            # workgroups waiting, the dispatcher hands free compute-unit slots to this stream's short launches first
-            prio = int(__import__("os").environ.get("SPADOT_SIDE_PRIORITY", "-1"))
-            st = torch.cuda.Stream(device=self.device, priority=prio)
+            # a high-priority HIP stream (hipStreamCreateWithPriority; this stack has two levels, 0 and -1): when both queues
+            # have workgroups waiting, the dispatcher hands free compute-unit slots to this stream's short launches first
+            # (round 4, same box: 596.7 / 596.5 -> 599.4 / 602.1 steps/s)
+            st = torch.cuda.Stream(device=self.device, priority=-1)
             self._svgp_stream = st
         return st
 

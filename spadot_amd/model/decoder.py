@@ -12,9 +12,6 @@ import torch.nn.functional as F
 from ..ops import grad_bias, linear_bias, ln_act, mlp_chain, mlp_chain_ok, recon_sqerr, recon_sqerr_ok, sqerr_sum, weight_image
 
 
-NOCAST = [__import__("os").environ.get("SPADOT_DEC_NOCAST", "1") == "1"]      # [False]: cast launch in front of the output map (A/B)
-
-
 def _hidden_stage(fan_in, fan_out):
     dense = nn.Linear(fan_in, fan_out)
     nn.init.xavier_uniform_(dense.weight)
@@ -41,7 +38,7 @@ class Decoder(nn.Module):
         """inv_scale * sum (y - decoder(latent))^2 (SpaDOT.py:89) without materialising the reconstruction separately: in the
         bf16 compute dtype the bias add, the squared error and its sum are one launch behind the output map's GEMM."""
         bf = self.compute_dtype == torch.bfloat16
-        nocast = bf and NOCAST[0]
+        nocast = bf
         # dz_extra: a gradient for latent_sample that arrives by no backward path of its own (ops.cluster_losses_fb); the hidden
         # stages' backward launch adds it
         h, last, hb = self._hidden(latent_sample, bf16_out=nocast, dx_add=dz_extra)

@@ -15,9 +15,6 @@ from ..ops import (stamp_if, BatchGraph, bn_act, cast_rows, dense_cd, first_map_
                    head_fc, head_fc_ok, hidden_map, linear_bias, weight_image)
 
 
-FIRST_MAP_OWN_WGRAD = [__import__("os").environ.get("SPADOT_FIRST_MAP_WGRAD", "1") == "1"]    # [False]: library (A/B runs)
-
-
 class SVGPEncoder(nn.Module):
     """encoder.py:7-34: [Linear, BatchNorm1d, LeakyReLU] per hidden size, then Linear -> (mu, var)."""
 
@@ -61,8 +58,7 @@ class SVGPEncoder(nn.Module):
             lin, bn, act = net[i], net[i + 1], net[i + 2]
             if i == 0 and self.compute_dtype != torch.float32 and h.dtype != torch.float32:
                 h = dense_cd(h.to(self.compute_dtype), lin.weight, lin)
-            elif (i == 0 and self.compute_dtype == torch.bfloat16 and FIRST_MAP_OWN_WGRAD[0]
-                  and first_map_seeds_ok(h, lin.weight, x_bf16)):
+            elif i == 0 and self.compute_dtype == torch.bfloat16 and first_map_seeds_ok(h, lin.weight, x_bf16):
                 h = first_map_seeds(h, lin.weight, x_bf16)
             elif i > 0 and h.dtype == torch.float32 and h.shape[1] == lin.in_features:
                 h = hidden_map(h, lin.weight)              # (same product; its backward dodges a library tile that stalls)
@@ -146,10 +142,6 @@ class GATEncoder(nn.Module):
         self.GAT_fc = nn.Linear(hidden_dim, GAT_z_dim * 2)
         nn.init.xavier_uniform_(self.GAT_fc.weight)
 
-    def top_parameters(self):
-        """The parameters above the second layer's output: layer 3 and the head (what a backward pass reaches first)."""
-        return list(self.gat3.parameters()) + list(self.GAT_fc.parameters())
-
     def above_second_dense(self):
         """The parameters whose gradients a backward pass has produced when it reaches the second layer's dense map: the head,
         layer 3 and the second layer's edge-phase parameters (everything but gat2.lin.weight and layer 1)."""
@@ -169,8 +161,8 @@ class GATEncoder(nn.Module):
         """GAT_fc output (mu | logvar) [rows or n, 2 z]: what ops.latent_head consumes.
         after_first_dense: optional callable run right after the first (largest) GEMM has been issued -- the
         composite model issues the start of its SVGP branch there, on another stream.
-        taps: optional dict; receives 'h1' and 'h2', the first and second layer's outputs (where a backward pass issued in
-        pieces cuts: everything above a tap is differentiated first, what is below it afterwards)."""
+        taps: optional dict; receives 'd2', the second layer's dense output (where a backward pass issued in pieces cuts:
+        everything above the tap is differentiated first, what is below it afterwards)."""
         lg = getattr(edge_index, "layer_graphs", None) if rows is not None else None
         g3 = getattr(edge_index, "seed_graph", None) if rows is not None else None
         if not isinstance(edge_index, BatchGraph):
@@ -199,23 +191,15 @@ class GATEncoder(nn.Module):
         if after_first_dense is not None:
             after_first_dense()
         h = self.gat1.edge(h, edge_index, act=True)
-        if taps is not None:
-            taps["h1"] = h
         if lg is not None and lg[1].n_tgt == rows:
             # only what the seeds' rows of layer 3 depend on: layer 2 for seeds + hop 1, layer 3 for the seeds
             h = self.gat2(h, lg[0], act=True, fresh=fresh, taps=taps, tap="d2")
-            if taps is not None:
-                taps["h2"] = h
             h = self.gat3(h, lg[1], act=False, fresh=fresh)
         elif g3 is not None and g3.n_tgt == rows:
             h = self.gat2(h, edge_index, act=True, fresh=fresh, taps=taps, tap="d2")
-            if taps is not None:
-                taps["h2"] = h
             h = self.gat3(h, g3, act=False, fresh=fresh)          # edge phase for the seeds only: same rows, ~n/rows less work
         else:
             h = self.gat2(h, edge_index, act=True, fresh=fresh, taps=taps, tap="d2")
-            if taps is not None:
-                taps["h2"] = h
             h = self.gat3(h, edge_index, act=False, fresh=fresh)
             if rows is not None:
                 h = h[:rows]

@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from .._lib import model_lib
-from ..ops import DGEMM_SMALL, stamp_if, _SPLIT, _check, _p, _stream, dgemm_small, elbo_reduce, kernel_matrix, rowdot, spd_inverse_logdet
+from ..ops import stamp_if, _SPLIT, _check, _p, _stream, elbo_reduce, kernel_matrix, rowdot, spd_inverse_logdet
 
 SWEEP_DIRECT_M = _SPLIT[0]      # up to here one sweep launch takes the matrices as they are (ops._spd_inverse_logdet_nograd)
 
@@ -84,22 +84,10 @@ class _SVGPCore(torch.autograd.Function):
         dw = c diag(K_nm dSigma K_mn) + mu (K_nm dt),   dmu = w (K_nm dt),   dvar = -dw w^2  (+ the direct terms)."""
 
     @staticmethod
-    def start(z, bc, rc, stop_before_sweep=False):
+    def start(z, bc, rc):
         """First half of forward, from z = (mu | logvar) [b, 2L] fp32: Sigma_l for every latent dim, the sweep launch
         (the long pole of the branch, ~0.2 ms on 2L compute units) and t.  Separate so that the caller can issue
-        it early.  stop_before_sweep: everything in front of the sweep launch only; finish_start() launches the sweep
-        (GraphedStepper's `svgp_head_first`: the short launches of this half as a graph of their own, in front of the GAT
-        branch's first GEMM instead of beside it)."""
-        if isinstance(z, dict):                    # the state a stop_before_sweep call returned: launch the sweep now
-            st = z
-            lib = model_lib()
-            with torch.no_grad():
-                m, L = rc.m, st["L"]
-                X = torch.empty((2 * L, m, m), dtype=F64, device=st["G"].device)
-                ld = torch.empty(2 * L, dtype=F64, device=st["G"].device)
-                _check(lib.spadot_spd_inverse_logdet2(_p(st["G"]), L, 2 * L, m, _p(rc.KjI), _p(rc.K2j), _p(X), _p(ld), _stream()),
-                       "spadot_spd_inverse_logdet2")
-            return st["mu"], st["var"], st["w"], X, ld, st["t"]
+        it early."""
         with torch.no_grad():
             z = z.contiguous().float()
             b, L = z.shape[0], z.shape[1] // 2
@@ -116,17 +104,9 @@ class _SVGPCore(torch.autograd.Function):
                        "spadot_svgp_pre2")
                 stamp_if(23)                                                 # (SPADOT_STAMPS=1 only: pre2 done)
                 G = torch.empty((L, m, m), dtype=F64, device=z.device)
-                if DGEMM_SMALL[0]:
-                    # G_l = c K_mn diag(w_l) K_nm and t = (mu w)^T K_nm on the fp64 matrix cores (csrc/gemm_f64.hip: 64 x 64 tiles
-                    # with a small footprint; the library's 64 x 32 / 16 x 16 tiles took 35 + 32 us in front of the inverse)
-                    dgemm_small(2, A, Kn, out=G, alpha=c)
-                    t = dgemm_small(2, muw, Kn)                              # [L, m]
-                else:
-                    torch.baddbmm(G, A.transpose(1, 2), Kn.unsqueeze(0).expand(L, b, m), beta=0.0, alpha=c, out=G)
-                    stamp_if(28)                                             # (SPADOT_STAMPS=1 only: G done)
-                    t = muw.T @ Kn                                           # [L, m]
-                if stop_before_sweep:
-                    return dict(mu=mu, var=var, w=w, G=G, t=t, L=L)
+                torch.baddbmm(G, A.transpose(1, 2), Kn.unsqueeze(0).expand(L, b, m), beta=0.0, alpha=c, out=G)
+                stamp_if(28)                                                 # (SPADOT_STAMPS=1 only: G done)
+                t = muw.T @ Kn                                               # [L, m]
                 stamp_if(17)                                                 # (SPADOT_STAMPS=1 only: Sigma built, in front of the inverse)
                 X = torch.empty((2 * L, m, m), dtype=F64, device=z.device)
                 ld = torch.empty(2 * L, dtype=F64, device=z.device)
@@ -165,7 +145,7 @@ class _SVGPCore(torch.autograd.Function):
         skl32 = torch.empty(1, dtype=torch.float32, device=dev)
         kl_const = rc.logdet_K_f - rc.mlogj - m
         holder = {"M": rc.M, "Kn": bc.K_nm, "S2": X[L:], "b": b}
-        if ELBO_LATE[0] is not None and not DGEMM_SMALL[0]:
+        if ELBO_LATE[0] is not None:
             # The loss tail waits for p_m and p_v only: K_nm S_l (half of X2 S_l), its row dot and a small kernel.  The other
             # half (P S_l), mv / tr and the ELBO scalars (l3, ce, kl, SVGP_KL: read by backward() and, as VALUES, by the
             # logging vector, which is queued too) are appended to the open queue and run off the critical chain.
@@ -185,7 +165,7 @@ class _SVGPCore(torch.autograd.Function):
                 holder["PS"] = PS
             ELBO_LATE[0].append(rest)
         else:
-            X2S = dgemm_small(0, X2, S) if DGEMM_SMALL[0] else torch.matmul(X2, S)     # [L, 2b, m]
+            X2S = torch.matmul(X2, S)                                        # [L, 2b, m]
             rd = rowdot(X2S, X2)                                             # [L, 2b]
             _check(lib.spadot_svgp_post_forward(_p(raw), _p(rd), _p(r), _p(Mr), _p(ld), _p(sm), _p(mu), _p(var), _p(bc.ktilde),
                                                 b, L, m, c, kl_const, b_over_N, _p(p_m), _p(mv), _p(p_v), _p(tr),
@@ -227,54 +207,40 @@ class _SVGPCore(torch.autograd.Function):
                                              _p(p_m), _p(p_v), _p(bc.ktilde), _p(Mr), _p(rc.M), b, L, m, c, ctx.bN, _p(g_mu),
                                              _p(g_var), _p(G1), _p(G2T), _p(g_kl), _p(gMr), _p(gM), _stream()),
                "spadot_svgp_post_backward")
-        if DGEMM_SMALL[0]:
-            # the same six products on csrc/gemm_f64.hip: the addends (gMr, gM) enter as C0, the diagonal scaling of
-            # D_l = X2^T diag(G2_l) X2 + gM rides on the operand load (no scaled copy of X2 per latent dimension)
-            dr = dgemm_small(2, G1, X2, C0=gMr, alpha=c, beta=1.0)                               # [L, m]
-            dt = dgemm_small(0, S, dr.unsqueeze(2)).squeeze(2)                                   # [L, m]
-            D = dgemm_small(2, X2, X2, C0=gM, rowscale=G2T, out=torch.empty((L, m, m), dtype=F64, device=dev))
-            KS = pre["X2S"][:, :b]                                                               # [L, b, m] = K_nm S_l (a view)
-            KSD = dgemm_small(0, KS, D)
-            q1 = rowdot(KSD.reshape(1, L * b, m), KS.contiguous().reshape(L * b, m)).reshape(L, b)
-            q2 = rowdot(dgemm_small(0, Kn, S2), Kn)                                              # diag(K_nm S2 K_mn)  [L, b]
-            Kdt = dgemm_small(1, Kn, dt)                                                         # [b, L]
+        dr = gMr.addmm_(G1.T, X2, alpha=c)                               # [L, m] (in place: no copy of gMr in front of the GEMM)
+        Kdt = None
+        if MID_BWD[0]:
+            # dt_l = S_l dr_l and K_nm dt^T are the forward's r = S t / raw = X2 r with other operands: the same two
+            # wave-per-row launches (spadot_svgp_mid) instead of a batched library GEMM with ONE output column
+            # (MT64x128x16: 41 us in the step) and a [b, m] x [m, L] product (27 us)
+            dt = torch.empty((L, m), dtype=F64, device=dev)
+            Kdt = torch.empty((b, L), dtype=F64, device=dev)
+            nparts = (m + 3) // 4 * 4
+            junk = torch.empty(L * m + L + L * nparts, dtype=F64, device=dev)
+            _check(lib.spadot_svgp_mid(_p(S), _p(dr), _p(rc.M), _p(Kn), L, m, b, _p(dt), _p(junk), _p(Kdt), _p(junk[L * m:]),
+                                       _p(junk[L * m + L:]), L * nparts, _stream()), "spadot_svgp_mid")
         else:
-            dr = gMr.addmm_(G1.T, X2, alpha=c)                               # [L, m] (in place: no copy of gMr in front of the GEMM)
-            Kdt = None
-            if MID_BWD[0]:
-                # dt_l = S_l dr_l and K_nm dt^T are the forward's r = S t / raw = X2 r with other operands: the same two
-                # wave-per-row launches (spadot_svgp_mid) instead of a batched library GEMM with ONE output column
-                # (MT64x128x16: 41 us in the step) and a [b, m] x [m, L] product (27 us)
-                dt = torch.empty((L, m), dtype=F64, device=dev)
-                Kdt = torch.empty((b, L), dtype=F64, device=dev)
-                nparts = (m + 3) // 4 * 4
-                junk = torch.empty(L * m + L + L * nparts, dtype=F64, device=dev)
-                _check(lib.spadot_svgp_mid(_p(S), _p(dr), _p(rc.M), _p(Kn), L, m, b, _p(dt), _p(junk), _p(Kdt), _p(junk[L * m:]),
-                                           _p(junk[L * m + L:]), L * nparts, _stream()), "spadot_svgp_mid")
-            else:
-                dt = torch.bmm(S, dr.unsqueeze(2)).squeeze(2)                # [L, m]
-            if Q1T[0] and T_IN_BACKWARD[0] and "Ta" not in pre and "q2" in pre:
-                _form_T(pre)                                                 # (A/B: T at the head of the backward instead of beside the tail)
-            if "Ta" in pre:
-                q1 = torch.empty((L, b), dtype=F64, device=dev)
-                _check(lib.spadot_svgp_q1t(_p(pre["Ta"]), _p(pre["Tb"]), _p(G2T), _p(pre["m0"]), _p(g_kl), L, b, b, _p(q1),
-                                           _stream()), "spadot_svgp_q1t")
-            else:
-                A2 = X2.unsqueeze(0) * G2T.unsqueeze(2)                      # [L, 2b, m]
-                D = torch.baddbmm(gM.expand(L, m, m), A2.transpose(1, 2), X2.unsqueeze(0).expand(L, 2 * b, m))
-                KS = _holder_KS(pre)                                         # [L, b, m] = K_nm S_l, contiguous
-                q1 = rowdot(torch.bmm(KS, D).reshape(1, L * b, m), KS.reshape(L * b, m)).reshape(L, b)
-            q2 = pre["q2"] if "q2" in pre else rowdot(torch.matmul(Kn, S2), Kn)     # diag(K_nm S2 K_mn)  [L, b]
-            if Kdt is None:
-                Kdt = Kn @ dt.T                                              # [b, L]
+            dt = torch.bmm(S, dr.unsqueeze(2)).squeeze(2)                # [L, m]
+        if "Ta" in pre:
+            q1 = torch.empty((L, b), dtype=F64, device=dev)
+            _check(lib.spadot_svgp_q1t(_p(pre["Ta"]), _p(pre["Tb"]), _p(G2T), _p(pre["m0"]), _p(g_kl), L, b, b, _p(q1),
+                                       _stream()), "spadot_svgp_q1t")
+        else:
+            A2 = X2.unsqueeze(0) * G2T.unsqueeze(2)                      # [L, 2b, m]
+            D = torch.baddbmm(gM.expand(L, m, m), A2.transpose(1, 2), X2.unsqueeze(0).expand(L, 2 * b, m))
+            KS = _holder_KS(pre)                                         # [L, b, m] = K_nm S_l, contiguous
+            q1 = rowdot(torch.bmm(KS, D).reshape(1, L * b, m), KS.reshape(L * b, m)).reshape(L, b)
+        q2 = pre["q2"] if "q2" in pre else rowdot(torch.matmul(Kn, S2), Kn)     # diag(K_nm S2 K_mn)  [L, b]
+        if Kdt is None:
+            Kdt = Kn @ dt.T                                              # [b, L]
         _check(lib.spadot_svgp_grad_tail(_p(q1), _p(q2), _p(Kdt), _p(p_v), _p(bc.ktilde), _p(p_m), _p(mu), _p(w), _p(g_kl),
                                          _p(g_mu), _p(g_var), b, L, c, None, None, _p(dz), _stream()), "spadot_svgp_grad_tail")
         return dz, None, None, None, None
 
 
-Q1T = [__import__("os").environ.get("SPADOT_SVGP_Q1T", "1") == "1"]
-T_IN_BACKWARD = [__import__("os").environ.get("SPADOT_SVGP_T_LATE", "0") == "1"]
-MID_BWD = [__import__("os").environ.get("SPADOT_SVGP_MIDBWD", "1") == "1"]
+# test hooks (tests/test_model_gpu.py compares the restructured backward with the plain one); both forms are the default path
+Q1T = [True]            # q1 through T = X2 S_l K_mn formed ahead of the backward (precompute_backward); [False]: the D_l route
+MID_BWD = [True]        # dt = S dr and K_nm dt^T on the forward's wave-per-row kernels; [False]: library products
 # a list while a caller wants the part of forward() the loss tail does not wait for queued instead of run (GraphedStepper's
 # svgp_pre stage runs the queue right behind the SVGP forward graph, beside the tail); None: forward() runs everything
 ELBO_LATE = [None]
@@ -303,13 +269,13 @@ def precompute_backward(holder):
     the backward pair of a cfg3 step), the contiguous K_nm S_l, and -- Q1T -- T = X2 S_l K_mn and m0 (below).  A forward
     that queued the rest of its ELBO (ELBO_LATE) must have had that queue run before.  No-op when already done."""
     h = holder
-    if h is None or "q2" in h or DGEMM_SMALL[0]:
+    if h is None or "q2" in h:
         return h
     Kn, S2, b = h["Kn"], h["S2"], h["b"]
     with torch.no_grad():
         h["q2"] = rowdot(torch.matmul(Kn, S2), Kn)
         _holder_KS(h)
-        if Q1T[0] and not T_IN_BACKWARD[0]:
+        if Q1T[0]:
             _form_T(h)
     return h
 
@@ -431,17 +397,6 @@ class SVGP(nn.Module):
         """z = SVGP_fc output (mu | logvar) [b, 2L].  Builds Sigma_l and launches the batched inverse; elbo_finish()
         does the rest.  Two calls so that the composite model can issue the GAT kernels in between."""
         return z, _SVGPCore.start(z.detach(), bc, self._rc())
-
-    def elbo_start_pre(self, bc, z):
-        """elbo_start() up to, not including, the sweep launch (None when this shape takes the split inverse: then nothing is
-        deferred); elbo_start_sweep() completes it."""
-        if self._rc().m > SWEEP_DIRECT_M:
-            return None
-        return z, _SVGPCore.start(z.detach(), bc, self._rc(), stop_before_sweep=True)
-
-    def elbo_start_sweep(self, bc, pre):
-        z, st = pre
-        return z, _SVGPCore.start(st, bc, self._rc())
 
     def _finish(self, bc, started):
         z, pre = started

@@ -77,8 +77,7 @@ def _gat_att_scratch(device, floats):
     return cur
 
 
-GAT_MFMA = [__import__("os").environ.get("SPADOT_GAT_MFMA", "1") == "1"]      # [False]: per-edge kernels everywhere (A/B runs)
-GAT_FOLD_ATT = [__import__("os").environ.get("SPADOT_GAT_FOLD_ATT", "1") == "1"]  # [False]: k_gat_datt_part for the att / bias gradients
+GAT_MFMA = [True]      # test hook -- [False]: the per-edge kernels everywhere (tests compare the two paths)
 
 
 def _mfma_plans(h, graph, H, C, concat):
@@ -119,8 +118,13 @@ class _GATEdgeMFMA(torch.autograd.Function):
         _check(lib.spadot_gat_logits(_p(h), DT_BF16, _p(a_s), _p(a_d), n, H, C, _p(s_src), _p(s_dst), _stream()), "spadot_gat_logits")
         alpha = torch.empty((graph.E, H), dtype=torch.float32, device=dev)
         img = pt.weight_image(H)
+        # a layer that will be differentiated: the same weights also into the by-SOURCE plan's image, which the backward
+        # product alpha^T g_pre reads (gradient-independent: written here, beside the SVGP branch, not on the backward chain)
+        ctx.owner = att_src.data_ptr()         # (two layers that share a graph keep their own backward image and partials)
+        img_s = ps.weight_image(H, owner=ctx.owner) if any(ctx.needs_input_grad[:4]) else None
         _check(lib.spadot_gat_alpha(_p(s_src), _p(s_dst), _p(graph.rowptr), _p(graph.col), _p(pt.cellq), nt, H, _p(alpha), _p(img),
-                                    _stream()), "spadot_gat_alpha")
+                                    _p(ps.cellq) if img_s is not None else None, _p(img_s), _stream()), "spadot_gat_alpha")
+        ctx.img_s = img_s
         # a padded input whose nodes are all targets (the first layer) hands its padding on: the next dense map then also
         # sees a row count that is a multiple of 128; the kernel writes the pad rows as zeros
         out_rows = h.shape[0] if (nt == n and h.shape[0] - n <= 4096) else nt
@@ -151,37 +155,28 @@ class _GATEdgeMFMA(torch.autograd.Function):
         # the block's 32 rows of h for it), then ONE fixed-order column sum over the blocks -- instead of k_gat_datt_part's
         # pass of its own over h and g_pre (25 us per layer).  The partial matrix belongs to the batch graph: rows a plan
         # does not have stay zero.
-        fold = GAT_FOLD_ATT[0]
         W3 = 3 * H * C
-        part = None
-        if fold:
-            R = max(pt.nb, ps.nb)
-            bufs = graph.__dict__.setdefault("_bwd_bufs", {})
-            part = bufs.get(("attpart", H, C))
-            if part is None or part.device != dev or part.shape != (R, W3):
-                part = bufs[("attpart", H, C)] = torch.zeros((R, W3), dtype=torch.float32, device=dev)
+        R = max(pt.nb, ps.nb)
+        bufs = graph.__dict__.setdefault("_bwd_bufs", {})
+        part = bufs.get(("attpart", H, C, ctx.owner))
+        if part is None or part.device != dev or part.shape != (R, W3):
+            part = bufs[("attpart", H, C, ctx.owner)] = torch.zeros((R, W3), dtype=torch.float32, device=dev)
         _check(lib.spadot_gat_edge_dot(_p(g_out), _p(out), _p(h), DT_BF16, _p(pt.rows), _p(pt.sptr), _p(pt.cols), _p(pt.cell),
-                                       pt.nb, pt.max_cols, H, C, int(ctx.act), _p(g_pre), _p(dz), _p(part) if fold else None, W3,
+                                       pt.nb, pt.max_cols, H, C, int(ctx.act), _p(g_pre), _p(dz), _p(part), W3,
                                        2 * H * C, _stream()), "spadot_gat_edge_dot")
-        img = ps.weight_image(H)
-        _check(lib.spadot_gat_softmax_backward(_p(alpha), _p(s_src), _p(s_dst), _p(graph.rowptr), _p(graph.col), _p(ps.cellq), nt, n,
-                                               H, _p(dz), _p(ds_dst), _p(img), _stream()), "spadot_gat_softmax_backward")
+        img = ctx.img_s            # (alpha in the by-source plan's layout: written by the forward pass)
+        _check(lib.spadot_gat_softmax_backward(_p(alpha), _p(s_src), _p(s_dst), _p(graph.rowptr), _p(graph.col), None, nt, n,
+                                               H, _p(dz), _p(ds_dst), None, _stream()), "spadot_gat_softmax_backward")
         # ds_src[j] = sum of dz over the outgoing edges of j: taken by the source-side product's workgroups for their own rows
-        # (GAT_FOLD_ATT; spadot_gat_ds_src as a launch of its own otherwise)
-        ds_src = None
-        if not fold:
-            ds_src = torch.empty((n, H), dtype=torch.float32, device=dev)
-            _check(lib.spadot_gat_ds_src(_p(dz), _p(graph.rowptr_t), _p(graph.eid_t), n, H, _p(ds_src), _stream()), "spadot_gat_ds_src")
         dh = torch.empty_like(h)                  # (h's pad rows, if any, get a zero gradient: written by the kernel)
         pad_ok = h.shape[0] - n <= 4096
         if not pad_ok:
             dh[n:].zero_()
         _check(lib.spadot_gat_aggregate(_p(g_pre), DT_BF16, _p(img), _p(ps.rows), _p(ps.sptr), _p(ps.cols), ps.nb, ps.max_cols, H, C, 1,
-                                        _p(a_s), _p(a_d), 0, _p(ds_src), _p(ds_dst), _p(dh), _p(h) if fold else None,
-                                        _p(part) if fold else None, W3, n, h.shape[0] if pad_ok else n,
-                                        _p(dz) if fold else None, _p(graph.rowptr_t) if fold else None,
-                                        _p(graph.eid_t) if fold else None, None, _stream()), "spadot_gat_aggregate")
-        if fold and ctx.flat3 is not None and _DIRECT_GRAD[0]:
+                                        _p(a_s), _p(a_d), 0, None, _p(ds_dst), _p(dh), _p(h), _p(part), W3, n,
+                                        h.shape[0] if pad_ok else n, _p(dz), _p(graph.rowptr_t), _p(graph.eid_t), None, _stream()),
+               "spadot_gat_aggregate")
+        if ctx.flat3 is not None and _DIRECT_GRAD[0]:
             # the three gradients lie back to back in the optimizer's flat gradient buffer: the column sum over the blocks
             # writes them THERE (no copy launch behind it), and -- nothing in the backward pass reads them -- not HERE, on the
             # chain in front of this layer's dense map (in the profiled step the first layer's column sum waited 79 us for a
@@ -199,14 +194,7 @@ class _GATEdgeMFMA(torch.autograd.Function):
                 job()
             return dh, fa, fd, fb_, None, None, None, None, None, None
         datt = torch.empty((3, H * C), dtype=torch.float32, device=dev)
-        if fold:
-            _check(lib.spadot_colsum(_p(part), part.shape[0], W3, _p(datt), _stream()), "spadot_colsum")
-        else:
-            floats = 3 * H * C * max(1, min((n + 15) // 16, 1024))
-            scratch = _gat_att_scratch(dev, floats)
-            _check(lib.spadot_gat_att_grad(_p(h), DT_BF16, _p(ds_src), _p(ds_dst), n, H, C, _p(scratch), floats,
-                                           _p(datt), ctypes.c_void_p(datt.data_ptr() + 4 * H * C), _p(g_pre), nt, _stream()),
-                   "spadot_gat_att_grad")
+        _check(lib.spadot_colsum(_p(part), part.shape[0], W3, _p(datt), _stream()), "spadot_colsum")
         return (dh, datt[0].view(ctx.att_shape).to(ctx.att_dtype), datt[1].view(ctx.att_shape).to(ctx.att_dtype),
                 datt[2].to(ctx.bias_dtype), None, None, None, None, None, None)
 
@@ -307,7 +295,6 @@ def gat_edge(h, att_src, att_dst, bias, graph, heads, channels, concat=True, act
 
 # ----------------------------------------------------------------------------- last GAT layer for the seeds, aggregate-first
 
-GAT_TAIL = [__import__("os").environ.get("SPADOT_GAT_TAIL", "1") == "1"]       # [False]: dense map over all source rows + gat_edge
 _BMM_OUT_DTYPE = [None]     # whether torch.bmm takes out_dtype= (probed on the first call)
 
 
@@ -336,7 +323,7 @@ def _bmm_f32(a, b, out=None):
 def gat_tail_ok(x, W, graph, H, C, concat):
     """Whether the aggregate-first form (csrc/gat_tail.hip) takes this layer: head mean, far fewer targets than source rows,
     K = W.shape[1] <= 2048 input channels."""
-    if not (GAT_TAIL[0] and not concat and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and x.dim() == 2 and x.is_contiguous()):
+    if not (not concat and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and x.dim() == 2 and x.is_contiguous()):
         return False
     K = W.shape[1]
     return bool(graph.n_tgt * 4 <= graph.n and x.shape[0] >= graph.n and x.shape[1] >= K and x.shape[1] % 8 == 0 and C % 8 == 0
@@ -505,39 +492,27 @@ def cast_rows(pairs):
         _check(lib.spadot_cast_rows_multi(src, dst, rows, K, Kp, n, _stream()), "spadot_cast_rows_multi")
 
 
-# csrc/gemm_bf16.hip under the GAT layers' dense maps.  Measured on one box (tools/gemm_bench.py, tools/ab_multi.sh, cfg3):
-# alone it beats the library at the layer shapes (9980 x 2048 x 3072: 110 vs 119 us, x 2048: 80 vs 90 us), inside the step it
-# loses (forward maps: 476 vs 489 steps/s; dx: 485 vs 490) -- its 256 workgroups hold every compute unit's registers and LDS
-# for the whole GEMM, and the latency-bound SVGP branch on the other stream, which bounds the forward pair, waits behind them;
-# the library's ~800 short-lived workgroups let that branch's small kernels in.  (Round 2: both uses opt-in.  Round 3: the
-# second layer's forward map and input gradient take it by default -- GEMM_FWD_SHAPES, GEMM_BUSY_CUS below -- the first
-# layer's, measured again in every form, stays on the library.)
-GEMM_FWD = [__import__("os").environ.get("SPADOT_GEMM_FWD", "0") == "1"]
-GEMM_DGRAD = [__import__("os").environ.get("SPADOT_GEMM_DGRAD", "1") == "1"]
-GEMM_DGRAD_MIN_WGS = [int(__import__("os").environ.get("SPADOT_GEMM_DGRAD_MIN_WGS", "240"))]
-GEMM_MAX_WGS = [int(__import__("os").environ.get("SPADOT_GEMM_MAXWG", "256"))]   # own GEMM only up to this many tiles (CUs left free)
-GEMM_OWN = [True]                                  # [False]: gemm_tn() itself goes to the library (tests)
+# csrc/gemm_bf16.hip under the GAT layers' dense maps.  Measured on one box (tools/gemm_bench.py, cfg3): alone it beats the
+# library at the layer shapes (9980 x 2048 x 3072: 110 vs 119 us, x 2048: 80 vs 90 us); inside the step the FIRST layer's forward
+# map loses in every form measured (its 256 workgroups hold every compute unit's registers and LDS for the whole GEMM while the
+# latency-bound SVGP branch on the other stream, which bounds the forward pair, waits behind them; the library's ~800
+# short-lived workgroups let that branch's small kernels in) and the third layer's is stream-K in the library (1.18 PFLOP/s);
+# the SECOND layer's forward map (+1.1 % of the step, round 3) and the input gradients take it.  The numbers of the forms that
+# lost are in DESIGN section 4 and profiles/r02-r04; the switches that selected them are gone (round 5).
+GEMM_DGRAD_MIN_WGS = 240           # the input-gradient GEMM takes the own kernel from this many 320 x 256 tiles on
+GEMM_MAX_WGS = 256                 # own GEMM only up to this many tiles (one round of the chip's compute units)
+GEMM_OWN = [True]                  # test hook -- [False]: gemm_tn() and the input gradient go to the library
 # compute units the OTHER stream holds while a forward map runs (the SVGP branch's inverse: one 512-thread workgroup per
 # matrix, 2 L = 40 of them for ~0.25 ms): gemm_tn() then cuts the row panels beyond one round of the free units into slices
-# of the contraction (spadot_gemm_tn_bf16_split).  0 = never.
-GEMM_BUSY_CUS = [int(__import__("os").environ.get("SPADOT_GEMM_BUSY_CUS", "40"))]
-# "Kp:Mmin[:Mmax],..." -- forward maps with that (padded) contraction width and row count go through the own kernel.  Default:
-# the second GAT layer at the benchmarked batch shape (~10^4 rows x 2048 -> 2048: 256 tiles, one round).  In the step the
-# library's 504 tiles of 160 x 256 run that map in 123-137 us (90 alone: it shares the chip with the SVGP branch's inverse and
-# its last round is then a third full), the own kernel's one round gave +1.1 % of the step (same-box A/B, round 3).  The first
-# layer (Kp 3072, beside the SVGP encoder's short launches) and the third (8031 rows: stream-K in the library, 1.18 PFLOP/s)
-# measured better on the library.  "none" = library everywhere.
-GEMM_FWD_SHAPES = [[tuple(int(v) for v in t.split(":")) for t in
-                    __import__("os").environ.get("SPADOT_GEMM_FWD_SHAPES", "2048:9000").split(",") if t and t != "none"]]
+# of the contraction (spadot_gemm_tn_bf16_split).
+GEMM_BUSY_CUS = 40
+# (padded contraction width, minimum rows) of the forward maps that go through the own kernel: the second GAT layer at the
+# benchmarked batch shape (~10^4 rows x 2048 -> 2048: 256 tiles, one round)
+GEMM_FWD_SHAPES = ((2048, 9000),)
 
 
 def _own_forward(M, Kp):
-    if GEMM_FWD[0]:
-        return True
-    for t in GEMM_FWD_SHAPES[0]:
-        if t[0] == Kp and M >= t[1] and (len(t) < 3 or M <= t[2]):
-            return True
-    return False
+    return any(t[0] == Kp and M >= t[1] for t in GEMM_FWD_SHAPES)
 
 
 def gemm_tn(x, w):
@@ -548,14 +523,14 @@ def gemm_tn(x, w):
     N = w.shape[0]
     if (GEMM_OWN[0] and x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.is_contiguous()
             and w.is_contiguous() and N % 256 == 0 and K % 64 == 0 and w.shape[1] == K and M >= 2560 and N >= 1024
-            and ((M + 319) // 320) * (N // 256) <= GEMM_MAX_WGS[0]):
+            and ((M + 319) // 320) * (N // 256) <= GEMM_MAX_WGS):
         out = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
         lib = model_lib()
         # a grid of exactly one round that will share the chip (GEMM_BUSY_CUS compute units held by the other stream's
         # inverse): the row panels that would form a second round are cut into quarter tiles along the contraction
         mt, nt_ = (M + 319) // 320, N // 256
-        tail = mt - (256 - GEMM_BUSY_CUS[0]) // nt_ if GEMM_BUSY_CUS[0] > 0 else 0
-        if 0 < tail < mt and mt * nt_ > 256 - GEMM_BUSY_CUS[0] and K >= 4 * 64:
+        tail = mt - (256 - GEMM_BUSY_CUS) // nt_ if GEMM_BUSY_CUS > 0 else 0
+        if 0 < tail < mt and mt * nt_ > 256 - GEMM_BUSY_CUS and K >= 4 * 64:
             need = int(lib.spadot_gemm_bf16_split_workspace(M, N, tail, 4))
             if need > 0:
                 ws = torch.empty(need, dtype=torch.float32, device=x.device)
@@ -573,8 +548,7 @@ def gemm_tn(x, w):
     return torch.nn.functional.linear(x, w)
 
 
-WGRAD_MIN_WGS = [int(__import__("os").environ.get("SPADOT_WGRAD_MIN_WGS", "200"))]   # same-box A/B: 2048 x 3000 (192 workgroups) is 0.4 % better on the library
-WGRAD_OWN = [__import__("os").environ.get("SPADOT_WGRAD_OWN", "1") == "1"]       # [False]: library GEMM for the weight gradients
+WGRAD_MIN_WGS = 200          # same-box A/B: 2048 x 3000 (192 workgroups) is 0.4 % better on the library
 
 
 _ZERO_ROWS = {}
@@ -592,7 +566,6 @@ def _zero_row(device):
     return z
 
 
-WGRAD_TILE_K = [int(__import__("os").environ.get("SPADOT_WGRAD_TILE_K", "0"))]    # 0: chosen per shape; 256 / 192: forced
 
 
 def wgrad_plan(N, K, Kp):
@@ -600,7 +573,7 @@ def wgrad_plan(N, K, Kp):
     width whose grid fills more of the chip's 256 compute units in one round; the narrow tile only where it gains a fifth
     (it reuses each staged byte less)."""
     best = None
-    for tk in ((256, 192) if WGRAD_TILE_K[0] == 0 else (WGRAD_TILE_K[0],)):
+    for tk in (256, 192):
         kt = (K + tk - 1) // tk
         if Kp < kt * tk:
             continue
@@ -614,7 +587,7 @@ def wgrad_plan(N, K, Kp):
         score = fill * (1.0 if tk == 256 else 0.85)
         if best is None or score > best[0]:
             best = (score, tk, slices, wgs)
-    if best is None or best[3] < WGRAD_MIN_WGS[0]:
+    if best is None or best[3] < WGRAD_MIN_WGS:
         return None
     return best[1], best[2], best[3]
 
@@ -624,7 +597,7 @@ def wgrad_bf16(g, x, K, out=None):
     (N % 256 == 0, the X rows readable up to the next multiple of the tile width), else the library."""
     M, N = g.shape
     Kp = x.shape[1]
-    if (WGRAD_OWN[0] and g.is_cuda and g.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and g.is_contiguous()
+    if (g.is_cuda and g.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and g.is_contiguous()
             and x.is_contiguous() and N % 256 == 0 and Kp % 8 == 0 and M >= 1024 and N >= 1024 and K >= 1024):
         if out is None:
             out = torch.empty((N, K), dtype=torch.float32, device=g.device)
@@ -681,8 +654,8 @@ class _DenseCD(torch.autograd.Function):
             # dx = g W: the same kernel as the forward map on the transposed weight image (contraction index contiguous)
             dx = None
             M_, Kp_ = g.shape[0], wbuf.shape[1]
-            if (GEMM_DGRAD[0] and GEMM_OWN[0] and g.is_cuda and g.dtype == torch.bfloat16 and M_ >= 2560 and Kp_ % 256 == 0
-                    and wbuf.shape[0] % 64 == 0 and wbuf.is_contiguous() and ((M_ + 319) // 320) * (Kp_ // 256) >= GEMM_DGRAD_MIN_WGS[0]):
+            if (GEMM_OWN[0] and g.is_cuda and g.dtype == torch.bfloat16 and M_ >= 2560 and Kp_ % 256 == 0
+                    and wbuf.shape[0] % 64 == 0 and wbuf.is_contiguous() and ((M_ + 319) // 320) * (Kp_ // 256) >= GEMM_DGRAD_MIN_WGS):
                 dx = torch.empty((M_, Kp_), dtype=torch.bfloat16, device=g.device)
                 rc = model_lib().spadot_gemm_nn_bf16(g.data_ptr(), g.shape[1], wbuf.data_ptr(), Kp_, dx.data_ptr(), Kp_, M_, Kp_,
                                                      g.shape[1], _stream())
@@ -719,8 +692,6 @@ class _FirstMapSeeds(torch.autograd.Function):
         ctx.K = K
         g = W.grad
         ctx.wgrad = g if (g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.shape == W.shape) else None
-        if sgemm_nt_slices_ok(x32, W):          # 512 x 3000 -> 256: 384 small workgroups instead of 57-72 us of library tiles
-            return sgemm_nt_slices(x32, W.detach())
         return torch.nn.functional.linear(x32[:, :K], W)
 
     @staticmethod
@@ -768,97 +739,9 @@ def _small_weight_grad(g, x):
     return g.t() @ x
 
 
-# The MLP stages' forward maps y = x W^T on csrc/gemm_f32.hip -- OFF by default: both forms lost to the library inside the
-# step (round 4, same-box A/B with tools/ab_step.sh).  The stepped form (16 dependent contraction steps per workgroup): 65 + 8 us
-# for the first map where the library takes 47-57 us beside the GAT branch's first GEMM.  The one-shot form (a workgroup's whole
-# slice staged in 136 KB of LDS by loads that are all in flight): neutral for the first map (564.8 against 566.8 steps/s) and
-# -6 % under the hidden map and SVGP_fc (532.6) -- a workgroup that needs most of a compute unit's LDS waits for a whole unit
-# to drain beside a GEMM, the same effect as the 1024-thread workgroups of DESIGN section 4.  What this branch needs is few
-# dependent steps AND a small footprint at once.
-SGEMM_SLICES = [__import__("os").environ.get("SPADOT_SGEMM_SLICES", "0") == "1"]    # [True]: csrc/gemm_f32.hip for the first map's forward
-HIDDEN_SLICES = [__import__("os").environ.get("SPADOT_HIDDEN_SLICES", "0") == "1"]  # ... and for the hidden map's forward and SVGP_fc
-
-
-def sgemm_nt_slices_ok(x, W):
-    return bool(SGEMM_SLICES[0] and x.is_cuda and x.dtype == torch.float32 and W.dtype == torch.float32 and x.dim() == 2 and W.dim() == 2
-                and x.stride(1) == 1 and W.is_contiguous() and x.shape[1] >= W.shape[1] and x.shape[0] * W.shape[0] <= (1 << 20))
-
-
-def sgemm_nt_slices(x, W, bias=None, slices=None):
-    """x[:, :K] W^T (+ bias) for x [M, >= K], W [N, K] in fp32 with the contraction cut into slices (include/spadot_model.h:
-    spadot_sgemm_nt_slices): a short output over a long contraction as many small workgroups instead of one round of
-    library tiles walking all of K."""
-    M, (N, K) = x.shape[0], W.shape
-    if slices is None:          # one slice up to 256 columns (one launch, no partials); beyond: slices of <= 256 columns, enough of
-        tiles = ((M + 63) // 64) * ((N + 63) // 64)         # them for ~1.5 rounds of the chip's 256 compute units
-        slices = 1 if K <= 256 else max((K + 251) // 252, min((384 + tiles - 1) // tiles, 64))
-    lib = model_lib()
-    ws = torch.empty(int(lib.spadot_sgemm_nt_slices_workspace(M, N, slices)), dtype=torch.float32, device=x.device)
-    out = torch.empty((M, N), dtype=torch.float32, device=x.device)
-    _check(lib.spadot_sgemm_nt_slices(_p(x), x.stride(0), _p(W), K, _p(out), N, _p(bias) if bias is not None else None, M, N, K, slices,
-                                      _p(ws), _stream()), "spadot_sgemm_nt_slices")
-    return out
-
-
-# Measured in the step (round 4, same box): 554 steps/s with the own fp64 kernel under all nine products against 594 with the
-# library -- one prefetch stage and two barriers per 32-wide contraction step make it latency-bound beside the GAT GEMMs
-# (G_l: 52 us against 27-35, D_l: 255 us against 58 + 95).  Kept for its tests and as the base of a deeper pipeline; off by default.
-DGEMM_SMALL = [__import__("os").environ.get("SPADOT_DGEMM_SMALL", "0") == "1"]     # [True]: csrc/gemm_f64.hip under the SVGP branch's fp64 products
-
-
-def _mat3(t):
-    """(pointer tensor, ld, batch stride, batch, rows, cols) of a 2-D or 3-D fp64 tensor whose rows are contiguous."""
-    if t.dim() == 2:
-        assert t.stride(1) == 1 or t.shape[1] == 1
-        return t, t.stride(0), 0, 1, t.shape[0], t.shape[1]
-    assert t.dim() == 3 and (t.stride(2) == 1 or t.shape[2] == 1)
-    return t, t.stride(1), (t.stride(0) if t.shape[0] > 1 else 0), t.shape[0], t.shape[1], t.shape[2]
-
-
-def dgemm_small(mode, A, B, out=None, C0=None, alpha=1.0, beta=1.0, rowscale=None):
-    """fp64  C[z] = alpha op(A[z]) op(B[z]) + beta C0[z]  on the fp64 matrix cores (include/spadot_model.h: spadot_dgemm_small).
-    mode 0: A [.., M, K] B [.., K, N];  mode 1: A [.., M, K] B [.., N, K];  mode 2: A [.., K, M] B [.., K, N].  2-D operands are
-    shared by all batch entries; rowscale (mode 2): [K] or [batch, K]-like view (any strides) scaling A's rows."""
-    _need_cuda(A, B)
-    assert A.dtype == torch.float64 and B.dtype == torch.float64
-    A_, lda, sA, bA, rA, cA = _mat3(A)
-    B_, ldb, sB, bB, rB, cB = _mat3(B)
-    M, K = (cA, rA) if mode == 2 else (rA, cA)
-    N = rB if mode == 1 else cB
-    assert (cB if mode == 1 else rB) == K, (A.shape, B.shape, mode)
-    batch = max(bA, bB, out.shape[0] if (out is not None and out.dim() == 3) else 1,
-                rowscale.shape[0] if (rowscale is not None and rowscale.dim() == 2) else 1)
-    assert bA in (1, batch) and bB in (1, batch)
-    if out is None:
-        out = torch.empty((batch, M, N) if (batch > 1 or A.dim() == 3 or B.dim() == 3) else (M, N), dtype=torch.float64, device=A.device)
-    C_, ldc, sC, bC, rC, cC = _mat3(out)
-    assert (rC, cC) == (M, N) and bC == batch and out.dtype == torch.float64
-    c0p, ldc0, sC0 = None, 0, 0
-    if C0 is not None:
-        C0_, ldc0, sC0, b0, r0, c0c = _mat3(C0)
-        assert (r0, c0c) == (M, N) and b0 in (1, batch) and C0.dtype == torch.float64
-        c0p = _p(C0_)
-    rsp, ldrs, srs = None, 0, 0
-    if rowscale is not None:
-        assert mode == 2 and rowscale.dtype == torch.float64
-        if rowscale.dim() == 1:
-            assert rowscale.shape[0] == K
-            ldrs, srs = rowscale.stride(0), 0
-        else:
-            assert rowscale.shape == (batch, K)
-            ldrs, srs = rowscale.stride(1), rowscale.stride(0)
-        rsp = _p(rowscale)
-    _check(model_lib().spadot_dgemm_small(mode, _p(A_), lda, sA, _p(B_), ldb, sB, _p(C_), ldc, sC, c0p, ldc0, sC0, rsp, ldrs, srs,
-                                          float(alpha), float(beta), M, N, K, batch, _stream()), "spadot_dgemm_small")
-    return out
-
-
-SGEMM_SMALL = [__import__("os").environ.get("SPADOT_SGEMM_SMALL", "1") == "1"]     # [False]: the library for the small fp32 products
-
-
 def sgemm_small_ok(*ts):
     """The small fp32 products of the MLP stages take csrc's k_sgemm_small: contiguous fp32 device matrices, small work."""
-    return SGEMM_SMALL[0] and all(t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.is_contiguous() for t in ts)
+    return all(t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.is_contiguous() for t in ts)
 
 
 def sgemm_small(mode, A, B, bias=None):
@@ -907,8 +790,6 @@ class _HiddenMap(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, W):
         ctx.save_for_backward(x, W)
-        if HIDDEN_SLICES[0] and sgemm_nt_slices_ok(x, W):
-            return sgemm_nt_slices(x, W.detach())
         return torch.nn.functional.linear(x, W)
 
     @staticmethod
@@ -938,8 +819,6 @@ class _LinearBias(torch.autograd.Function):
         ctx.cd = cd
         if cd is None or cd == torch.float32:
             ctx.save_for_backward(x, W)
-            if HIDDEN_SLICES[0] and W.shape[1] <= 256 and sgemm_nt_slices_ok(x, W) and b.dtype == torch.float32:
-                return sgemm_nt_slices(x, W.detach(), b.detach().contiguous())        # (SVGP_fc: 512 x 64 -> 20, one small launch)
             return torch.addmm(b, x, W.t())
         # compute-dtype operands, fp32 accumulate AND fp32 result (no rounding of the output to the compute dtype,
         # no cast launch after the GEMM); the images are kept for the backward pass.  Small dependent launches cost
@@ -1085,7 +964,7 @@ def ln_act(x, ln, slope=0.01):
 
 # ----------------------------------------------------------------------------- fused hidden stages (csrc/mlp_chain.hip)
 
-MLP_CHAIN = [__import__("os").environ.get("SPADOT_MLP_CHAIN", "1") == "1"]     # [False]: one launch per piece (A/B runs, tests)
+MLP_CHAIN = [True]     # test hook -- [False]: one launch per piece (tests compare the two paths)
 
 
 def _ptr_array(tensors):
@@ -1229,8 +1108,6 @@ def grad_bias(x, extra):
     return _GradBias.apply(x, extra)
 
 
-HEAD_FC_FWD = [__import__("os").environ.get("SPADOT_HEAD_FC_FWD", "0") == "1"]
-HEAD_FC = [__import__("os").environ.get("SPADOT_HEAD_FC", "1") == "1"]          # [False]: h.float() + linear_bias (A/B, tests)
 
 
 class _HeadFC(torch.autograd.Function):
@@ -1242,13 +1119,9 @@ class _HeadFC(torch.autograd.Function):
     def forward(ctx, h, W, bias):
         b, K = h.shape
         N = W.shape[0]
-        if HEAD_FC_FWD[0]:
-            out = torch.empty((b, N), dtype=torch.float32, device=h.device)
-            _check(model_lib().spadot_headfc_forward(_p(h), _p(W), _p(bias), b, K, N, _p(out), _stream()), "spadot_headfc_forward")
-        else:
-            # (the one-launch forward exists and is tested, but measured 18-35 us at the end of the forward pair against
-            # 5 + 7 us for the cast + library GEMM: the step keeps those)
-            out = torch.addmm(bias, h.float(), W.t())
+        # (a one-launch forward from the bf16 rows measured 18-35 us at the end of the forward pair against 5 + 7 us for the
+        # cast + library GEMM, round 2: removed in round 5)
+        out = torch.addmm(bias, h.float(), W.t())
         ctx.save_for_backward(h, W)
         ctx.flat_out = _contiguous_grad_block((W, bias))
         return out
@@ -1273,7 +1146,7 @@ class _HeadFC(torch.autograd.Function):
 
 
 def head_fc_ok(h, W, bias):
-    return bool(HEAD_FC[0] and h.is_cuda and h.dtype == torch.bfloat16 and h.dim() == 2 and h.is_contiguous()
+    return bool(h.is_cuda and h.dtype == torch.bfloat16 and h.dim() == 2 and h.is_contiguous()
                 and W.dtype == torch.float32 and W.is_contiguous() and bias is not None and W.shape[0] <= 32
                 and h.shape[1] % 8 == 0 and W.shape[1] == h.shape[1] and W.data_ptr() % 16 == 0 and h.data_ptr() % 16 == 0
                 and W.numel() * 4 <= 65536)
@@ -1535,7 +1408,7 @@ SWEEP_MAX_M = 310      # largest matrix the register/LDS-resident sweep kernel t
 # against 1.26 ms as 2; tools/spd_split.py).  279 = the largest m whose 9 x 9 tiles stay in registers.  Alone the two-block
 # form wins from ~256 on, but its ~25 short launches queue behind the GAT branch's GEMM workgroups inside the step: with m =
 # 261 / 262 (two of the benchmark's five time points) one launch gave 559.3 / 561.8 steps/s against 557.3 / 556.8 (same box).
-_SPLIT = [int(__import__("os").environ.get("SPADOT_SWEEP_SPLIT", "279"))]
+_SPLIT = [279]        # (a list: tests lower it to run the two-block elimination on small matrices)
 
 
 def _sweep_kernel(A):
@@ -1672,7 +1545,6 @@ def sqerr_sum(y, yhat, inv_scale):
     return _SqErr.apply(y, yhat, inv_scale)
 
 
-RECON_FUSED = [__import__("os").environ.get("SPADOT_RECON_FUSED", "1") == "1"]   # [False]: linear_bias + sqerr_sum (A/B, tests)
 
 
 class _LinearSqErr(torch.autograd.Function):
@@ -1736,7 +1608,7 @@ class _LinearSqErr(torch.autograd.Function):
 
 
 def recon_sqerr_ok(h, W, bias, y):
-    return bool(RECON_FUSED[0] and h.is_cuda and h.dtype == torch.float32 and y.dtype == torch.float32 and h.dim() == 2
+    return bool(h.is_cuda and h.dtype == torch.float32 and y.dtype == torch.float32 and h.dim() == 2
                 and y.dim() == 2 and h.shape[1] % 4 == 0 and W.shape[1] % 4 == 0 and y.shape == (h.shape[0], W.shape[0])
                 and h.shape[0] <= 4096
                 and bias is not None)
@@ -1955,8 +1827,9 @@ class FlatAdamW:
         finally:
             _DIRECT_GRAD[0] = False
             POST_CHAIN[0] = None
-        for job in post:
-            job()
+        with torch.no_grad():
+            for job in post:
+                job()
         # (a gradient that already IS the flat view -- written in place by ops.dense_cd -- needs no copy)
         pairs = [(p.grad, g) for p, g in zip(self.params, grads) if g is not None and g.data_ptr() != p.grad.data_ptr()]
         dst = [d for d, _ in pairs]
@@ -1979,13 +1852,19 @@ class FlatAdamW:
         finally:
             _DIRECT_GRAD[0] = False
             POST_CHAIN[0] = None
-        for job in post:            # what the stage's backward functions left for its end (ops.POST_CHAIN)
-            job()
+        with torch.no_grad():
+            for job in post:        # what the stage's backward functions left for its end (ops.POST_CHAIN)
+                job()
         pg = grads[:len(params)]
         pairs = [(p.grad, g) for p, g in zip(params, pg) if g is not None and g.data_ptr() != p.grad.data_ptr()]
         self._zero_unreached(params, pg)
         if pairs:
-            torch._foreach_copy_([d for d, _ in pairs], [s for _, s in pairs])
+            try:
+                torch._foreach_copy_([d for d, _ in pairs], [s for _, s in pairs])
+            except RuntimeError as ex:          # say WHICH slot refused the write (a .grad that is not a flat-buffer view any more)
+                bad = [(tuple(d.shape), d.requires_grad, d.is_leaf, d.data_ptr() - self.flat_grad.data_ptr()) for d, _ in pairs
+                       if d.requires_grad or not (0 <= d.data_ptr() - self.flat_grad.data_ptr() < 4 * self.count)]
+                raise RuntimeError(f"{ex}; offending gradient slots (shape, requires_grad, is_leaf, byte offset in flat_grad): {bad}") from ex
         return grads[len(params):]
 
     def _zero_unreached(self, params, grads):

@@ -118,7 +118,7 @@ def _cache_batch_inputs(dataloaders, datasets, model_config):
         loc, Y, _ = datasets[tp]
         G = Y.shape[1]
         Gp = (G + 127) // 128 * 128 if Y.element_size() == 2 else G
-        rpad = int(model_config.get("batch_row_pad", os.environ.get("SPADOT_ROW_PAD", "128"))) if Y.element_size() == 2 else 0
+        rpad = int(model_config.get("batch_row_pad", 128)) if Y.element_size() == 2 else 0
         for b in batches:
             if b is None:
                 continue
@@ -403,24 +403,40 @@ class GraphedStepper:
     """Training steps as replayed hipGraphs (torch.cuda.CUDAGraph on ROCm = hipGraph).
 
     The unshuffled loader makes every (time point, batch) recur each epoch with identical shapes and
-    index tensors, and the step has no host synchronisation, so the ~500 launches of one step (forward,
+    index tensors, and the step has no host synchronisation, so the launches of one step (forward,
     backward, clip, AdamW, on two streams) are captured once per (time point, batch, active loss terms)
-    and replayed: the CPU issues one hipGraphLaunch instead of ~500 kernel launches.  First visit of a key
-    runs eagerly (warm-up: library handles, SVGP batch constants), the second visit captures, later
-    visits replay.  Anything that changes between replays lives in device memory at a fixed address: beta1
-    (a 0-dim tensor), K-means labels/centres and OT plans (copied in place), the optimizer's step count.
+    and replayed.  First visit of a key runs eagerly (warm-up: library handles, SVGP batch constants), the second
+    visit captures, later visits replay.  Anything that changes between replays lives in device memory at a fixed
+    address: beta1 (entry 1 of the loss-weight vector), K-means labels/centres and OT plans (copied in place), the
+    optimizer's step count.
+
+    Arrangements (DESIGN section 7 has the table; round 5 pruned the measured-and-lost ones):
+      single graph   `staged_graphs: false` (and ranks that SHARE a device): the whole step body as one graph per key;
+      staged         the default: EIGHT graphs per key on two streams --
+                         gat_fwd (main) || svgp_fwd (side)
+                         tail: loss tail forward + its backward (main) || svgp_pre: rest of the ELBO + the
+                               gradient-independent half of the SVGP backward (side)
+                         gat_bwd_a: head, layer 3, layer 2's edge phase (main)
+                         gat_bwd_b: layer 2's dense map, layer 1 (main) || svgp_bwd, then `late`: the gradient work
+                               that only the optimizer reads, queued by the stages above (ops.DEFERRED) (side)
+                     + the update as two graphs (gradient norm + SVGP encoder, then the rest: chained());
+      staged + bucketed exchange   the same graphs between the two collectives of a data-parallel step (grad_sync_async);
+      eager          no stepper at all (training_step / forward_backward).
     """
+
+    STAGES = ("gat_fwd", "svgp_fwd", "tail", "svgp_bwd", "gat_bwd_a", "gat_bwd_b", "late", "svgp_pre")
+    SIDE_STAGES = (1, 3, 6, 7)
 
     def __init__(self, model, optimizer, model_config, dataloader_dict, grad_sync=None, grad_sync_async=None):
         """grad_sync (data-parallel replicas): callable on the flat gradient buffer, e.g. an RCCL all-reduce, issued
-        between the replay of the forward + backward graph(s) and the clip + AdamW graph (nothing of the collective is
+        between the replay of the forward + backward graph(s) and the clip + AdamW graphs (nothing of the collective is
         captured).
         grad_sync_async: callable on a slice of the flat gradient buffer returning a handle with .wait() (e.g.
         `dist.all_reduce(view, async_op=True)`).  With it, staged graphs and an optimizer built with
-        `last=model.GATEncoder.first_layer_parameters()`, the exchange is BUCKETED and overlapped: everything but the
-        first GAT layer's gradients is all-reduced while that layer's backward (its edge kernels and the largest
-        weight-gradient GEMM, the last thing a backward pass computes) is still running, the rest right after.
-        Every rank issues the same two collectives per step in the same order, whatever path it takes."""
+        `last=model.GATEncoder.first_layer_parameters()`, the exchange is BUCKETED: everything but the first GAT layer's
+        gradients leaves when the queue of deferred gradient work has run (the side stream: ~135 us before the main stream
+        finishes the first layer's backward), the first layer's gradients when the main stream has.  Every rank issues the
+        same two collectives per step in the same order, whatever path it takes."""
         self.model, self.opt, self.cfg, self.dd = model, optimizer, model_config, dataloader_dict
         self.grad_sync, self.grad_sync_async = grad_sync, grad_sync_async
         self.beta1_t = _loss_weights(model, model_config, 0.0)     # (lambda1, -beta1, beta2, omiga1..3); entry 1 rewritten per step
@@ -428,41 +444,31 @@ class GraphedStepper:
         self.opt_graph = None
         self.pool = self.pool_side = None
         self._groups = None
-        # staged (six-graph) replay: the default, except for replicas that SHARE a device (the one-GPU rehearsal of the
-        # multi-rank path): there the multi-stream replays of the processes time-slice against each other
-        # (2 steps/s against 97), so those keep the two-graph form
+        # staged replay is the default, except for replicas that SHARE a device (the one-GPU rehearsal of the multi-rank
+        # path): there the multi-stream replays of the processes time-slice against each other (2 steps/s against 97), so
+        # those keep the single-graph form
         import torch.distributed as dist
         multi = grad_sync is not None or (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
         shared = multi and _ranks_share_a_device(torch.device(model_config["device"]))
-        self.staged = bool(model_config.get("staged_graphs", os.environ.get("SPADOT_STAGED_GRAPHS", "0" if shared else "1") == "1"))
+        self.staged = bool(model_config.get("staged_graphs", not shared))
         first = {id(p) for p in model.GATEncoder.first_layer_parameters()}
         self.overlap = bool(self.staged and grad_sync_async is not None and optimizer.tail_offset is not None
                             and {id(p) for p in optimizer.tail_params} == first
-                            and model_config.get("overlap_grad_sync", os.environ.get("SPADOT_OVERLAP_GRAD_SYNC", "1") == "1"))
+                            and model_config.get("overlap_grad_sync", True))
         # every launch of the step is ours or a plain library GEMM (the SPD inverse has no library factorisation at
         # any number of inducing points: ops._spd_inverse_logdet_nograd), so the step is always capturable
         self.capturable = True
-        # which graph of a pair is launched first: 'm' main (GAT) / 's' side (SVGP), forward pair then backward pair
-        self.issue_order = (os.environ.get("SPADOT_ISSUE_ORDER", "mm") + "mm")[:2]
-        # option (off): the GAT backward as TWO graphs cut at the second layer's output, with the SVGP backward graph
-        # launched between them, so that it starts behind the ~12 nodes of the head + layer 3 instead of behind all ~40
-        # nodes of the GAT backward (under rocprofv3 it starts ~350 us late and ends ~90 us after the GAT backward).
-        # Measured without the profiler (round 3, same box, interleaved): 528.0 steps/s without against 524.2 with the
-        # split -- the SVGP backward then runs beside layer 2's GEMMs instead of layer 1's, no shorter overall.
-        self.split_bwd = bool(self.staged and not self.overlap
-                              and model_config.get("split_gat_backward", os.environ.get("SPADOT_SPLIT_BWD", "0") == "1"))
         self._beta1 = None
         # step() returns a copy of the graph's loss vector by default; a caller that consumes it on the same stream before its
         # next step (the training loop's `tot += ...`) may take the graph's own buffer and save the copy launch
-        self.clone_output = os.environ.get("SPADOT_STEP_NOCLONE") != "1"
+        self.clone_output = True
         self.version = getattr(model, "_state_version", 0)
         # parity checks only: with keep_latents set before a key is captured, latents[(tp, batch)] is the final_latent
         # tensor of that key's tail graph (rewritten by every replay)
         self.keep_latents, self.latents = False, {}
         # the optimizer keeps the bf16 images of the GAT layers' weights current (its update kernel writes them), so the
         # steps need no weight-cast launch; anything else that rewrites parameters must refresh them
-        if model_config.get("optimizer_weight_images", os.environ.get("SPADOT_OPT_IMAGES", "1") == "1") \
-                and hasattr(optimizer, "maintain_image"):
+        if model_config.get("optimizer_weight_images", True) and hasattr(optimizer, "maintain_image"):
             object.__setattr__(model.GATEncoder, "_image_optimizer", optimizer)
             object.__setattr__(model.decoder, "_image_optimizer", optimizer)       # (the output map's weight: decoder.py)
             if not getattr(model, "_image_refresh_hook", False):
@@ -474,54 +480,15 @@ class GraphedStepper:
                 model.register_load_state_dict_post_hook(_refresh)
                 object.__setattr__(model, "_image_refresh_hook", True)
         self._images_version = getattr(optimizer, "images_version", 0)
-        # update in two graphs around an event (see update(), chained()); needs FlatAdamW(first=...)
-        self.split_update = bool(model_config.get("split_update", os.environ.get("SPADOT_SPLIT_UPDATE", "1") == "1"))
+        # the update in two graphs around an event (see update(), chained()); needs FlatAdamW(first=...)
         self._head_event, self._head_ready, self._chain = None, False, False
-        # svgp_head_first (round 4): the SVGP branch's ~8 short launches in front of its inverse (encoder, Sigma build) run
-        # 180-240 us beside the GAT branch's first GEMM -- each of them waits for a compute-unit slot that a GEMM workgroup
-        # vacates (timeline) -- against ~100 us alone, and the inverse behind them ends the forward pair ~100 us after the GAT
-        # branch (stage stamps).  With this switch they are a graph of their own and the GAT branch's graph is launched behind
-        # them (the main stream waits for an event recorded between the two SVGP graphs): the GAT branch starts later, the
-        # inverse much earlier.
-        self.svgp_head_first = bool(self.staged and model_config.get("svgp_head_first", os.environ.get("SPADOT_SVGP_HEAD", "0") == "1"))
-        # defer_wgrad (round 4): gradient work that only the optimizer reads -- the second GAT layer's weight gradient (87 + 37 us
-        # with its slice sum), the last layer's weight / attention-vector chain (~48 us), the decoder output map's weight gradient
-        # (18 us) -- is taken OFF the GAT backward's dependency chain: the backward functions queue it (ops.DEFERRED), the GAT
-        # backward becomes two graphs cut behind the second layer's edge phase with an event between them, and the queue runs
-        # as a graph of its own on the SIDE stream behind the SVGP backward, which ends ~360 us before the GAT backward (stage
-        # stamps).  Same kernels, same operands, same results; only where and when they run changes.
-        self.defer_wgrad = bool(self.staged and not self.overlap and not self.split_bwd
-                                and model_config.get("defer_wgrad", os.environ.get("SPADOT_DEFER_WGRAD", "1") == "1")
-                                and hasattr(model.GATEncoder, "above_second_dense"))
-        if self.defer_wgrad:
-            self.svgp_head_first = False
-            # (SPADOT_DEFER_L2=0: the second layer's weight gradient stays on the main stream, only the small jobs are queued)
-            object.__setattr__(model.GATEncoder.gat2, "defer_wgrad",
-                               bool(model_config.get("defer_layer2_wgrad", os.environ.get("SPADOT_DEFER_L2", "1") == "1")))
+        # gradient work that only the optimizer reads -- the second GAT layer's weight gradient and attention / bias sums, the
+        # last layer's weight / attention-vector chain, the decoder output map's weight gradient, column sums of parameter
+        # gradients, the loss VALUES -- is queued by the backward functions of the staged form (ops.DEFERRED) and replayed as
+        # the `late` graph on the side stream: the layer's flag only PERMITS the queueing
+        if self.staged:
+            object.__setattr__(model.GATEncoder.gat2, "defer_wgrad", True)
         self._late_event = None
-        self._enc_event = None
-        # svgp_pre (round 4): the gradient-independent products of the SVGP backward (svgp.precompute_backward: ~140 us of its
-        # ~500 us chain inside the backward pair) as a graph of their own on the side stream, launched right behind the SVGP
-        # forward: they run while the loss tail occupies the main stream and the side stream would otherwise idle
-        want_pre = bool(model_config.get("svgp_precompute", os.environ.get("SPADOT_SVGP_PRE", "1") == "1"))
-        self.svgp_pre = bool(self.defer_wgrad and want_pre)
-        # ... and in the stepper's other staged forms (the five graphs without a queue, the six of the bucketed gradient exchange:
-        # what data-parallel ranks replay) as one more graph behind the tail's, without the late ELBO (their loss values are
-        # computed inside the tail)
-        self.svgp_pre_generic = bool(self.staged and not self.defer_wgrad and not self.split_bwd and not self.svgp_head_first and want_pre)
-        # svgp_elbo_late: the SVGP forward hands p_m / p_v to the tail and leaves the rest of its ELBO (P S_l, mv, tr, the scalars)
-        # to the svgp_pre stage (svgp.ELBO_LATE)
-        self.svgp_elbo_late = bool(self.svgp_pre and os.environ.get("SPADOT_LATE_STREAM", "0") != "1"
-                                   and model_config.get("svgp_elbo_late", os.environ.get("SPADOT_SVGP_ELBO_LATE", "1") == "1"))
-        # cluster_fb: the K-means / OT terms and their gradient in one launch, the gradient added by the decoder's backward
-        # launch (ops.cluster_losses_fb): two launches fewer on the loss tail's chain.  Only where the backward seed is certain:
-        # the staged tail's backward_partial.
-        self.cluster_fb = bool((self.defer_wgrad or self.svgp_pre_generic)
-                               and model_config.get("cluster_fb", os.environ.get("SPADOT_CLUSTER_FB", "1") == "1"))
-        # late_stream (round 4, opt-in): the deferred gradient work on a third stream and memory pool of its own
-        self.late_stream = bool(self.defer_wgrad and model_config.get("late_stream", os.environ.get("SPADOT_LATE_STREAM", "0") == "1"))
-        self._late_stream = None
-        self.pool_late = None
         self.stamps = (torch.zeros(32, dtype=torch.int64, device=next(model.parameters()).device)
                        if os.environ.get("SPADOT_STAMPS") == "1" else None)
         if self.stamps is not None:
@@ -534,8 +501,6 @@ class GraphedStepper:
             reg = weakref.WeakSet()
             object.__setattr__(model, "_steppers", reg)
         reg.add(self)
-        # the update's four launches issued directly instead of as graphs (A/B: a graph boundary costs ~15-20 us of idle stream)
-        self.eager_update = bool(model_config.get("eager_update", os.environ.get("SPADOT_EAGER_UPDATE", "0") == "1"))
 
     def _body(self, tp_i, tp, bi, epoch, with_update=True):
         losses = forward_backward(self.model, self.cfg, self.dd, tp_i, tp, bi, epoch, self.beta1_t,
@@ -555,18 +520,15 @@ class GraphedStepper:
         return g, out
 
     def update(self):
-        """clip + AdamW as its own graph (data-parallel path: after the gradient exchange): eager once, then one
-        replayed graph shared by all keys.  With an optimizer that has a `first` group (the SVGP encoder's parameters:
-        FlatAdamW(first=...)) the update is TWO graphs -- gradient norm + the first group, then everything else -- with
-        an event between them that the next step's SVGP branch waits for instead of the whole update (chained())."""
+        """clip + AdamW as graphs of their own (shared by all keys): eager once, then replayed.  With an optimizer that has
+        a `first` group (the SVGP encoder's parameters: FlatAdamW(first=...)) the update is TWO graphs -- gradient norm +
+        the first group, then everything else -- with an event between them that the next step's SVGP branch waits for
+        instead of the whole update (chained())."""
         if getattr(self.opt, "images_version", 0) != self._images_version:     # the update's image table changed:
             self._images_version = self.opt.images_version                      # a captured launch carries the old one
             self.opt_graph = None if self.opt_graph in (None, False) else False
-        split = self.split_update and getattr(self.opt, "head_count", 0) > 0
-        if not split:
-            if not self.capturable:
-                self.opt.step()
-            elif self.opt_graph is None:
+        if getattr(self.opt, "head_count", 0) <= 0:
+            if self.opt_graph is None:
                 self.opt.step()
                 self.opt_graph = False                  # warmed up; capture on the next call
             elif self.opt_graph is False:
@@ -578,12 +540,11 @@ class GraphedStepper:
         if self._head_event is None:
             self._head_event = torch.cuda.Event()
         main = torch.cuda.current_stream()
-        if not self.capturable or self.opt_graph is None or self.eager_update:
+        if self.opt_graph is None:
             self.opt.step_head()
             self._head_event.record(main)
             self.opt.step_rest()
-            if self.capturable and not self.eager_update:
-                self.opt_graph = False
+            self.opt_graph = False
         else:
             if self.opt_graph is False:
                 head, rest = self.opt.step_head, self.opt.step_rest
@@ -643,8 +604,6 @@ class GraphedStepper:
         if self._beta1 != float(beta1):               # (constant within an epoch: one fill launch per epoch, not per step)
             self.beta1_t[1].fill_(-float(beta1))
             self._beta1 = float(beta1)
-        if not self.capturable:
-            return self._body(tp_i, tp, bi, epoch, with_update=with_update)
         if self.staged:
             return self._run_staged(tp_i, tp, bi, epoch, with_update)
         key = (tp, bi, epoch >= 1, epoch >= self.cfg["ot_epoch"] and tp_i != 0, with_update)
@@ -660,10 +619,8 @@ class GraphedStepper:
         g.replay()
         return out.clone() if self.clone_output else out
 
-    # ---- staged mode: the step as SIX graphs instead of one.  A replayed hipGraph runs its two branches mostly
-    # one after the other (tools/graph_probe.py); two graphs replayed on two streams do overlap.  So: GAT forward
-    # (main stream) || SVGP forward (side stream), tail forward + backward, GAT backward || SVGP backward, optimizer.
-    # Graphs that may run at the same time capture into different memory pools.
+    # ---- staged mode.  A replayed hipGraph runs its two branches mostly one after the other (tools/graph_probe.py); two
+    # graphs replayed on two streams do overlap.  Graphs that may run at the same time capture into different memory pools.
     def _stages(self, tp_i, tp, bi, epoch):
         model, cfg, dd, opt = self.model, self.cfg, self.dd, self.opt
         batch = dd["dataloaders"][tp][bi]
@@ -675,6 +632,8 @@ class GraphedStepper:
         do_ot = bool(epoch >= cfg["ot_epoch"] and tp_i != 0)
         P = self._param_groups()
         st = {}
+        from .. import ops as _ops
+        from ..model import svgp as _svgp
 
         # Batch inputs: the cached gathers (prepare_dataloader) live at fixed addresses.  Without the cache the rows
         # are gathered INSIDE the stages, i.e. inside the captured graphs -- a gather made out here would hand the
@@ -682,14 +641,13 @@ class GraphedStepper:
         # its own stream: the GAT branch all n_sub rows, the SVGP branch (and the tail after it) the seeds' rows.
         def gat_fwd():
             y_all = batch.y if cached else Y[batch.n_id]
-            st["zg"] = model.branch_gat(y_all, batch.graph, b, taps=st if (self.overlap or self.split_bwd or self.defer_wgrad) else None)
+            st["zg"] = model.branch_gat(y_all, batch.graph, b, taps=st)          # (taps: st["d2"], where the backward is cut)
 
         def svgp_fwd():
-            from ..model import svgp as _svgp
             st["xs"] = batch.x[:b] if cached else loc[seeds]
             st["ys"] = batch.y[:b] if cached else Y[seeds]
-            if self.svgp_elbo_late:             # the part of the ELBO the tail does not wait for goes to the svgp_pre stage
-                _svgp.ELBO_LATE[0] = st.setdefault("svgp_late", [])
+            # the part of the ELBO the tail does not wait for goes to the svgp_pre stage (svgp.ELBO_LATE)
+            _svgp.ELBO_LATE[0] = st.setdefault("svgp_late", [])
             try:
                 st["pm"], st["pv"], st["skl"] = model.branch_svgp(st["xs"], st["ys"], tp, b, batch_key=(tp, bi),
                                                                   y_seed32=getattr(batch, "y_seed32", None) if cached else None)
@@ -697,17 +655,7 @@ class GraphedStepper:
                 _svgp.ELBO_LATE[0] = None
             st["svgp_holder"] = _svgp.holder_of(st["pm"])
 
-        def svgp_fwd_head():
-            st["xs"] = batch.x[:b] if cached else loc[seeds]
-            st["ys"] = batch.y[:b] if cached else Y[seeds]
-            st["svgp_state"] = model.branch_svgp_head(st["xs"], st["ys"], tp, b, batch_key=(tp, bi),
-                                                      y_seed32=getattr(batch, "y_seed32", None) if cached else None)
-
-        def svgp_fwd_rest():
-            st["pm"], st["pv"], st["skl"] = model.branch_svgp_rest(st["svgp_state"])
-
         def svgp_pre():             # rest of the ELBO + gradient-independent part of the SVGP backward (side stream, beside the tail)
-            from ..model import svgp as _svgp
             with torch.no_grad():
                 for job in st.pop("svgp_late", []):
                     job()
@@ -720,7 +668,7 @@ class GraphedStepper:
             def hook(z):
                 # K-means / OT terms AND their gradient w.r.t. z in one launch (the seeds of this stage's backward are the
                 # loss weights: backward_partial's constant-one seed through mix_losses); the decoder's backward adds it
-                if not (self.cluster_fb and (do_km or do_ot)):
+                if not (do_km or do_ot):
                     return None
                 res = _cluster_terms(model, cfg, tp, tp_i, seeds, z, do_km, do_ot, weights=self.beta1_t)
                 if res is None:
@@ -741,16 +689,19 @@ class GraphedStepper:
             g = st["g"]
             opt.backward_partial([st["pm"], st["pv"], st["skl"]], [g[1], g[2], g[3]], P["svgp"])
 
-        def gat_bwd():
-            opt.backward_partial([st["zg"]], [st["g"][0]], P["gat"])
+        def gat_bwd_a():            # head, layer 3, the second layer's edge phase; stops at the second layer's dense output
+            st["gd2"] = opt.backward_partial([st["zg"]], [st["g"][0]], P["gat_above_d2"], extra_inputs=[st["d2"]])[0]
 
-        def gat_bwd_hi():           # layers 3, 2 and the head; stops at the first layer's output
-            st["gh1"] = opt.backward_partial([st["zg"]], [st["g"][0]], P["gat_hi"], extra_inputs=[st["h1"]])[0]
+        def gat_bwd_b():            # the second layer's dense map (its weight gradient queued) and layer 1
+            opt.backward_partial([st["d2"]], [st["gd2"]], P["gat_below_d2"])
 
-        def gat_bwd_lo():           # the first layer: its edge backward and the largest weight gradient
-            opt.backward_partial([st["h1"]], [st["gh1"]], P["gat_lo"])
-
-        from .. import ops as _ops
+        def late():                 # what the three stages above queued: side stream, behind the SVGP backward
+            # (no tape: the queued closures hold saved activations that require grad, and a library product written with
+            # out= into a flat-gradient view would otherwise make the whole flat buffer a non-leaf -- found by the
+            # ChickenHeart-shaped bf16 run of round 5, whose 747-spot time point takes the library path)
+            with torch.no_grad():
+                for job in st.pop("late", []):
+                    job()
 
         def queued(fn):             # off-chain gradient work of `fn` goes to st["late"] instead of being launched
             def run():
@@ -761,38 +712,7 @@ class GraphedStepper:
                     _ops.DEFERRED[0] = None
             return run
 
-        def gat_bwd_a():            # head, layer 3, the second layer's edge phase; stops at the second layer's dense output
-            st["gd2"] = opt.backward_partial([st["zg"]], [st["g"][0]], P["gat_above_d2"], extra_inputs=[st["d2"]])[0]
-
-        def gat_bwd_b():            # the second layer's dense map (its weight gradient queued) and layer 1
-            opt.backward_partial([st["d2"]], [st["gd2"]], P["gat_below_d2"])
-
-        def late():                 # what the three stages above queued: side stream, behind the SVGP backward
-            jobs = st.pop("late", [])
-            for job in jobs:
-                job()
-
-        def gat_bwd_top():          # the head and layer 3; stops at the second layer's output
-            st["gh2"] = opt.backward_partial([st["zg"]], [st["g"][0]], P["gat_top"], extra_inputs=[st["h2"]])[0]
-
-        def gat_bwd_rest():         # layers 2 and 1
-            opt.backward_partial([st["h2"]], [st["gh2"]], P["gat_rest"])
-
-        if self.overlap:
-            fns = (gat_fwd, svgp_fwd, tail, svgp_bwd, gat_bwd_hi, gat_bwd_lo)
-        elif self.split_bwd:
-            fns = (gat_fwd, svgp_fwd, tail, svgp_bwd, gat_bwd_top, gat_bwd_rest)
-        else:
-            fns = (gat_fwd, svgp_fwd, tail, svgp_bwd, gat_bwd)
-        if self.defer_wgrad:
-            fns = (gat_fwd, svgp_fwd, queued(tail), svgp_bwd, queued(gat_bwd_a), queued(gat_bwd_b), late)
-            if self.svgp_pre:
-                fns = fns + (svgp_pre,)
-        if self.svgp_pre_generic:
-            fns = fns + (svgp_pre,)         # (last: _issue_staged launches it on the side stream behind the tail's graph)
-        if self.svgp_head_first:
-            # a SEVENTH stage: the SVGP branch's short launches in front of its inverse as a graph of their own (see __init__)
-            fns = fns + (svgp_fwd_head, svgp_fwd_rest)
+        fns = (gat_fwd, svgp_fwd, queued(tail), svgp_bwd, queued(gat_bwd_a), queued(gat_bwd_b), late, svgp_pre)
         if self.stamps is not None:
             # measurement aid (SPADOT_STAMPS=1): a device timestamp at the head and the end of every stage graph
             # (slots 2 k, 2 k + 1), read back by tools/stage_stamps.py -- when each stage really starts with no profiler attached
@@ -808,175 +728,88 @@ class GraphedStepper:
             fns = tuple(stamped(k, fn) for k, fn in enumerate(fns))
         return fns
 
-    def _late_stream_obj(self):
-        if self._late_stream is None:
-            self._late_stream = torch.cuda.Stream(device=torch.device(self.cfg["device"]),
-                                                  priority=int(os.environ.get("SPADOT_LATE_PRIORITY", "0")))
-        return self._late_stream
-
     def _param_groups(self):
         if self._groups is None:
             own = {id(p) for p in self.opt.params}
             gat = [p for p in self.model.GATEncoder.parameters() if id(p) in own]
             svgp = [p for p in self.model.SVGPEncoder.parameters() if id(p) in own]
             taken = {id(p) for p in gat + svgp}
-            lo = {id(p) for p in self.model.GATEncoder.first_layer_parameters()}
-            top = {id(p) for p in self.model.GATEncoder.top_parameters()}
-            self._groups = {"gat": gat, "svgp": svgp, "tail": [p for p in self.opt.params if id(p) not in taken],
-                            "gat_lo": [p for p in gat if id(p) in lo], "gat_hi": [p for p in gat if id(p) not in lo],
-                            "gat_top": [p for p in gat if id(p) in top], "gat_rest": [p for p in gat if id(p) not in top]}
-            if hasattr(self.model.GATEncoder, "above_second_dense"):
-                above = {id(p) for p in self.model.GATEncoder.above_second_dense()}
-                self._groups["gat_above_d2"] = [p for p in gat if id(p) in above]
-                self._groups["gat_below_d2"] = [p for p in gat if id(p) not in above]
+            above = {id(p) for p in self.model.GATEncoder.above_second_dense()}
+            self._groups = {"svgp": svgp, "tail": [p for p in self.opt.params if id(p) not in taken],
+                            "gat_above_d2": [p for p in gat if id(p) in above],
+                            "gat_below_d2": [p for p in gat if id(p) not in above]}
         return self._groups
 
     def _issue_staged(self, fns, two_streams=True):
-        """The stages in order: `fns` are the replay methods of their graphs (GAT stages on the main stream, SVGP
-        stages beside them on the side stream) or, on the eager warm-up visit, the stage callables themselves (one
-        stream).  Five stages end with the whole GAT backward; six (bucketed exchange) with the GAT backward above
-        the first layer, the all-reduce of everything but the first layer's gradients, the first layer's backward
-        beside it, and the all-reduce of the rest."""
+        """The stages in order: `fns` are the replay methods of their graphs (GAT stages on the main stream, the SVGP stages
+        and the queue beside them on the side stream) or, on the eager warm-up visit, the stage callables themselves (one
+        stream).  With the bucketed exchange the all-reduce of everything but the first layer's gradients is issued behind
+        the queue (side stream), the first layer's behind the main stream's last graph."""
+        gat_fwd, svgp_fwd, tail, svgp_bwd, gat_bwd_a, gat_bwd_b, late, svgp_pre = fns
         main = torch.cuda.current_stream()
-        side = self.model._side_stream() if two_streams else main
-        skip = os.environ.get("SPADOT_SKIP_STAGE")          # timing experiments only (wrong results): leave one stage out
-        if skip is not None and two_streams:
-            fns = list(fns)
-            fns[int(skip)] = lambda: None
+        if not two_streams:
+            gat_fwd(); svgp_fwd(); svgp_pre()
+            res = tail()
+            svgp_bwd(); gat_bwd_a(); gat_bwd_b(); late()
+            if self.overlap:
+                self._exchange_buckets(main, main)
+            return res
+        side = self.model._side_stream()
         # Issue order inside a pair: the GAT graph (main stream, the longer one) FIRST.  A graph launch costs the host
-        # ~2.5 us per node, and the graph launched second only starts once the first has been handed over: with the
-        # ~45-node SVGP graph in front, the main stream sat idle for 120 us (forward) and 190 us (backward) per step
-        # (rocprofv3 timeline, profiles/r02).  The side stream's wait on `main` is recorded before the GAT launch, so it
-        # covers the work in front of the pair, not the GAT graph itself.
-        if two_streams:
-            if self._chain and self._head_ready and self._head_event is not None:
-                side.wait_event(self._head_event)        # (chained(): the previous step's update of the SVGP encoder)
-            else:
-                side.wait_stream(main)
-            self._head_ready = False
-        if self.defer_wgrad and len(fns) in (7, 8):
-            # (gat_fwd, svgp_fwd, tail, svgp_bwd, gat_bwd_a, gat_bwd_b, late[, svgp_pre])
-            if not two_streams:
-                for k in ((0, 1, 7, 2, 3, 4, 5, 6) if len(fns) == 8 else (0, 1, 2, 3, 4, 5, 6)):
-                    r = fns[k]()
-                    if k == 2:
-                        res = r
-                return res
-            fns[0]()
-            with torch.cuda.stream(side):
-                fns[1]()
-            main.wait_stream(side)                       # (an event behind the SVGP forward: what follows on `side` is not waited for)
-            res = fns[2]()
-            if len(fns) == 8:                            # (launched behind the tail: the host hands the critical graph over first)
-                with torch.cuda.stream(side):
-                    fns[7]()
-            side.wait_stream(main)
-            fns[4]()
-            if self._late_event is None:
-                self._late_event = torch.cuda.Event()
-            self._late_event.record(main)
-            with torch.cuda.stream(side):
-                fns[3]()
-            fns[5]()
-            if self.late_stream:
-                # the queued gradient work on a THIRD stream: it starts when its inputs exist (the event behind the first
-                # GAT backward graph), not behind the SVGP backward
-                late = self._late_stream_obj()
-                late.wait_event(self._late_event)
-                with torch.cuda.stream(late):
-                    fns[6]()
-                main.wait_stream(late)
-            else:
-                with torch.cuda.stream(side):
-                    side.wait_event(self._late_event)
-                    fns[6]()
-            main.wait_stream(side)
-            return res
-        pre = None
-        if self.svgp_pre_generic:
-            pre, fns = fns[-1], fns[:-1]
-            assert len(fns) == (6 if self.overlap else 5)
-        head_first = self.svgp_head_first and len(fns) >= 7
-        if head_first:
-            head, rest = fns[-2], fns[-1]
-            fns = fns[:-2]
-            if two_streams:
-                if self._enc_event is None:
-                    self._enc_event = torch.cuda.Event()
-                with torch.cuda.stream(side):
-                    head()
-                    self._enc_event.record(side)
-                main.wait_event(self._enc_event)
-                fns[0]()
-                with torch.cuda.stream(side):
-                    rest()
-            else:
-                head()
-                rest()
-                fns[0]()
-        elif self.issue_order[0] == "m" and two_streams:
-            fns[0]()
-            with torch.cuda.stream(side):
-                fns[1]()
+        # ~2.5 us per node, and the graph launched second only starts once the first has been handed over.  The side
+        # stream's wait on `main` is recorded before the GAT launch, so it covers the work in front of the pair.
+        if self._chain and self._head_ready and self._head_event is not None:
+            side.wait_event(self._head_event)        # (chained(): the previous step's update of the SVGP encoder)
         else:
-            with torch.cuda.stream(side):
-                fns[1]()
-            fns[0]()
-        if two_streams:
-            main.wait_stream(side)
-        res = fns[2]()
-        if pre is not None:                  # gradient-independent half of the SVGP backward: side stream, beside the tail
-            if two_streams:
-                with torch.cuda.stream(side):
-                    pre()
-            else:
-                pre()
-        if two_streams:
             side.wait_stream(main)
-        if len(fns) == 6 and self.split_bwd:
-            # head + layer 3 (main), then the SVGP backward (side: it waits for the tail only), then layers 2 and 1 (main)
-            fns[4]()
-            if two_streams:
-                with torch.cuda.stream(side):
-                    fns[3]()
-            else:
-                fns[3]()
-            fns[5]()
-            if two_streams:
-                main.wait_stream(side)
-            return res
-        if self.issue_order[1] == "m" and two_streams:
-            fns[4]()
-            with torch.cuda.stream(side):
-                fns[3]()
-        else:
-            with torch.cuda.stream(side):
-                fns[3]()
-            fns[4]()
-        if two_streams:
-            main.wait_stream(side)
+        self._head_ready = False
+        gat_fwd()
+        with torch.cuda.stream(side):
+            svgp_fwd()
+        main.wait_stream(side)                       # (an event behind the SVGP forward: what follows on `side` is not waited for)
+        res = tail()
+        with torch.cuda.stream(side):                # (launched behind the tail: the host hands the critical graph over first)
+            svgp_pre()
+        side.wait_stream(main)
+        gat_bwd_a()
+        if self._late_event is None:
+            self._late_event = torch.cuda.Event()
+        self._late_event.record(main)
+        with torch.cuda.stream(side):
+            svgp_bwd()
+        gat_bwd_b()
+        with torch.cuda.stream(side):
+            # the queue reads what the tail and gat_bwd_a produced (the event) and, of gat_bwd_b, only operands that exist
+            # before that stage starts (ops._DenseCD.backward checks it: its incoming gradient needs no copy)
+            side.wait_event(self._late_event)
+            late()
         if self.overlap:
-            cut = self.opt.tail_offset
-            w1 = self.grad_sync_async(self.opt.flat_grad[:cut])
-            fns[5]()
-            w2 = self.grad_sync_async(self.opt.flat_grad[cut:])
-            w1.wait()
-            w2.wait()
+            self._exchange_buckets(main, side)
+        main.wait_stream(side)
         return res
 
-    def exchange_idle(self):
-        """A replica without a batch in this step (its flat gradient is zero) joins the step's two collectives."""
+    def _exchange_buckets(self, main, side):
+        """The step's two collectives, in this order on every rank: flat_grad[:tail_offset] (everything but the first GAT
+        layer: final when the side stream's queue has run) and the tail (the first layer: final when the main stream's last
+        backward graph has).  The process group's stream waits for the stream each is issued on; both are waited for on
+        the main stream (the update follows there)."""
         cut = self.opt.tail_offset
-        w1 = self.grad_sync_async(self.opt.flat_grad[:cut])
+        with torch.cuda.stream(side):
+            w1 = self.grad_sync_async(self.opt.flat_grad[:cut])
         w2 = self.grad_sync_async(self.opt.flat_grad[cut:])
         w1.wait()
         w2.wait()
+
+    def exchange_idle(self):
+        """A replica without a batch in this step (its flat gradient is zero) joins the step's two collectives."""
+        main = torch.cuda.current_stream()
+        self._exchange_buckets(main, main)
 
     def _run_staged(self, tp_i, tp, bi, epoch, with_update):
         key = (tp, bi, epoch >= 1, epoch >= self.cfg["ot_epoch"] and tp_i != 0, "staged")
         if key in self.graphs:
             graphs, out = self.graphs[key]
-            self._issue_staged([(g.replay if g is not None else None) for g in graphs])
+            self._issue_staged([g.replay for g in graphs])
             res = out.clone() if self.clone_output else out
         elif key not in self.seen:                                          # warm-up visit: eager, same stages
             self.seen.add(key)
@@ -986,37 +819,19 @@ class GraphedStepper:
             if self.pool is None:
                 self.pool, self.pool_side = torch.cuda.graph_pool_handle(), torch.cuda.graph_pool_handle()
             torch.cuda.synchronize()
-            graphs = []
             out = None
-            nf = len(fns)
-            graphs = [None] * nf
-            # capture order = data order: with svgp_head_first the SVGP forward is the two graphs at the END of the list (the
-            # one-graph form at index 1 is not captured), and they must exist before the tail reads their outputs
-            order = list(range(nf))
-            if self.svgp_head_first:
-                order = [0, nf - 2, nf - 1] + list(range(2, nf - 2))
-            if self.defer_wgrad and nf == 8:             # svgp_pre fills the holder the SVGP backward's capture reads
-                order = [0, 1, 7, 2, 3, 4, 5, 6]
-            if self.svgp_pre_generic:
-                order = [0, 1, nf - 1] + list(range(2, nf - 1))
-            for k in order:
-                fn = fns[k]
+            graphs = [None] * len(fns)
+            # capture order = data order (svgp_pre fills the holder the SVGP backward's capture reads)
+            for k in (0, 1, 7, 2, 3, 4, 5, 6):
                 g = torch.cuda.CUDAGraph()
-                side_stage = (k in (1, 3) or (self.svgp_head_first and k >= nf - 2)
-                              or (self.defer_wgrad and nf in (7, 8) and k in (6, 7))
-                              or (self.svgp_pre_generic and k == nf - 1))
-                pool = self.pool_side if side_stage else self.pool           # the SVGP stages run beside the GAT ones
-                if self.late_stream and self.defer_wgrad and nf in (7, 8) and k == 6:
-                    if self.pool_late is None:
-                        self.pool_late = torch.cuda.graph_pool_handle()
-                    pool = self.pool_late                                     # (runs beside BOTH other streams' graphs)
+                pool = self.pool_side if k in self.SIDE_STAGES else self.pool      # the side stream's graphs run beside the others
                 with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
-                    r = fn()
+                    r = fns[k]()
                 if k == 2:
                     out = r
                 graphs[k] = g
             self.graphs[key] = (graphs, out)
-            self._issue_staged([(g.replay if g is not None else None) for g in graphs])
+            self._issue_staged([g.replay for g in graphs])
             res = out.clone() if self.clone_output else out
         if with_update:
             self.update()
@@ -1028,10 +843,10 @@ class GraphedStepper:
         return self._run(tp_i, tp, bi, epoch, beta1, False)
 
     def step(self, tp_i, tp, bi, epoch, beta1):
-        if self.grad_sync is None:                  # single replica: the optimizer step is part of the step graph
+        if self.grad_sync is None:                  # single replica: the update follows the backward directly
             return self._run(tp_i, tp, bi, epoch, beta1, True)
         res = self.fb(tp_i, tp, bi, epoch, beta1)
-        if not self.overlap:                        # (bucketed exchange: already done beside the backward pass)
+        if not self.overlap:                        # (bucketed exchange: already issued behind the backward stages)
             self.grad_sync(self.opt.flat_grad)
         self.update()
         return res

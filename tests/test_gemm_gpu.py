@@ -215,75 +215,3 @@ def test_gemm_nn_matches_fp32_reference(M, N, K):
     err = (outs[0].float() - ref).abs()
     assert bool((err <= 2.0 ** -8 * ref.abs() + 1e-5 * mag + 1e-30).all()), float(err.max())
     assert torch.equal(outs[0], outs[1])
-
-
-# ------------------------------------------------------------------ small fp64 products on the fp64 matrix cores (csrc/gemm_f64.hip)
-
-@pytest.mark.parametrize("mode,batch,M,N,K,shareA,shareB", [
-    (2, 10, 236, 236, 512, False, True),      # G_l = c K_mn diag(w_l) K_nm  (svgp.py:62-66)
-    (2, 1, 10, 236, 512, True, True),         # t = (mu w)^T K_nm
-    (0, 10, 1024, 236, 236, True, False),     # X2 S_l
-    (0, 10, 236, 1, 236, False, False),       # S_l dr_l (a matrix-vector product)
-    (1, 1, 512, 10, 236, True, True),         # K_nm dt^T
-    (0, 3, 65, 67, 33, False, False), (1, 2, 1, 1, 1, False, False), (2, 4, 130, 63, 129, False, False), (0, 1, 64, 64, 32, True, True),
-])
-def test_dgemm_small_matches_torch_fp64(mode, batch, M, N, K, shareA, shareB):
-    """csrc k_dgemm_small (v_mfma_f64_16x16x4_f64, 64 x 64 tiles) against torch.matmul in fp64: every mode, shared and batched
-    operands, ragged sizes, addend and scale, and the row scaling of the TN mode; repeated calls bit-identical."""
-    from spadot_amd import ops
-    rng = np.random.default_rng(mode * 1000 + M + N + K)
-    shA = (K, M) if mode == 2 else (M, K)
-    shB = (N, K) if mode == 1 else (K, N)
-    A = torch.as_tensor(rng.normal(size=(shA if shareA else (batch,) + shA)), device=DEV)
-    B = torch.as_tensor(rng.normal(size=(shB if shareB else (batch,) + shB)), device=DEV)
-    C0 = torch.as_tensor(rng.normal(size=(M, N)), device=DEV)
-    opA = A.transpose(-1, -2) if mode == 2 else A
-    opB = B.transpose(-1, -2) if mode == 1 else B
-    ref = torch.matmul(opA, opB)
-    got = ops.dgemm_small(mode, A, B)
-    assert got.shape == ref.shape
-    scale = float(ref.abs().max()) + 1e-300
-    assert float((got - ref).abs().max()) <= 1e-12 * scale * max(1, K) ** 0.5
-    got2 = ops.dgemm_small(mode, A, B)
-    assert torch.equal(got, got2)
-    # alpha, beta, addend shared by the batch entries
-    out = torch.empty_like(ref)
-    ops.dgemm_small(mode, A, B, out=out, C0=C0, alpha=0.75, beta=-2.0)
-    ref2 = 0.75 * ref - 2.0 * C0
-    assert float((out - ref2).abs().max()) <= 1e-12 * (float(ref2.abs().max()) + 1e-300) * max(1, K) ** 0.5
-    if mode == 2:          # rows of A scaled along the contraction, one scale vector per batch entry, A and B shared
-        nb = 3
-        rs = torch.as_tensor(rng.uniform(0.5, 2.0, size=(nb, K)), device=DEV)
-        As, Bs = (A if A.dim() == 2 else A[0]), (B if B.dim() == 2 else B[0])
-        refr = torch.matmul((As.unsqueeze(0) * rs.unsqueeze(-1)).transpose(-1, -2), Bs)          # [nb, M, N]
-        gotr = ops.dgemm_small(2, As, Bs, rowscale=rs, C0=C0)
-        assert gotr.shape == refr.shape
-        refr = refr + C0
-        assert float((gotr - refr).abs().max()) <= 1e-12 * (float(refr.abs().max()) + 1e-300) * max(1, K) ** 0.5
-        # a strided scale view (columns of a [K, nb] matrix), as the SVGP branch passes w[:, l]
-        rs_t = rs.t().contiguous()                                                               # [K, nb]
-        gotv = ops.dgemm_small(2, As, Bs, rowscale=rs_t.t(), C0=C0)
-        assert torch.equal(gotv, gotr)
-
-
-@pytest.mark.parametrize("M,N,K,ldx,slices", [(512, 256, 3000, 3072, None), (512, 64, 256, 256, 4), (235, 33, 70, 70, 3), (1, 1, 1, 1, 1),
-                                              (64, 20, 64, 64, None), (300, 130, 1001, 1001, 7)])
-def test_sgemm_nt_slices_matches_fp64(M, N, K, ldx, slices, monkeypatch):
-    """csrc k_sgemm_nt_slices / k_sgemm_nt_oneshot + k_slices_sum (y = x W^T + b with the contraction in slices) against fp64: the
-    SVGP encoder's first map shape with its zero-padded rows (one-shot form: aligned rows, K % 4 == 0), ragged sizes and
-    unaligned leading dimensions (stepped form); bit-repeatable.  (Off by default in the step -- DESIGN section 4, round 4 --
-    so the switch is set here.)"""
-    from spadot_amd import ops
-    monkeypatch.setattr(ops, "SGEMM_SLICES", [True])
-    rng = np.random.default_rng(M + N + K)
-    x = torch.zeros((M, ldx), dtype=torch.float32, device=DEV)
-    x[:, :K] = torch.as_tensor(rng.normal(size=(M, K)), dtype=torch.float32)
-    W = torch.as_tensor(rng.normal(size=(N, K)), dtype=torch.float32, device=DEV)
-    b = torch.as_tensor(rng.normal(size=N), dtype=torch.float32, device=DEV)
-    assert ops.sgemm_nt_slices_ok(x, W)
-    y = ops.sgemm_nt_slices(x, W, b, slices)
-    ref = x[:, :K].double() @ W.double().T + b.double()
-    np.testing.assert_allclose(y.cpu().numpy(), ref.cpu().numpy(), rtol=2e-5, atol=2e-5 * K ** 0.5)
-    assert torch.equal(y, ops.sgemm_nt_slices(x, W, b, slices))
-    y0 = ops.sgemm_nt_slices(x, W, None, slices)
-    np.testing.assert_allclose(y0.cpu().numpy(), (ref - b.double()).cpu().numpy(), rtol=2e-5, atol=2e-5 * K ** 0.5)

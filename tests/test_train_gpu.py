@@ -379,11 +379,12 @@ def test_full_size_chained_replay_matches_unchained_replay_bf16():
     assert diff[0] <= max(5 * noise[0], 2e-5) and diff[1] <= max(5 * noise[1], 2e-6) and diff[2] <= max(5 * noise[2], 2e-5)
 
 
-def test_bucketed_exchange_splits_the_backward_without_changing_the_gradient():
-    """Optimizer built with the first GAT layer's parameters last + an async exchange hook: the staged replay cuts
-    the GAT backward at the first layer's output, hands `flat_grad[:tail_offset]` to the exchange BEFORE that layer's
-    backward and the tail after it; the flat gradient must equal the unsplit staged replay's, bit for bit, and the
-    first bucket must already be final when it is handed over."""
+def test_bucketed_exchange_hands_over_final_buckets_without_changing_the_gradient():
+    """Optimizer built with the first GAT layer's parameters last + an async exchange hook (what data-parallel ranks on their
+    own devices use, round 5): the SAME staged graphs as a single GPU replays -- the queue of deferred gradient work included --
+    with `flat_grad[:tail_offset]` handed to the exchange behind the queue (side stream) and the first layer's gradients behind
+    the main stream's last backward graph.  The flat gradient must equal the staged replay's without an exchange, bit for bit,
+    both buckets must be FINAL when they are handed over, and their order is fixed."""
     from spadot_amd.model import SpaDOT
     from spadot_amd.ops import FlatAdamW
     from spadot_amd.synthetic import make_dataset
@@ -396,7 +397,7 @@ def test_bucketed_exchange_splits_the_backward_without_changing_the_gradient():
     dd = tu.prepare_dataloader(data, cfg)
     model = SpaDOT.SpaDOT(cfg, dd).to(DEV)
     first = model.GATEncoder.first_layer_parameters()
-    opt = FlatAdamW(model.parameters(), lr=cfg["lr"], last=first)
+    opt = FlatAdamW(model.parameters(), lr=cfg["lr"], last=first, first=model.SVGPEncoder.parameters())
     cut = opt.tail_offset
     assert cut is not None and opt.count - cut >= sum(p.numel() for p in first)
     assert all(p.grad.data_ptr() >= opt.flat_grad.data_ptr() + 4 * cut for p in first)
@@ -411,17 +412,13 @@ def test_bucketed_exchange_splits_the_backward_without_changing_the_gradient():
             pass
 
     def fake_async(view):
+        # (the clone is enqueued on the stream the exchange is issued on -- where a process group's stream would start waiting)
         seen.append((view.data_ptr() - opt.flat_grad.data_ptr(), view.numel(), view.clone()))
         return Handle()
 
-    # (the unsplit five-graph form WITHOUT the queue of round 4 -- deferred gradient work and the late ELBO need it, the bucketed
-    # form cannot take them: "bit for bit" is about where the backward is cut, not about two routes through the same algebra;
-    # those are compared, to rounding, in test_deferred_weight_gradients_leave_the_same_gradient.  Both forms here DO take the
-    # SVGP backward's precomputed half and the fused cluster launch: svgp_pre_generic)
-    plain = tu.GraphedStepper(model, opt, dict(cfg, staged_graphs=True, defer_wgrad=False), dd)
+    plain = tu.GraphedStepper(model, opt, dict(cfg, staged_graphs=True), dd)
     split = tu.GraphedStepper(model, opt, dict(cfg, staged_graphs=True), dd, grad_sync=lambda f: f, grad_sync_async=fake_async)
-    assert split.overlap and not plain.overlap and not plain.defer_wgrad and not plain.svgp_pre
-    assert plain.svgp_pre_generic and split.svgp_pre_generic and plain.cluster_fb and split.cluster_fb
+    assert split.overlap and not plain.overlap and split.staged and plain.staged
     for rep in range(4):                                   # eager, capture + replay, replay, replay
         for bi in range(2):
             la = plain.fb(1, 1, bi, cfg["ot_epoch"], 0.5)
@@ -434,6 +431,11 @@ def test_bucketed_exchange_splits_the_backward_without_changing_the_gradient():
             np.testing.assert_array_equal(opt.flat_grad.cpu().numpy(), ga.cpu().numpy())
             assert [(o_, n_) for o_, n_, _ in seen] == [(0, cut), (4 * cut, opt.count - cut)]
             np.testing.assert_array_equal(seen[0][2].cpu().numpy(), ga[:cut].cpu().numpy())    # final when handed over
+            np.testing.assert_array_equal(seen[1][2].cpu().numpy(), ga[cut:].cpu().numpy())
+    # a replica without a batch in a step joins the same two collectives in the same order
+    del seen[:]
+    split.exchange_idle()
+    assert [(o_, n_) for o_, n_, _ in seen] == [(0, cut), (4 * cut, opt.count - cut)]
 
 
 def _dp_worker(rank, world, port, q, staged=None, granularity="batch"):
@@ -712,16 +714,60 @@ def test_weight_images_follow_every_writer_of_the_weights():
     assert not opt.maintain_image(enc.gat1.lin.weight, weight_image(enc.gat1.lin.weight, 256, torch.bfloat16, enc.gat1))
 
 
+def test_small_timepoint_bf16_staged_replay_matches_eager():
+    """A time point with fewer than 1 024 spots in the bf16 compute dtype (ChickenHeart's first: 747): the weight-gradient and
+    dense-map kernels refuse such row counts and the LIBRARY products run instead -- the deferred ones inside the `late`
+    queue, i.e. outside any autograd backward.  Round 5's ChickenHeart-shaped run found that such a product written with out=
+    into a flat-gradient view from a saved activation that requires grad turned the whole flat buffer into a non-leaf (the
+    queue now runs without a tape).  Staged replay == eager step, flat buffer still a plain leaf, replay after replay; G is
+    not a multiple of 4 either (2 954 genes there)."""
+    from spadot_amd.model import SpaDOT
+    from spadot_amd.ops import FlatAdamW
+    from spadot_amd.synthetic import make_dataset
+    from spadot_amd.utils import _train_utils as tu, _utils
+    data = make_dataset(2, [747, 1966], 602, seed=4)
+    cfg = _utils.load_model_config(types.SimpleNamespace(config=None))
+    cfg.update(input_dim=602, timepoints=[0, 1], device=torch.device(DEV), compute_dtype=torch.bfloat16, inducing_point_nums=300)
+    _utils.set_seed(cfg["seed"])
+    dd = tu.prepare_dataloader(data, cfg)
+    model = SpaDOT.SpaDOT(cfg, dd).to(DEV)
+    opt = FlatAdamW(model.parameters(), lr=cfg["lr"], first=model.SVGPEncoder.parameters())
+    tu._update_Kmeans(model, cfg, dd)
+    tu._update_OT_matrix(model, cfg)
+    model.train()
+    model.fixed_noise = (torch.zeros((512, 10), device=DEV), torch.zeros((512, 10), device=DEV))
+    staged = tu.GraphedStepper(model, opt, dict(cfg, staged_graphs=True), dd)
+    ep = cfg["ot_epoch"]
+    pgrad = lambda: torch.cat([p.grad.reshape(-1) for p in opt.params])
+    for rep in range(3):
+        for tp_i, tp, bi in ((0, 0, 1), (1, 1, 3), (0, 0, 0)):          # partial last batches (235, 430 seeds) and a full one
+            staged.beta1_t[1].fill_(-0.5)
+            la = tu.forward_backward(model, cfg, dd, tp_i, tp, bi, ep, staged.beta1_t, optimizer=opt)
+            ga = pgrad().clone()
+            for p in opt.params:
+                p.grad.fill_(7.0)
+            lb = staged.fb(tp_i, tp, bi, ep, 0.5)
+            torch.cuda.synchronize()
+            assert not opt.flat_grad.requires_grad and all(not p.grad.requires_grad for p in opt.params)
+            gb = pgrad()
+            assert torch.isfinite(lb).all() and torch.isfinite(gb).all()
+            np.testing.assert_allclose(lb.cpu().numpy(), la.cpu().numpy(), rtol=1e-4, atol=1e-5)
+            np.testing.assert_allclose(gb.cpu().numpy(), ga.cpu().numpy(), rtol=2e-3, atol=2e-4 * float(ga.abs().max()))
+    for k in range(4):
+        out = staged.step(k % 2, k % 2, k % 2, ep, 0.5)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all() and torch.isfinite(opt.flat_param).all()
+
+
 def test_deferred_weight_gradients_leave_the_same_gradient():
-    """GraphedStepper(defer_wgrad): the second GAT layer's weight gradient, the last layer's weight / attention-vector chain and
-    the decoder output map's weight gradient are queued by the backward functions and run later on the side stream (round 4).
-    Same kernels on the same operands: the flat gradient of a replayed step equals the one the stepper leaves with the switch
-    off, to the run-to-run noise of the replay itself (measured here by replaying twice; bit-identical when the library's
-    products are) -- bf16, 4000 spots x 1200 genes: the matrix-core paths and the aggregate-first last layer.
-    The switch also carries the other single-GPU reorderings of round 4 (they need its queue and its extra stage): the SVGP
-    backward's gradient-independent half formed beside the tail with q1 through T = X2 S K_mn, the posterior handed over before
-    the ELBO scalars, the fused cluster launch with its gradient added by the decoder chain -- other routes through the same
-    algebra, so the comparison is to rounding (1e-7 of the largest gradient entry), not bit for bit."""
+    """The staged replay (the default arrangement): the second GAT layer's weight gradient and attention / bias sums, the last
+    layer's weight / attention-vector chain and the decoder output map's weight gradient are queued by the backward functions
+    and run later on the side stream; the SVGP backward's gradient-independent half is formed beside the tail with q1 through
+    T = X2 S K_mn, the posterior is handed over before the ELBO scalars, the cluster terms and their gradient are one launch.
+    Against the SINGLE-GRAPH replay of the same batches (`staged_graphs: false`: the plain step body, nothing queued, nothing
+    precomputed): other routes through the same algebra, so the comparison is to rounding (1e-7 of the largest gradient entry
+    beyond the single-graph replay's own run-to-run noise), not bit for bit -- bf16, 4000 spots x 1200 genes: the matrix-core
+    paths and the aggregate-first last layer."""
     from spadot_amd.model import SpaDOT
     from spadot_amd.ops import FlatAdamW
     from spadot_amd.synthetic import make_dataset
@@ -738,12 +784,10 @@ def test_deferred_weight_gradients_leave_the_same_gradient():
     tu._update_OT_matrix(model, cfg)
     model.train()
     model.fixed_noise = (torch.zeros((512, 10), device=DEV), torch.zeros((512, 10), device=DEV))
-    on = tu.GraphedStepper(model, opt, dict(cfg, staged_graphs=True, defer_wgrad=True), dd)
-    off = tu.GraphedStepper(model, opt, dict(cfg, staged_graphs=True, defer_wgrad=False), dd)
-    assert on.defer_wgrad and not off.defer_wgrad
-    assert on.svgp_pre and on.svgp_elbo_late and on.cluster_fb and not (off.svgp_pre or off.svgp_elbo_late)
-    assert off.svgp_pre_generic and off.cluster_fb          # (the five-graph form keeps the precomputed half and the fused launch)
-    object.__setattr__(model.GATEncoder.gat2, "defer_wgrad", True)      # (the flag on the layer only permits queueing)
+    on = tu.GraphedStepper(model, opt, dict(cfg, staged_graphs=True), dd)
+    off = tu.GraphedStepper(model, opt, dict(cfg, staged_graphs=False), dd)
+    assert on.staged and not off.staged
+    assert model.GATEncoder.gat2.defer_wgrad            # (the flag on the layer only permits queueing: nothing queues in `off`)
     ep = cfg["ot_epoch"]
     for rep in range(3):                                   # eager, capture + replay, replay
         for bi in (0, 2):

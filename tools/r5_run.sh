@@ -1,0 +1,24 @@
+# one-off GPU call of round 5 (removed at the end of the round; results go to profiles/r05/)
+set -eo pipefail
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r5
+mkdir -p $O
+case "$1" in
+tests)
+  timeout -k 10 1000 python -m pytest tests -m gpu -x -q 2>&1 | tail -25 > $O/tests.txt; cat $O/tests.txt ;;
+probe)
+  bash tools/gat_probe.sh "" "-DEDOT_PROBE=1" "-DEDOT_PROBE=2" "-DEDOT_PROBE=4" "-DEDOT_PROBE=8" "-DEDOT_PROBE=7" 2>&1 | tee $O/gat_probe.txt
+  timeout -k 10 300 python tools/e2e_chickenheart.py bf16 > $O/e2e_chickenheart_bf16.txt 2> $O/e2e_bf16.err || tail -4 $O/e2e_bf16.err ;;
+m1)
+  timeout -k 10 400 python -m pytest tests/test_gat_mfma_gpu.py tests/test_gat_tail_gpu.py tests/test_train_gpu.py -x -q -k "gat or deferred or staged or bucketed" 2>&1 | tail -5
+  timeout -k 10 300 python tools/tail_f32_diag.py 2>&1 | grep -v Warn | tee $O/tail_f32_diag.txt
+  bash tools/ab_step.sh "SPADOT_ATT_FLAT=0" "SPADOT_ATT_FLAT=1" 2>&1 | tee $O/ab_att_flat.txt
+  SPADOT_STAMPS=1 timeout -k 10 300 python tools/stage_stamps.py > $O/stage_stamps_att_flat.txt 2> $O/stamps.err || tail -5 $O/stamps.err
+  cat $O/stage_stamps_att_flat.txt
+  timeout -k 10 300 python bench.py --preset cfg2 --leg train --no-cpu-baseline --repeats 5 > $O/bench_cfg2.json 2> $O/bench_cfg2.err || tail -5 $O/bench_cfg2.err
+  python tools/bench_value.py cfg2 < $O/bench_cfg2.json
+  timeout -k 10 400 python bench.py --preset cfg5shape --leg train --no-cpu-baseline --repeats 5 > $O/bench_cfg5shape.json 2> $O/bench_cfg5shape.err || tail -5 $O/bench_cfg5shape.err
+  python tools/bench_value.py cfg5shape < $O/bench_cfg5shape.json
+  timeout -k 10 500 python tools/e2e_chickenheart.py > $O/e2e_chickenheart.txt 2> $O/e2e.err || tail -5 $O/e2e.err
+  grep -v "^Epoch\|^Calculating\|^The graph" $O/e2e_chickenheart.txt | tail -40 ;;
+esac

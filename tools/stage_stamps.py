@@ -22,7 +22,7 @@ from spadot_amd.ops import FlatAdamW  # noqa: E402
 from spadot_amd.synthetic import make_dataset  # noqa: E402
 from spadot_amd.utils import _train_utils as tu, _utils  # noqa: E402
 
-NAMES = {0: "gat_fwd", 1: "svgp_fwd", 2: "tail", 3: "svgp_bwd", 4: "gat_bwd", 5: "stage5", 6: "stage6", 7: "stage7", 12: "upd_head", 13: "upd_rest"}
+NAMES = {0: "gat_fwd", 1: "svgp_fwd", 2: "tail", 3: "svgp_bwd", 4: "gat_bwd_a", 5: "gat_bwd_b", 6: "late", 7: "svgp_pre", 12: "upd_head", 13: "upd_rest"}
 
 
 def main():
@@ -65,15 +65,12 @@ def main():
     rel = a - t0
     med = np.median(rel, axis=0)
     print(f"median over {len(rows)} replayed steps (us, relative to the start of the GAT forward graph):")
-    head_first = os.environ.get("SPADOT_SVGP_HEAD") == "1"
-    if head_first:
-        NAMES[5], NAMES[6] = "svgp_head", "svgp_rest"
     for k, name in sorted(NAMES.items()):
         s, e = med[2 * k], med[2 * k + 1]
         if a[:, 2 * k].max() == 0:
             continue
         print(f"  {name:10s} start {s:9.1f}  end {e:9.1f}  ({e - s:7.1f})")
-    sv_start, sv_end = (med[12], med[13]) if head_first else (med[2], med[3])          # the SVGP forward's last graph
+    sv_start, sv_end = med[2], med[3]
     if a[:, 16].max() > 0:
         print(f"  inside svgp_fwd: encoder {med[16] - med[2]:.1f} us, Sigma build {med[17] - med[16]:.1f}, inverse {med[18] - med[17]:.1f}, "
               f"behind the inverse {med[3] - med[18]:.1f}")
@@ -81,8 +78,8 @@ def main():
         print(f"  inside the encoder: first map {med[19] - med[2]:.1f} us, BN {med[20] - med[19]:.1f}, hidden map {med[21] - med[20]:.1f}, "
               f"BN {med[22] - med[21]:.1f}, SVGP_fc {med[16] - med[22]:.1f}; Sigma build: pre2 {med[23] - med[16]:.1f}, G {med[28] - med[23]:.1f}, "
               f"t {med[17] - med[28]:.1f}")
-    print(f"  svgp_bwd starts {med[6] - med[5]:.1f} us after the tail ends; gat_bwd starts {med[8] - med[5]:.1f} us after the tail ends")
-    print(f"  svgp_fwd ends {sv_end - med[1]:+.1f} us relative to gat_fwd's end; svgp_bwd ends {med[7] - med[9]:+.1f} us relative to gat_bwd's end")
+    print(f"  svgp_bwd starts {med[6] - med[5]:.1f} us after the tail ends; gat_bwd_a starts {med[8] - med[5]:.1f} us after the tail ends")
+    print(f"  svgp_fwd ends {sv_end - med[1]:+.1f} us relative to gat_fwd's end; the queue (late) ends {med[13] - med[11]:+.1f} us relative to gat_bwd_b's end")
     print(f"  step period (upd_rest end of this step - upd_rest end of the previous one is not stamped): gat_fwd start -> upd_rest end {med[27]:.1f} us")
 
 
