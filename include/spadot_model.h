@@ -258,6 +258,26 @@ int spadot_kmeans_assign(const void *x, const void *centers, int n, int k, int d
 int spadot_sgemm_small(int mode, const float *A, int lda, const float *B, int ldb, float *C, int ldc, int M, int N, int K,
                        const float *bias, int batch, long long strideA, long long strideB, long long strideC, void *stream);
 
+/* ---- The SVGP encoder behind its first map as three launches (csrc/enc_fused.hip, round 5; encoder.py:7-34 in training mode) ----
+ * h1 [b x F1] (fp32, the first map's output without its bias) -> BatchNorm1d + LeakyReLU -> y1 -> hidden map -> h2 [b x F2] ->
+ * BatchNorm1d + LeakyReLU -> y2 -> SVGP_fc -> z [b x Q].  The two maps cross workgroups as PARTIAL PRODUCTS in a caller-owned
+ * workspace (spadot_enc_fused_workspace floats: part [F1 / 16][b][F2], then pz [F2 / 4][b][Q]), summed in group order by the
+ * next launch: spadot_enc_bn_map (statistics of 16 columns of h1, y1, running statistics, part), spadot_enc_bn_fc (h2 = sum of
+ * part -- stored without the map's bias, which BatchNorm's lin_bias carries --, y2, running statistics, pz), and either
+ * spadot_enc_sum_z (z = bias + sum of pz) or spadot_svgp_pre2_partials (spadot_svgp_pre2 reading z from pz; it also stores z).
+ * b <= 512, F1 % 16 == 0, F2 % 4 == 0, F2 <= 128, Q <= 32.  y1 is bit for bit what spadot_bn_act_forward writes. */
+int spadot_enc_fused_supported(int b, int F1, int F2, int Q);
+long long spadot_enc_fused_workspace(int b, int F1, int F2, int Q);
+int spadot_enc_bn_map(const float *h1, const float *lin_bias, const float *gamma, const float *beta, float *running_mean,
+                      float *running_var, long long *num_batches_tracked, int b, int F1, double momentum, double eps, double slope,
+                      float *y1, float *save_mean, float *save_invstd, const float *W2, int F2, float *part, void *stream);
+int spadot_enc_bn_fc(const float *part, int nparts, const float *lin_bias, const float *gamma, const float *beta, float *running_mean,
+                     float *running_var, long long *num_batches_tracked, int b, int F2, double momentum, double eps, double slope,
+                     float *h2, float *y2, float *save_mean, float *save_invstd, const float *Wfc, int Q, float *pz, void *stream);
+int spadot_enc_sum_z(const float *pz, int nparts, const float *bias, int b, int Q, float *z, void *stream);
+int spadot_svgp_pre2_partials(const float *pz, int nparts, const float *bias, const double *Kn, int b, int L, int m, float *z,
+                              double *mu, double *var, double *w, double *muw, double *A, void *stream);
+
 /* Measurement aid: buf[slot] = the device's constant-rate timestamp counter (100 MHz: 10 ns units) when the launch runs.
  * Launched at the head and the end of a captured stage it dates the stage on the GPU with no profiler attached. */
 int spadot_stamp(unsigned long long *buf, int slot, void *stream);
@@ -336,7 +356,8 @@ int spadot_gat_mfma_supported(int dtype, int H, int C, int max_cols);
  *   spadot_gat_tail_headmean         out [n_tgt][C] = 1/H sum_h O[h] + bias            (O [H][n_tgt][C] = A_h W_h^T, a library GEMM)
  *   spadot_gat_tail_colsum_rows      column sums of g [rows][C] in fp32 (the bias gradient)
  *   spadot_gat_tail_edge_backward    dz [E][H] = d logit per edge (through aggregation, softmax and leaky_relu), ds_dst [n_tgt][H]
- *   spadot_gat_tail_source_backward  dx [rows_out][lddx] (rows n .. rows_out - 1 zero), ds_src [n][H]
+ *   spadot_gat_tail_source_backward  dx [rows_out][lddx] (rows n .. rows_out - 1 zero), ds_src [n][H]; with act_out (the layer's
+ *                                    input rows [rows_out][ldm], may be NULL) dx is multiplied by `slope` where act_out <= 0
  *   spadot_gat_tail_dwvec            per-block partials [spadot_gat_tail_dwvec_rows(n)][2 H][K] of d wv (spadot_colsum adds them)
  *   spadot_gat_tail_wvec_backward    dW (+)= att (x) d wv per row of W, datt = W d wv
  * All sums in fixed orders, no atomics: repeated calls are bit-identical. */
@@ -355,7 +376,7 @@ int spadot_gat_tail_edge_backward(const void *x, int dtype, int ldx, const void 
                                   const int *col, int n_tgt, int H, int K, float *dz, float *ds_dst, void *stream);
 int spadot_gat_tail_source_backward(const void *dA, int dtype, const float *alpha, const float *dz, const float *ds_dst, const float *wv,
                                     const int *rowptr_t, const int *col_t, const int *eid_t, int n, int n_tgt, int rows_out, int H, int K,
-                                    void *dx, int lddx, float *ds_src, void *stream);
+                                    void *dx, int lddx, float *ds_src, const void *act_out, int ldm, double slope, void *stream);
 int spadot_gat_tail_dwvec_rows(int n);
 int spadot_gat_tail_dwvec(const void *x, int dtype, int ldx, const float *ds_src, const float *ds_dst, int n, int n_tgt, int H, int K,
                           float *part, void *stream);
@@ -388,6 +409,11 @@ int spadot_gemm_tn_bf16(const void *A, int lda, const void *B, int ldb, void *C,
 /* The same kernel with B stored [K x N] (contraction index = row; transposed LDS reads for that operand): C = A . B, the
  * input gradient of a dense map (dx = g W with W the [N_out x K_in] weight image).  Same shape conditions. */
 int spadot_gemm_nn_bf16(const void *A, int lda, const void *B, int ldb, void *C, int ldc, int M, int N, int K, void *stream);
+/* ... with C[m][n] multiplied by `slope` wherever act_out[m][n] <= 0 (act_out [M x N] bf16, row stride ldm): the input gradient
+ * of a dense map, dx = g W, times the LeakyReLU' of the activation that produced the map's INPUT (encoder.py:56-57) -- handed
+ * to the layer below already masked, so that its edge backward neither reads its own output nor writes a masked copy. */
+int spadot_gemm_nn_bf16_masked(const void *A, int lda, const void *B, int ldb, void *C, int ldc, int M, int N, int K,
+                               const void *act_out, int ldm, double slope, void *stream);
 /* spadot_gemm_tn_bf16 with the LAST `tail_row_tiles` row panels (320 rows each) cut into `slices` (2..8) slices of the
  * contraction; fp32 partial tiles in the caller's `workspace` (spadot_gemm_bf16_split_workspace floats, 16-byte aligned),
  * added in slice order and rounded once to bf16 by a second launch: bit-reproducible.  For a map whose grid is exactly one

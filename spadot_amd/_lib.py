@@ -185,7 +185,7 @@ def model_lib():
         "spadot_gat_tail_colsum_rows": [vp, ci, ci, ci, vp, vp],
         "spadot_gat_tail_scale_colsum": [vp, ci, ci, ci, cd, vp, vp, vp],
         "spadot_gat_tail_edge_backward": [vp, ci, ci, vp, vp, vp, vp, vp, ci, ci, ci, vp, vp, vp],
-        "spadot_gat_tail_source_backward": [vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, ci, vp, vp],
+        "spadot_gat_tail_source_backward": [vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, ci, vp, vp, ci, cd, vp],
         "spadot_gat_tail_dwvec_rows": [ci],
         "spadot_gat_tail_dwvec": [vp, ci, ci, vp, vp, ci, ci, ci, ci, vp, vp],
         "spadot_gat_tail_wvec_backward": [vp, ci, vp, vp, vp, ci, ci, ci, vp, ci, ci, vp, vp, vp],
@@ -193,6 +193,12 @@ def model_lib():
         "spadot_gat_edge_dot": [vp, vp, vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, ci, ci, vp],
         "spadot_gemm_tn_bf16": [vp, ci, vp, ci, vp, ci, ci, ci, ci, vp],
         "spadot_gemm_nn_bf16": [vp, ci, vp, ci, vp, ci, ci, ci, ci, vp],
+        "spadot_enc_fused_supported": [ci, ci, ci, ci],
+        "spadot_enc_bn_map": [vp, vp, vp, vp, vp, vp, vp, ci, ci, cd, cd, cd, vp, vp, vp, vp, ci, vp, vp],
+        "spadot_enc_bn_fc": [vp, ci, vp, vp, vp, vp, vp, vp, ci, ci, cd, cd, cd, vp, vp, vp, vp, vp, ci, vp, vp],
+        "spadot_enc_sum_z": [vp, ci, vp, ci, ci, vp, vp],
+        "spadot_svgp_pre2_partials": [vp, ci, vp, vp, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp],
+        "spadot_gemm_nn_bf16_masked": [vp, ci, vp, ci, vp, ci, ci, ci, ci, vp, ci, cd, vp],
         "spadot_gemm_tn_bf16_split": [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, vp],
         "spadot_gemm_wgrad_bf16": [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, vp, vp, vp],
         "spadot_gemm_wgrad_bf16_tiled": [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp],
@@ -253,6 +259,8 @@ def model_lib():
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = ci
+    lib.spadot_enc_fused_workspace.argtypes = [ci, ci, ci, ci]
+    lib.spadot_enc_fused_workspace.restype = ll
     lib.spadot_gemm_bf16_split_workspace.argtypes = [ci, ci, ci, ci]
     lib.spadot_gemm_bf16_split_workspace.restype = ll
     lib.spadot_gemm_wgrad_bf16_workspace.argtypes = [ci, ci, ci, ci]

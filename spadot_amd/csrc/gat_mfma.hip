@@ -551,7 +551,7 @@ __global__ __launch_bounds__(NT, EDOT_WGS) void k_gat_edot(const __bf16 *__restr
                 }
                 g = make_uint4(gw[0], gw[1], gw[2], gw[3]);
             }
-            if (!(EDOT_PROBE & 1)) *reinterpret_cast<uint4 *>(g_pre + off) = g;
+            if (g_pre != nullptr && !(EDOT_PROBE & 1)) *reinterpret_cast<uint4 *>(g_pre + off) = g;
         }
         *reinterpret_cast<uint4 *>(gt + (size_t)r * GS + (size_t)((pc ^ (r & XM)) * 16)) = g;
     }
@@ -675,7 +675,8 @@ int spadot_gat_edge_dot(const void *g_out, const void *out, const void *h, int d
                         const int *plan_sptr, const int *plan_cols, const int *plan_cell, int nb, int max_cols, int H,
                         int C, int act, void *g_pre, float *dz, float *bias_part, int part_width, int part_col, void *stream) {
     if (!spadot_gat_mfma_supported(dtype, H, C, max_cols) || nb <= 0) return -22;
-    if (!g_out || !h || !plan_rows || !plan_sptr || !plan_cols || !plan_cell || !g_pre || !dz || (act && !out)) return -22;
+    // (g_pre may be NULL when act == 0: the caller then keeps using g_out -- a gradient that arrived already masked)
+    if (!g_out || !h || !plan_rows || !plan_sptr || !plan_cols || !plan_cell || !dz || (act && (!out || !g_pre))) return -22;
     if (bias_part && (part_col < 0 || part_col % 2 || part_width % 2 || part_width < part_col + H * C || ((uintptr_t)bias_part & 7))) return -22;
     hipStream_t st_ = (hipStream_t)stream;
     const unsigned grid = 8u * (unsigned)((nb * H + 7) / 8);

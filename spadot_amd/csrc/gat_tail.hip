@@ -569,7 +569,10 @@ __global__ __launch_bounds__(NT) void k_tail_src_bwd(const T *__restrict__ dA, c
                                                      const float *__restrict__ ds_dst, const float *__restrict__ wv,
                                                      const int *__restrict__ rowptr_t, const int *__restrict__ col_t,
                                                      const int *__restrict__ eid_t, int n, int n_tgt, int rows_out, int K,
-                                                     T *__restrict__ dx, int lddx, float *__restrict__ ds_src) {
+                                                     T *__restrict__ dx, int lddx, float *__restrict__ ds_src,
+                                                     const T *__restrict__ msk, int ldm, float slope) {
+    // msk (optional, the layer's INPUT rows x [rows_out x ldm]): dx is multiplied by `slope` where x <= 0 -- x is the activated
+    // output of the layer below, so this is that layer's LeakyReLU' applied to its incoming gradient as it is produced
     constexpr int Q = 2 * H, ROWS = 8, MAXE = 128;
     // the block's edge records are fetched ONCE, together, into LDS (row pointers -> edge ids / targets -> alpha, d logit:
     // three dependent loads for the whole block instead of three per row); the row loop then only gathers dA rows
@@ -622,7 +625,15 @@ __global__ __launch_bounds__(NT) void k_tail_src_bwd(const T *__restrict__ dA, c
                     if (t == h) ds_src[(size_t)j * H + h] = dss[h];
                 }
             }
-            if (j < rows_out && live) store8<T>(dx + (size_t)j * lddx + k, acc);
+            if (j < rows_out && live) {
+                if (msk != nullptr) {
+                    float mv[8];
+                    load8<T>(msk + (size_t)j * ldm + k, mv);
+#pragma unroll
+                    for (int q = 0; q < 8; q++) if (!(mv[q] > 0.f)) acc[q] *= slope;
+                }
+                store8<T>(dx + (size_t)j * lddx + k, acc);
+            }
 #pragma unroll
             for (int q = 0; q < 8; q++) acc[q] = 0.f;
 #pragma unroll
@@ -688,7 +699,15 @@ __global__ __launch_bounds__(NT) void k_tail_src_bwd(const T *__restrict__ dA, c
             for (int h = 0; h < H; h++)
                 if (t == h) ds_src[(size_t)j * H + h] = dss[h];
         }
-        if (live) store8<T>(dx + (size_t)j * lddx + k, acc);
+        if (live) {
+            if (msk != nullptr) {
+                float mv[8];
+                load8<T>(msk + (size_t)j * ldm + k, mv);
+#pragma unroll
+                for (int q = 0; q < 8; q++) if (!(mv[q] > 0.f)) acc[q] *= slope;
+            }
+            store8<T>(dx + (size_t)j * lddx + k, acc);
+        }
     }
 }
 
@@ -883,14 +902,15 @@ int spadot_gat_tail_edge_backward(const void *x, int dtype, int ldx, const void 
 
 int spadot_gat_tail_source_backward(const void *dA, int dtype, const float *alpha, const float *dz, const float *ds_dst, const float *wv,
                                     const int *rowptr_t, const int *col_t, const int *eid_t, int n, int n_tgt, int rows_out, int H, int K,
-                                    void *dx, int lddx, float *ds_src, void *stream) {
+                                    void *dx, int lddx, float *ds_src, const void *act_out, int ldm, double slope, void *stream) {
+    if (act_out && (ldm < K || ldm % 8 || ((uintptr_t)act_out & 15))) return -22;
     if (!dA || !alpha || !dz || !ds_dst || !wv || !rowptr_t || !col_t || !eid_t || !dx || !ds_src || n <= 0 || n_tgt <= 0 || n_tgt > n ||
         rows_out < n || !spadot_gat_tail_supported(dtype, H, K) || lddx < K || lddx % 8)
         return -22;
     hipStream_t st = (hipStream_t)stream;
     const int rows = 8, grid = (rows_out + rows - 1) / rows;
 #define SBWD(T_) TAIL_DISPATCH_H(H, hipLaunchKernelGGL((k_tail_src_bwd<T_, HH>), dim3(grid), dim3(NT), 0, st, (const T_ *)dA, alpha, dz, ds_dst, \
-                                                         wv, rowptr_t, col_t, eid_t, n, n_tgt, rows_out, K, (T_ *)dx, lddx, ds_src))
+                                                         wv, rowptr_t, col_t, eid_t, n, n_tgt, rows_out, K, (T_ *)dx, lddx, ds_src, (const T_ *)act_out, ldm, (float)slope))
     if (dtype == DT_BF16) { SBWD(__bf16); } else { SBWD(float); }
 #undef SBWD
     return rc_last();

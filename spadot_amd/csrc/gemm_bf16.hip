@@ -61,7 +61,7 @@ template <bool BT>
 __global__ __launch_bounds__(NT, 1) void k_gemm_bf16(const __bf16 *__restrict__ A, int lda, const __bf16 *__restrict__ B,
                                                     int ldb, __bf16 *__restrict__ C, int ldc, int M, int N, int K,
                                                     int mtiles, int ntiles, int full_items, int S, int nk_slice,
-                                                    float *__restrict__ part) {
+                                                    float *__restrict__ part, const __bf16 *__restrict__ msk, int ldm, float slope) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // tile of this workgroup: the ntiles column tiles of one row panel are consecutive work items of one XCD.  Items
     // 0 .. full_items - 1 are whole tiles (the grid's first 8 ceil(full_items / 8) workgroups); the tiles behind them (the last
@@ -268,6 +268,9 @@ __global__ __launch_bounds__(NT, 1) void k_gemm_bf16(const __bf16 *__restrict__ 
         return;
     }
     // ---- epilogue: per wave and 32-row tile, accumulators -> bf16 [32 x 64] patch in LDS -> 128-byte row pieces
+    // msk (optional, same shape as C): C[m][n] is multiplied by `slope` where msk[m][n] <= 0 -- the LeakyReLU' of the layer
+    // whose OUTPUT msk is, applied to that layer's incoming gradient as this GEMM produces it (round 5: the GAT edge
+    // backward then neither reads that output nor writes a masked copy of the gradient: 82 MB less per layer)
     unsigned char *patch = smem + (size_t)wave * 4096;            // 32 rows x 128 B, private to the wave
     // element (row m, column n) of acc[i][j]: lane m (+32: hh), register e -> n = (e & 3) + 8 (e >> 2) + 4 hh
 #pragma unroll
@@ -285,7 +288,20 @@ __global__ __launch_bounds__(NT, 1) void k_gemm_bf16(const __bf16 *__restrict__ 
         for (int p = 0; p < 4; p++) {
             const int pr = p * 8 + (lane >> 3), pc = lane & 7;    // 8 rows per pass, 8 x 16 B per row
             const int gm = m0 + wm * 160 + i * 32 + pr;
-            const uint4 v = *reinterpret_cast<const uint4 *>(patch + pr * 128 + pc * 16);
+            uint4 v = *reinterpret_cast<const uint4 *>(patch + pr * 128 + pc * 16);
+            if (msk != nullptr && gm < M) {
+                const uint4 mk = *reinterpret_cast<const uint4 *>(msk + (size_t)gm * ldm + n0 + wn * 64 + pc * 8);
+                unsigned vw[4] = {v.x, v.y, v.z, v.w};
+                const unsigned mw[4] = {mk.x, mk.y, mk.z, mk.w};
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    float lo = __uint_as_float(vw[e] << 16), hi = __uint_as_float(vw[e] & 0xffff0000u);
+                    if (!(__uint_as_float(mw[e] << 16) > 0.f)) lo *= slope;
+                    if (!(__uint_as_float(mw[e] & 0xffff0000u) > 0.f)) hi *= slope;
+                    vw[e] = pack2(lo, hi);
+                }
+                v = make_uint4(vw[0], vw[1], vw[2], vw[3]);
+            }
             if (gm < M) *reinterpret_cast<uint4 *>(C + (size_t)gm * ldc + n0 + wn * 64 + pc * 8) = v;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -316,7 +332,9 @@ __global__ __launch_bounds__(256) void k_gemm_tail_reduce(const float *__restric
 }  // namespace
 
 template <bool BT>
-static int launch_gemm(const void *A, int lda, const void *B, int ldb, void *C, int ldc, int M, int N, int K, void *stream) {
+static int launch_gemm(const void *A, int lda, const void *B, int ldb, void *C, int ldc, int M, int N, int K, void *stream,
+                       const void *msk = nullptr, int ldm = 0, float slope = 1.f) {
+    if (msk && (ldm < N || ldm % 8 || ((uintptr_t)msk & 15))) return -22;
     if (M <= 0 || N <= 0 || K <= 0 || N % BN != 0 || K % BK != 0 || lda < K || ldb < (BT ? N : K) || ldc < N) return -22;
     if (((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((uintptr_t)C & 15) || lda % 8 || ldb % 8 || ldc % 8) return -22;
     // the per-lane LDS-DMA source offsets are 32-bit (row * row stride in bytes): an operand image of 4 GiB or more would
@@ -330,7 +348,8 @@ static int launch_gemm(const void *A, int lda, const void *B, int ldb, void *C, 
     const int mtiles = (M + BM - 1) / BM, ntiles = N / BN;
     const unsigned grid = 8u * (unsigned)((mtiles * ntiles + 7) / 8);
     hipLaunchKernelGGL(k_gemm_bf16<BT>, dim3(grid), dim3(NT), LDS_BYTES, (hipStream_t)stream, (const __bf16 *)A, lda,
-                       (const __bf16 *)B, ldb, (__bf16 *)C, ldc, M, N, K, mtiles, ntiles, mtiles * ntiles, 1, K / BK, (float *)nullptr);
+                       (const __bf16 *)B, ldb, (__bf16 *)C, ldc, M, N, K, mtiles, ntiles, mtiles * ntiles, 1, K / BK, (float *)nullptr,
+                       (const __bf16 *)msk, ldm, slope);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
@@ -364,7 +383,8 @@ extern "C" int spadot_gemm_tn_bf16_split(const void *A, int lda, const void *B, 
     const int full_items = (mtiles - tail_row_tiles) * ntiles, tail_tiles = tail_row_tiles * ntiles;
     const unsigned grid = 8u * (unsigned)((full_items + 7) / 8) + (unsigned)(tail_tiles * S);
     hipLaunchKernelGGL(k_gemm_bf16<false>, dim3(grid), dim3(NT), LDS_BYTES, (hipStream_t)stream, (const __bf16 *)A, lda,
-                       (const __bf16 *)B, ldb, (__bf16 *)C, ldc, M, N, K, mtiles, ntiles, full_items, S, nk_slice, workspace);
+                       (const __bf16 *)B, ldb, (__bf16 *)C, ldc, M, N, K, mtiles, ntiles, full_items, S, nk_slice, workspace,
+                       (const __bf16 *)nullptr, 0, 1.f);
     hipLaunchKernelGGL(k_gemm_tail_reduce, dim3((unsigned)(tail_tiles * (BM / 8))), dim3(256), 0, (hipStream_t)stream,
                        (const float *)workspace, S, ntiles, mtiles - tail_row_tiles, (__bf16 *)C, ldc, M);
     return hipGetLastError() == hipSuccess ? 0 : -5;
@@ -379,4 +399,12 @@ extern "C" int spadot_gemm_tn_bf16(const void *A, int lda, const void *B, int ld
 extern "C" int spadot_gemm_nn_bf16(const void *A, int lda, const void *B, int ldb, void *C, int ldc, int M, int N, int K,
                                    void *stream) {
     return launch_gemm<true>(A, lda, B, ldb, C, ldc, M, N, K, stream);
+}
+
+// ... with C[m][n] multiplied by `slope` wherever act_out[m][n] <= 0 (act_out [M x N] bf16, row stride ldm): dx = (g W) * LeakyReLU'
+// of the activation whose output act_out is -- the input gradient of a dense map handed to the layer below already masked
+extern "C" int spadot_gemm_nn_bf16_masked(const void *A, int lda, const void *B, int ldb, void *C, int ldc, int M, int N, int K,
+                                          const void *act_out, int ldm, double slope, void *stream) {
+    if (!act_out) return -22;
+    return launch_gemm<true>(A, lda, B, ldb, C, ldc, M, N, K, stream, act_out, ldm, (float)slope);
 }

@@ -11,8 +11,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..graph import build_batch_graph
-from ..ops import (stamp_if, BatchGraph, bn_act, cast_rows, dense_cd, first_map_seeds, first_map_seeds_ok, gat_edge, gat_tail, gat_tail_ok,
-                   head_fc, head_fc_ok, hidden_map, linear_bias, weight_image)
+from ..ops import (stamp_if, BatchGraph, bn_act, cast_rows, dense_cd, encoder_mid, encoder_mid_ok, first_map_seeds, first_map_seeds_ok,
+                   gat_edge, gat_tail, gat_tail_ok, head_fc, head_fc_ok, hidden_map, linear_bias, weight_image)
 
 
 class SVGPEncoder(nn.Module):
@@ -35,10 +35,14 @@ class SVGPEncoder(nn.Module):
         mu, logvar = torch.chunk(self.pre_head(x), 2, dim=1)
         return mu, torch.exp(logvar)
 
-    def pre_head(self, x, x_bf16=None):
+    def pre_head(self, x, x_bf16=None, defer_fc=False):
         """SVGP_fc output (mu | logvar) [b, 2 z].  x_bf16 (optional, training in the bf16 compute dtype): the bf16 image
         [b, G padded] of the same rows -- the first map's weight gradient is then taken from it on the matrix cores
-        (ops.first_map_seeds), the forward stays the fp32 product of x."""
+        (ops.first_map_seeds), the forward stays the fp32 product of x.
+        defer_fc (training, round 5): the stages behind the first map run as two launches that leave SVGP_fc as partial
+        products (ops.encoder_mid); with defer_fc the result tensor is NOT filled here -- it carries `_enc_partials` =
+        (partials, their number, SVGP_fc's bias) and the SVGP stage's first kernel sums them, storing the result on the way
+        (svgp.elbo_start(partials=...)).  Only callers that hand the result straight to that stage may ask for it."""
         net = list(self.SVGP_encoder_net)
         fused = self.training                          # eval mode (running statistics) takes the library modules
         if not fused:
@@ -54,7 +58,26 @@ class SVGPEncoder(nn.Module):
         # training: per hidden size  Linear (bias folded into the next kernel) -> BatchNorm + LeakyReLU in ONE launch;
         # the G -> hidden map is the only large GEMM of this branch: compute dtype on MFMA (fp32 accumulate)
         h = x
-        for i in range(0, len(net), 3):
+        start = 0
+        if len(net) == 6 and h.dtype == torch.float32 and h.is_cuda:
+            # two hidden stages on fp32 rows (the model's shape): first map, then -- where csrc/enc_fused.hip takes the sizes --
+            # everything up to SVGP_fc in two launches
+            lin, bn, act = net[0], net[1], net[2]
+            if self.compute_dtype == torch.bfloat16 and first_map_seeds_ok(h, lin.weight, x_bf16):
+                h1 = first_map_seeds(h, lin.weight, x_bf16)
+            else:
+                h1 = F.linear(h[:, :lin.in_features], lin.weight)
+            stamp_if(19)
+            if encoder_mid_ok(h1, net[3].weight, self.SVGP_fc.weight):
+                z, pz, npz = encoder_mid(h1, lin.bias, bn, act.negative_slope, net[3].weight, net[3].bias, net[4],
+                                         net[5].negative_slope, self.SVGP_fc.weight, self.SVGP_fc.bias, fill=not defer_fc)
+                if defer_fc:
+                    z._enc_partials = (pz, npz, self.SVGP_fc.bias.detach())
+                return z
+            h = bn_act(h1, lin.bias, bn, act.negative_slope)
+            stamp_if(20)
+            start = 3
+        for i in range(start, len(net), 3):
             lin, bn, act = net[i], net[i + 1], net[i + 2]
             if i == 0 and self.compute_dtype != torch.float32 and h.dtype != torch.float32:
                 h = dense_cd(h.to(self.compute_dtype), lin.weight, lin)
@@ -97,7 +120,7 @@ class GATConv(nn.Module):
         nn.init.uniform_(self.att_src, -bound, bound)
         nn.init.uniform_(self.att_dst, -bound, bound)
 
-    def forward(self, x, graph, act=False, fresh=False, taps=None, tap=None):
+    def forward(self, x, graph, act=False, fresh=False, taps=None, tap=None, in_cell=None, act_cell=None):
         """taps / tap (optional): the dense map's output is stored as taps[tap] -- where a backward pass issued in pieces cuts
         between this layer's edge phase and its dense map (GraphedStepper `defer_wgrad`)."""
         # head mean over few targets (the encoder's last layer for the seeds): aggregate first, map the n_tgt aggregated
@@ -109,26 +132,27 @@ class GATConv(nn.Module):
                 wimg = weight_image(self.lin.weight, x.shape[1], x.dtype, self)
                 if not fresh:
                     wimg[:, :self.in_channels].copy_(self.lin.weight.detach())
-            return gat_tail(x, self.lin.weight, wimg, self.att_src, self.att_dst, self.bias, graph, self.heads, self.out_channels)
-        d = self.dense(x, fresh)
+            return gat_tail(x, self.lin.weight, wimg, self.att_src, self.att_dst, self.bias, graph, self.heads, self.out_channels,
+                            in_cell=in_cell)
+        d = self.dense(x, fresh, in_cell=in_cell)
         if taps is not None and tap is not None:
             taps[tap] = d
-        return self.edge(d, graph, act)
+        return self.edge(d, graph, act, act_cell=act_cell)
 
-    def dense(self, x, fresh=False):
+    def dense(self, x, fresh=False, in_cell=None):
         """h = x W^T  [n, H*C] (MFMA GEMM in the compute dtype; x may be K-padded).  fresh: the compute-dtype image
         of the weight is already current (GATEncoder casts the three layers' weights in one launch)."""
         cd = self.compute_dtype
         if cd == torch.float32:
             return F.linear(x[:, :self.in_channels].float(), self.lin.weight)
-        return dense_cd(x.to(cd), self.lin.weight, self, fresh=fresh, defer=getattr(self, "defer_wgrad", False))
+        return dense_cd(x.to(cd), self.lin.weight, self, fresh=fresh, defer=getattr(self, "defer_wgrad", False), in_cell=in_cell)
 
-    def edge(self, h, graph, act=False):
+    def edge(self, h, graph, act=False, act_cell=None):
         """Everything after the dense map (ops.gat_edge)."""
         if not isinstance(graph, BatchGraph):
             graph = build_batch_graph(graph, h.shape[0], h.device)
         return gat_edge(h, self.att_src, self.att_dst, self.bias, graph, self.heads, self.out_channels, self.concat, act,
-                        defer=getattr(self, "defer_wgrad", False))
+                        defer=getattr(self, "defer_wgrad", False), act_cell=act_cell)
 
 
 class GATEncoder(nn.Module):
@@ -190,11 +214,14 @@ class GATEncoder(nn.Module):
         h = self.gat1.dense(x, fresh)
         if after_first_dense is not None:
             after_first_dense()
-        h = self.gat1.edge(h, edge_index, act=True)
+        # c1 / c2: one-step mailboxes between a layer's fused activation and the op that consumes its output (ops._GATEdgeMFMA:
+        # the consumer hands the gradient back already multiplied by the activation's derivative)
+        c1, c2 = ({}, {}) if self.training else (None, None)
+        h = self.gat1.edge(h, edge_index, act=True, act_cell=c1)
         if lg is not None and lg[1].n_tgt == rows:
             # only what the seeds' rows of layer 3 depend on: layer 2 for seeds + hop 1, layer 3 for the seeds
-            h = self.gat2(h, lg[0], act=True, fresh=fresh, taps=taps, tap="d2")
-            h = self.gat3(h, lg[1], act=False, fresh=fresh)
+            h = self.gat2(h, lg[0], act=True, fresh=fresh, taps=taps, tap="d2", in_cell=c1, act_cell=c2)
+            h = self.gat3(h, lg[1], act=False, fresh=fresh, in_cell=c2)
         elif g3 is not None and g3.n_tgt == rows:
             h = self.gat2(h, edge_index, act=True, fresh=fresh, taps=taps, tap="d2")
             h = self.gat3(h, g3, act=False, fresh=fresh)          # edge phase for the seeds only: same rows, ~n/rows less work

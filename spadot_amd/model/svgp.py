@@ -84,11 +84,13 @@ class _SVGPCore(torch.autograd.Function):
         dw = c diag(K_nm dSigma K_mn) + mu (K_nm dt),   dmu = w (K_nm dt),   dvar = -dw w^2  (+ the direct terms)."""
 
     @staticmethod
-    def start(z, bc, rc):
+    def start(z, bc, rc, partials=None):
         """First half of forward, from z = (mu | logvar) [b, 2L] fp32: Sigma_l for every latent dim, the sweep launch
         (the long pole of the branch, ~0.2 ms on 2L compute units) and t.  Separate so that the caller can issue
-        it early."""
+        it early.  partials = (pz, their number, SVGP_fc's bias): z is NOT filled yet -- the encoder left SVGP_fc as partial
+        products (encoder.SVGPEncoder.pre_head(defer_fc=True)) and the first kernel here sums them, storing z on the way."""
         with torch.no_grad():
+            assert partials is None or (z.dtype == torch.float32 and z.is_contiguous())
             z = z.contiguous().float()
             b, L = z.shape[0], z.shape[1] // 2
             m, c = rc.m, bc.c
@@ -100,8 +102,13 @@ class _SVGPCore(torch.autograd.Function):
                 # L matrices -- while it loads (no copy / add launches in front of the inverse: every short launch of
                 # this branch waits for a free slot beside the GAT branch's GEMMs)
                 A = torch.empty((L, b, m), dtype=F64, device=z.device)       # diag(w_l) K_nm, written by the pre kernel
-                _check(lib.spadot_svgp_pre2(_p(z), _p(Kn), b, L, m, _p(mu), _p(var), _p(w), _p(muw), _p(A), _stream()),
-                       "spadot_svgp_pre2")
+                if partials is not None:
+                    pz, npz, bfc = partials
+                    _check(lib.spadot_svgp_pre2_partials(_p(pz), int(npz), _p(bfc), _p(Kn), b, L, m, _p(z), _p(mu), _p(var), _p(w), _p(muw),
+                                                         _p(A), _stream()), "spadot_svgp_pre2_partials")
+                else:
+                    _check(lib.spadot_svgp_pre2(_p(z), _p(Kn), b, L, m, _p(mu), _p(var), _p(w), _p(muw), _p(A), _stream()),
+                           "spadot_svgp_pre2")
                 stamp_if(23)                                                 # (SPADOT_STAMPS=1 only: pre2 done)
                 G = torch.empty((L, m, m), dtype=F64, device=z.device)
                 torch.baddbmm(G, A.transpose(1, 2), Kn.unsqueeze(0).expand(L, b, m), beta=0.0, alpha=c, out=G)
@@ -113,6 +120,9 @@ class _SVGPCore(torch.autograd.Function):
                 _check(lib.spadot_spd_inverse_logdet2(_p(G), L, 2 * L, m, _p(rc.KjI), _p(rc.K2j), _p(X), _p(ld), _stream()),
                        "spadot_spd_inverse_logdet2")
                 return mu, var, w, X, ld, t
+            if partials is not None:
+                pz, npz, bfc = partials
+                _check(lib.spadot_enc_sum_z(_p(pz), int(npz), _p(bfc), b, 2 * L, _p(z), _stream()), "spadot_enc_sum_z")
             _check(lib.spadot_svgp_pre(_p(z), b, L, _p(mu), _p(var), _p(w), _p(muw), _stream()), "spadot_svgp_pre")
             A = Kn.unsqueeze(0) * w.T.unsqueeze(2)                           # [L, b, m] = diag(w_l) K_nm
             buf = torch.empty((2 * L, m, m), dtype=F64, device=mu.device)
@@ -393,10 +403,10 @@ class SVGP(nn.Module):
         p_m, p_v, _, out4 = self._finish(bc, self.elbo_start(bc, z))
         return p_m, p_v, out4[0], out4[2], out4[1]
 
-    def elbo_start(self, bc, z):
+    def elbo_start(self, bc, z, partials=None):
         """z = SVGP_fc output (mu | logvar) [b, 2L].  Builds Sigma_l and launches the batched inverse; elbo_finish()
         does the rest.  Two calls so that the composite model can issue the GAT kernels in between."""
-        return z, _SVGPCore.start(z.detach(), bc, self._rc())
+        return z, _SVGPCore.start(z.detach(), bc, self._rc(), partials)
 
     def _finish(self, bc, started):
         z, pre = started

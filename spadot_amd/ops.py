@@ -101,7 +101,7 @@ class _GATEdgeMFMA(torch.autograd.Function):
     the transposed plan."""
 
     @staticmethod
-    def forward(ctx, h, att_src, att_dst, bias, graph, H, C, act, plans, defer=False):
+    def forward(ctx, h, att_src, att_dst, bias, graph, H, C, act, plans, defer=False, act_cell=None):
         _need_cuda(h, att_src, att_dst, bias)
         lib = model_lib()
         pt, ps = plans
@@ -136,6 +136,12 @@ class _GATEdgeMFMA(torch.autograd.Function):
         ctx.graph, ctx.H, ctx.C, ctx.act, ctx.plans = graph, H, C, act, plans
         ctx.bias_dtype, ctx.att_shape, ctx.att_dtype = bias.dtype, att_src.shape, att_src.dtype
         ctx.flat3, ctx.defer = _adjacent_flat_grads((att_src, att_dst, bias), H * C), bool(defer)
+        # act_cell (a dict shared with the op that consumes `out`): armed here, it tells that consumer that it may hand the
+        # gradient back ALREADY multiplied by this layer's LeakyReLU'(out) -- it holds `out` as its input -- and say so by setting
+        # cell["premasked"] in its backward (ops._DenseCD, ops._GATTail); backward() below then skips its own masking
+        ctx.cell = act_cell if (act and act_cell is not None) else None
+        if ctx.cell is not None:
+            ctx.cell["armed"], ctx.cell["rows"], ctx.cell["slope"] = True, out_rows, ACT_SLOPE
         return out
 
     @staticmethod
@@ -147,7 +153,11 @@ class _GATEdgeMFMA(torch.autograd.Function):
         n, nt = graph.n, graph.n_tgt
         dev = h.device
         g_out = g_out.contiguous().to(h.dtype)
-        g_pre = torch.empty((nt, H * C), dtype=h.dtype, device=dev)
+        # a gradient that arrives already multiplied by LeakyReLU'(out) (the consumer of `out` did it as it produced the gradient):
+        # no read of `out`, no masked copy -- the source-side product reads g_out itself
+        premasked = ctx.cell is not None and bool(ctx.cell.pop("premasked", False))
+        act_here = 0 if premasked else int(ctx.act)
+        g_pre = g_out if premasked else torch.empty((nt, H * C), dtype=h.dtype, device=dev)
         dz = torch.empty((graph.E, H), dtype=torch.float32, device=dev)
         ds_dst = torch.empty((n, H), dtype=torch.float32, device=dev)      # (rows >= nt zeroed by the softmax kernel)
         # attention-vector and bias gradients: per-block partial sums left by the two matrix-core kernels (the bias columns by
@@ -162,7 +172,7 @@ class _GATEdgeMFMA(torch.autograd.Function):
         if part is None or part.device != dev or part.shape != (R, W3):
             part = bufs[("attpart", H, C, ctx.owner)] = torch.zeros((R, W3), dtype=torch.float32, device=dev)
         _check(lib.spadot_gat_edge_dot(_p(g_out), _p(out), _p(h), DT_BF16, _p(pt.rows), _p(pt.sptr), _p(pt.cols), _p(pt.cell),
-                                       pt.nb, pt.max_cols, H, C, int(ctx.act), _p(g_pre), _p(dz), _p(part), W3,
+                                       pt.nb, pt.max_cols, H, C, act_here, None if premasked else _p(g_pre), _p(dz), _p(part), W3,
                                        2 * H * C, _stream()), "spadot_gat_edge_dot")
         img = ctx.img_s            # (alpha in the by-source plan's layout: written by the forward pass)
         _check(lib.spadot_gat_softmax_backward(_p(alpha), _p(s_src), _p(s_dst), _p(graph.rowptr), _p(graph.col), None, nt, n,
@@ -192,11 +202,14 @@ class _GATEdgeMFMA(torch.autograd.Function):
                 POST_CHAIN[0].append(job)
             else:
                 job()
-            return dh, fa, fd, fb_, None, None, None, None, None, None
+            return dh, fa, fd, fb_, None, None, None, None, None, None, None
         datt = torch.empty((3, H * C), dtype=torch.float32, device=dev)
         _check(lib.spadot_colsum(_p(part), part.shape[0], W3, _p(datt), _stream()), "spadot_colsum")
         return (dh, datt[0].view(ctx.att_shape).to(ctx.att_dtype), datt[1].view(ctx.att_shape).to(ctx.att_dtype),
-                datt[2].to(ctx.bias_dtype), None, None, None, None, None, None)
+                datt[2].to(ctx.bias_dtype), None, None, None, None, None, None, None)
+
+
+ACT_SLOPE = 0.01        # F.leaky_relu's default slope (encoder.py:56-57): the activation fused into gat_edge(act=True)
 
 
 def _adjacent_flat_grads(params, width):
@@ -282,14 +295,15 @@ class _GATEdge(torch.autograd.Function):
                 dbias.to(ctx.bias_dtype), None, None, None, None, None)
 
 
-def gat_edge(h, att_src, att_dst, bias, graph, heads, channels, concat=True, act=False, defer=False):
+def gat_edge(h, att_src, att_dst, bias, graph, heads, channels, concat=True, act=False, defer=False, act_cell=None):
     """Everything of one GATConv layer after the dense map h = x W^T: attention logits, edge softmax,
     aggregation, bias, optional leaky_relu(0.01), head concat/mean.  att_src / att_dst: [1, H, C] parameters.
     defer: the layer's attention-vector / bias gradient sum may be queued in ops.DEFERRED (the caller runs that queue only
-    when this layer's backward kernels have finished: GraphedStepper, the second layer)."""
+    when this layer's backward kernels have finished: GraphedStepper, the second layer).
+    act_cell: a dict to share with the op that consumes the result (dense_cd / gat_tail `in_cell`): see _GATEdgeMFMA.forward."""
     plans = _mfma_plans(h, graph, heads, channels, concat) if h.is_cuda else None
     if plans is not None:
-        return _GATEdgeMFMA.apply(h, att_src, att_dst, bias, graph, heads, channels, act, plans, defer)
+        return _GATEdgeMFMA.apply(h, att_src, att_dst, bias, graph, heads, channels, act, plans, defer, act_cell)
     return _GATEdge.apply(h, att_src, att_dst, bias, graph, heads, channels, concat, act)
 
 
@@ -339,7 +353,7 @@ class _GATTail(torch.autograd.Function):
     w = W_h^T att folded into dW (rank-2 update per head) and datt = W_h d w."""
 
     @staticmethod
-    def forward(ctx, x, W, wimg, att_src, att_dst, bias, graph, H, C):
+    def forward(ctx, x, W, wimg, att_src, att_dst, bias, graph, H, C, in_cell=None):
         _need_cuda(x, W, att_src, att_dst, bias)
         lib = model_lib()
         dt = _DT[x.dtype]
@@ -374,6 +388,9 @@ class _GATTail(torch.autograd.Function):
         okv = lambda g_, p_: g_ if (g_ is not None and g_.dtype == torch.float32 and g_.is_contiguous() and g_.shape == p_.shape) else None
         ctx.wgrad = okv(g, W)
         ctx.agrad = (okv(att_src.grad, att_src), okv(att_dst.grad, att_dst))     # flat-gradient views (FlatAdamW)
+        # in_cell: x is the activated output of a gat_edge(act=True, act_cell=in_cell) over exactly these rows: dx may leave
+        # already multiplied by that activation's derivative (see _GATEdgeMFMA.forward)
+        ctx.in_cell = in_cell if (in_cell is not None and in_cell.get("armed") and in_cell.get("rows") == x.shape[0]) else None
         return out
 
     @staticmethod
@@ -407,8 +424,12 @@ class _GATTail(torch.autograd.Function):
         dx = torch.empty_like(x) if Kp == K else torch.zeros_like(x)      # (pad columns of the input: zero gradient)
         ds_src = torch.empty((n, H), dtype=torch.float32, device=dev)
         _check(lib.spadot_gat_tail_source_backward(_p(dA), dt, _p(alpha), _p(dz), _p(ds_dst), _p(wv), _p(graph.rowptr_t), _p(graph.col_t),
-                                                   _p(graph.eid_t), n, nt, x.shape[0], H, K, _p(dx), Kp, _p(ds_src), _stream()),
+                                                   _p(graph.eid_t), n, nt, x.shape[0], H, K, _p(dx), Kp, _p(ds_src),
+                                                   _p(x) if ctx.in_cell is not None else None, Kp,
+                                                   float(ctx.in_cell["slope"]) if ctx.in_cell is not None else 1.0, _stream()),
                "spadot_gat_tail_source_backward")
+        if ctx.in_cell is not None:
+            ctx.in_cell["premasked"] = True
         R = int(lib.spadot_gat_tail_dwvec_rows(n))
 
         def weight_side(datt_src_ptr, datt_dst_ptr, with_dw):
@@ -424,16 +445,16 @@ class _GATTail(torch.autograd.Function):
         if defer:
             ga_s, ga_d = ctx.agrad
             DEFERRED[0].append(lambda: weight_side(_p(ga_s), _p(ga_d), True))
-            return dx, dW, None, ga_s, ga_d, dbias.to(ctx.bias_dtype), None, None, None
+            return dx, dW, None, ga_s, ga_d, dbias.to(ctx.bias_dtype), None, None, None, None
         datt = torch.empty((2, H * C), dtype=torch.float32, device=dev)
         weight_side(_p(datt), ctypes.c_void_p(datt.data_ptr() + 4 * H * C), False)
         return (dx, dW, None, datt[0].view(ctx.att_shape).to(ctx.att_dtype), datt[1].view(ctx.att_shape).to(ctx.att_dtype),
-                dbias.to(ctx.bias_dtype), None, None, None)
+                dbias.to(ctx.bias_dtype), None, None, None, None)
 
 
-def gat_tail(x, W, wimg, att_src, att_dst, bias, graph, heads, channels):
+def gat_tail(x, W, wimg, att_src, att_dst, bias, graph, heads, channels, in_cell=None):
     """The whole GATConv(concat = False) layer -- dense map included -- for the first graph.n_tgt nodes as targets."""
-    return _GATTail.apply(x, W, wimg, att_src, att_dst, bias, graph, heads, channels)
+    return _GATTail.apply(x, W, wimg, att_src, att_dst, bias, graph, heads, channels, in_cell)
 
 
 # ----------------------------------------------------------------------------- dense maps in the compute dtype
@@ -627,10 +648,13 @@ class _DenseCD(torch.autograd.Function):
     gradient in fp32 straight out of the GEMM (no bf16 round trip)."""
 
     @staticmethod
-    def forward(ctx, x, W, wbuf, fresh, defer=False):
+    def forward(ctx, x, W, wbuf, fresh, defer=False, in_cell=None):
         N, K = W.shape
         Kp = x.shape[1]
         ctx.defer = bool(defer)
+        # in_cell: see _GATTail.forward (x is the activated output of the layer below, over exactly these rows and columns)
+        ctx.in_cell = in_cell if (in_cell is not None and in_cell.get("armed") and in_cell.get("rows") == x.shape[0]
+                                  and x.dtype == torch.bfloat16 and x.is_contiguous()) else None
         assert Kp >= K and wbuf.shape == (N, Kp) and wbuf.dtype == x.dtype
         if not fresh:                              # (fresh: the caller has just cast W into wbuf, e.g. ops.cast_rows)
             wbuf[:, :K].copy_(W)                   # cast into the persistent padded image (pad columns stay zero)
@@ -657,8 +681,15 @@ class _DenseCD(torch.autograd.Function):
             if (GEMM_OWN[0] and g.is_cuda and g.dtype == torch.bfloat16 and M_ >= 2560 and Kp_ % 256 == 0
                     and wbuf.shape[0] % 64 == 0 and wbuf.is_contiguous() and ((M_ + 319) // 320) * (Kp_ // 256) >= GEMM_DGRAD_MIN_WGS):
                 dx = torch.empty((M_, Kp_), dtype=torch.bfloat16, device=g.device)
-                rc = model_lib().spadot_gemm_nn_bf16(g.data_ptr(), g.shape[1], wbuf.data_ptr(), Kp_, dx.data_ptr(), Kp_, M_, Kp_,
-                                                     g.shape[1], _stream())
+                if ctx.in_cell is not None and x.shape == (M_, Kp_):
+                    # the LeakyReLU' of the layer below in this GEMM's epilogue (x IS that layer's activated output)
+                    rc = model_lib().spadot_gemm_nn_bf16_masked(g.data_ptr(), g.shape[1], wbuf.data_ptr(), Kp_, dx.data_ptr(), Kp_, M_,
+                                                                Kp_, g.shape[1], x.data_ptr(), Kp_, float(ctx.in_cell["slope"]), _stream())
+                    if rc == 0:
+                        ctx.in_cell["premasked"] = True
+                else:
+                    rc = model_lib().spadot_gemm_nn_bf16(g.data_ptr(), g.shape[1], wbuf.data_ptr(), Kp_, dx.data_ptr(), Kp_, M_, Kp_,
+                                                         g.shape[1], _stream())
                 if rc == -22:
                     dx = None
                 elif rc != 0:
@@ -674,7 +705,7 @@ class _DenseCD(torch.autograd.Function):
                 dW = ctx.wgrad
             else:
                 dW = wgrad_bf16(g, x, ctx.K, ctx.wgrad if (ctx.wgrad is not None and _DIRECT_GRAD[0]) else None)
-        return dx, dW, None, None, None
+        return dx, dW, None, None, None, None
 
 
 class _FirstMapSeeds(torch.autograd.Function):
@@ -867,11 +898,11 @@ def weight_image(W, width, dtype, holder, tag="_wpad"):
     return buf
 
 
-def dense_cd(x, W, holder, tag="_wpad", fresh=False, defer=False):
+def dense_cd(x, W, holder, tag="_wpad", fresh=False, defer=False, in_cell=None):
     """x [n, Kp >= K] in the compute dtype, W fp32 [N, K]; `holder` (a module) keeps the padded compute-dtype
     image of W between calls.  fresh=True: the image already holds the current W (cast by the caller).  defer=True: this
     map's weight gradient may be queued (ops.DEFERRED) instead of launched inside the backward pass."""
-    return _DenseCD.apply(x, W, weight_image(W, x.shape[1], x.dtype, holder, tag), fresh, defer)
+    return _DenseCD.apply(x, W, weight_image(W, x.shape[1], x.dtype, holder, tag), fresh, defer, in_cell)
 
 
 # ----------------------------------------------------------------------------- small-MLP stages
@@ -960,6 +991,97 @@ def ln_act(x, ln, slope=0.01):
     """leaky_relu(LayerNorm(x)) over the last dimension of a 2-D fp32 tensor, one launch forward, two backward."""
     assert ln.elementwise_affine and len(ln.normalized_shape) == 1
     return _LNAct.apply(x, ln.weight, ln.bias, ln.eps, slope)
+
+
+# ----------------------------------------------------------------------------- SVGP encoder behind its first map (csrc/enc_fused.hip)
+
+def encoder_mid_ok(h1, W2, Wfc):
+    """Whether the three-launch form takes the encoder's stages behind the first map: fp32 rows of the training batch."""
+    return bool(h1.is_cuda and h1.dtype == torch.float32 and h1.dim() == 2 and h1.is_contiguous() and W2.dtype == torch.float32
+                and W2.is_contiguous() and Wfc.is_contiguous() and W2.shape[1] == h1.shape[1] and Wfc.shape[1] == W2.shape[0]
+                and W2.data_ptr() % 16 == 0
+                and model_lib().spadot_enc_fused_supported(h1.shape[0], h1.shape[1], W2.shape[0], Wfc.shape[0]))
+
+
+class _EncoderMid(torch.autograd.Function):
+    """[BatchNorm1d + LeakyReLU] -> hidden map -> [BatchNorm1d + LeakyReLU] -> SVGP_fc of encoder.py:7-34 (training mode) as TWO
+    launches whose cross-workgroup data are partial products in global memory (include/spadot_model.h: spadot_enc_*), instead of
+    bn_act, hidden_map, bn_act, linear_bias (four launches, each waiting for a compute-unit slot beside the GAT branch's GEMMs).
+    Returns (z, pz): z [b, Q] is FILLED only when `fill` (one more small launch); otherwise the consumer of the partials pz fills it
+    (spadot_svgp_pre2_partials: the SVGP stage's first kernel reads the partials and stores z on the way).
+    Backward: the same kernels and products as the four separate ops, in their order."""
+
+    @staticmethod
+    def forward(ctx, h1, b1, g1, be1, bn1, slope1, W2, b2, g2, be2, bn2, slope2, Wfc, bfc, fill):
+        _need_cuda(h1, W2, Wfc)
+        lib = model_lib()
+        b, F1 = h1.shape
+        F2, Q = W2.shape[0], Wfc.shape[0]
+        dev = h1.device
+        np1, np2 = F1 // 16, F2 // 4
+        ws = torch.empty(int(lib.spadot_enc_fused_workspace(b, F1, F2, Q)), dtype=torch.float32, device=dev)
+        part, pz = ws[:np1 * b * F2], ws[np1 * b * F2:]
+        y1 = torch.empty((b, F1), dtype=torch.float32, device=dev)
+        h2 = torch.empty((b, F2), dtype=torch.float32, device=dev)
+        y2 = torch.empty((b, F2), dtype=torch.float32, device=dev)
+        st = torch.empty(2 * F1 + 2 * F2, dtype=torch.float32, device=dev)
+        sm1, si1, sm2, si2 = st[:F1], st[F1:2 * F1], st[2 * F1:2 * F1 + F2], st[2 * F1 + F2:]
+        mom = lambda bn: 0.1 if bn.momentum is None else float(bn.momentum)
+        _check(lib.spadot_enc_bn_map(_p(h1), _p(b1), _p(g1), _p(be1), _p(bn1.running_mean), _p(bn1.running_var),
+                                     _p(bn1.num_batches_tracked), b, F1, mom(bn1), float(bn1.eps), float(slope1), _p(y1), _p(sm1), _p(si1),
+                                     _p(W2), F2, _p(part), _stream()), "spadot_enc_bn_map")
+        _check(lib.spadot_enc_bn_fc(_p(part), np1, _p(b2), _p(g2), _p(be2), _p(bn2.running_mean), _p(bn2.running_var),
+                                    _p(bn2.num_batches_tracked), b, F2, mom(bn2), float(bn2.eps), float(slope2), _p(h2), _p(y2), _p(sm2),
+                                    _p(si2), _p(Wfc), Q, _p(pz), _stream()), "spadot_enc_bn_fc")
+        z = torch.empty((b, Q), dtype=torch.float32, device=dev)
+        if fill:
+            _check(lib.spadot_enc_sum_z(_p(pz), np2, _p(bfc), b, Q, _p(z), _stream()), "spadot_enc_sum_z")
+        ctx.save_for_backward(h1, b1, g1, y1, sm1, si1, W2, b2, g2, h2, y2, sm2, si2, Wfc)
+        ctx.slopes = (float(slope1), float(slope2))
+        ctx.mark_non_differentiable(pz)
+        return z, pz
+
+    @staticmethod
+    def backward(ctx, dz, _unused):
+        h1, b1, g1, y1, sm1, si1, W2, b2, g2, h2, y2, sm2, si2, Wfc = ctx.saved_tensors
+        lib = model_lib()
+        b, F1 = h1.shape
+        F2, Q = W2.shape[0], Wfc.shape[0]
+        dev = h1.device
+        dz = dz.contiguous().float()
+        # SVGP_fc (ops._LinearBias.backward)
+        dbfc = torch.empty(Q, dtype=torch.float32, device=dev)
+        _check(lib.spadot_colsum(_p(dz), b, Q, _p(dbfc), _stream()), "spadot_colsum")
+        dy2 = dz @ Wfc
+        dWfc = _small_weight_grad(dz, y2)
+        # second BatchNorm + LeakyReLU (ops._BNAct.backward)
+        dh2 = torch.empty_like(h2)
+        dg2 = torch.empty(F2, dtype=torch.float32, device=dev)
+        dbe2 = torch.empty(F2, dtype=torch.float32, device=dev)
+        _check(lib.spadot_bn_act_backward(_p(dy2), _p(y2), _p(h2), DT_F32, None if b2 is None else _p(b2), _p(g2), _p(sm2), _p(si2), b, F2,
+                                          ctx.slopes[1], _p(dh2), _p(dg2), _p(dbe2), _stream()), "spadot_bn_act_backward")
+        # hidden map (ops._HiddenMap.backward)
+        small = sgemm_small_ok(dh2, W2) and b * F2 * F1 <= _SMALL_WORK
+        dy1 = sgemm_small(0, dh2, W2) if small else dh2 @ W2
+        small = sgemm_small_ok(dh2, y1) and b * F2 * F1 <= _SMALL_WORK
+        dW2 = wgrad_small(dh2, y1) if small else dh2.t() @ y1
+        # first BatchNorm + LeakyReLU
+        dh1 = torch.empty_like(h1)
+        dg1 = torch.empty(F1, dtype=torch.float32, device=dev)
+        dbe1 = torch.empty(F1, dtype=torch.float32, device=dev)
+        _check(lib.spadot_bn_act_backward(_p(dy1.contiguous()), _p(y1), _p(h1), DT_F32, None if b1 is None else _p(b1), _p(g1), _p(sm1),
+                                          _p(si1), b, F1, ctx.slopes[0], _p(dh1), _p(dg1), _p(dbe1), _stream()), "spadot_bn_act_backward")
+        # (the batch mean removes a per-feature shift: the biases of the two maps in front of a BatchNorm have zero gradients)
+        return (dh1, None if b1 is None else _const_zeros(b1), dg1, dbe1, None, None, dW2, None if b2 is None else _const_zeros(b2),
+                dg2, dbe2, None, None, dWfc, dbfc, None)
+
+
+def encoder_mid(h1, lin1_bias, bn1, slope1, W2, lin2_bias, bn2, slope2, Wfc, bfc, fill=True):
+    """(z, pz, number of partials): see _EncoderMid."""
+    assert bn1.training and bn2.training and bn1.track_running_stats and bn2.track_running_stats and bn1.affine and bn2.affine
+    z, pz = _EncoderMid.apply(h1, lin1_bias, bn1.weight, bn1.bias, bn1, slope1, W2, lin2_bias, bn2.weight, bn2.bias, bn2, slope2,
+                               Wfc, bfc, fill)
+    return z, pz, W2.shape[0] // 4
 
 
 # ----------------------------------------------------------------------------- fused hidden stages (csrc/mlp_chain.hip)

@@ -229,6 +229,20 @@ def gather_small_plans(local_plans, plan, shape, device):
     return {p: out[i] for i, p in enumerate(pairs)}
 
 
+def reduce_epoch_losses(sums, counts, plan):
+    """The reference's per-epoch loss record (_train_utils.py:219-224: for every time point the MEAN of its batches' loss
+    vectors, the record = the SUM of those means over the time points) from per-rank partial sums.
+    sums [T, n_terms], counts [T] (float tensors on the collectives' device): this rank's sum of loss vectors and number of
+    batches per time point (rows of time points it drew nothing from stay zero).  One all-reduce of a T x (n_terms + 1)
+    tensor; every rank gets the same record, and it is what a single process computes from all batches -- whatever P is."""
+    buf = torch.cat([sums.double(), counts.double().reshape(-1, 1)], dim=1)
+    if plan.world_size > 1:
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    tot, cnt = buf[:, :-1], buf[:, -1:]
+    means = torch.where(cnt > 0, tot / cnt.clamp(min=1.0), torch.zeros_like(tot))
+    return means.sum(dim=0)
+
+
 def run_epoch(plan, batches_per_tp, order, compute_grad, zero_grad, flat_grad, apply_update, exchange=None,
               set_grad_scale=None):
     """One synchronous data-parallel epoch.
@@ -268,9 +282,11 @@ def run_epoch(plan, batches_per_tp, order, compute_grad, zero_grad, flat_grad, a
 
 def train_SpaDOT_parallel(dataloader_dict, model_config, verbose=False):
     """Data-parallel counterpart of _train_utils.train_SpaDOT (must be called by every rank with
-    dataloader_dict built for plan.data_timepoints()).  Returns (model, per-epoch loss dict of the
-    LOCAL batches)."""
+    dataloader_dict built for plan.data_timepoints()).  Returns (model, loss_df) like train_SpaDOT: loss_df's column of an
+    epoch is the reference's loss.csv row (sum over time points of the per-time-point batch means, _train_utils.py:219-224),
+    reduced over the ranks -- the same on every rank and the same quantity a single process reports."""
     import random
+    from collections import OrderedDict
     from .model import SpaDOT
     from .ops import FlatAdamW
     from .utils import _train_utils as tu
@@ -305,7 +321,9 @@ def train_SpaDOT_parallel(dataloader_dict, model_config, verbose=False):
     if missing:         # (its centres and labels would be gathered as all-zero from this rank, silently)
         raise ValueError(f"rank {rank}: time points {missing} are this rank's to refit but their rows are not in "
                          "dataloader_dict['datasets']")
-    losses = {}
+    loss_dict = OrderedDict()
+    tp_row = {tp: i for i, tp in enumerate(model_config["timepoints"])}
+    n_terms = len(tu.LOSS_NAMES)
     # replayed hipGraphs, as in the single-replica trainer: one forward+backward graph per (time point, batch),
     # the all-reduce of the flat gradient between replays (not captured), one clip + AdamW graph
     stepper = (tu.GraphedStepper(model, opt, model_config, dataloader_dict, grad_sync=sync,
@@ -323,20 +341,23 @@ def train_SpaDOT_parallel(dataloader_dict, model_config, verbose=False):
         beta1 = float(beta1s[epoch])
         model.train()
         random.shuffle(order)
-        acc = []
+        sums = torch.zeros((len(tp_row), n_terms), dtype=torch.float32, device=device)
+        counts = torch.zeros(len(tp_row), dtype=torch.float32, device=device)
 
         def compute_grad(tp_i, tp, bi):
             if stepper is not None:
-                acc.append(stepper.fb(tp_i, tp, bi, epoch, beta1))
+                l = stepper.fb(tp_i, tp, bi, epoch, beta1)
             else:
-                acc.append(tu.forward_backward(model, model_config, dataloader_dict, tp_i, tp, bi, epoch, beta1,
-                                               optimizer=opt))
+                l = tu.forward_backward(model, model_config, dataloader_dict, tp_i, tp, bi, epoch, beta1, optimizer=opt)
+            sums[tp_row[tp]] += l.float()           # (in-stream: the stepper's own loss buffer may be rewritten by the next replay)
+            counts[tp_row[tp]] += 1.0
 
         with (stepper.chained() if stepper is not None else contextlib.nullcontext()):
             _, n_mine = run_epoch(plan, batches_per_tp, order, compute_grad, opt.zero_grad, opt.flat_grad,
                                   stepper.update if stepper is not None else opt.step, exchange=exchange,
                                   set_grad_scale=lambda x: opt.grad_scale.fill_(x))
-        losses[epoch] = torch.stack(acc).mean(0).cpu().tolist() if acc else None
+        rec = reduce_epoch_losses(sums, counts, plan).cpu().tolist()
+        loss_dict[epoch] = OrderedDict(zip(tu.LOSS_NAMES, rec))
         average_buffers(model, weight=n_mine)
         # inference + K-means refit of a time point on ONE rank; centres (and, where other ranks train on that time
         # point's batches, labels) to everyone
@@ -364,4 +385,5 @@ def train_SpaDOT_parallel(dataloader_dict, model_config, verbose=False):
             K = model_config["n_clusters"]
             for (a, b), g in gather_small_plans(local, plan, (K, K), device).items():
                 tu._set_gamma(model, f"{a}_{b}", g, device)
-    return model, losses
+    import pandas as pd
+    return model, pd.DataFrame.from_dict(loss_dict)

@@ -566,6 +566,79 @@ def test_bn_act_matches_batchnorm_leakyrelu(ops, b, F_, dt):
     assert float(lbd.grad.abs().max()) == 0.0 and float(lbr.grad.abs().max()) < 1e-9      # the batch mean removes the shift
 
 
+@pytest.mark.parametrize("b,G,hid", [(512, 300, (256, 64)), (235, 96, (256, 64)), (64, 40, (32, 16))])
+def test_svgp_encoder_fused_stages_match_the_reference_modules(ops, b, G, hid):
+    """SVGPEncoder.pre_head in training mode (encoder.py:7-34) with the stages behind the first map as two launches
+    (csrc/enc_fused.hip: partial products across workgroups, round 5) against torch's own modules in fp64: the output z, both
+    BatchNorms' running statistics and counters, every parameter's gradient and the input's -- and the same again through the
+    deferred form, where SVGP_fc's partial products are summed by the SVGP stage's first kernel (svgp.elbo_start(partials=...))."""
+    from spadot_amd.model.encoder import SVGPEncoder
+    from spadot_amd.model import svgp as sv
+    torch.manual_seed(b + G)
+    enc = SVGPEncoder(G, 10, list(hid)).to(DEV)
+    ref = torch.nn.Sequential()
+    dims = [G] + list(hid)
+    mods = []
+    for i in range(len(hid)):
+        mods += [torch.nn.Linear(dims[i], dims[i + 1]), torch.nn.BatchNorm1d(dims[i + 1]), torch.nn.LeakyReLU()]
+    ref = torch.nn.Sequential(*mods).double()
+    fc = torch.nn.Linear(hid[-1], 20).double()
+    with torch.no_grad():
+        for k in (0, 1, 3, 4):
+            for pn in ("weight", "bias"):
+                getattr(enc.SVGP_encoder_net[k], pn).copy_(torch.randn_like(getattr(enc.SVGP_encoder_net[k], pn)) * (0.05 if k in (0, 3) else 0.5)
+                                                           + (1.0 if (k in (1, 4) and pn == "weight") else 0.0))
+                getattr(ref[k], pn).copy_(getattr(enc.SVGP_encoder_net[k], pn).double().cpu())
+        fc.weight.copy_(enc.SVGP_fc.weight.double().cpu()); fc.bias.copy_(enc.SVGP_fc.bias.double().cpu())
+    x = torch.randn((b, G), device=DEV)
+    w = torch.randn((b, 20), device=DEV)
+    xr = x.double().cpu().requires_grad_(True)
+    ref.train()
+    zr = fc(ref(xr))
+    (zr * w.double().cpu()).sum().backward()
+    enc.train()
+    assert ops.encoder_mid_ok(torch.empty((b, hid[0]), device=DEV), enc.SVGP_encoder_net[3].weight, enc.SVGP_fc.weight)
+    xd = x.clone().requires_grad_(True)
+    z = enc.pre_head(xd)
+    assert not hasattr(z, "_enc_partials")
+    (z * w).sum().backward()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(z.detach().cpu().numpy(), zr.detach().numpy(), rtol=2e-4, atol=2e-5)
+    for k in (1, 4):
+        np.testing.assert_allclose(enc.SVGP_encoder_net[k].running_mean.cpu().numpy(), ref[k].running_mean.numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(enc.SVGP_encoder_net[k].running_var.cpu().numpy(), ref[k].running_var.numpy(), rtol=1e-5, atol=1e-6)
+        assert int(enc.SVGP_encoder_net[k].num_batches_tracked) == 1
+    pairs = [("x", xd.grad, xr.grad), ("fc.W", enc.SVGP_fc.weight.grad, fc.weight.grad), ("fc.b", enc.SVGP_fc.bias.grad, fc.bias.grad)]
+    for k in (0, 1, 3, 4):
+        pairs.append((f"{k}.weight", enc.SVGP_encoder_net[k].weight.grad, ref[k].weight.grad))
+        if k in (1, 4):
+            pairs.append((f"{k}.bias", enc.SVGP_encoder_net[k].bias.grad, ref[k].bias.grad))
+    for name, a, r in pairs:
+        r = r.numpy()
+        np.testing.assert_allclose(a.float().cpu().numpy(), r, rtol=5e-4, atol=5e-4 * np.abs(r).max(), err_msg=name)
+    for k in (0, 3):                                    # a Linear bias in front of BatchNorm: zero gradient
+        assert float(enc.SVGP_encoder_net[k].bias.grad.abs().max()) == 0.0
+    # the deferred form: z is filled by the SVGP stage's first kernel from the partials -- same z, same downstream values
+    m = 23
+    mod = sv.SVGP(dict(device=DEV, kernel_type="Gaussian", kernel_scale=0.1), np.random.default_rng(0).uniform(0, 1, (m, 2)), 4000.0)
+    xy = torch.as_tensor(np.random.default_rng(1).uniform(0, 1, (b, 2))).to(DEV)
+    bc = mod.batch_constants(xy)
+    with torch.no_grad():
+        z_plain = enc.pre_head(x)
+        st_plain = mod.elbo_start(bc, z_plain)
+        z_def = enc.pre_head(x, defer_fc=True)
+        assert hasattr(z_def, "_enc_partials")
+        st_def = mod.elbo_start(bc, z_def, partials=z_def._enc_partials)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(z_def.cpu().numpy(), z_plain.cpu().numpy(), rtol=1e-6, atol=1e-7)
+    for u, v in zip(st_plain[1][:3], st_def[1][:3]):            # mu, var, w
+        np.testing.assert_allclose(v.cpu().numpy(), u.cpu().numpy(), rtol=1e-6, atol=1e-9)
+    # bit-repeatable
+    with torch.no_grad():
+        z2 = enc.pre_head(x)
+    assert torch.equal(z2, z_plain)
+
+
 @pytest.mark.parametrize("b,F_", [(512, 64), (512, 256), (19, 100)])
 def test_ln_act_matches_layernorm_leakyrelu(ops, b, F_):
     rng = np.random.default_rng(b * 3 + F_)

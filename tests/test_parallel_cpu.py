@@ -257,3 +257,53 @@ def test_batch_granular_epoch_four_ranks_over_gloo():
         grad.div_(contributors)
         opt.step()
     np.testing.assert_allclose(res[0][2], flat.numpy(), rtol=1e-12, atol=1e-14)
+
+
+def _loss_worker(rank, world, port, q, gran):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        tps = [0, 1, 2, 3, 4]
+        plan = par.ShardPlan(tps, world, rank, granularity=gran, batches_per_tp=BATCHES5)
+        per_rank, _ = par.epoch_schedule(plan, BATCHES5, ORDER5)
+        sums, counts = torch.zeros((5, 7)), torch.zeros(5)
+        for tp_i, tp, bi in per_rank[rank]:
+            sums[tp] += _batch_loss(tp, bi)
+            counts[tp] += 1.0
+        q.put((rank, par.reduce_epoch_losses(sums, counts, plan).numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def _batch_loss(tp, bi):
+    """A made-up loss vector per (time point, batch): what a step would have returned."""
+    g = torch.Generator().manual_seed(100 * tp + bi)
+    return torch.rand(7, generator=g) * (tp + 1)
+
+
+@pytest.mark.parametrize("world,gran", [(2, "batch"), (4, "batch"), (2, "timepoint")])
+def test_epoch_loss_record_is_the_reference_quantity_whatever_the_rank_count(world, gran):
+    """parallel.reduce_epoch_losses: the per-epoch record every rank ends with = the reference's loss.csv row
+    (_train_utils.py:219-224: for each time point the mean of its batches' loss vectors, summed over the time points) --
+    identical on all ranks and equal to what ONE process computes from all batches (P = 1), for both shard granularities."""
+    want = torch.zeros(7, dtype=torch.float64)
+    for tp, nb in BATCHES5.items():
+        want += torch.stack([_batch_loss(tp, bi) for bi in range(nb)]).double().mean(0)
+    one = par.reduce_epoch_losses(torch.stack([sum(_batch_loss(tp, bi) for bi in range(nb)) for tp, nb in sorted(BATCHES5.items())]),
+                                  torch.tensor([float(nb) for _, nb in sorted(BATCHES5.items())]),
+                                  par.ShardPlan([0, 1, 2, 3, 4], 1, 0, granularity="batch", batches_per_tp=BATCHES5))
+    np.testing.assert_allclose(one.numpy(), want.numpy(), rtol=1e-6)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_loss_worker, args=(r, world, port, q, gran)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, rec in res:
+        assert rec.shape == (7,)
+        np.testing.assert_array_equal(rec, res[0][1])                          # the same record on every rank
+        np.testing.assert_allclose(rec, one.numpy(), rtol=1e-6)               # ... and the P = 1 record

@@ -158,7 +158,7 @@ def test_chained_steps_leave_the_bits_unchained_steps_leave(monkeypatch):
     """GraphedStepper.chained(): the SVGP branch of step k + 1 waits for the FIRST graph of step k's update (gradient norm + the
     SVGP encoder's parameters: FlatAdamW(first=...)) instead of the whole update.  Same launches on the same two streams,
     only one wait is earlier: parameters, BatchNorm statistics and losses must agree with the unchained run and with the
-    one-graph update (split_update off) to the run-to-run noise of the step itself (a few ulp: 1e-7 relative, measured with
+    one-graph update (an optimizer without a `first` group) to the run-to-run noise of the step itself (a few ulp: 1e-7 relative, measured with
     tools/chain_check.py -- the library's small GEMMs are not bit-repeatable); a branch that read the encoder's parameters
     one update late would be off by ~1e-4."""
     from spadot_amd.model import SpaDOT
@@ -172,11 +172,14 @@ def test_chained_steps_leave_the_bits_unchained_steps_leave(monkeypatch):
     results = []
     for mode in ("one_graph", "unchained", "chained"):
         _utils.set_seed(7)
-        cfg["split_update"] = mode != "one_graph"
         dd = tu.prepare_dataloader(data, cfg)
         model = SpaDOT.SpaDOT(cfg, dd).to(DEV)
-        opt = FlatAdamW(model.parameters(), lr=cfg["lr"], first=model.SVGPEncoder.parameters())
-        assert opt.head_count == sum((p.numel() + 3) // 4 * 4 for p in model.SVGPEncoder.parameters())
+        if mode == "one_graph":                    # no `first` group: the update is one graph
+            opt = FlatAdamW(model.parameters(), lr=cfg["lr"])
+            assert opt.head_count == 0
+        else:
+            opt = FlatAdamW(model.parameters(), lr=cfg["lr"], first=model.SVGPEncoder.parameters())
+            assert opt.head_count == sum((p.numel() + 3) // 4 * 4 for p in model.SVGPEncoder.parameters())
         tu._update_Kmeans(model, cfg, dd)
         tu._update_OT_matrix(model, cfg)
         model.train()
@@ -466,7 +469,7 @@ def _dp_worker(rank, world, port, q, staged=None, granularity="batch"):
             assert [b is not None for b in dd["dataloaders"][1]] == [bi in cfg["owned_batches"][1] for bi in range(5)]
         model, losses = par.train_SpaDOT_parallel(dd, cfg)
         flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu().numpy()
-        q.put((rank, flat, sorted(model.gammas), sorted(model.kmeans_center_dict), losses[1]))
+        q.put((rank, flat, sorted(model.gammas), sorted(model.kmeans_center_dict), np.asarray(losses[1], dtype=np.float64)))
     finally:
         dist.destroy_process_group()
 
@@ -492,8 +495,9 @@ def test_data_parallel_training_two_ranks_one_gpu(staged, granularity):
     np.testing.assert_array_equal(f0, f1)              # replicas identical after 2 epochs
     assert g0 == g1 == ["0_1", "1_2"]                  # every rank holds every (sharded) pair plan
     assert c0 == c1 == [0, 1, 2]                       # centres of all time points everywhere
-    assert np.isfinite(l0).all() and np.isfinite(l1).all()
-    assert l0[6] > 0 and l1[6] > 0                     # OT term live on both ranks (ot_epoch = 1; tp 2 on rank 0, tp 1 on rank 1)
+    assert np.isfinite(l0).all() and l0.shape == (7,)
+    np.testing.assert_array_equal(l0, l1)              # the epoch's loss record is the reduced one: the same on every rank
+    assert l0[6] > 0                                   # OT term live (ot_epoch = 1)
 
 
 def test_device_kmeans_vs_sklearn():

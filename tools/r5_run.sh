@@ -6,6 +6,13 @@ mkdir -p $O
 case "$1" in
 tests)
   timeout -k 10 1000 python -m pytest tests -m gpu -x -q 2>&1 | tail -25 > $O/tests.txt; cat $O/tests.txt ;;
+tests2)
+  timeout -k 10 1100 python -m pytest tests -m gpu -x -q 2>&1 | tail -25 > $O/tests2.txt; cat $O/tests2.txt ;;
+prof)
+  bash tools/profile_preset.sh cfg2 f32 r05 2>&1 | tail -60
+  bash tools/profile_preset.sh cfg5shape bf16 r05 2>&1 | tail -60
+  timeout -k 10 400 python tools/e2e_chickenheart.py > $O/e2e_chickenheart.txt 2> $O/e2e.err || tail -5 $O/e2e.err
+  grep -v "^Epoch\|^Calculating\|^The graph\|^OT iter" $O/e2e_chickenheart.txt | tail -40 ;;
 probe)
   bash tools/gat_probe.sh "" "-DEDOT_PROBE=1" "-DEDOT_PROBE=2" "-DEDOT_PROBE=4" "-DEDOT_PROBE=8" "-DEDOT_PROBE=7" 2>&1 | tee $O/gat_probe.txt
   timeout -k 10 300 python tools/e2e_chickenheart.py bf16 > $O/e2e_chickenheart_bf16.txt 2> $O/e2e_bf16.err || tail -4 $O/e2e_bf16.err ;;
