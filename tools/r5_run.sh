@@ -8,6 +8,21 @@ tests)
   timeout -k 10 1000 python -m pytest tests -m gpu -x -q 2>&1 | tail -25 > $O/tests.txt; cat $O/tests.txt ;;
 tests2)
   timeout -k 10 1100 python -m pytest tests -m gpu -x -q 2>&1 | tail -25 > $O/tests2.txt; cat $O/tests2.txt ;;
+ot)
+  timeout -k 10 600 python -m pytest tests/test_ot_gpu.py -x -q 2>&1 | tail -8
+  timeout -k 10 300 python bench.py --leg sinkhorn --no-cpu-baseline > $O/bench_sink.json 2> $O/bench_sink.err || tail -5 $O/bench_sink.err
+  python - <<'PY'
+import json
+d = json.loads(open("gpurun_out/r5/bench_sink.json").read().strip().splitlines()[-1])
+print({k: d["sinkhorn"].get(k) for k in ("value", "cost_setup_s", "pair_end_to_end_s", "full_solve_s", "iters_per_s_with_convergence_checks")})
+PY
+  ;;
+ab2)
+  bash tools/ab_step.sh "SPADOT_ENC_FUSED=1 SPADOT_PREMASK=1" "SPADOT_ENC_FUSED=0 SPADOT_PREMASK=1" "SPADOT_ENC_FUSED=1 SPADOT_PREMASK=0" 2>&1 | tee $O/ab_enc_premask.txt ;;
+m2)
+  bash tools/ab_step.sh "X=1" 2>&1 | tee $O/bench_train_now.txt
+  SPADOT_STAMPS=1 timeout -k 10 300 python tools/stage_stamps.py > $O/stage_stamps_now.txt 2> $O/stamps.err || tail -5 $O/stamps.err
+  cat $O/stage_stamps_now.txt ;;
 prof)
   bash tools/profile_preset.sh cfg2 f32 r05 2>&1 | tail -60
   bash tools/profile_preset.sh cfg5shape bf16 r05 2>&1 | tail -60
