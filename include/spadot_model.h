@@ -278,6 +278,21 @@ int spadot_enc_sum_z(const float *pz, int nparts, const float *bias, int b, int 
 int spadot_svgp_pre2_partials(const float *pz, int nparts, const float *bias, const double *Kn, int b, int L, int m, float *z,
                               double *mu, double *var, double *w, double *muw, double *A, void *stream);
 
+/* ---- The decoder's output map, the reconstruction term and their backward as one launch (csrc/recon_fb.hip, round 5) ----------
+ * decoder.py:3-20 (last Linear: hidden K = 256 -> G) + SpaDOT.py:89 (recon = inv_scale * sum (y - (h W^T + bias))^2) forward AND
+ * backward for a gradient seed known at forward time: grad_weight[0] = d loss / d recon (the loss weight lambda1,
+ * _train_utils.py:205-212, a device scalar).  h_bf16 [b x K], W_bf16 [G x K] (bf16 images of h and of the weight), y [b x G] fp32.
+ * Leaves: g_bf16 [b x G] = -2 inv_scale grad_weight (y - o - bias) in bf16 (the weight gradient g^T h is the caller's GEMM),
+ * dh [b x K] fp32 = g W (gene blocks summed in block order), in `workspace` (spadot_recon_fb_workspace floats) behind the
+ * per-gene-block partials of dh the bias-gradient partials dbp [ceil(b / 128)][G] (sum them: spadot_colsum), and in loss_parts
+ * (ceil(b / 128) * ceil(G / 128) doubles) the partial sums of (y - o - bias)^2 (spadot_sum_parts with scale = inv_scale gives the
+ * term's value).  The fp32 image of o = h W^T is never formed.  K == 256, G % 8 == 0, G >= 128. */
+int spadot_recon_fb_supported(int b, int K, int G);
+long long spadot_recon_fb_workspace(int b, int K, int G);
+int spadot_recon_fb(const void *h_bf16, const void *W_bf16, const float *bias, const float *y, int b, int K, int G, double inv_scale,
+                    const float *grad_weight, void *g_bf16, float *workspace, double *loss_parts, float *dh, void *stream);
+int spadot_sum_parts(const double *part, int n, double scale, float *out, void *stream);
+
 /* Measurement aid: buf[slot] = the device's constant-rate timestamp counter (100 MHz: 10 ns units) when the launch runs.
  * Launched at the head and the end of a captured stage it dates the stage on the GPU with no profiler attached. */
 int spadot_stamp(unsigned long long *buf, int slot, void *stream);

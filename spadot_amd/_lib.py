@@ -194,6 +194,9 @@ def model_lib():
         "spadot_gemm_tn_bf16": [vp, ci, vp, ci, vp, ci, ci, ci, ci, vp],
         "spadot_gemm_nn_bf16": [vp, ci, vp, ci, vp, ci, ci, ci, ci, vp],
         "spadot_enc_fused_supported": [ci, ci, ci, ci],
+        "spadot_recon_fb_supported": [ci, ci, ci],
+        "spadot_recon_fb": [vp, vp, vp, vp, ci, ci, ci, cd, vp, vp, vp, vp, vp, vp],
+        "spadot_sum_parts": [vp, ci, cd, vp, vp],
         "spadot_enc_bn_map": [vp, vp, vp, vp, vp, vp, vp, ci, ci, cd, cd, cd, vp, vp, vp, vp, ci, vp, vp],
         "spadot_enc_bn_fc": [vp, ci, vp, vp, vp, vp, vp, vp, ci, ci, cd, cd, cd, vp, vp, vp, vp, vp, ci, vp, vp],
         "spadot_enc_sum_z": [vp, ci, vp, ci, ci, vp, vp],
@@ -259,6 +262,8 @@ def model_lib():
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = ci
+    lib.spadot_recon_fb_workspace.argtypes = [ci, ci, ci]
+    lib.spadot_recon_fb_workspace.restype = ll
     lib.spadot_enc_fused_workspace.argtypes = [ci, ci, ci, ci]
     lib.spadot_enc_fused_workspace.restype = ll
     lib.spadot_gemm_bf16_split_workspace.argtypes = [ci, ci, ci, ci]

@@ -16,7 +16,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # shared object -> translation units
 TARGETS = {
     "libspadot_ot.so": ["ot_sinkhorn.hip", "ot_cost.hip", "ot_small.hip"],
-    "libspadot_model.so": ["model_kernels.hip", "gat_mfma.hip", "gemm_bf16.hip", "gemm_wgrad_bf16.hip", "mlp_chain.hip", "gat_tail.hip", "enc_fused.hip"],
+    "libspadot_model.so": ["model_kernels.hip", "gat_mfma.hip", "gemm_bf16.hip", "gemm_wgrad_bf16.hip", "mlp_chain.hip", "gat_tail.hip", "enc_fused.hip", "recon_fb.hip"],
 }
 
 # per-source extra flags.  ot_sinkhorn: the fused pass keeps its whole register budget (256 VGPRs) for the row band;

@@ -1,0 +1,251 @@
+// recon_fb.hip -- the decoder's output map, the reconstruction term and their backward as ONE launch on the matrix cores
+// (gfx950, wave64, bf16 operands, fp32 accumulation).
+//
+// Reference arithmetic: /root/reference/SpaDOT/model/decoder.py:3-20 (the last Linear, hidden -> G) and
+// /root/reference/SpaDOT/model/SpaDOT.py:89 (recon = sum (y - decoder(z))^2 / G) with their backward for a KNOWN seed:
+// d elbo / d recon is the loss weight lambda1 (/root/reference/SpaDOT/utils/_train_utils.py:205-212), a device scalar that
+// exists when the forward pass runs -- the staged step's tail differentiates right behind its own forward, so forward and
+// backward of this stage are one kernel (the idea of ops.cluster_losses_fb).
+//
+// What it replaces on the loss tail's dependency chain (one stream of dependent launches, ~20-30 us each beside the side
+// stream's fp64 GEMMs): library GEMM o = h W^T [b x G] (23 us), k_bias_sqerr_bwd (30 us), library GEMM dh = g W (29 us) --
+// and the 6 MB fp32 image of o, which is never formed now.
+//   workgroup = 128 rows x 128 genes:  o = h W_blk^T   -> d = y - (o + bias), sum d^2 (fp64 partial), g = coef d (bf16, stored:
+//   the weight gradient g^T h is a library GEMM that only the optimizer waits for), column sums of g (bias gradient partial),
+//   dh_partial [128 x K] = g W_blk (second product, contraction over the block's 128 genes).
+// The partial dh of the G / 128 gene blocks are summed in block order by k_recon_fb_reduce (fixed order: bit-repeatable).
+// MFMA operands (v_mfma_f32_32x32x16_bf16: A lane -> row l & 31, B lane -> column l & 31, both with k = 8 (l >> 5) .. + 7;
+// D register e of lane l -> row (e & 3) + 8 (e >> 2) + 4 (l >> 5), column l & 31):
+//   product 1:  D1 [gene x row]  A = W rows (16 bytes of a W row straight from global / L2), B = h rows (likewise)
+//   product 2:  D2 [chan x row]  A = W_blk^T fragments by transposed LDS reads (ds_read_b64_tr_b16) of the block's W rows
+//               staged row-major (row stride = 64 mod 256 bytes), B = g rows from the LDS image the epilogue of product 1 wrote
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdint>
+
+#include "../../include/spadot_model.h"
+#include "per_device.h"
+
+namespace {
+
+constexpr int K = 256;                       // hidden width (decoder_layers[-1]); the only instantiation the model uses
+constexpr int BR = 128, BG = 128;            // rows x genes per workgroup
+constexpr int NT = 256;
+constexpr int WROW = 2 * K + 64;             // staged W row stride (bytes): = 64 mod 256 (transposed reads conflict-free)
+constexpr int DROW = 2 * BG + 16;            // g image row stride (bytes): = 16 mod 256 (plain 16-byte reads conflict-free)
+constexpr int LDS_W = BG * WROW;             // 73 728
+constexpr int LDS_D = BR * DROW;             // 34 816
+constexpr int LDS_DB = 4 * BG * 4;           // per-wave column sums
+constexpr int LDS_BYTES = LDS_W + LDS_D + LDS_DB;
+
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef short s4 __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ unsigned short bf16_bits(float x) { return __builtin_bit_cast(unsigned short, (__bf16)x); }
+__device__ __forceinline__ unsigned pack2(float lo, float hi) { return (unsigned)bf16_bits(lo) | ((unsigned)bf16_bits(hi) << 16); }
+
+__global__ __launch_bounds__(NT, 1) void k_recon_fb(const __bf16 *__restrict__ hb, const __bf16 *__restrict__ W,
+                                                    const float *__restrict__ bias, const float *__restrict__ y, int b, int G,
+                                                    double inv_scale, const float *__restrict__ gw, __bf16 *__restrict__ gc,
+                                                    float *__restrict__ dbp, double *__restrict__ lossp, float *__restrict__ dxp) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *wl = smem;
+    unsigned char *dl = smem + LDS_W;
+    float *dbl = reinterpret_cast<float *>(smem + LDS_W + LDS_D);
+    __shared__ double lsh[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int gb = blockIdx.x, rb = blockIdx.y;
+    const int g0 = gb * BG, r0 = rb * BR;
+    const int hh = lane >> 5, l31 = lane & 31;
+
+    // ---- the block's W rows -> LDS (row-major, 512 bytes + 64 per row); genes past G are zero rows
+#pragma unroll 4
+    for (int it = 0; it < BG * (2 * K / 16) / NT; it++) {
+        const int idx = it * NT + tid, row = idx >> 5, piece = idx & 31;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (g0 + row < G) v = *reinterpret_cast<const uint4 *>(W + (size_t)(g0 + row) * K + piece * 8);
+        *reinterpret_cast<uint4 *>(wl + row * WROW + piece * 16) = v;
+    }
+
+    // ---- product 1: D1 [gene tile t (32 genes) x this wave's 32 rows], contraction over the K hidden channels
+    const int r = r0 + 32 * wave + l31;
+    const int rc = min(r, b - 1);
+    f16v acc1[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc1[t][i] = 0.f;
+    const __bf16 *hrow = hb + (size_t)rc * K + 8 * hh;
+    const __bf16 *wrow[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) wrow[t] = W + (size_t)min(g0 + 32 * t + l31, G - 1) * K + 8 * hh;
+#pragma unroll 4
+    for (int ks = 0; ks < K / 16; ks++) {
+        const bf8 hf = *reinterpret_cast<const bf8 *>(hrow + 16 * ks);
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const bf8 wf = *reinterpret_cast<const bf8 *>(wrow[t] + 16 * ks);
+            acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, hf, acc1[t], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue 1: d = y - (o + bias); loss partial; g = coef d -> bf16 image in LDS; column sums of g over this wave's rows
+    const double coef = -2.0 * inv_scale * (double)gw[0];
+    const bool row_on = r < b;
+    double loss = 0.0;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int gl = 32 * t + 8 * q + 4 * hh;                     // four consecutive genes of this lane's row
+            const int g = g0 + gl;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (row_on && g < G) {                                       // (G % 4 == 0: the four genes are inside together)
+                const float4 yv = *reinterpret_cast<const float4 *>(y + (size_t)r * G + g);
+                const float4 bv = *reinterpret_cast<const float4 *>(bias + g);
+                const float ye[4] = {yv.x, yv.y, yv.z, yv.w}, be[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const double d = (double)ye[e] - (double)(acc1[t][4 * q + e] + be[e]);
+                    loss += d * d;
+                    v[e] = (float)(coef * d);
+                }
+            }
+            *reinterpret_cast<uint2 *>(dl + (32 * wave + l31) * DROW + gl * 2) = make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
+            // column sums over the wave's 32 rows (lanes with equal hh): butterfly over l31
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                float s = v[e];
+#pragma unroll
+                for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+                if (l31 == 0) dbl[wave * BG + gl + e] = s;
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) loss += __shfl_xor(loss, off, 64);
+    if (lane == 0) lsh[wave] = loss;
+    __syncthreads();
+    if (tid == 0) lossp[rb * gridDim.x + gb] = ((lsh[0] + lsh[1]) + lsh[2]) + lsh[3];
+    if (tid < BG && g0 + tid < G)
+        dbp[(size_t)rb * G + g0 + tid] = ((dbl[tid] + dbl[BG + tid]) + dbl[2 * BG + tid]) + dbl[3 * BG + tid];
+    // g rows of this block to global memory (bf16, whole 16-byte pieces: G % 8 == 0), for the weight gradient g^T h
+    {
+        const int row = tid >> 1, half = tid & 1;
+        if (r0 + row < b) {
+#pragma unroll
+            for (int p = 0; p < 8; p++) {
+                const int gl = half * 64 + p * 8;
+                if (g0 + gl < G)
+                    *reinterpret_cast<uint4 *>(gc + (size_t)(r0 + row) * G + g0 + gl) = *reinterpret_cast<const uint4 *>(dl + row * DROW + gl * 2);
+            }
+        }
+    }
+
+    // ---- product 2: D2 [channel tile ct (32 channels) x this wave's 32 rows] = W_blk^T g^T, contraction over the block's 128 genes
+    f16v acc2[8];
+#pragma unroll
+    for (int ct = 0; ct < 8; ct++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc2[ct][i] = 0.f;
+    const int g16 = (lane >> 4) & 1, qq = (lane & 15) >> 2, pp = lane & 3;
+    const unsigned char *wtr = wl + (8 * hh + qq) * WROW + (16 * g16 + 4 * pp) * 2;
+    const unsigned char *drow = dl + (32 * wave + l31) * DROW + 16 * hh;
+#pragma unroll 2
+    for (int gs = 0; gs < BG / 16; gs++) {
+        const bf8 gf = *reinterpret_cast<const bf8 *>(drow + gs * 32);
+        const unsigned char *wbase = wtr + gs * 16 * WROW;
+#pragma unroll
+        for (int ct = 0; ct < 8; ct++) {
+            const s4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4 __attribute__((address_space(3))) *)(wbase + ct * 64));
+            const s4 x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4 __attribute__((address_space(3))) *)(wbase + ct * 64 + 4 * WROW));
+            const bf8 wf = __builtin_bit_cast(bf8, __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7));
+            acc2[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, gf, acc2[ct], 0, 0, 0);
+        }
+    }
+    if (row_on) {
+        float *dst = dxp + ((size_t)gb * b + r) * K;
+#pragma unroll
+        for (int ct = 0; ct < 8; ct++)
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                *reinterpret_cast<float4 *>(dst + 32 * ct + 8 * q + 4 * hh) =
+                    make_float4(acc2[ct][4 * q], acc2[ct][4 * q + 1], acc2[ct][4 * q + 2], acc2[ct][4 * q + 3]);
+    }
+}
+
+// dh[e] = sum over the gene blocks of dxp[blk][e] (block order), four elements per thread
+__global__ __launch_bounds__(256) void k_recon_fb_reduce(const float *__restrict__ dxp, int nblk, long long n4, float *__restrict__ dh) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n4) return;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < nblk; k += 4) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            v[u] = (k + u < nblk) ? reinterpret_cast<const float4 *>(dxp)[(long long)(k + u) * n4 + e] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 4; u++) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+    }
+    reinterpret_cast<float4 *>(dh)[e] = acc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int spadot_recon_fb_supported(int b, int Kin, int G) {
+    return b > 0 && b <= 4096 && Kin == K && G >= BG && G % 8 == 0;
+}
+
+// floats of caller-owned workspace: dxp [ceil(G / 128)][b][K], then dbp [ceil(b / 128)][G]; doubles: lossp [ceil(b / 128) ceil(G / 128)]
+long long spadot_recon_fb_workspace(int b, int Kin, int G) {
+    if (!spadot_recon_fb_supported(b, Kin, G)) return -22;
+    return (long long)((G + BG - 1) / BG) * b * K + (long long)((b + BR - 1) / BR) * G;
+}
+
+int spadot_recon_fb(const void *h_bf16, const void *W_bf16, const float *bias, const float *y, int b, int Kin, int G, double inv_scale,
+                    const float *grad_weight, void *g_bf16, float *workspace, double *loss_parts, float *dh, void *stream) {
+    if (!spadot_recon_fb_supported(b, Kin, G) || !h_bf16 || !W_bf16 || !bias || !y || !grad_weight || !g_bf16 || !workspace ||
+        !loss_parts || !dh)
+        return -22;
+    if (((uintptr_t)h_bf16 & 15) || ((uintptr_t)W_bf16 & 15) || ((uintptr_t)bias & 15) || ((uintptr_t)y & 15) || ((uintptr_t)g_bf16 & 15) ||
+        ((uintptr_t)workspace & 15) || ((uintptr_t)dh & 15))
+        return -22;
+    static PerDeviceFlag attr_set;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)k_recon_fb, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return -5;
+        attr_set = true;
+    }
+    const int GB = (G + BG - 1) / BG, RB = (b + BR - 1) / BR;
+    float *dxp = workspace, *dbp = workspace + (size_t)GB * b * K;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_recon_fb, dim3(GB, RB), dim3(NT), LDS_BYTES, st, (const __bf16 *)h_bf16, (const __bf16 *)W_bf16, bias, y, b, G,
+                       inv_scale, grad_weight, (__bf16 *)g_bf16, dbp, loss_parts, dxp);
+    const long long n4 = (long long)b * K / 4;
+    hipLaunchKernelGGL(k_recon_fb_reduce, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (const float *)dxp, GB, n4, dh);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+}  // extern "C"
+
+namespace {
+__global__ __launch_bounds__(256) void k_sum_parts_d(const double *__restrict__ part, int n, double scale, float *__restrict__ out) {
+    __shared__ double sh[4];
+    double acc = 0.0;
+    for (int k = threadIdx.x; k < n; k += 256) acc += part[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (float)((((sh[0] + sh[1]) + sh[2]) + sh[3]) * scale);
+}
+}  // namespace
+
+// out[0] = scale * sum of n doubles (fixed order): the VALUE of the reconstruction term from spadot_recon_fb's loss partials
+extern "C" int spadot_sum_parts(const double *part, int n, double scale, float *out, void *stream) {
+    if (!part || !out || n < 1) return -22;
+    hipLaunchKernelGGL(k_sum_parts_d, dim3(1), dim3(256), 0, (hipStream_t)stream, part, n, scale, out);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}

@@ -119,11 +119,12 @@ class SpaDOT(nn.Module):
         stamp_if(18)                                            # (inverse done; slot 17 = in front of it, set in svgp.py)
         return svgp.elbo_finish(bc, started)
 
-    def tail(self, zg, p_m, p_v, y, batch_size, noise=None, y_seed32=None, z_hook=None):
+    def tail(self, zg, p_m, p_v, y, batch_size, noise=None, y_seed32=None, z_hook=None, recon_weight=None):
         """Latent head + decoder + reconstruction: (recon, GAT_KL, alignment, final_latent).  y_seed32: the seeds' rows
         of y already in fp32 (cached batches keep them: no cast launch per step).  z_hook(final_latent): called between the
         latent head and the decoder; may return a gradient for final_latent that no backward path of its own delivers (the
-        cluster terms' dz, formed by their forward launch): the decoder's backward adds it."""
+        cluster terms' dz, formed by their forward launch): the decoder's backward adds it.  recon_weight: see
+        Decoder.recon_loss(grad_weight=...)."""
         b = batch_size
         Ls, Lg = self.SVGP_z_dim, self.GAT_z_dim
         noise = noise if noise is not None else getattr(self, "fixed_noise", None)
@@ -131,7 +132,7 @@ class SpaDOT(nn.Module):
         final_latent, GAT_KL, alignment_loss = latent_head(zg, p_m, p_v, eps, Ls, Lg, self._rng_state())
         yb32 = y_seed32 if y_seed32 is not None else y[:b, :self.input_dim].float()
         dz_extra = z_hook(final_latent) if z_hook is not None else None
-        recon_loss = self.decoder.recon_loss(final_latent, yb32, 1.0 / self.input_dim, dz_extra=dz_extra)
+        recon_loss = self.decoder.recon_loss(final_latent, yb32, 1.0 / self.input_dim, dz_extra=dz_extra, grad_weight=recon_weight)
         return recon_loss, GAT_KL, alignment_loss, final_latent
 
     @staticmethod

@@ -9,7 +9,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..ops import grad_bias, linear_bias, ln_act, mlp_chain, mlp_chain_ok, recon_sqerr, recon_sqerr_ok, sqerr_sum, weight_image
+from ..ops import (grad_bias, linear_bias, ln_act, mlp_chain, mlp_chain_ok, recon_fb_ok, recon_sqerr, recon_sqerr_fb, recon_sqerr_ok,
+                   sqerr_sum, weight_image)
 
 
 def _hidden_stage(fan_in, fan_out):
@@ -34,14 +35,21 @@ class Decoder(nn.Module):
         # hidden -> G is the only large GEMM here: compute dtype on MFMA (fp32 accumulate), fp32 result
         return linear_bias(h, last.weight, last.bias, self.compute_dtype)
 
-    def recon_loss(self, latent_sample, y, inv_scale, dz_extra=None):
+    def recon_loss(self, latent_sample, y, inv_scale, dz_extra=None, grad_weight=None):
         """inv_scale * sum (y - decoder(latent))^2 (SpaDOT.py:89) without materialising the reconstruction separately: in the
-        bf16 compute dtype the bias add, the squared error and its sum are one launch behind the output map's GEMM."""
+        bf16 compute dtype the bias add, the squared error and its sum are one launch behind the output map's GEMM.
+        grad_weight (a device scalar, optional): the caller PROMISES that the backward pass will be seeded with exactly this
+        tensor as d loss / d recon (GraphedStepper's tail: the loss weight lambda1 through mix_losses); the output map, the
+        term and their backward are then ONE launch (ops.recon_sqerr_fb) -- which refuses any other seed."""
         bf = self.compute_dtype == torch.bfloat16
         nocast = bf
         # dz_extra: a gradient for latent_sample that arrives by no backward path of its own (ops.cluster_losses_fb); the hidden
         # stages' backward launch adds it
         h, last, hb = self._hidden(latent_sample, bf16_out=nocast, dx_add=dz_extra)
+        if bf and grad_weight is not None:
+            wim = self._output_image(last.weight)
+            if recon_fb_ok(h, last.weight, last.bias, y, hb, wim, grad_weight):
+                return recon_sqerr_fb(h, last.weight, last.bias, y, inv_scale, hb, wim, grad_weight)
         if bf and recon_sqerr_ok(h, last.weight, last.bias, y):
             # no cast launch between the hidden stages and the output map: the chain's launch leaves a bf16 copy of its result,
             # and under an optimizer that keeps bf16 weight images current the map's weight needs none either

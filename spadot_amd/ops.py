@@ -1729,6 +1729,80 @@ class _LinearSqErr(torch.autograd.Function):
         return dh, dW, db, None, None, None, None
 
 
+class _ReconFB(torch.autograd.Function):
+    """_LinearSqErr with forward AND backward in ONE launch (csrc/recon_fb.hip) for a gradient seed known when the forward runs:
+    gw = d loss / d recon, the loss weight lambda1 as a device scalar (GraphedStepper's loss-weight vector, entry 0 -- what
+    _MixLosses.backward hands over for the constant-one seed).  The output map o = h W^T is never written; g = d recon / d o in
+    bf16 (for the weight gradient g^T h, a library GEMM only the optimizer waits for) and dh = g W leave the forward launch.
+    backward() returns them and REFUSES a seed other than the promised one (like ops.cluster_losses_fb)."""
+
+    @staticmethod
+    def forward(ctx, h, W, bias, y, inv_scale, hc, Wc, gw):
+        lib = model_lib()
+        b, K = h.shape
+        G = W.shape[0]
+        dev = h.device
+        nfl = int(lib.spadot_recon_fb_workspace(b, K, G))
+        GB, RB = (G + 127) // 128, (b + 127) // 128
+        ws = torch.empty(nfl, dtype=torch.float32, device=dev)
+        lossp = torch.empty(GB * RB, dtype=torch.float64, device=dev)
+        gc = torch.empty((b, G), dtype=torch.bfloat16, device=dev)
+        dh = torch.empty((b, K), dtype=torch.float32, device=dev)
+        _check(lib.spadot_recon_fb(_p(hc), _p(Wc), _p(bias), _p(y), b, K, G, float(inv_scale), _p(gw), _p(gc), _p(ws), _p(lossp), _p(dh),
+                                   _stream()), "spadot_recon_fb")
+        out = torch.empty(1, dtype=torch.float32, device=dev)
+
+        def value(lossp=lossp, out=out):
+            _check(lib.spadot_sum_parts(_p(lossp), GB * RB, float(inv_scale), _p(out), _stream()), "spadot_sum_parts")
+
+        if DEFERRED[0] is not None:            # the VALUE of the term feeds only the logging vector: queued
+            DEFERRED[0].append(value)
+        else:
+            value()
+        ctx.save_for_backward(hc, gc, dh)
+        ctx.dbp = ws[GB * b * K:].view(RB, G)
+        ctx.seed = gw.data_ptr()
+        ok = lambda g_, p_: g_ if (g_ is not None and g_.dtype == torch.float32 and g_.is_contiguous() and g_.shape == p_.shape) else None
+        ctx.wgrad, ctx.bgrad = ok(W.grad, W), ok(bias.grad, bias)      # views of the flat gradient buffer (FlatAdamW): written in place
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None or g.data_ptr() != ctx.seed:
+            raise RuntimeError("recon_sqerr_fb: backward seeded with something other than the weight its gradient was formed for "
+                               "(the forward launch already holds d loss / d h for THAT seed)")
+        hc, gc, dh = ctx.saved_tensors
+        lib = model_lib()
+        dbp = ctx.dbp
+        direct = _DIRECT_GRAD[0]
+        db = ctx.bgrad if (direct and ctx.bgrad is not None) else torch.empty(dbp.shape[1], dtype=torch.float32, device=dh.device)
+        dW = ctx.wgrad if (direct and ctx.wgrad is not None) else torch.empty((gc.shape[1], hc.shape[1]), dtype=torch.float32, device=dh.device)
+
+        def rest(dbp=dbp, db=db, dW=dW, gc=gc, hc=hc):
+            _check(lib.spadot_colsum(_p(dbp), dbp.shape[0], dbp.shape[1], _p(db), _stream()), "spadot_colsum")
+            torch.mm(gc.t(), hc, out_dtype=torch.float32, out=dW)
+
+        if direct and ctx.wgrad is not None and ctx.bgrad is not None and _deferring():
+            DEFERRED[0].append(rest)           # nothing in the backward pass reads them: off the chain
+        else:
+            with torch.no_grad():
+                rest()
+        return dh, dW, db, None, None, None, None, None
+
+
+def recon_fb_ok(h, W, bias, y, hc, Wc, gw):
+    ok = lambda t_, like: (t_ is not None and t_.dtype == torch.bfloat16 and t_.is_contiguous() and t_.shape == like.shape)
+    return bool(gw is not None and gw.is_cuda and gw.dtype == torch.float32 and h.is_cuda and h.dtype == torch.float32 and h.dim() == 2
+                and y.dtype == torch.float32 and y.is_contiguous() and y.shape == (h.shape[0], W.shape[0]) and bias is not None
+                and bias.dtype == torch.float32 and bias.is_contiguous() and bias.data_ptr() % 16 == 0 and y.data_ptr() % 16 == 0
+                and ok(hc, h) and ok(Wc, W) and model_lib().spadot_recon_fb_supported(h.shape[0], h.shape[1], W.shape[0]))
+
+
+def recon_sqerr_fb(h, W, bias, y, inv_scale, h_bf16, W_image, grad_weight):
+    """recon_sqerr whose gradient is formed by the forward launch for the seed `grad_weight` (a device scalar): see _ReconFB."""
+    return _ReconFB.apply(h, W, bias, y, inv_scale, h_bf16, W_image, grad_weight)
+
+
 def recon_sqerr_ok(h, W, bias, y):
     return bool(h.is_cuda and h.dtype == torch.float32 and y.dtype == torch.float32 and h.dim() == 2
                 and y.dim() == 2 and h.shape[1] % 4 == 0 and W.shape[1] % 4 == 0 and y.shape == (h.shape[0], W.shape[0])

@@ -677,7 +677,8 @@ class GraphedStepper:
                 return res[2]
 
             recon, gkl, align, z = model.tail(leaves[0], leaves[1], leaves[2], st["ys"], b,
-                                              y_seed32=getattr(batch, "y_seed32", None) if cached else None, z_hook=hook)
+                                              y_seed32=getattr(batch, "y_seed32", None) if cached else None, z_hook=hook,
+                                              recon_weight=self.beta1_t[0])      # (the seed mix_losses hands this term: lambda1)
             km, ot = (box["km"], box["ot"]) if "km" in box else _cluster_terms(model, cfg, tp, tp_i, seeds, z, do_km, do_ot)
             elbo, losses = mix_losses(self.beta1_t, (recon, leaves[3], gkl, align, km, ot))
             st["g"] = opt.backward_partial(elbo, None, P["tail"], extra_inputs=leaves)

@@ -236,3 +236,55 @@ def test_reconstruction_term_from_ready_bf16_operands():
     hh, WW, bb = (t.clone().requires_grad_(True) for t in (h, W, bias))
     loss = ops.recon_sqerr(hh, WW, bb, y, 1.0 / G, h[:, :8].bfloat16().contiguous(), W.half())
     assert torch.equal(loss.detach(), res[0][0])
+
+
+@pytest.mark.parametrize("b,G", [(512, 3000), (430, 2000), (100, 136), (235, 5000)])
+def test_recon_forward_and_backward_in_one_launch_match_the_two_gemm_path(b, G):
+    """ops.recon_sqerr_fb (csrc/recon_fb.hip, round 5): the decoder's output map, the reconstruction term and their backward for
+    a seed known at forward time, one launch on the matrix cores, against ops.recon_sqerr (library GEMM, bias + squared error,
+    library GEMM) on the same bf16 operands and against fp64: value, d/dh, dW, dbias; partial row and gene blocks; bit-repeatable;
+    a backward seeded with anything but the promised scalar is refused."""
+    from spadot_amd import ops
+    K = 256
+    g = torch.Generator(device=DEV).manual_seed(b + G)
+    h = torch.randn((b, K), device=DEV, generator=g)
+    hb = h.bfloat16()
+    W = torch.randn((G, K), device=DEV, generator=g) * 0.06
+    Wb = W.bfloat16()
+    bias = torch.randn(G, device=DEV, generator=g) * 0.1
+    y = torch.randn((b, G), device=DEV, generator=g)
+    inv = 1.0 / G
+    weights = torch.tensor([0.1, -0.5, 1e-4, 0.1, 0.1, 1.0], device=DEV)
+    gw = weights[0]
+    assert ops.recon_fb_ok(h, W, bias, y, hb, Wb, gw)
+
+    def run_fb():
+        hh, WW, bb = h.clone().requires_grad_(True), W.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+        out = ops.recon_sqerr_fb(hh, WW, bb, y, inv, hb, Wb, gw)
+        dh, dW, db = torch.autograd.grad(out, [hh, WW, bb], grad_outputs=weights[0])
+        return out.detach().clone(), dh.clone(), dW.clone(), db.clone()
+
+    hh, WW, bb = h.clone().requires_grad_(True), W.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    ref = ops.recon_sqerr(hh, WW, bb, y, inv, hb, Wb)
+    rdh, rdW, rdb = torch.autograd.grad(ref, [hh, WW, bb], grad_outputs=weights[0])
+    out, dh, dW, db = run_fb()
+    torch.cuda.synchronize()
+    # fp64 from the same bf16-rounded operands
+    o64 = hb.double() @ Wb.double().t() + bias.double()
+    d64 = y.double() - o64
+    assert abs(float(out) - float((d64 ** 2).sum() * inv)) <= 1e-5 * float((d64 ** 2).sum() * inv)
+    assert abs(float(out) - float(ref)) <= 1e-5 * abs(float(ref))
+    g64 = -2.0 * inv * 0.1 * d64
+    np.testing.assert_allclose(db.cpu().numpy(), g64.sum(0).cpu().numpy(), rtol=5e-3, atol=5e-3 * float(g64.sum(0).abs().max()))
+    np.testing.assert_allclose(db.cpu().numpy(), rdb.cpu().numpy(), rtol=1e-4, atol=1e-5 * float(rdb.abs().max()) + 1e-9)
+    sc = float(rdh.abs().max())
+    np.testing.assert_allclose(dh.cpu().numpy(), rdh.cpu().numpy(), rtol=2e-3, atol=2e-3 * sc)       # (g is rounded to bf16 in both paths)
+    np.testing.assert_allclose(dh.cpu().numpy(), (g64 @ Wb.double()).cpu().numpy(), rtol=2e-2, atol=1e-2 * sc)
+    np.testing.assert_allclose(dW.cpu().numpy(), rdW.cpu().numpy(), rtol=2e-3, atol=2e-3 * float(rdW.abs().max()))
+    out2, dh2, dW2, db2 = run_fb()
+    assert torch.equal(out, out2) and torch.equal(dh, dh2) and torch.equal(db, db2)
+    # another seed is refused
+    hh = h.clone().requires_grad_(True)
+    out3 = ops.recon_sqerr_fb(hh, W.clone().requires_grad_(True), bias.clone().requires_grad_(True), y, inv, hb, Wb, gw)
+    with pytest.raises(RuntimeError):
+        torch.autograd.grad(out3, [hh], grad_outputs=torch.tensor(0.1, device=DEV))

@@ -769,8 +769,8 @@ def test_deferred_weight_gradients_leave_the_same_gradient():
     and run later on the side stream; the SVGP backward's gradient-independent half is formed beside the tail with q1 through
     T = X2 S K_mn, the posterior is handed over before the ELBO scalars, the cluster terms and their gradient are one launch.
     Against the SINGLE-GRAPH replay of the same batches (`staged_graphs: false`: the plain step body, nothing queued, nothing
-    precomputed): other routes through the same algebra, so the comparison is to rounding (1e-7 of the largest gradient entry
-    beyond the single-graph replay's own run-to-run noise), not bit for bit -- bf16, 4000 spots x 1200 genes: the matrix-core
+    precomputed, the reconstruction stage as GEMM + kernel + GEMM): other routes through the same algebra, so the comparison is
+    to rounding (1e-4 of the largest gradient entry beyond the single-graph replay's own run-to-run noise), not bit for bit -- bf16, 4000 spots x 1200 genes: the matrix-core
     paths and the aggregate-first last layer."""
     from spadot_amd.model import SpaDOT
     from spadot_amd.ops import FlatAdamW
@@ -808,8 +808,12 @@ def test_deferred_weight_gradients_leave_the_same_gradient():
             # cannot widen its own tolerance (the library's split-K GEMMs are the only non-bit-repeatable launches of the step)
             assert noise <= 1e-6 * scale, (noise, scale)
             diff = float((opt.flat_grad - ga).abs().max())
-            assert diff <= 4.0 * noise + 1e-7 * scale, (diff, noise)
-            np.testing.assert_allclose(lb.cpu().numpy(), la.cpu().numpy(), rtol=1e-6, atol=1e-7)
+            # (1e-7 until the reconstruction stage became one launch: its output map accumulates in another order than the
+            # library's, which flips the bf16 rounding of a few entries of d recon / d o -- 2^-9 of an entry each -- and moves
+            # the gradients that are sums over them by ~1e-5 of their scale; measured 0.8e-5 and 2.6e-5 on the two batches.  A queued write
+            # that is lost or lands on the wrong operand is off by the scale itself: the poison above makes that visible)
+            assert diff <= 4.0 * noise + 1e-4 * scale, (diff, noise)
+            np.testing.assert_allclose(lb.cpu().numpy(), la.cpu().numpy(), rtol=1e-5, atol=1e-6)
     # the gradients that travel through the queue are really there: the last layer's, the second layer's weight gradient, and
     # (round 5) the attention-vector / bias sums of the two matrix-core layers -- the second layer's through the queue, the first
     # layer's at the end of its backward stage, both written straight into the flat buffer

@@ -17,6 +17,19 @@ d = json.loads(open("gpurun_out/r5/bench_sink.json").read().strip().splitlines()
 print({k: d["sinkhorn"].get(k) for k in ("value", "cost_setup_s", "pair_end_to_end_s", "full_solve_s", "iters_per_s_with_convergence_checks")})
 PY
   ;;
+prof3)
+  bash tools/profile_preset.sh cfg3 bf16 r05 2>&1 | tail -5
+  timeout -k 10 300 python bench.py --spots 1650 --genes 2954 --timepoints 4 --leg train --no-cpu-baseline --steps 12 --warmup 2 > $O/bench_chickenheart_shape.json 2> $O/bench_ch.err || tail -5 $O/bench_ch.err
+  python - <<'PY'
+import json
+d = json.loads(open("gpurun_out/r5/bench_chickenheart_shape.json").read().strip().splitlines()[-1])
+print("chickenheart-like (4 x 1650 x 2954):", d["value"], "steps/s;", d.get("epoch"))
+PY
+  ;;
+t3)
+  timeout -k 10 900 python -m pytest tests/test_mlp_chain_gpu.py tests/test_train_gpu.py tests/test_step_parity_gpu.py -x -q -k "recon or staged or deferred or cfg3 or chained or small_timepoint" > $O/t3.txt 2>&1 || { grep -B2 -A14 "^>" $O/t3.txt | head -60; tail -5 $O/t3.txt; exit 1; }
+  tail -3 $O/t3.txt
+  bash tools/ab_step.sh "X=1" 2>&1 | tail -2 ;;
 ab2)
   bash tools/ab_step.sh "SPADOT_ENC_FUSED=1 SPADOT_PREMASK=1" "SPADOT_ENC_FUSED=0 SPADOT_PREMASK=1" "SPADOT_ENC_FUSED=1 SPADOT_PREMASK=0" 2>&1 | tee $O/ab_enc_premask.txt ;;
 m2)
