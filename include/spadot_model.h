@@ -284,13 +284,17 @@ int spadot_svgp_pre2_partials(const float *pz, int nparts, const float *bias, co
  * _train_utils.py:205-212, a device scalar).  h_bf16 [b x K], W_bf16 [G x K] (bf16 images of h and of the weight), y [b x G] fp32.
  * Leaves: g_bf16 [b x G] = -2 inv_scale grad_weight (y - o - bias) in bf16 (the weight gradient g^T h is the caller's GEMM),
  * dh [b x K] fp32 = g W (gene blocks summed in block order), in `workspace` (spadot_recon_fb_workspace floats) behind the
- * per-gene-block partials of dh the bias-gradient partials dbp [ceil(b / 128)][G] (sum them: spadot_colsum), and in loss_parts
- * (ceil(b / 128) * ceil(G / 128) doubles) the partial sums of (y - o - bias)^2 (spadot_sum_parts with scale = inv_scale gives the
- * term's value).  The fp32 image of o = h W^T is never formed.  K == 256, G % 8 == 0, G >= 128. */
+ * per-gene-block partials of dh the bias-gradient partials dbp [ceil(b / 64)][G] (sum them: spadot_colsum), and in loss_parts
+ * (ceil(b / 64) * ceil(G / 128) doubles) the partial sums of (y - o - bias)^2 (spadot_sum_parts with scale = inv_scale gives the
+ * term's value).  The fp32 image of o = h W^T is never formed.  WT_bf16 [K x ldt]: the TRANSPOSED bf16 image of the weight, rows
+ * padded to ldt >= G rounded up to 128 (the second product reads it like the first reads W: 16 bytes per lane straight from
+ * memory, no weight tile in LDS -- the workgroups stay small enough to be placed beside another stream's GEMMs).
+ * K == 256, G % 8 == 0, G >= 128. */
 int spadot_recon_fb_supported(int b, int K, int G);
 long long spadot_recon_fb_workspace(int b, int K, int G);
-int spadot_recon_fb(const void *h_bf16, const void *W_bf16, const float *bias, const float *y, int b, int K, int G, double inv_scale,
-                    const float *grad_weight, void *g_bf16, float *workspace, double *loss_parts, float *dh, void *stream);
+int spadot_recon_fb(const void *h_bf16, const void *W_bf16, const void *WT_bf16, int ldt, const float *bias, const float *y, int b, int K,
+                    int G, double inv_scale, const float *grad_weight, void *g_bf16, float *workspace, double *loss_parts, float *dh,
+                    void *stream);
 int spadot_sum_parts(const double *part, int n, double scale, float *out, void *stream);
 
 /* Measurement aid: buf[slot] = the device's constant-rate timestamp counter (100 MHz: 10 ns units) when the launch runs.

@@ -195,7 +195,7 @@ def model_lib():
         "spadot_gemm_nn_bf16": [vp, ci, vp, ci, vp, ci, ci, ci, ci, vp],
         "spadot_enc_fused_supported": [ci, ci, ci, ci],
         "spadot_recon_fb_supported": [ci, ci, ci],
-        "spadot_recon_fb": [vp, vp, vp, vp, ci, ci, ci, cd, vp, vp, vp, vp, vp, vp],
+        "spadot_recon_fb": [vp, vp, vp, ci, vp, vp, ci, ci, ci, cd, vp, vp, vp, vp, vp, vp],
         "spadot_sum_parts": [vp, ci, cd, vp, vp],
         "spadot_enc_bn_map": [vp, vp, vp, vp, vp, vp, vp, ci, ci, cd, cd, cd, vp, vp, vp, vp, ci, vp, vp],
         "spadot_enc_bn_fc": [vp, ci, vp, vp, vp, vp, vp, vp, ci, ci, cd, cd, cd, vp, vp, vp, vp, vp, ci, vp, vp],

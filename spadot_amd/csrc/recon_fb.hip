@@ -17,109 +17,123 @@
 // MFMA operands (v_mfma_f32_32x32x16_bf16: A lane -> row l & 31, B lane -> column l & 31, both with k = 8 (l >> 5) .. + 7;
 // D register e of lane l -> row (e & 3) + 8 (e >> 2) + 4 (l >> 5), column l & 31):
 //   product 1:  D1 [gene x row]  A = W rows (16 bytes of a W row straight from global / L2), B = h rows (likewise)
-//   product 2:  D2 [chan x row]  A = W_blk^T fragments by transposed LDS reads (ds_read_b64_tr_b16) of the block's W rows
-//               staged row-major (row stride = 64 mod 256 bytes), B = g rows from the LDS image the epilogue of product 1 wrote
+//   product 2:  D2 [chan x row]  A = rows of the TRANSPOSED weight image WT [K x Gp] (16 bytes straight from global / L2 as
+//               well), B = g rows from the LDS image the epilogue of product 1 wrote
+// No weight tile is staged in LDS: the first version did (73 KB for the block's W rows, transposed reads for product 2) and
+// took 89 us inside the step against ~20 alone -- a workgroup that needs most of a compute unit's LDS waits for a whole
+// unit to drain beside the side stream's fp64 GEMMs (the lesson of DESIGN section 4, once more).  The caller keeps WT current
+// (a 1.5 MB transposed copy per step, made where the main stream has slack).
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdint>
 
 #include "../../include/spadot_model.h"
-#include "per_device.h"
 
 namespace {
 
 constexpr int K = 256;                       // hidden width (decoder_layers[-1]); the only instantiation the model uses
-constexpr int BR = 128, BG = 128;            // rows x genes per workgroup
+constexpr int BR = 64, BG = 128;             // rows x genes per workgroup
 constexpr int NT = 256;
-constexpr int WROW = 2 * K + 64;             // staged W row stride (bytes): = 64 mod 256 (transposed reads conflict-free)
 constexpr int DROW = 2 * BG + 16;            // g image row stride (bytes): = 16 mod 256 (plain 16-byte reads conflict-free)
-constexpr int LDS_W = BG * WROW;             // 73 728
-constexpr int LDS_D = BR * DROW;             // 34 816
-constexpr int LDS_DB = 4 * BG * 4;           // per-wave column sums
-constexpr int LDS_BYTES = LDS_W + LDS_D + LDS_DB;
+constexpr int LDS_D = BR * DROW;             // 17 408
 
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
-typedef short s4 __attribute__((ext_vector_type(4)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ unsigned short bf16_bits(float x) { return __builtin_bit_cast(unsigned short, (__bf16)x); }
 __device__ __forceinline__ unsigned pack2(float lo, float hi) { return (unsigned)bf16_bits(lo) | ((unsigned)bf16_bits(hi) << 16); }
 
+// One workgroup = 64 rows x 128 genes, four waves: wave (rt, gh) takes row tile rt (32 rows) and, in product 1, gene half gh
+// (two 32-gene tiles), in product 2 channel half gh (four 32-channel tiles).  Inside the step a dependent memory round trip
+// costs 3-5 us (the side stream's fp64 GEMMs keep the memory system busy), so EVERY global operand of the workgroup -- both
+// products' weight fragments, the h fragments, y and the bias -- is requested at the top, before the first MFMA: one round
+// trip for the whole kernel (the first version walked ~12 of them: 90 us in the step against ~20 alone).  One workgroup per
+// compute unit: the fragments live in ~400 registers.
 __global__ __launch_bounds__(NT, 1) void k_recon_fb(const __bf16 *__restrict__ hb, const __bf16 *__restrict__ W,
+                                                    const __bf16 *__restrict__ WT, int ldt,
                                                     const float *__restrict__ bias, const float *__restrict__ y, int b, int G,
                                                     double inv_scale, const float *__restrict__ gw, __bf16 *__restrict__ gc,
                                                     float *__restrict__ dbp, double *__restrict__ lossp, float *__restrict__ dxp) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *wl = smem;
-    unsigned char *dl = smem + LDS_W;
-    float *dbl = reinterpret_cast<float *>(smem + LDS_W + LDS_D);
+    __shared__ __attribute__((aligned(16))) unsigned char dl[LDS_D];
+    __shared__ float dbl[2 * BG];
     __shared__ double lsh[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rt = wave & 1, gh = wave >> 1;
     const int gb = blockIdx.x, rb = blockIdx.y;
     const int g0 = gb * BG, r0 = rb * BR;
     const int hh = lane >> 5, l31 = lane & 31;
-
-    // ---- the block's W rows -> LDS (row-major, 512 bytes + 64 per row); genes past G are zero rows
-#pragma unroll 4
-    for (int it = 0; it < BG * (2 * K / 16) / NT; it++) {
-        const int idx = it * NT + tid, row = idx >> 5, piece = idx & 31;
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (g0 + row < G) v = *reinterpret_cast<const uint4 *>(W + (size_t)(g0 + row) * K + piece * 8);
-        *reinterpret_cast<uint4 *>(wl + row * WROW + piece * 16) = v;
-    }
-
-    // ---- product 1: D1 [gene tile t (32 genes) x this wave's 32 rows], contraction over the K hidden channels
-    const int r = r0 + 32 * wave + l31;
+    const int r = r0 + 32 * rt + l31;
     const int rc = min(r, b - 1);
-    f16v acc1[4];
+    const bool row_on = r < b;
+
+    // ---- all requests first
+    bf8 hf[K / 16], wf[2][K / 16], w2[4][BG / 16];
+    float4 yv[2][4], bv[2][4];
+    {
+        const __bf16 *hrow = hb + (size_t)rc * K + 8 * hh;
 #pragma unroll
-    for (int t = 0; t < 4; t++)
+        for (int ks = 0; ks < K / 16; ks++) hf[ks] = *reinterpret_cast<const bf8 *>(hrow + 16 * ks);
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const __bf16 *wrow = W + (size_t)min(g0 + 64 * gh + 32 * t + l31, G - 1) * K + 8 * hh;
+#pragma unroll
+            for (int ks = 0; ks < K / 16; ks++) wf[t][ks] = *reinterpret_cast<const bf8 *>(wrow + 16 * ks);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                // (G % 4 == 0: four genes are inside together.  UNCONDITIONAL loads from a clamped address -- a predicated load
+                // is a branch, and the compiler waits for every outstanding load at its join: the first build of this kernel
+                // had ten such waits in a row; what lies outside is masked in the epilogue)
+                const int g = min(g0 + 64 * gh + 32 * t + 8 * q + 4 * hh, G - 4);
+                yv[t][q] = *reinterpret_cast<const float4 *>(y + (size_t)rc * G + g);
+                bv[t][q] = *reinterpret_cast<const float4 *>(bias + g);
+            }
+        const __bf16 *wt0 = WT + (size_t)(128 * gh + l31) * ldt + g0 + 8 * hh;
+#pragma unroll
+        for (int ct = 0; ct < 4; ct++)
+#pragma unroll
+            for (int gs = 0; gs < BG / 16; gs++) w2[ct][gs] = *reinterpret_cast<const bf8 *>(wt0 + (size_t)(32 * ct) * ldt + 16 * gs);
+    }
+    const double coef = -2.0 * inv_scale * (double)gw[0];
+
+    // ---- product 1: D1 [gene tile (32 genes) x this wave's 32 rows], contraction over the K hidden channels
+    f16v acc1[2];
+#pragma unroll
+    for (int t = 0; t < 2; t++)
 #pragma unroll
         for (int i = 0; i < 16; i++) acc1[t][i] = 0.f;
-    const __bf16 *hrow = hb + (size_t)rc * K + 8 * hh;
-    const __bf16 *wrow[4];
 #pragma unroll
-    for (int t = 0; t < 4; t++) wrow[t] = W + (size_t)min(g0 + 32 * t + l31, G - 1) * K + 8 * hh;
-#pragma unroll 4
-    for (int ks = 0; ks < K / 16; ks++) {
-        const bf8 hf = *reinterpret_cast<const bf8 *>(hrow + 16 * ks);
+    for (int ks = 0; ks < K / 16; ks++)
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const bf8 wf = *reinterpret_cast<const bf8 *>(wrow[t] + 16 * ks);
-            acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, hf, acc1[t], 0, 0, 0);
-        }
-    }
+        for (int t = 0; t < 2; t++) acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t][ks], hf[ks], acc1[t], 0, 0, 0);
 
     // ---- epilogue 1: d = y - (o + bias); loss partial; g = coef d -> bf16 image in LDS; column sums of g over this wave's rows
-    const double coef = -2.0 * inv_scale * (double)gw[0];
-    const bool row_on = r < b;
     double loss = 0.0;
 #pragma unroll
-    for (int t = 0; t < 4; t++) {
+    for (int t = 0; t < 2; t++) {
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const int gl = 32 * t + 8 * q + 4 * hh;                     // four consecutive genes of this lane's row
-            const int g = g0 + gl;
-            float v[4] = {0.f, 0.f, 0.f, 0.f};
-            if (row_on && g < G) {                                       // (G % 4 == 0: the four genes are inside together)
-                const float4 yv = *reinterpret_cast<const float4 *>(y + (size_t)r * G + g);
-                const float4 bv = *reinterpret_cast<const float4 *>(bias + g);
-                const float ye[4] = {yv.x, yv.y, yv.z, yv.w}, be[4] = {bv.x, bv.y, bv.z, bv.w};
+            const int gl = 64 * gh + 32 * t + 8 * q + 4 * hh;             // four consecutive genes of this lane's row
+            const bool on = row_on && g0 + gl < G;
+            const float ye[4] = {yv[t][q].x, yv[t][q].y, yv[t][q].z, yv[t][q].w};
+            const float be[4] = {bv[t][q].x, bv[t][q].y, bv[t][q].z, bv[t][q].w};
+            float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const double d = (double)ye[e] - (double)(acc1[t][4 * q + e] + be[e]);
-                    loss += d * d;
-                    v[e] = (float)(coef * d);
-                }
+            for (int e = 0; e < 4; e++) {
+                const double d = on ? (double)ye[e] - (double)(acc1[t][4 * q + e] + be[e]) : 0.0;
+                loss += d * d;
+                v[e] = (float)(coef * d);
             }
-            *reinterpret_cast<uint2 *>(dl + (32 * wave + l31) * DROW + gl * 2) = make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
+            *reinterpret_cast<uint2 *>(dl + (32 * rt + l31) * DROW + gl * 2) = make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
             // column sums over the wave's 32 rows (lanes with equal hh): butterfly over l31
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 float s = v[e];
 #pragma unroll
                 for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-                if (l31 == 0) dbl[wave * BG + gl + e] = s;
+                if (l31 == 0) dbl[rt * BG + gl + e] = s;
             }
         }
     }
@@ -128,15 +142,14 @@ __global__ __launch_bounds__(NT, 1) void k_recon_fb(const __bf16 *__restrict__ h
     if (lane == 0) lsh[wave] = loss;
     __syncthreads();
     if (tid == 0) lossp[rb * gridDim.x + gb] = ((lsh[0] + lsh[1]) + lsh[2]) + lsh[3];
-    if (tid < BG && g0 + tid < G)
-        dbp[(size_t)rb * G + g0 + tid] = ((dbl[tid] + dbl[BG + tid]) + dbl[2 * BG + tid]) + dbl[3 * BG + tid];
+    if (tid < BG && g0 + tid < G) dbp[(size_t)rb * G + g0 + tid] = dbl[tid] + dbl[BG + tid];
     // g rows of this block to global memory (bf16, whole 16-byte pieces: G % 8 == 0), for the weight gradient g^T h
     {
-        const int row = tid >> 1, half = tid & 1;
+        const int row = tid >> 2, quarter = tid & 3;
         if (r0 + row < b) {
 #pragma unroll
-            for (int p = 0; p < 8; p++) {
-                const int gl = half * 64 + p * 8;
+            for (int p = 0; p < 4; p++) {
+                const int gl = quarter * 32 + p * 8;
                 if (g0 + gl < G)
                     *reinterpret_cast<uint4 *>(gc + (size_t)(r0 + row) * G + g0 + gl) = *reinterpret_cast<const uint4 *>(dl + row * DROW + gl * 2);
             }
@@ -144,30 +157,23 @@ __global__ __launch_bounds__(NT, 1) void k_recon_fb(const __bf16 *__restrict__ h
     }
 
     // ---- product 2: D2 [channel tile ct (32 channels) x this wave's 32 rows] = W_blk^T g^T, contraction over the block's 128 genes
-    f16v acc2[8];
+    // (genes past G: the g image holds zeros there and WT's rows are padded to a multiple of 128, so nothing is read out of bounds)
+    f16v acc2[4];
 #pragma unroll
-    for (int ct = 0; ct < 8; ct++)
+    for (int ct = 0; ct < 4; ct++)
 #pragma unroll
         for (int i = 0; i < 16; i++) acc2[ct][i] = 0.f;
-    const int g16 = (lane >> 4) & 1, qq = (lane & 15) >> 2, pp = lane & 3;
-    const unsigned char *wtr = wl + (8 * hh + qq) * WROW + (16 * g16 + 4 * pp) * 2;
-    const unsigned char *drow = dl + (32 * wave + l31) * DROW + 16 * hh;
-#pragma unroll 2
+    const unsigned char *drow = dl + (32 * rt + l31) * DROW + 16 * hh;
+#pragma unroll
     for (int gs = 0; gs < BG / 16; gs++) {
         const bf8 gf = *reinterpret_cast<const bf8 *>(drow + gs * 32);
-        const unsigned char *wbase = wtr + gs * 16 * WROW;
 #pragma unroll
-        for (int ct = 0; ct < 8; ct++) {
-            const s4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4 __attribute__((address_space(3))) *)(wbase + ct * 64));
-            const s4 x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4 __attribute__((address_space(3))) *)(wbase + ct * 64 + 4 * WROW));
-            const bf8 wf = __builtin_bit_cast(bf8, __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7));
-            acc2[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, gf, acc2[ct], 0, 0, 0);
-        }
+        for (int ct = 0; ct < 4; ct++) acc2[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2[ct][gs], gf, acc2[ct], 0, 0, 0);
     }
     if (row_on) {
-        float *dst = dxp + ((size_t)gb * b + r) * K;
+        float *dst = dxp + ((size_t)gb * b + r) * K + 128 * gh;
 #pragma unroll
-        for (int ct = 0; ct < 8; ct++)
+        for (int ct = 0; ct < 4; ct++)
 #pragma unroll
             for (int q = 0; q < 4; q++)
                 *reinterpret_cast<float4 *>(dst + 32 * ct + 8 * q + 4 * hh) =
@@ -199,29 +205,26 @@ int spadot_recon_fb_supported(int b, int Kin, int G) {
     return b > 0 && b <= 4096 && Kin == K && G >= BG && G % 8 == 0;
 }
 
-// floats of caller-owned workspace: dxp [ceil(G / 128)][b][K], then dbp [ceil(b / 128)][G]; doubles: lossp [ceil(b / 128) ceil(G / 128)]
+// floats of caller-owned workspace: dxp [ceil(G / 128)][b][K], then dbp [ceil(b / 64)][G]; doubles: lossp [ceil(b / 64) ceil(G / 128)]
 long long spadot_recon_fb_workspace(int b, int Kin, int G) {
     if (!spadot_recon_fb_supported(b, Kin, G)) return -22;
     return (long long)((G + BG - 1) / BG) * b * K + (long long)((b + BR - 1) / BR) * G;
 }
 
-int spadot_recon_fb(const void *h_bf16, const void *W_bf16, const float *bias, const float *y, int b, int Kin, int G, double inv_scale,
-                    const float *grad_weight, void *g_bf16, float *workspace, double *loss_parts, float *dh, void *stream) {
-    if (!spadot_recon_fb_supported(b, Kin, G) || !h_bf16 || !W_bf16 || !bias || !y || !grad_weight || !g_bf16 || !workspace ||
-        !loss_parts || !dh)
+int spadot_recon_fb(const void *h_bf16, const void *W_bf16, const void *WT_bf16, int ldt, const float *bias, const float *y, int b, int Kin,
+                    int G, double inv_scale, const float *grad_weight, void *g_bf16, float *workspace, double *loss_parts, float *dh,
+                    void *stream) {
+    if (!spadot_recon_fb_supported(b, Kin, G) || !h_bf16 || !W_bf16 || !WT_bf16 || !bias || !y || !grad_weight || !g_bf16 || !workspace ||
+        !loss_parts || !dh || ldt < (G + BG - 1) / BG * BG || ldt % 8 || ((uintptr_t)WT_bf16 & 15))
         return -22;
     if (((uintptr_t)h_bf16 & 15) || ((uintptr_t)W_bf16 & 15) || ((uintptr_t)bias & 15) || ((uintptr_t)y & 15) || ((uintptr_t)g_bf16 & 15) ||
         ((uintptr_t)workspace & 15) || ((uintptr_t)dh & 15))
         return -22;
-    static PerDeviceFlag attr_set;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)k_recon_fb, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return -5;
-        attr_set = true;
-    }
     const int GB = (G + BG - 1) / BG, RB = (b + BR - 1) / BR;
     float *dxp = workspace, *dbp = workspace + (size_t)GB * b * K;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_recon_fb, dim3(GB, RB), dim3(NT), LDS_BYTES, st, (const __bf16 *)h_bf16, (const __bf16 *)W_bf16, bias, y, b, G,
+    hipLaunchKernelGGL(k_recon_fb, dim3(GB, RB), dim3(NT), 0, st, (const __bf16 *)h_bf16, (const __bf16 *)W_bf16, (const __bf16 *)WT_bf16, ldt,
+                       bias, y, b, G,
                        inv_scale, grad_weight, (__bf16 *)g_bf16, dbp, loss_parts, dxp);
     const long long n4 = (long long)b * K / 4;
     hipLaunchKernelGGL(k_recon_fb_reduce, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (const float *)dxp, GB, n4, dh);

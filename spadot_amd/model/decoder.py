@@ -48,8 +48,9 @@ class Decoder(nn.Module):
         h, last, hb = self._hidden(latent_sample, bf16_out=nocast, dx_add=dz_extra)
         if bf and grad_weight is not None:
             wim = self._output_image(last.weight)
-            if recon_fb_ok(h, last.weight, last.bias, y, hb, wim, grad_weight):
-                return recon_sqerr_fb(h, last.weight, last.bias, y, inv_scale, hb, wim, grad_weight)
+            wimT = self._output_image_T(wim) if wim is not None else None
+            if recon_fb_ok(h, last.weight, last.bias, y, hb, wim, wimT, grad_weight):
+                return recon_sqerr_fb(h, last.weight, last.bias, y, inv_scale, hb, wim, wimT, grad_weight)
         if bf and recon_sqerr_ok(h, last.weight, last.bias, y):
             # no cast launch between the hidden stages and the output map: the chain's launch leaves a bf16 copy of its result,
             # and under an optimizer that keeps bf16 weight images current the map's weight needs none either
@@ -70,6 +71,32 @@ class Decoder(nn.Module):
             return None
         opt.sync_images()
         return im
+
+    def _output_image_T(self, wim, refresh=None):
+        """The TRANSPOSED bf16 image [K, G rounded up to 128] of the output map's weight (ops.recon_sqerr_fb reads it for the
+        input gradient).  Brought up to date from `wim` (the image the optimizer keeps current) by one strided copy: at the
+        head of a step when a stepper calls step_begin() -- the main stream has slack there -- else right here."""
+        G, K = wim.shape
+        Gp = (G + 127) // 128 * 128
+        t = getattr(self, "_wout_T", None)
+        if t is None or t.shape != (K, Gp) or t.device != wim.device:
+            t = torch.zeros((K, Gp), dtype=torch.bfloat16, device=wim.device)
+            object.__setattr__(self, "_wout_T", t)
+            object.__setattr__(self, "_wout_T_fresh", False)
+        if refresh is True or (refresh is None and not getattr(self, "_wout_T_fresh", False)):
+            with torch.no_grad():
+                t[:, :G].copy_(wim.t())
+        object.__setattr__(self, "_wout_T_fresh", bool(refresh))          # (consumed by the step's recon_loss call)
+        return t
+
+    def step_begin(self):
+        """Called by GraphedStepper at the head of a step (inside its first captured stage): refreshes what the loss tail reads
+        besides the optimizer-maintained images -- the transposed output-map image -- where the main stream has slack."""
+        if self.compute_dtype != torch.bfloat16 or not self.training:
+            return
+        wim = self._output_image(list(self.decoder_net)[-1].weight)
+        if wim is not None:
+            self._output_image_T(wim, refresh=True)
 
     def _hidden(self, latent_sample, bf16_out=False, dx_add=None):
         stages = list(self.decoder_net)

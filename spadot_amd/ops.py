@@ -1737,19 +1737,19 @@ class _ReconFB(torch.autograd.Function):
     backward() returns them and REFUSES a seed other than the promised one (like ops.cluster_losses_fb)."""
 
     @staticmethod
-    def forward(ctx, h, W, bias, y, inv_scale, hc, Wc, gw):
+    def forward(ctx, h, W, bias, y, inv_scale, hc, Wc, WcT, gw):
         lib = model_lib()
         b, K = h.shape
         G = W.shape[0]
         dev = h.device
         nfl = int(lib.spadot_recon_fb_workspace(b, K, G))
-        GB, RB = (G + 127) // 128, (b + 127) // 128
+        GB, RB = (G + 127) // 128, (b + 63) // 64
         ws = torch.empty(nfl, dtype=torch.float32, device=dev)
         lossp = torch.empty(GB * RB, dtype=torch.float64, device=dev)
         gc = torch.empty((b, G), dtype=torch.bfloat16, device=dev)
         dh = torch.empty((b, K), dtype=torch.float32, device=dev)
-        _check(lib.spadot_recon_fb(_p(hc), _p(Wc), _p(bias), _p(y), b, K, G, float(inv_scale), _p(gw), _p(gc), _p(ws), _p(lossp), _p(dh),
-                                   _stream()), "spadot_recon_fb")
+        _check(lib.spadot_recon_fb(_p(hc), _p(Wc), _p(WcT), WcT.shape[1], _p(bias), _p(y), b, K, G, float(inv_scale), _p(gw), _p(gc), _p(ws),
+                                   _p(lossp), _p(dh), _stream()), "spadot_recon_fb")
         out = torch.empty(1, dtype=torch.float32, device=dev)
 
         def value(lossp=lossp, out=out):
@@ -1787,20 +1787,23 @@ class _ReconFB(torch.autograd.Function):
         else:
             with torch.no_grad():
                 rest()
-        return dh, dW, db, None, None, None, None, None
+        return dh, dW, db, None, None, None, None, None, None
 
 
-def recon_fb_ok(h, W, bias, y, hc, Wc, gw):
+def recon_fb_ok(h, W, bias, y, hc, Wc, WcT, gw):
     ok = lambda t_, like: (t_ is not None and t_.dtype == torch.bfloat16 and t_.is_contiguous() and t_.shape == like.shape)
-    return bool(gw is not None and gw.is_cuda and gw.dtype == torch.float32 and h.is_cuda and h.dtype == torch.float32 and h.dim() == 2
+    okT = (WcT is not None and WcT.dtype == torch.bfloat16 and WcT.is_contiguous() and WcT.dim() == 2 and WcT.shape[0] == W.shape[1]
+           and WcT.shape[1] >= (W.shape[0] + 127) // 128 * 128 and WcT.shape[1] % 8 == 0 and WcT.data_ptr() % 16 == 0)
+    return bool(okT and gw is not None and gw.is_cuda and gw.dtype == torch.float32 and h.is_cuda and h.dtype == torch.float32 and h.dim() == 2
                 and y.dtype == torch.float32 and y.is_contiguous() and y.shape == (h.shape[0], W.shape[0]) and bias is not None
                 and bias.dtype == torch.float32 and bias.is_contiguous() and bias.data_ptr() % 16 == 0 and y.data_ptr() % 16 == 0
                 and ok(hc, h) and ok(Wc, W) and model_lib().spadot_recon_fb_supported(h.shape[0], h.shape[1], W.shape[0]))
 
 
-def recon_sqerr_fb(h, W, bias, y, inv_scale, h_bf16, W_image, grad_weight):
-    """recon_sqerr whose gradient is formed by the forward launch for the seed `grad_weight` (a device scalar): see _ReconFB."""
-    return _ReconFB.apply(h, W, bias, y, inv_scale, h_bf16, W_image, grad_weight)
+def recon_sqerr_fb(h, W, bias, y, inv_scale, h_bf16, W_image, W_image_T, grad_weight):
+    """recon_sqerr whose gradient is formed by the forward launch for the seed `grad_weight` (a device scalar): see _ReconFB.
+    W_image_T: the transposed bf16 image of W, [K, G rounded up to 128] (zero pad columns)."""
+    return _ReconFB.apply(h, W, bias, y, inv_scale, h_bf16, W_image, W_image_T, grad_weight)
 
 
 def recon_sqerr_ok(h, W, bias, y):

@@ -640,6 +640,7 @@ class GraphedStepper:
         # graphs the address of a temporary that is gone by the first replay.  Each branch gathers what it reads on
         # its own stream: the GAT branch all n_sub rows, the SVGP branch (and the tail after it) the seeds' rows.
         def gat_fwd():
+            model.decoder.step_begin()         # (the loss tail's transposed weight image: made here, where this stream has slack)
             y_all = batch.y if cached else Y[batch.n_id]
             st["zg"] = model.branch_gat(y_all, batch.graph, b, taps=st)          # (taps: st["d2"], where the backward is cut)
 

@@ -256,11 +256,13 @@ def test_recon_forward_and_backward_in_one_launch_match_the_two_gemm_path(b, G):
     inv = 1.0 / G
     weights = torch.tensor([0.1, -0.5, 1e-4, 0.1, 0.1, 1.0], device=DEV)
     gw = weights[0]
-    assert ops.recon_fb_ok(h, W, bias, y, hb, Wb, gw)
+    WT = torch.zeros((K, (G + 127) // 128 * 128), device=DEV, dtype=torch.bfloat16)
+    WT[:, :G] = Wb.t()
+    assert ops.recon_fb_ok(h, W, bias, y, hb, Wb, WT, gw)
 
     def run_fb():
         hh, WW, bb = h.clone().requires_grad_(True), W.clone().requires_grad_(True), bias.clone().requires_grad_(True)
-        out = ops.recon_sqerr_fb(hh, WW, bb, y, inv, hb, Wb, gw)
+        out = ops.recon_sqerr_fb(hh, WW, bb, y, inv, hb, Wb, WT, gw)
         dh, dW, db = torch.autograd.grad(out, [hh, WW, bb], grad_outputs=weights[0])
         return out.detach().clone(), dh.clone(), dW.clone(), db.clone()
 
@@ -285,6 +287,6 @@ def test_recon_forward_and_backward_in_one_launch_match_the_two_gemm_path(b, G):
     assert torch.equal(out, out2) and torch.equal(dh, dh2) and torch.equal(db, db2)
     # another seed is refused
     hh = h.clone().requires_grad_(True)
-    out3 = ops.recon_sqerr_fb(hh, W.clone().requires_grad_(True), bias.clone().requires_grad_(True), y, inv, hb, Wb, gw)
+    out3 = ops.recon_sqerr_fb(hh, W.clone().requires_grad_(True), bias.clone().requires_grad_(True), y, inv, hb, Wb, WT, gw)
     with pytest.raises(RuntimeError):
         torch.autograd.grad(out3, [hh], grad_outputs=torch.tensor(0.1, device=DEV))

@@ -30,6 +30,10 @@ t3)
   timeout -k 10 900 python -m pytest tests/test_mlp_chain_gpu.py tests/test_train_gpu.py tests/test_step_parity_gpu.py -x -q -k "recon or staged or deferred or cfg3 or chained or small_timepoint" > $O/t3.txt 2>&1 || { grep -B2 -A14 "^>" $O/t3.txt | head -60; tail -5 $O/t3.txt; exit 1; }
   tail -3 $O/t3.txt
   bash tools/ab_step.sh "X=1" 2>&1 | tail -2 ;;
+ab3)
+  bash tools/ab_step.sh "SPADOT_RECON_FB=1" "SPADOT_RECON_FB=0" 2>&1 | tee $O/ab_recon_fb.txt
+  SPADOT_STAMPS=1 timeout -k 10 300 python tools/stage_stamps.py > $O/stage_stamps_recon_fb.txt 2> $O/stamps.err || tail -5 $O/stamps.err
+  head -14 $O/stage_stamps_recon_fb.txt | tail -11 ;;
 ab2)
   bash tools/ab_step.sh "SPADOT_ENC_FUSED=1 SPADOT_PREMASK=1" "SPADOT_ENC_FUSED=0 SPADOT_PREMASK=1" "SPADOT_ENC_FUSED=1 SPADOT_PREMASK=0" 2>&1 | tee $O/ab_enc_premask.txt ;;
 m2)
