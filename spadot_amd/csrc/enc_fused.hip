@@ -57,13 +57,16 @@ __global__ __launch_bounds__(ENT) void k_enc_bn_map(const float *__restrict__ h1
     __shared__ __attribute__((aligned(16))) float ys[512 * YS];
     const int cl = threadIdx.x & (EC - 1), rg = threadIdx.x / EC;
     const int c0 = blockIdx.x * EC, c = c0 + cl;
-    const float add = lb ? lb[c] : 0.f;
+    // All loads of the launch are issued HERE, unconditionally (rows past b re-read row b - 1 and are masked below): a
+    // predicated load is a branch, and the compiler drains the load queue at its join -- the first form of this kernel
+    // (`i < b ? h1[..] : 0`) was 32 dependent round trips, ~40 of its 45 us in the step.
+    const float *__restrict__ lbp = lb ? lb : gamma;
     float v[ERPT];
 #pragma unroll
-    for (int r = 0; r < ERPT; r++) {
-        const int i = rg + r * ERG;
-        v[r] = i < b ? h1[(size_t)i * F1 + c] + add : 0.f;
-    }
+    for (int r = 0; r < ERPT; r++) v[r] = h1[(size_t)min(rg + r * ERG, b - 1) * F1 + c];
+    const float add = lb ? lbp[c] : 0.f, gam = gamma[c], bet = beta[c], rm0 = run_mean[c], rv0 = run_var[c];
+#pragma unroll
+    for (int r = 0; r < ERPT; r++) v[r] = rg + r * ERG < b ? v[r] + add : 0.f;
     float s = 0.f;
 #pragma unroll
     for (int r = 0; r < ERPT; r++)
@@ -76,7 +79,7 @@ __global__ __launch_bounds__(ENT) void k_enc_bn_map(const float *__restrict__ h1
     const float var = col_sum16(ss, sh, cl, rg) / (float)b;
     const float invstd = rsqrtf(var + eps);
     {
-        const float g = gamma[c] * invstd, o = beta[c];
+        const float g = gam * invstd, o = bet;
 #pragma unroll
         for (int r = 0; r < ERPT; r++) {
             const int i = rg + r * ERG;
@@ -89,8 +92,8 @@ __global__ __launch_bounds__(ENT) void k_enc_bn_map(const float *__restrict__ h1
         }
         if (rg == 0) {
             save_mean[c] = mean; save_invstd[c] = invstd;
-            run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean;
-            run_var[c] = (1.f - momentum) * run_var[c] + momentum * var * ((float)b / (float)(b > 1 ? b - 1 : 1));
+            run_mean[c] = (1.f - momentum) * rm0 + momentum * mean;
+            run_var[c] = (1.f - momentum) * rv0 + momentum * var * ((float)b / (float)(b > 1 ? b - 1 : 1));
         }
     }
     if (nbt && blockIdx.x == 0 && threadIdx.x == 0) nbt[0] += 1;
@@ -132,27 +135,45 @@ __global__ __launch_bounds__(256) void k_enc_bn_fc(const float *__restrict__ par
     __shared__ float wf[MAX_Q][4];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int c0 = blockIdx.x * 4;
-    if (t < Q * 4) wf[t >> 2][t & 3] = Wfc[(size_t)(t >> 2) * F2 + c0 + (t & 3)];
+    // every load of the launch up front and unconditional (see k_enc_bn_map): rows past b re-read row b - 1, masked below
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float v[2][4];
     bool in[2];
+    float4 acc2[2] = {zero4, zero4};
+    const float *pr0 = part + (size_t)min(t, b - 1) * F2 + c0, *pr1 = part + (size_t)min(t + 256, b - 1) * F2 + c0;
+    auto pass = [&](int g0) __attribute__((always_inline)) {      // eight groups' partials of both rows in flight together, added in group order
+        float4 pa[8], pb[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const size_t go = (size_t)min(g0 + k, NP - 1) * b * F2;
+            pa[k] = *reinterpret_cast<const float4 *>(pr0 + go);
+            pb[k] = *reinterpret_cast<const float4 *>(pr1 + go);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (g0 + k < NP) {
+                acc2[0].x += pa[k].x; acc2[0].y += pa[k].y; acc2[0].z += pa[k].z; acc2[0].w += pa[k].w;
+                acc2[1].x += pb[k].x; acc2[1].y += pb[k].y; acc2[1].z += pb[k].z; acc2[1].w += pb[k].w;
+            }
+    };
+    // the small operands ride with the first pass (a loop's first pass would wait for whatever was issued before it)
+    const float wfv = Wfc[(size_t)(min(t, Q * 4 - 1) >> 2) * F2 + c0 + (t & 3)];
+    const float4 add4r = *reinterpret_cast<const float4 *>((lb ? lb : gamma) + c0);
+    const float4 add4 = lb ? add4r : zero4;
+    const float4 gam4 = *reinterpret_cast<const float4 *>(gamma + c0), bet4 = *reinterpret_cast<const float4 *>(beta + c0);
+    const float rm0 = run_mean[c0 + (t & 3)], rv0 = run_var[c0 + (t & 3)];
+    pass(0);
+    for (int g0 = 8; g0 < NP; g0 += 8) pass(g0);
+    if (t < Q * 4) wf[t >> 2][t & 3] = wfv;
 #pragma unroll
     for (int r = 0; r < 2; r++) {
         const int i = t + 256 * r;
         in[r] = i < b;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (in[r]) {
-#pragma unroll 8
-            for (int g = 0; g < NP; g++) {
-                const float4 p = *reinterpret_cast<const float4 *>(part + ((size_t)g * b + i) * F2 + c0);
-                acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
-            }
-            *reinterpret_cast<float4 *>(h2 + (size_t)i * F2 + c0) = acc;          // (without the map's bias: BatchNorm's lb carries it)
-        }
-        v[r][0] = acc.x; v[r][1] = acc.y; v[r][2] = acc.z; v[r][3] = acc.w;
+        if (in[r]) *reinterpret_cast<float4 *>(h2 + (size_t)i * F2 + c0) = acc2[r];   // (without the map's bias: BatchNorm's lb carries it)
+        v[r][0] = acc2[r].x; v[r][1] = acc2[r].y; v[r][2] = acc2[r].z; v[r][3] = acc2[r].w;
     }
-    float add[4], mean[4], invstd[4], var[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) add[k] = lb ? lb[c0 + k] : 0.f;
+    float mean[4], invstd[4], var[4];
+    const float add[4] = {add4.x, add4.y, add4.z, add4.w};
 #pragma unroll
     for (int r = 0; r < 2; r++)
 #pragma unroll
@@ -182,13 +203,13 @@ __global__ __launch_bounds__(256) void k_enc_bn_fc(const float *__restrict__ par
     if (t < 4) {
         const int c = c0 + t;
         save_mean[c] = mean[t]; save_invstd[c] = invstd[t];
-        run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean[t];
-        run_var[c] = (1.f - momentum) * run_var[c] + momentum * var[t] * ((float)b / (float)(b > 1 ? b - 1 : 1));
+        run_mean[c] = (1.f - momentum) * rm0 + momentum * mean[t];
+        run_var[c] = (1.f - momentum) * rv0 + momentum * var[t] * ((float)b / (float)(b > 1 ? b - 1 : 1));
     }
     if (nbt && blockIdx.x == 0 && t == 0) nbt[0] += 1;
     float g4[4], o4[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) { g4[k] = gamma[c0 + k] * invstd[k]; o4[k] = beta[c0 + k]; }
+    for (int k = 0; k < 4; k++) { g4[k] = (&gam4.x)[k] * invstd[k]; o4[k] = (&bet4.x)[k]; }
     float *pg = pz + (size_t)blockIdx.x * b * Q;
 #pragma unroll
     for (int r = 0; r < 2; r++) {

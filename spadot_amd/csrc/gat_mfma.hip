@@ -98,15 +98,29 @@ __global__ __launch_bounds__(256) void k_gat_alpha(const float *__restrict__ s_s
     if (i >= n_tgt) return;
     const int hd = lane % H, es = lane / H;
     const int p0 = rowptr[i], deg = rowptr[i + 1] - p0;
+    if (deg <= 0) return;                                              // (wave-uniform: nothing to write)
     const float sd = s_dst[(size_t)i * H + hd];
     const int npass = (deg + EP - 1) / EP;
+    // Three round trips, not one or two per pass: the row pointer; then EVERY per-edge index of the first four passes (source
+    // id and the cells of both weight images), loaded unconditionally from a clamped position (a predicated load is a
+    // branch the compiler drains the queue at); then the sources' logit halves.
+    const int plast = p0 + deg - 1;
+    const int *__restrict__ cq_s = acell_s ? cellq_s : cellq;
+    int cj[4], cq_t[4], cq_u[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const int pc = min(p0 + t * EP + es, plast);
+        cj[t] = col[pc]; cq_t[t] = cellq[pc]; cq_u[t] = cq_s[pc];
+    }
+    float sv[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) sv[t] = s_src[(size_t)cj[t] * H + hd];
     float ev[4];
     float m = -INFINITY;
 #pragma unroll
     for (int t = 0; t < 4; t++) {
         const int p = p0 + t * EP + es;
-        ev[t] = -INFINITY;
-        if (t < npass && p < p0 + deg) ev[t] = leaky(s_src[(size_t)col[p] * H + hd] + sd, ATT_SLOPE);
+        ev[t] = (t < npass && p < p0 + deg) ? leaky(sv[t] + sd, ATT_SLOPE) : -INFINITY;
         m = fmaxf(m, ev[t]);
     }
     for (int t = 4; t < npass; t++) {
@@ -128,8 +142,8 @@ __global__ __launch_bounds__(256) void k_gat_alpha(const float *__restrict__ s_s
         if (t < npass && p < p0 + deg) {
             const float a = __expf(ev[t] - m) * inv;
             alpha[(size_t)p * H + hd] = a;
-            acell_put(acell, acell_off(cellq[p], H, hd), a);
-            if (acell_s) acell_put(acell_s, acell_off(cellq_s[p], H, hd), a);
+            acell_put(acell, acell_off(cq_t[t], H, hd), a);
+            if (acell_s) acell_put(acell_s, acell_off(cq_u[t], H, hd), a);
         }
     }
     for (int t = 4; t < npass; t++) {
@@ -160,15 +174,31 @@ __global__ __launch_bounds__(256) void k_gat_softmax_bwd(const float *__restrict
     }
     const int hd = lane % H, es = lane / H;
     const int p0 = rowptr[i], deg = rowptr[i + 1] - p0;
+    if (deg <= 0) {                                                    // (wave-uniform)
+        if (lane < H) ds_dst[(size_t)i * H + lane] = 0.f;
+        return;
+    }
     const float sd = s_dst[(size_t)i * H + hd];
     const int npass = (deg + EP - 1) / EP;
+    // as in k_gat_alpha: every per-edge value of the first four passes in ONE round trip (unconditional loads from a clamped
+    // position), the sources' logit halves in a second one
+    const int plast = p0 + deg - 1;
+    const int *__restrict__ cq_s = acell_s ? cellq_s : col;            // (any readable int array when there is no image)
     float av[4], dv[4];
+    int cj[4], cq_u[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const int pc = min(p0 + t * EP + es, plast);
+        av[t] = alpha[(size_t)pc * H + hd]; dv[t] = dz[(size_t)pc * H + hd]; cj[t] = col[pc]; cq_u[t] = cq_s[pc];
+    }
+    float sv[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) sv[t] = s_src[(size_t)cj[t] * H + hd];
     float dsum = 0.f;
 #pragma unroll
     for (int t = 0; t < 4; t++) {
         const int p = p0 + t * EP + es;
-        av[t] = 0.f; dv[t] = 0.f;
-        if (t < npass && p < p0 + deg) { av[t] = alpha[(size_t)p * H + hd]; dv[t] = dz[(size_t)p * H + hd]; }
+        if (!(t < npass && p < p0 + deg)) { av[t] = 0.f; dv[t] = 0.f; }
         dsum += av[t] * dv[t];
     }
     for (int t = 4; t < npass; t++) {
@@ -177,21 +207,21 @@ __global__ __launch_bounds__(256) void k_gat_softmax_bwd(const float *__restrict
     }
     dsum = head_sum<H>(dsum);
     float dsd = 0.f;
-    auto finish = [&](int p, float a, float da) __attribute__((always_inline)) {
-        const float z = s_src[(size_t)col[p] * H + hd] + sd;
+    auto finish = [&](int p, float a, float da, float ss, int cqe) __attribute__((always_inline)) {
+        const float z = ss + sd;
         const float d = a * (da - dsum) * (z > 0.f ? 1.f : ATT_SLOPE);
         dz[(size_t)p * H + hd] = d;
         dsd += d;
-        if (acell_s) acell_put(acell_s, acell_off(cellq_s[p], H, hd), a);
+        if (acell_s) acell_put(acell_s, acell_off(cqe, H, hd), a);
     };
 #pragma unroll
     for (int t = 0; t < 4; t++) {
         const int p = p0 + t * EP + es;
-        if (t < npass && p < p0 + deg) finish(p, av[t], dv[t]);
+        if (t < npass && p < p0 + deg) finish(p, av[t], dv[t], sv[t], cq_u[t]);
     }
     for (int t = 4; t < npass; t++) {
         const int p = p0 + t * EP + es;
-        if (p < p0 + deg) finish(p, alpha[(size_t)p * H + hd], dz[(size_t)p * H + hd]);
+        if (p < p0 + deg) finish(p, alpha[(size_t)p * H + hd], dz[(size_t)p * H + hd], s_src[(size_t)col[p] * H + hd], acell_s ? cellq_s[p] : 0);
     }
     dsd = head_sum<H>(dsd);
     if (es == 0) ds_dst[(size_t)i * H + hd] = dsd;
@@ -527,33 +557,47 @@ __global__ __launch_bounds__(NT, EDOT_WGS) void k_gat_edot(const __bf16 *__restr
     const int b = item / H, hd = item - b * H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t hoff = (size_t)hd * C, HC = (size_t)H * C;
+    // Every load below is UNCONDITIONAL, from a clamped address, and all requests of a phase are issued before the first
+    // use: a predicated load is a branch, and hipcc waits for everything outstanding at its join -- the first form of
+    // this prologue (`if (node >= 0) load`) was eight dependent round trips, 28 of the kernel's 63 us
+    // (profiles/r05/gat_probe.txt).  Rows without a node are masked after the fact.
+    const int s0 = sptr[b], ntile = (EDOT_PROBE & 8) ? 0 : (sptr[b + 1] - s0) / 32;
+    const int sl = lane & 31, hh = lane >> 5;
+    int sid_next = wave < ntile ? pcol[s0 + wave * 32 + sl] : 0;          // (first tile's column id: rides with the row ids)
     int nodes[2 * NTW];
 #pragma unroll
     for (int m = 0; m < 2 * NTW; m++) nodes[m] = prow[b * ROWS + (m * NT + tid) / PPR];
+    u32x4 gv[2 * NTW];
+#pragma unroll
+    for (int m = 0; m < 2 * NTW; m++) {
+        const int pc = (m * NT + tid) % PPR;
+        gv[m] = *reinterpret_cast<const u32x4 *>(g_out + (size_t)max(nodes[m], 0) * HC + hoff + (size_t)pc * 8);
+    }
+    if (act && !(EDOT_PROBE & 1)) {
+        u32x4 ov[2 * NTW];
+#pragma unroll
+        for (int m = 0; m < 2 * NTW; m++) {
+            const int pc = (m * NT + tid) % PPR;
+            ov[m] = *reinterpret_cast<const u32x4 *>(outp + (size_t)max(nodes[m], 0) * HC + hoff + (size_t)pc * 8);
+        }
+#pragma unroll
+        for (int m = 0; m < 2 * NTW; m++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                float lo = __uint_as_float(gv[m][e] << 16), hi = __uint_as_float(gv[m][e] & 0xffff0000u);
+                if (!(__uint_as_float(ov[m][e] << 16) > 0.f)) lo *= ACT_SLOPE;
+                if (!(__uint_as_float(ov[m][e] & 0xffff0000u) > 0.f)) hi *= ACT_SLOPE;
+                gv[m][e] = pack2(lo, hi);
+            }
+    }
 #pragma unroll
     for (int m = 0; m < 2 * NTW; m++) {
         const int pi = m * NT + tid, r = pi / PPR, pc = pi - r * PPR;
-        const int node = nodes[m];
-        uint4 g = make_uint4(0u, 0u, 0u, 0u);
-        if (node >= 0) {
-            const size_t off = (size_t)node * HC + hoff + (size_t)pc * 8;
-            g = *reinterpret_cast<const uint4 *>(g_out + off);
-            if (act && !(EDOT_PROBE & 1)) {
-                const uint4 o = *reinterpret_cast<const uint4 *>(outp + off);
-                unsigned gw[4] = {g.x, g.y, g.z, g.w};
-                const unsigned ow[4] = {o.x, o.y, o.z, o.w};
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    float lo = __uint_as_float(gw[e] << 16), hi = __uint_as_float(gw[e] & 0xffff0000u);
-                    if (!(__uint_as_float(ow[e] << 16) > 0.f)) lo *= ACT_SLOPE;
-                    if (!(__uint_as_float(ow[e] & 0xffff0000u) > 0.f)) hi *= ACT_SLOPE;
-                    gw[e] = pack2(lo, hi);
-                }
-                g = make_uint4(gw[0], gw[1], gw[2], gw[3]);
-            }
-            if (g_pre != nullptr && !(EDOT_PROBE & 1)) *reinterpret_cast<uint4 *>(g_pre + off) = g;
-        }
-        *reinterpret_cast<uint4 *>(gt + (size_t)r * GS + (size_t)((pc ^ (r & XM)) * 16)) = g;
+        const bool on = nodes[m] >= 0;
+        const u32x4 g = on ? gv[m] : u32x4{0u, 0u, 0u, 0u};
+        if (on && g_pre != nullptr && !(EDOT_PROBE & 1))
+            *reinterpret_cast<u32x4 *>(g_pre + (size_t)nodes[m] * HC + hoff + (size_t)pc * 8) = g;
+        *reinterpret_cast<u32x4 *>(gt + (size_t)r * GS + (size_t)((pc ^ (r & XM)) * 16)) = g;
     }
     __syncthreads();
     if (bias_part != nullptr && C == 2 * NT) {
@@ -569,13 +613,19 @@ __global__ __launch_bounds__(NT, EDOT_WGS) void k_gat_edot(const __bf16 *__restr
         *reinterpret_cast<float2 *>(bias_part + (size_t)b * part_width + part_col + hoff + 2 * tid) = make_float2(b0, b1);
     }
 
-    const int s0 = sptr[b], ntile = (EDOT_PROBE & 8) ? 0 : (sptr[b + 1] - s0) / 32;
-    const int sl = lane & 31, hh = lane >> 5;
+    // Per tile three things come from memory: the column id (needed first), the 32 pieces of the source row, and the 16
+    // cell ids the results are scattered through.  In program order they were three dependent round trips per tile; now
+    // the next tile's column id and this tile's cell ids are requested in front of the row pieces, so only those are waited for.
     for (int nt = wave; nt < ntile; nt += 4) {
-        const int sid = (EDOT_PROBE & 2) ? pcol[s0] : pcol[s0 + nt * 32 + sl];
+        const int sid = (EDOT_PROBE & 2) ? pcol[s0] : sid_next;
         const __bf16 *xrow = Xh + (size_t)sid * HC + hoff + 16 * hh;
         const unsigned char *grow = gt + (size_t)sl * GS;
         const int gx = sl & XM;                                       // this row's chunk XOR
+        const int *cq = cell + ((size_t)(s0 / KSTEP) + 2 * nt + (sl >> 4)) * (KSTEP * ROWS) + (sl & 15);
+        int ce[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) ce[i] = cq[((i & 3) + 8 * (i >> 2) + 4 * hh) * KSTEP];
+        sid_next = pcol[s0 + min(nt + 4, ntile - 1) * 32 + sl];
         f16v acc;
 #pragma unroll
         for (int i = 0; i < 16; i++) acc[i] = 0.f;
@@ -589,11 +639,9 @@ __global__ __launch_bounds__(NT, EDOT_WGS) void k_gat_edot(const __bf16 *__restr
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, x1, acc, 0, 0, 0);
         }
         // acc[i] = dA[row (i & 3) + 8 (i >> 2) + 4 hh][column slot nt * 32 + sl]
-        const int *cq = cell + ((size_t)(s0 / KSTEP) + 2 * nt + (sl >> 4)) * (KSTEP * ROWS) + (sl & 15);
 #pragma unroll
         for (int i = 0; i < 16; i++) {
-            const int r = (i & 3) + 8 * (i >> 2) + 4 * hh;
-            const int e = cq[r * KSTEP];
+            const int e = ce[i];
             if (e >= 0 && (!(EDOT_PROBE & 4) || acc[i] == 123.f)) dz[(size_t)e * H + hd] = acc[i];
         }
     }

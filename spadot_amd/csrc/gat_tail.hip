@@ -65,28 +65,30 @@ template <> __device__ __forceinline__ void store8<__bf16>(__bf16 *p, const floa
 }
 
 // the same eight elements kept PACKED until they are used (bf16: 4 registers instead of 8)
+// (native vector types: arrays of HIP's float4 / uint4 classes are not promoted to registers and end up in scratch memory)
+typedef float tf32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned tu32x4 __attribute__((ext_vector_type(4)));
 template <typename T> struct Raw8;
-template <> struct Raw8<float> { float4 a, b; };
-template <> struct Raw8<__bf16> { uint4 v; };
+template <> struct Raw8<float> { tf32x4 a, b; };
+template <> struct Raw8<__bf16> { tu32x4 v; };
 template <typename T> __device__ __forceinline__ Raw8<T> load8_raw(const T *p);
 template <> __device__ __forceinline__ Raw8<float> load8_raw<float>(const float *p) {
     Raw8<float> r;
-    r.a = *reinterpret_cast<const float4 *>(p); r.b = *reinterpret_cast<const float4 *>(p + 4);
+    r.a = *reinterpret_cast<const tf32x4 *>(p); r.b = *reinterpret_cast<const tf32x4 *>(p + 4);
     return r;
 }
 template <> __device__ __forceinline__ Raw8<__bf16> load8_raw<__bf16>(const __bf16 *p) {
     Raw8<__bf16> r;
-    r.v = *reinterpret_cast<const uint4 *>(p);
+    r.v = *reinterpret_cast<const tu32x4 *>(p);
     return r;
 }
 __device__ __forceinline__ void unpack8(const Raw8<float> &r, float *o) {
-    o[0] = r.a.x; o[1] = r.a.y; o[2] = r.a.z; o[3] = r.a.w; o[4] = r.b.x; o[5] = r.b.y; o[6] = r.b.z; o[7] = r.b.w;
+#pragma unroll
+    for (int e = 0; e < 4; e++) { o[e] = r.a[e]; o[4 + e] = r.b[e]; }
 }
 __device__ __forceinline__ void unpack8(const Raw8<__bf16> &r, float *o) {
-    o[0] = __uint_as_float(r.v.x << 16); o[1] = __uint_as_float(r.v.x & 0xffff0000u);
-    o[2] = __uint_as_float(r.v.y << 16); o[3] = __uint_as_float(r.v.y & 0xffff0000u);
-    o[4] = __uint_as_float(r.v.z << 16); o[5] = __uint_as_float(r.v.z & 0xffff0000u);
-    o[6] = __uint_as_float(r.v.w << 16); o[7] = __uint_as_float(r.v.w & 0xffff0000u);
+#pragma unroll
+    for (int e = 0; e < 4; e++) { o[2 * e] = __uint_as_float(r.v[e] << 16); o[2 * e + 1] = __uint_as_float(r.v[e] & 0xffff0000u); }
 }
 
 __device__ __forceinline__ float wave_sum_f(float x) {
@@ -583,15 +585,40 @@ __global__ __launch_bounds__(NT) void k_tail_src_bwd(const T *__restrict__ dA, c
     const int k = t * 8;
     const bool live = k < K;
     const int j0 = (int)blockIdx.x * ROWS, j1 = min(rows_out, j0 + ROWS);
-    if (t <= ROWS) rp[t] = rowptr_t[min(j0 + t, n)];
+    // Everything a row's completion needs -- the targets' logit gradients of the block's rows and this thread's pieces of the
+    // mask rows -- is requested HERE, unconditionally from clamped positions, together with the row pointers and the logit
+    // vectors.  (Loaded where they are used, inside flush(), they were a predicated load each: a branch hipcc drains the load
+    // queue at, ~5 dependent round trips per row, 8 rows per workgroup.)
+    __shared__ float dsd_s[ROWS][H];
+    const int rp_t = rowptr_t[min(j0 + min(t, ROWS), n)];
+    const int kk0 = live ? k : 0;
     float w[Q][8];
 #pragma unroll
-    for (int q = 0; q < Q; q++) {
-        if (live) load8<float>(wv + (size_t)q * K + k, w[q]);
-        else
+    for (int q = 0; q < Q; q++) load8<float>(wv + (size_t)q * K + kk0, w[q]);
+    float dsd_t;
+    {
+        const int rr = min(t / H, ROWS - 1), j = j0 + rr;
+        dsd_t = ds_dst[(size_t)min(j, n_tgt - 1) * H + (t % H)];
+        if (!(j < n_tgt)) dsd_t = 0.f;
+    }
+    const T *mp = msk != nullptr ? msk : dx;                         // (no mask: any readable rows, the values are not used)
+    const int mld = msk != nullptr ? ldm : lddx;
+    Raw8<T> mraw[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) mraw[r] = load8_raw<T>(mp + (size_t)min(j0 + r, rows_out - 1) * mld + kk0);
+    if (!live) {
+#pragma unroll
+        for (int q = 0; q < Q; q++)
 #pragma unroll
             for (int e = 0; e < 8; e++) w[q][e] = 0.f;
     }
+    if (t <= ROWS) rp[t] = rp_t;
+    if (t < ROWS * H) dsd_s[t / H][t % H] = dsd_t;
+    // (which row is being completed is a run-time value: the pieces wait in LDS, every thread its own column -- a register
+    // array indexed at run time would live in scratch memory)
+    __shared__ Raw8<T> msk_s[ROWS][NT];
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) msk_s[r][t] = mraw[r];
     __syncthreads();
     const int base = rp[0], nE = rp[ROWS] - base;
     const bool staged = nE <= MAXE;
@@ -619,7 +646,7 @@ __global__ __launch_bounds__(NT) void k_tail_src_bwd(const T *__restrict__ dA, c
             if (j < n) {
 #pragma unroll
                 for (int h = 0; h < H; h++) {
-                    const float dsd = j < n_tgt ? ds_dst[(size_t)j * H + h] : 0.f;
+                    const float dsd = dsd_s[rr][h];
 #pragma unroll
                     for (int q = 0; q < 8; q++) acc[q] = fmaf(dss[h], w[2 * h][q], fmaf(dsd, w[2 * h + 1][q], acc[q]));
                     if (t == h) ds_src[(size_t)j * H + h] = dss[h];
@@ -628,7 +655,7 @@ __global__ __launch_bounds__(NT) void k_tail_src_bwd(const T *__restrict__ dA, c
             if (j < rows_out && live) {
                 if (msk != nullptr) {
                     float mv[8];
-                    load8<T>(msk + (size_t)j * ldm + k, mv);
+                    unpack8(msk_s[rr][t], mv);
 #pragma unroll
                     for (int q = 0; q < 8; q++) if (!(mv[q] > 0.f)) acc[q] *= slope;
                 }

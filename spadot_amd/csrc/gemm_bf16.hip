@@ -273,8 +273,26 @@ __global__ __launch_bounds__(NT, 1) void k_gemm_bf16(const __bf16 *__restrict__ 
     // backward then neither reads that output nor writes a masked copy of the gradient: 82 MB less per layer)
     unsigned char *patch = smem + (size_t)wave * 4096;            // 32 rows x 128 B, private to the wave
     // element (row m, column n) of acc[i][j]: lane m (+32: hh), register e -> n = (e & 3) + 8 (e >> 2) + 4 hh
+    // The mask pieces of row tile i + 1 are requested before tile i is written out, UNCONDITIONALLY from a clamped row (a load
+    // under `if (gm < M)` is a branch hipcc drains the load queue at: the first form of this epilogue was 20 dependent round
+    // trips per workgroup).
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const bool masked = msk != nullptr;
+    const __bf16 *mbase = (masked ? msk : C) + n0 + wn * 64 + (lane & 7) * 8;
+    const int mld = masked ? ldm : ldc;
+    auto mask_row = [&](int i, int p) __attribute__((always_inline)) { return min(m0 + wm * 160 + i * 32 + p * 8 + (lane >> 3), M - 1); };
+    u32x4 mkb[2][4];                                              // (two named sets, no copy: a copy is a use, i.e. a wait)
+    if (masked) {
+#pragma unroll
+        for (int p = 0; p < 4; p++) mkb[0][p] = *reinterpret_cast<const u32x4 *>(mbase + (size_t)mask_row(0, p) * mld);
+    }
 #pragma unroll
     for (int i = 0; i < 5; i++) {
+        if (masked && i + 1 < 5) {
+#pragma unroll
+            for (int p = 0; p < 4; p++) mkb[(i + 1) & 1][p] = *reinterpret_cast<const u32x4 *>(mbase + (size_t)mask_row(i + 1, p) * mld);
+        }
+        __builtin_amdgcn_sched_barrier(0);                        // (the scheduler sinks these loads to their use otherwise)
 #pragma unroll
         for (int j = 0; j < 2; j++)
 #pragma unroll
@@ -288,21 +306,17 @@ __global__ __launch_bounds__(NT, 1) void k_gemm_bf16(const __bf16 *__restrict__ 
         for (int p = 0; p < 4; p++) {
             const int pr = p * 8 + (lane >> 3), pc = lane & 7;    // 8 rows per pass, 8 x 16 B per row
             const int gm = m0 + wm * 160 + i * 32 + pr;
-            uint4 v = *reinterpret_cast<const uint4 *>(patch + pr * 128 + pc * 16);
-            if (msk != nullptr && gm < M) {
-                const uint4 mk = *reinterpret_cast<const uint4 *>(msk + (size_t)gm * ldm + n0 + wn * 64 + pc * 8);
-                unsigned vw[4] = {v.x, v.y, v.z, v.w};
-                const unsigned mw[4] = {mk.x, mk.y, mk.z, mk.w};
+            u32x4 v = *reinterpret_cast<const u32x4 *>(patch + pr * 128 + pc * 16);
+            if (masked) {
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
-                    float lo = __uint_as_float(vw[e] << 16), hi = __uint_as_float(vw[e] & 0xffff0000u);
-                    if (!(__uint_as_float(mw[e] << 16) > 0.f)) lo *= slope;
-                    if (!(__uint_as_float(mw[e] & 0xffff0000u) > 0.f)) hi *= slope;
-                    vw[e] = pack2(lo, hi);
+                    float lo = __uint_as_float(v[e] << 16), hi = __uint_as_float(v[e] & 0xffff0000u);
+                    if (!(__uint_as_float(mkb[i & 1][p][e] << 16) > 0.f)) lo *= slope;
+                    if (!(__uint_as_float(mkb[i & 1][p][e] & 0xffff0000u) > 0.f)) hi *= slope;
+                    v[e] = pack2(lo, hi);
                 }
-                v = make_uint4(vw[0], vw[1], vw[2], vw[3]);
             }
-            if (gm < M) *reinterpret_cast<uint4 *>(C + (size_t)gm * ldc + n0 + wn * 64 + pc * 8) = v;
+            if (gm < M) *reinterpret_cast<u32x4 *>(C + (size_t)gm * ldc + n0 + wn * 64 + pc * 8) = v;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }

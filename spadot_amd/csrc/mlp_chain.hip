@@ -27,6 +27,8 @@ constexpr int RBF = 4;                  // rows per workgroup, forward
 constexpr int RBB = 8;                  // rows per workgroup, backward
 constexpr int LDW = MAXD + 4;           // LDS row stride (floats): 16-byte aligned rows, off the 256-byte bank period
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 struct Stage {
     const float *W, *bias, *gamma, *beta;
     float *a, *y, *mean, *invstd;       // saved by forward, read by backward
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(256) void k_mlp_chain_fwd(const float *__restrict__
 constexpr int WST = 16384;                                  // floats of W staged at a time (64 KiB)
 constexpr int LPR = 256 / RBB;                              // lanes per row in the per-row phase
 constexpr int LDS_BWD_FLOATS = 4 * RBB * LDW + 2 * RBB + MAXD + WST;
-__global__ __launch_bounds__(256) void k_mlp_chain_bwd(const float *__restrict__ dy_last, const float *__restrict__ x, int b,
+__global__ __launch_bounds__(256, 1) void k_mlp_chain_bwd(const float *__restrict__ dy_last, const float *__restrict__ x, int b,
                                                        Chain ch, float *__restrict__ dx_out, float *__restrict__ ws,
                                                        int ws_width, const float *__restrict__ dx_add) {
     extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
@@ -140,11 +142,19 @@ __global__ __launch_bounds__(256) void k_mlp_chain_bwd(const float *__restrict__
     float *wrow = ws + (size_t)blockIdx.x * ws_width;
     {   // incoming gradient of the last stage
         const int d = ch.s[ch.n - 1].dout;
+        // All loads first, UNCONDITIONAL from a clamped position and masked afterwards.  (Written as `cond ? load : 0` -- the form
+        // this kernel had until round 5 -- every load is a branch and hipcc drains the load queue at its join: ~50 dependent
+        // round trips per stage where the comment promised one.)
         float v[RBB * MAXD / 256];
 #pragma unroll
-        for (int u = 0; u < RBB * MAXD / 256; u++) {               // all loads first (fixed trip count, predicated)
-            const int e = t + u * 256, r = e / d, j = e - r * d;
-            v[u] = (e < RBB * d && r0 + r < b) ? dy_last[(size_t)(r0 + r) * d + j] : 0.f;
+        for (int u = 0; u < RBB * MAXD / 256; u++) {
+            const int e = min(t + u * 256, RBB * d - 1), r = e / d, j = e - r * d;
+            v[u] = dy_last[(size_t)min(r0 + r, b - 1) * d + j];
+        }
+#pragma unroll
+        for (int u = 0; u < RBB * MAXD / 256; u++) {
+            const int e = t + u * 256;
+            if (!(e < RBB * d && r0 + e / d < b)) v[u] = 0.f;
         }
 #pragma unroll
         for (int u = 0; u < RBB * MAXD / 256; u++) {
@@ -164,31 +174,35 @@ __global__ __launch_bounds__(256) void k_mlp_chain_bwd(const float *__restrict__
             // round trip instead of one per unrolled group
             constexpr int NE = RBB * MAXD / 256, NW = WST / 4 / 256;
             float vx[NE], vy[NE], va[NE];
-            float4 vw[NW];
+            f32x4 vw[NW];                              // (a native vector: arrays of HIP's float4 class stay in scratch memory)
+#pragma unroll
+            for (int u = 0; u < NE; u++) {
+                const int e = min(t + u * 256, RBB * din - 1), r = e / din, k = e - r * din;
+                vx[u] = xin[(size_t)min(r0 + r, b - 1) * din + k];
+                const int e2 = min(t + u * 256, RBB * dout - 1), r2 = e2 / dout, j = e2 - r2 * dout;
+                const size_t o2 = (size_t)min(r0 + r2, b - 1) * dout + j;
+                vy[u] = s.y[o2];
+                va[u] = s.a[o2];
+            }
+            {   // (also when the stage needs no dx: an array assigned under a condition stays in scratch memory)
+                const f32x4 *src = reinterpret_cast<const f32x4 *>(s.W);
+#pragma unroll
+                for (int u = 0; u < NW; u++) vw[u] = src[min(t + u * 256, jc * tk - 1)];
+            }
+            const int rr = min(r0 + (t & (RBB - 1)), b - 1);
+            const float mean_t = s.mean[rr], inv_t = s.invstd[rr], gam_t = s.gamma[min(t, dout - 1)];
 #pragma unroll
             for (int u = 0; u < NE; u++) {
                 const int e = t + u * 256;
-                const int r = e / din, k = e - r * din;
-                vx[u] = (e < RBB * din && r0 + r < b) ? xin[(size_t)(r0 + r) * din + k] : 0.f;
-                const int r2 = e / dout, j = e - r2 * dout;
-                const bool on = e < RBB * dout && r0 + r2 < b;
-                vy[u] = on ? s.y[(size_t)(r0 + r2) * dout + j] : 0.f;
-                va[u] = on ? s.a[(size_t)(r0 + r2) * dout + j] : 0.f;
-            }
-            if (need_dx) {
-                const float4 *src = reinterpret_cast<const float4 *>(s.W);
-#pragma unroll
-                for (int u = 0; u < NW; u++) {
-                    const int e = t + u * 256;
-                    vw[u] = e < jc * tk ? src[e] : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
+                if (!(e < RBB * din && r0 + e / din < b)) vx[u] = 0.f;
+                if (!(e < RBB * dout && r0 + e / dout < b)) { vy[u] = 0.f; va[u] = 0.f; }
             }
             if (t < RBB) {
                 const bool live = r0 + t < b;
-                rmean[t] = live ? s.mean[r0 + t] : 0.f;
-                rinv[t] = live ? s.invstd[r0 + t] : 0.f;
+                rmean[t] = live ? mean_t : 0.f;
+                rinv[t] = live ? inv_t : 0.f;
             }
-            if (t < dout) gam[t] = s.gamma[t];
+            if (t < dout) gam[t] = gam_t;
             __syncthreads();                   // (rmean / rinv / gam; and the previous stage's C has finished writing gz)
 #pragma unroll
             for (int u = 0; u < NE; u++) {
@@ -203,7 +217,7 @@ __global__ __launch_bounds__(256) void k_mlp_chain_bwd(const float *__restrict__
                 }
             }
             if (need_dx) {
-                float4 *dst = reinterpret_cast<float4 *>(wst);
+                f32x4 *dst = reinterpret_cast<f32x4 *>(wst);
 #pragma unroll
                 for (int u = 0; u < NW; u++) {
                     const int e = t + u * 256;

@@ -610,22 +610,36 @@ __global__ __launch_bounds__(SWEEP_NT) void k_spd_sweep(const double *__restrict
     const bool live = t < ntiles;
     SweepTile<TS, RSMAX> tile;
     tile.bord = piv + m + 16 + t;
+    // The tile arrives one row at a time through BUFFER loads: one 32-bit row offset per row, the column as an immediate, the
+    // range check of the descriptor instead of a guard (what lies past the matrix reads as zero and is replaced by the identity
+    // padding; a null add0 / add1 is a descriptor of zero bytes).  All 3 TS loads of a row are issued before the first is used.
+    // The first form (`if (live && i < m && j < m) v = rowp[c]`, then two more guarded loads) made every element a chain of
+    // branches the compiler drains the load queue at: 3 TS^2 = 243 dependent round trips at TS = 9, about half of the
+    // kernel's 305 us in the step (profiles/r05/ab_unpredicated_loads.txt).
+    const unsigned mbytes = (unsigned)m * (unsigned)m * 8u;
+    const auto rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(Am), 0, mbytes, 0x00020000);
+    const auto r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(add0), 0, add0 ? mbytes : 0u, 0x00020000);
+    const auto r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(add1), 0, (hi && add1) ? mbytes : 0u, 0x00020000);
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
     for (int r = 0; r < TS; r++) {
         const int i = ti * TS + r;
-        const size_t roff = (size_t)min(i, m - 1) * m + tj * TS;          // one base offset per tile row
-        const double *rowp = Am + roff;
+        const unsigned voff = ((unsigned)min(i, m - 1) * (unsigned)m + (unsigned)(tj * TS)) * 8u;
+        u32x2 va[TS], v0[TS], v1[TS];
+#pragma unroll
+        for (int c = 0; c < TS; c++) {
+            va[c] = __builtin_amdgcn_raw_buffer_load_b64(rA, voff + 8u * c, 0, 0);
+            v0[c] = __builtin_amdgcn_raw_buffer_load_b64(r0, voff + 8u * c, 0, 0);
+            v1[c] = __builtin_amdgcn_raw_buffer_load_b64(r1, voff + 8u * c, 0, 0);
+        }
 #pragma unroll
         for (int c = 0; c < TS; c++) {
             const int j = tj * TS + c;
-            double v = (i == j) ? 1.0 : 0.0;                             // padding: identity
-            if (live && i < m && j < m) {
-                v = rowp[c];
-                if (add0) v += add0[roff + c];
-                if (hi && add1) v += add1[roff + c];
-            }
-            tile.set(r, c, v);
+            // (an absent term reads as +0.0 through its empty descriptor: no branch in this phase)
+            const double v = (__builtin_bit_cast(double, va[c]) + __builtin_bit_cast(double, v0[c])) + __builtin_bit_cast(double, v1[c]);
+            tile.set(r, c, (live && i < m && j < m) ? v : ((i == j) ? 1.0 : 0.0));      // padding: identity
         }
+        __builtin_amdgcn_sched_barrier(0);      // rows one after the other: all 3 TS^2 loads hoisted to the top spill the tile
     }
     // Pivot k = kt*TS + kr with kr unrolled: which register of a tile holds the pivot row / column is then
     // known at compile time (no per-element selects; the selects were ~80% of the instructions issued).
@@ -1500,18 +1514,23 @@ __global__ __launch_bounds__(BN_NT) void k_bn_act_fwd(const TX *__restrict__ x, 
     const int cl = threadIdx.x & (BN_COLS - 1), rg = threadIdx.x / BN_COLS;
     const int c = blockIdx.x * BN_COLS + cl;
     const bool on = c < F;
-    const float add = (on && lb) ? lb[c] : 0.f;
+    const int c1 = min(c, F - 1);
+    const float add_r = (lb ? lb : gamma)[c1];
+    const float add = (on && lb) ? add_r : 0.f;
     if (b <= BN_RG * BN_RPT) {
         // up to 512 rows (the training batch): a thread's 32 rows are loaded ONCE, all loads in flight together, and the three
         // passes run out of registers -- the looped form below pays ~24 dependent memory latencies (18-33 us for 0.1-0.5 MB
         // beside the GAT branch's GEMM, at the head of the step's forward critical chain; rocprofv3 timeline, round 4).
         // Same values, same summation order: bit-identical to the looped form.
+        // (UNCONDITIONAL loads from a clamped position, masked afterwards: a predicated load is a branch, and the compiler
+        // drains the load queue at its join -- written as `(on && i < b) ? load : 0` these 32 loads were 32 round trips)
         float v[BN_RPT];
+        const int cc = min(c, F - 1);
 #pragma unroll
-        for (int r = 0; r < BN_RPT; r++) {
-            const int i = rg + r * BN_RG;
-            v[r] = (on && i < b) ? ld<TX>(x + (size_t)i * F + c) + add : 0.f;
-        }
+        for (int r = 0; r < BN_RPT; r++) v[r] = ld<TX>(x + (size_t)min(rg + r * BN_RG, b - 1) * F + cc);
+        const float gam_r = gamma[cc], bet_r = beta[cc], rm_r = run_mean[cc], rv_r = run_var[cc];      // (ride with the rows)
+#pragma unroll
+        for (int r = 0; r < BN_RPT; r++) v[r] = (on && rg + r * BN_RG < b) ? v[r] + add : 0.f;
         float s = 0.f;
 #pragma unroll
         for (int r = 0; r < BN_RPT; r++)
@@ -1524,7 +1543,7 @@ __global__ __launch_bounds__(BN_NT) void k_bn_act_fwd(const TX *__restrict__ x, 
         const float var = bn_col_sum(ss, sh, cl, rg) / (float)b;
         const float invstd = rsqrtf(var + eps);
         if (on) {
-            const float g = gamma[c] * invstd, o = beta[c];
+            const float g = gam_r * invstd, o = bet_r;
 #pragma unroll
             for (int r = 0; r < BN_RPT; r++) {
                 const int i = rg + r * BN_RG;
@@ -1535,8 +1554,8 @@ __global__ __launch_bounds__(BN_NT) void k_bn_act_fwd(const TX *__restrict__ x, 
             }
             if (rg == 0) {
                 save_mean[c] = mean; save_invstd[c] = invstd;
-                run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean;
-                run_var[c] = (1.f - momentum) * run_var[c] + momentum * var * ((float)b / (float)(b > 1 ? b - 1 : 1));
+                run_mean[c] = (1.f - momentum) * rm_r + momentum * mean;
+                run_var[c] = (1.f - momentum) * rv_r + momentum * var * ((float)b / (float)(b > 1 ? b - 1 : 1));
             }
         }
         if (nbt && blockIdx.x == 0 && threadIdx.x == 0) nbt[0] += 1;
@@ -1580,18 +1599,25 @@ __global__ __launch_bounds__(BN_NT) void k_bn_act_bwd(const float *__restrict__ 
     const int cl = threadIdx.x & (BN_COLS - 1), rg = threadIdx.x / BN_COLS;
     const int c = blockIdx.x * BN_COLS + cl;
     const bool on = c < F;
-    const float add = (on && lb) ? lb[c] : 0.f;
-    const float mean = on ? save_mean[c] : 0.f, invstd = on ? save_invstd[c] : 0.f;
+    const int c1 = min(c, F - 1);
+    const float add_r = (lb ? lb : gamma)[c1], mean_r = save_mean[c1], invstd_r = save_invstd[c1], gamma_r = gamma[c1];
+    const float add = (on && lb) ? add_r : 0.f;
+    const float mean = on ? mean_r : 0.f, invstd = on ? invstd_r : 0.f;
     if (b <= BN_RG * BN_RPT) {          // one load of the thread's rows, both passes out of registers (see k_bn_act_fwd)
+        // unconditional loads from a clamped position, masked afterwards (see k_bn_act_fwd): 96 loads in three groups
         float dzv[BN_RPT], xh[BN_RPT];
+        const int cc = min(c, F - 1);
+#pragma unroll
+        for (int r = 0; r < BN_RPT; r++) dzv[r] = dy[(size_t)min(rg + r * BN_RG, b - 1) * F + cc];
 #pragma unroll
         for (int r = 0; r < BN_RPT; r++) {
-            const int i = rg + r * BN_RG;
-            const bool in = on && i < b;
-            const size_t e = (size_t)(in ? i : 0) * F + (in ? c : 0);
-            const float dyv = in ? dy[e] : 0.f, yv = in ? y[e] : 0.f, xv = in ? ld<TX>(x + e) : 0.f;
-            dzv[r] = dyv * (yv > 0.f ? 1.f : slope);
-            xh[r] = (xv + add - mean) * invstd;
+            const float yv = y[(size_t)min(rg + r * BN_RG, b - 1) * F + cc];
+            dzv[r] = (on && rg + r * BN_RG < b) ? dzv[r] * (yv > 0.f ? 1.f : slope) : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < BN_RPT; r++) {
+            const float xv = ld<TX>(x + (size_t)min(rg + r * BN_RG, b - 1) * F + cc);
+            xh[r] = (xv + add - mean) * invstd;      // (rows past b: never summed, never stored)
         }
         float sb = 0.f, sg = 0.f;
 #pragma unroll
@@ -1600,7 +1626,7 @@ __global__ __launch_bounds__(BN_NT) void k_bn_act_bwd(const float *__restrict__ 
         sb = bn_col_sum(sb, sh, cl, rg);
         sg = bn_col_sum(sg, sh, cl, rg);
         if (on) {
-            const float g = gamma[c] * invstd, mb = sb / (float)b, mg = sg / (float)b;
+            const float g = gamma_r * invstd, mb = sb / (float)b, mg = sg / (float)b;
 #pragma unroll
             for (int r = 0; r < BN_RPT; r++) {
                 const int i = rg + r * BN_RG;

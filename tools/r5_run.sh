@@ -26,6 +26,10 @@ d = json.loads(open("gpurun_out/r5/bench_chickenheart_shape.json").read().strip(
 print("chickenheart-like (4 x 1650 x 2954):", d["value"], "steps/s;", d.get("epoch"))
 PY
   ;;
+t4)
+  timeout -k 10 900 python -m pytest tests/test_gat_mfma_gpu.py tests/test_model_gpu.py tests/test_train_gpu.py tests/test_step_parity_gpu.py -x -q -k "gat or fused or encoder or staged or deferred or cfg3" > $O/t4.txt 2>&1 || { grep -B2 -A14 "^>" $O/t4.txt | head -60; tail -5 $O/t4.txt; exit 1; }
+  tail -3 $O/t4.txt
+  bash tools/ab_step.sh "X=1" 2>&1 | tail -2 ;;
 t3)
   timeout -k 10 900 python -m pytest tests/test_mlp_chain_gpu.py tests/test_train_gpu.py tests/test_step_parity_gpu.py -x -q -k "recon or staged or deferred or cfg3 or chained or small_timepoint" > $O/t3.txt 2>&1 || { grep -B2 -A14 "^>" $O/t3.txt | head -60; tail -5 $O/t3.txt; exit 1; }
   tail -3 $O/t3.txt
