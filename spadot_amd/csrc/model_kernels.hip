@@ -329,15 +329,20 @@ __global__ __launch_bounds__(CS_NT) void k_colsum_parts(const float *__restrict_
     const int cx = threadIdx.x & 63, gy = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cx;
     float acc = 0.f;
-    if (c < width) {
+    {
+        // sixteen loads in flight, added in ascending order.  UNCONDITIONAL loads from a clamped position, masked afterwards:
+        // written as `(sb + u < s1) ? part[..] : 0` (until round 5) each load was a branch with the load queue drained at its
+        // join -- 20 dependent round trips for the 312 block partials of a GAT layer, 56-63 us for 7.7 MB at the end of the
+        // step's critical chain.
+        const int cc = min(c, width - 1);
         const int per = (nslab + CS_GY - 1) / CS_GY;
         const int s0 = gy * per, s1 = min(nslab, s0 + per);
-        for (int sb = s0; sb < s1; sb += 8) {              // eight loads in flight, added in ascending order
-            float q[8];
+        for (int sb = s0; sb < s1; sb += 16) {
+            float q[16];
 #pragma unroll
-            for (int u = 0; u < 8; u++) q[u] = (sb + u < s1) ? part[(size_t)(sb + u) * width + c] : 0.f;
+            for (int u = 0; u < 16; u++) q[u] = part[(size_t)min(sb + u, nslab - 1) * width + cc];
 #pragma unroll
-            for (int u = 0; u < 8; u++) acc += q[u];
+            for (int u = 0; u < 16; u++) acc += (sb + u < s1) ? q[u] : 0.f;
         }
     }
     sh[gy][cx] = acc;
@@ -1841,6 +1846,7 @@ __global__ __launch_bounds__(256) void k_latent_head_bwd(const float *__restrict
 //   prev [Kp, D] centres of the previous time point; gamma [Kp, Kl] row-normalised plan; cluster_list [Kl].
 //   work (saved for the backward): means [K*D] | cnt [K] | n_distinct | lab [b] (as floats).
 constexpr int CL_MAXK = 64, CL_MAXD = 64, CL_KREG = 16;
+constexpr int CL_MAX_DYN_LDS = 108 * 1024;        // 160 KiB less the kernel's static arrays (centres, previous centres, plan: 48.6 KiB)
 // FB: the same launch also writes dz = d(g_km km + g_ot ot) / dz for gradient seeds that are known when the forward runs (the
 // loss weights, device scalars): k_cluster_losses_bwd's arithmetic on the state this kernel has in LDS anyway.  Host-side
 // conditions (spadot_cluster_losses_fb): the fast path (K <= CL_KREG), the whole batch in ONE chunk, and room for
@@ -1856,16 +1862,45 @@ __global__ __launch_bounds__(512) void k_cluster_losses_fwd(const float *__restr
                                                             const float *__restrict__ g_ot = nullptr, float *__restrict__ dz = nullptr) {
     // Latency-bound single workgroup: everything that is scanned repeatedly sits in LDS and the scans are
     // branch-free and unrolled, so the LDS reads of successive rows are in flight together.
+    // Global memory is read ONCE, at the top: every operand of the launch (centres, previous centres, plan, cluster list,
+    // seed ids -> labels, the first chunk of the latent rows, the gradient seeds) is requested before the first is used, with
+    // unconditional loads from clamped positions -- until round 5 each phase fetched what it needed where it needed it, mostly
+    // through predicated loads (a branch each, the load queue drained at its join): ~40 dependent round trips in a 29 us kernel.
     __shared__ double sh[16];
     __shared__ float s_means[CL_MAXK * CL_MAXD];  // centres first, batch means once the sums are complete
+    __shared__ float s_prev[CL_MAXK * CL_MAXD];   // previous centres
+    __shared__ float s_gam[CL_MAXK * CL_MAXK];    // plan
+    __shared__ int s_cl[CL_MAXK];                 // cluster list
     __shared__ int s_cnt[CL_MAXK];
-    extern __shared__ float s_dyn[];              // chunk_rows * D latent values (>= CL_MAXK * D: reused for the
-    float *s_z = s_dyn;                           // previous centres), then chunk_rows labels, then segment partials
+    extern __shared__ float s_dyn[];              // chunk_rows * D latent values, then chunk_rows labels, then segment partials
+    float *s_z = s_dyn;
     int *s_lab = (int *)(s_dyn + (size_t)chunk_rows * D);
     float *s_part = s_dyn + (size_t)chunk_rows * D + chunk_rows;       // [512 / D][K][D + 1] (fast path)
     float *w_means = work, *w_cnt = work + (size_t)K * D, *w_nd = w_cnt + K, *w_lab = w_nd + 1;
     const int t = threadIdx.x;
-    for (int e = t; e < K * D; e += blockDim.x) s_means[e] = centres[e];
+    constexpr int ZB = 20;                        // latent values per thread and batch (b = 512, D = 20: the whole chunk in one)
+    const int KD = K * D, KpD = do_ot ? Kp * D : 1, KpKl = do_ot ? Kp * Kl : 1, Kl1 = do_ot ? Kl : 1;
+    const float *prev_p = do_ot ? prev : centres, *gam_p = do_ot ? gamma : centres;
+    const long long *cl_p = do_ot ? cluster_list : seed_ids;
+    const int rows0 = min(chunk_rows, b);
+    const long long sid0 = seed_ids[min(t, rows0 - 1)];
+    const float c0 = centres[min(t, KD - 1)], p0 = prev_p[min(t, KpD - 1)], g0 = gam_p[min(t, KpKl - 1)];
+    const int cl0 = (int)cl_p[min(t, Kl1 - 1)];
+    float gk_r = 0.f, go_r = 0.f;
+    if constexpr (FB) { gk_r = (g_km ? g_km : centres)[0]; go_r = (g_ot ? g_ot : centres)[0]; }
+    float zr[ZB];
+#pragma unroll
+    for (int u = 0; u < ZB; u++) zr[u] = z[min(t + u * 512, rows0 * D - 1)];
+    const int lab0 = (int)labels_all[sid0];
+    if (t < KD) s_means[t] = c0;
+    for (int e = t + 512; e < KD; e += 512) s_means[e] = centres[e];
+    if (do_ot) {
+        if (t < KpD) s_prev[t] = p0;
+        for (int e = t + 512; e < KpD; e += 512) s_prev[e] = prev[e];
+        if (t < KpKl) s_gam[t] = g0;
+        for (int e = t + 512; e < KpKl; e += 512) s_gam[e] = gamma[e];
+        if (t < Kl) s_cl[t] = cl0;
+    }
     constexpr int PAIRS = (CL_MAXK * CL_MAXD + 511) / 512;
     float ps[PAIRS];
     int pc[PAIRS];
@@ -1875,12 +1910,35 @@ __global__ __launch_bounds__(512) void k_cluster_losses_fwd(const float *__restr
     for (int r0 = 0; r0 < b; r0 += chunk_rows) {           // one chunk when the batch fits (b = 512, D = 20: 40 KB)
         const int rows = min(chunk_rows, b - r0);
         __syncthreads();
-#pragma unroll 5
-        for (int e = t; e < rows * D; e += blockDim.x) s_z[e] = z[(size_t)r0 * D + e];      // (unrolled: loads in flight together)
-        for (int i = t; i < chunk_rows; i += blockDim.x) {
-            const int lab = i < rows ? (int)labels_all[seed_ids[r0 + i]] : -1;      // -1: matches no cluster
-            s_lab[i] = lab;
-            if (i < rows) w_lab[r0 + i] = (float)lab;
+        if (r0 == 0) {                                          // the first chunk is in registers already
+#pragma unroll
+            for (int u = 0; u < ZB; u++)
+                if (t + u * 512 < rows * D) s_z[t + u * 512] = zr[u];
+            for (int e = t + ZB * 512; e < rows * D; e += 512) s_z[e] = z[e];
+            if (t < chunk_rows) {
+                const int lab = t < rows ? lab0 : -1;               // -1: matches no cluster
+                s_lab[t] = lab;
+                if (t < rows) w_lab[t] = (float)lab;
+            }
+            for (int i = t + 512; i < chunk_rows; i += 512) {
+                const int lab = i < rows ? (int)labels_all[seed_ids[i]] : -1;
+                s_lab[i] = lab;
+                if (i < rows) w_lab[i] = (float)lab;
+            }
+        } else {
+            for (int e0 = 0; e0 < rows * D; e0 += ZB * 512) {
+                float zb[ZB];
+#pragma unroll
+                for (int u = 0; u < ZB; u++) zb[u] = z[(size_t)r0 * D + min(e0 + t + u * 512, rows * D - 1)];
+#pragma unroll
+                for (int u = 0; u < ZB; u++)
+                    if (e0 + t + u * 512 < rows * D) s_z[e0 + t + u * 512] = zb[u];
+            }
+            for (int i = t; i < chunk_rows; i += 512) {
+                const int lab = (int)labels_all[seed_ids[r0 + min(i, rows - 1)]];
+                s_lab[i] = i < rows ? lab : -1;
+                if (i < rows) w_lab[r0 + i] = (float)lab;
+            }
         }
         __syncthreads();
         if (K <= CL_KREG && D <= (int)blockDim.x) {
@@ -1959,8 +2017,6 @@ __global__ __launch_bounds__(512) void k_cluster_losses_fwd(const float *__restr
             if (d == 0) s_cnt[k] = pc[u];
         }
     }
-    if (do_ot)                                                        // previous centres into the idle row buffer
-        for (int e = t; e < Kp * D; e += blockDim.x) s_z[e] = prev[e];
     __syncthreads();
     int nd = 0;
     for (int k = 0; k < K; k++) nd += s_cnt[k] > 0;
@@ -1971,11 +2027,11 @@ __global__ __launch_bounds__(512) void k_cluster_losses_fwd(const float *__restr
     double ot = 0.0;
     if (do_ot)
         for (int pq = t; pq < Kp * Kl; pq += blockDim.x) {
-            const int p = pq / Kl, q = pq - p * Kl, k = (int)cluster_list[q];
+            const int p = pq / Kl, q = pq - p * Kl, k = s_cl[q];
             float a = 0.f;
 #pragma unroll 4
-            for (int d = 0; d < D; d++) { const float e = s_z[p * D + d] - s_means[k * D + d]; a += e * e; }
-            ot += (double)gamma[pq] * (double)sqrtf(a);
+            for (int d = 0; d < D; d++) { const float e = s_prev[p * D + d] - s_means[k * D + d]; a += e * e; }
+            ot += (double)s_gam[pq] * (double)sqrtf(a);
         }
     ot = block_sum_d(ot, sh);
     if (t == 0) {
@@ -1983,28 +2039,29 @@ __global__ __launch_bounds__(512) void k_cluster_losses_fwd(const float *__restr
         out2[1] = do_ot ? (float)(ot / ((double)Kp * Kl)) : 0.f;
     }
     if constexpr (FB) {
-        // s_means = batch means, s_cnt = counts, s_z[0 .. Kp D) = previous centres, s_lab = the batch's labels (one chunk)
+        // s_means = batch means, s_cnt = counts, s_prev = previous centres, s_z / s_lab = the batch's rows and labels (one chunk)
         float *s_cen = s_part, *s_dm = s_part + (size_t)K * D, *s_dist = s_part + 2 * (size_t)K * D;
-        const float gk = (do_km && g_km) ? g_km[0] : 0.f, go = (do_ot && g_ot) ? g_ot[0] : 0.f;
+        const float gk = (do_km && g_km) ? gk_r : 0.f, go = (do_ot && g_ot) ? go_r : 0.f;
         __syncthreads();                                  // (block_sum_d's scratch and s_part are free now)
-        for (int pq = t; pq < K * D; pq += blockDim.x) { s_dm[pq] = 0.f; s_cen[pq] = centres[pq]; }
+        if (t < KD) { s_dm[t] = 0.f; s_cen[t] = c0; }
+        for (int pq = t + 512; pq < K * D; pq += blockDim.x) { s_dm[pq] = 0.f; s_cen[pq] = centres[pq]; }
         if (do_ot)
             for (int pq = t; pq < Kp * Kl; pq += blockDim.x) {
-                const int p = pq / Kl, q = pq - p * Kl, k = (int)cluster_list[q];
+                const int p = pq / Kl, q = pq - p * Kl, k = s_cl[q];
                 float a = 0.f;
 #pragma unroll 4
-                for (int e = 0; e < D; e++) { const float df = s_means[k * D + e] - s_z[p * D + e]; a += df * df; }
+                for (int e = 0; e < D; e++) { const float df = s_means[k * D + e] - s_prev[p * D + e]; a += df * df; }
                 s_dist[pq] = sqrtf(a);
             }
         __syncthreads();
         if (do_ot)
             for (int qd = t; qd < Kl * D; qd += blockDim.x) {
-                const int q = qd / D, d = qd - q * D, k = (int)cluster_list[q];
+                const int q = qd / D, d = qd - q * D, k = s_cl[q];
                 if (s_cnt[k] <= 0) continue;
                 float acc = 0.f;
                 for (int p = 0; p < Kp; p++) {
                     const float dist = s_dist[p * Kl + q];
-                    if (dist > 0.f) acc += gamma[p * Kl + q] * (s_means[k * D + d] - s_z[p * D + d]) / dist;
+                    if (dist > 0.f) acc += s_gam[p * Kl + q] * (s_means[k * D + d] - s_prev[p * D + d]) / dist;
                 }
                 s_dm[k * D + d] = go * acc / ((float)Kp * Kl) / (float)s_cnt[k];
             }
@@ -2014,7 +2071,7 @@ __global__ __launch_bounds__(512) void k_cluster_losses_fwd(const float *__restr
 #pragma unroll 4
         for (int e = t; e < b * D; e += blockDim.x) {
             const int i = e / D, d = e - i * D, k = s_lab[i];
-            dz[e] = ck * (z[e] - s_cen[k * D + d]) + s_dm[k * D + d];
+            dz[e] = ck * (s_z[e] - s_cen[k * D + d]) + s_dm[k * D + d];
         }
     }
 }
@@ -2503,8 +2560,9 @@ int spadot_cluster_losses_forward(const float *z, const long long *labels_all, c
     chunk = (chunk + 7) / 8 * 8;
     size_t lds = sizeof(float) * (size_t)chunk * D + sizeof(int) * (size_t)chunk;
     if (K <= CL_KREG && D <= 512) lds += sizeof(float) * (size_t)(512 / D) * K * (D + 1);
+    if (lds > (size_t)CL_MAX_DYN_LDS) return -22;
     static PerDeviceFlag attr_set;     
-    if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_cluster_losses_fwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); attr_set = true; }
+    if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_cluster_losses_fwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, CL_MAX_DYN_LDS); attr_set = true; }
     hipLaunchKernelGGL(k_cluster_losses_fwd<false>, dim3(1), dim3(512), lds, (hipStream_t)stream, z, labels_all, seed_ids, centres,
                        prev_centres, gamma, cluster_list, b, D, K, Kp, Kl, do_km, do_ot, out2, work, chunk);
     return hipGetLastError() == hipSuccess ? 0 : -5;
@@ -2525,8 +2583,9 @@ int spadot_cluster_losses_fb(const float *z, const long long *labels_all, const 
     const size_t part = (size_t)(512 / D) * K * (D + 1);
     if (K > CL_KREG || chunk < b || part < 2 * (size_t)K * D + (do_ot ? (size_t)Kp * Kl : 0)) return -95;
     const size_t lds = sizeof(float) * (size_t)chunk * D + sizeof(int) * (size_t)chunk + sizeof(float) * part;
+    if (lds > (size_t)CL_MAX_DYN_LDS) return -95;
     static PerDeviceFlag attr_set;     
-    if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_cluster_losses_fwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); attr_set = true; }
+    if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_cluster_losses_fwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, CL_MAX_DYN_LDS); attr_set = true; }
     hipLaunchKernelGGL(k_cluster_losses_fwd<true>, dim3(1), dim3(512), lds, (hipStream_t)stream, z, labels_all, seed_ids, centres,
                        prev_centres, gamma, cluster_list, b, D, K, Kp, Kl, do_km, do_ot, out2, work, chunk, g_km, g_ot, dz);
     return hipGetLastError() == hipSuccess ? 0 : -5;

@@ -185,16 +185,18 @@ __global__ __launch_bounds__(NT, 1) void k_recon_fb(const __bf16 *__restrict__ h
 __global__ __launch_bounds__(256) void k_recon_fb_reduce(const float *__restrict__ dxp, int nblk, long long n4, float *__restrict__ dh) {
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
     if (e >= n4) return;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int k = 0; k < nblk; k += 4) {
-        float4 v[4];
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(dxp) + e;
+    for (int k = 0; k < nblk; k += 8) {          // eight blocks' pieces in flight (unconditional loads, clamped block), added in order
+        f32x4 v[8];
 #pragma unroll
-        for (int u = 0; u < 4; u++)
-            v[u] = (k + u < nblk) ? reinterpret_cast<const float4 *>(dxp)[(long long)(k + u) * n4 + e] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int u = 0; u < 8; u++) v[u] = src[(long long)min(k + u, nblk - 1) * n4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+        for (int u = 0; u < 8; u++)
+            if (k + u < nblk) acc += v[u];
     }
-    reinterpret_cast<float4 *>(dh)[e] = acc;
+    reinterpret_cast<f32x4 *>(dh)[e] = acc;
 }
 
 }  // namespace

@@ -26,6 +26,33 @@ d = json.loads(open("gpurun_out/r5/bench_chickenheart_shape.json").read().strip(
 print("chickenheart-like (4 x 1650 x 2954):", d["value"], "steps/s;", d.get("epoch"))
 PY
   ;;
+ablib)
+  # same-box A/B of two BUILDS of libspadot_model.so (tmp_ab/libspadot_model_prev.so = the library of an earlier commit, same ABI)
+  L=spadot_amd/csrc/libspadot_model.so
+  cp $L /tmp/new.so
+  for round in 1 2; do
+    cp tmp_ab/libspadot_model_prev.so $L
+    timeout -k 10 400 python bench.py --leg train --no-cpu-baseline --no-epoch --repeats 7 > $O/ablib_prev_$round.json 2> $O/ablib.err || { tail -5 $O/ablib.err; cp /tmp/new.so $L; exit 1; }
+    python tools/bench_value.py "previous library" < $O/ablib_prev_$round.json
+    cp /tmp/new.so $L
+    timeout -k 10 400 python bench.py --leg train --no-cpu-baseline --no-epoch --repeats 7 > $O/ablib_new_$round.json 2> $O/ablib.err || { tail -5 $O/ablib.err; exit 1; }
+    python tools/bench_value.py "this tree" < $O/ablib_new_$round.json
+  done
+  SPADOT_STAMPS=1 timeout -k 10 300 python tools/stage_stamps.py > $O/stage_stamps_unpred.txt 2> $O/stamps.err || tail -5 $O/stamps.err
+  head -14 $O/stage_stamps_unpred.txt | tail -11 ;;
+abq)
+  timeout -k 10 300 python -m pytest tests/test_mlp_chain_gpu.py -x -q -k "recon" 2>&1 | tail -2
+  bash tools/ab_step.sh "SPADOT_WGRAD_Q=late" "SPADOT_WGRAD_Q=post" "SPADOT_WGRAD_Q=inline" 2>&1 | tee $O/ab_wgrad_queue.txt
+  for q in post inline; do
+    SPADOT_WGRAD_Q=$q SPADOT_STAMPS=1 timeout -k 10 300 python tools/stage_stamps.py > $O/stage_stamps_wgrad_$q.txt 2> $O/stamps.err || tail -5 $O/stamps.err
+    echo "== $q"; head -14 $O/stage_stamps_wgrad_$q.txt | tail -9
+  done ;;
+t6)
+  timeout -k 10 900 python -m pytest tests/test_gemm_gpu.py tests/test_model_gpu.py tests/test_gat_mfma_gpu.py tests/test_train_gpu.py -x -q -k "wgrad or colsum or gat or staged or deferred or cluster" > $O/t6.txt 2>&1 || { grep -B2 -A14 "^>" $O/t6.txt | head -60; tail -5 $O/t6.txt; exit 1; }
+  tail -3 $O/t6.txt ;;
+t5)
+  timeout -k 10 900 python -m pytest tests/test_model_gpu.py tests/test_train_gpu.py tests/test_step_parity_gpu.py -x -q -k "cluster or loss or glue or staged or deferred or cfg3 or fused" > $O/t5.txt 2>&1 || { grep -B2 -A14 "^>" $O/t5.txt | head -60; tail -5 $O/t5.txt; exit 1; }
+  tail -3 $O/t5.txt ;;
 t4)
   timeout -k 10 900 python -m pytest tests/test_gat_mfma_gpu.py tests/test_model_gpu.py tests/test_train_gpu.py tests/test_step_parity_gpu.py -x -q -k "gat or fused or encoder or staged or deferred or cfg3" > $O/t4.txt 2>&1 || { grep -B2 -A14 "^>" $O/t4.txt | head -60; tail -5 $O/t4.txt; exit 1; }
   tail -3 $O/t4.txt
