@@ -291,6 +291,64 @@ __global__ __launch_bounds__(NT) void k_tail_aggregate(const T *__restrict__ x, 
     const int p0 = rowptr[i], deg = rowptr[i + 1] - p0;
     const int k = t * 8;
     const bool live = k < K;
+    if (deg > 0 && deg <= CH) {
+        // Every seed of a kNN graph: all edges in one chunk.  Seven dependent round trips instead of ~16 (row pointer; source ids;
+        // logit halves; the source rows in batches of eight, every load unconditional -- a batch's tail re-reads the last edge's
+        // row with weight zero): the general form below re-fetches ids and logits in each of its three passes and gathers four
+        // rows at a time.  Same arithmetic in the same order (wave = head for the statistics, edges ascending in the sums).
+        __shared__ float lg[CH][H];
+        if (t < CH) cs[t] = col[p0 + min(t, deg - 1)];
+        const float sd_t = s[(size_t)i * Q + 2 * (t % H) + 1];       // (thread u: head u % H)
+        __syncthreads();
+        for (int u = t; u < CH * H; u += NT) {                        // (CH H <= NT for H <= 4; two passes at H = 8)
+            const int e = u / H, hd = u - e * H;
+            const float sv = s[(size_t)cs[e] * Q + 2 * hd];
+            lg[e][hd] = e < deg ? leaky(sv + sd_t, ATT_SLOPE) : -INFINITY;
+        }
+        __syncthreads();
+        for (int hd = wid; hd < H; hd += 4) {
+            const float z = lg[lane][hd];
+            const float m = wave_max_f(z);
+            const float sum = wave_sum_f(lane < deg ? __expf(z - m) : 0.f) + 1e-16f;
+            if (lane == 0) { mx[hd] = m; den[hd] = sum; }
+        }
+        __syncthreads();
+        for (int u = t; u < CH * H; u += NT) {
+            const int e = u / H, hd = u - e * H;
+            const float a = e < deg ? __expf(lg[e][hd] - mx[hd]) / den[hd] : 0.f;
+            al[e][hd] = a;
+            if (e < deg) alpha_out[(size_t)(p0 + e) * H + hd] = a;
+        }
+        __syncthreads();
+        float acc[H][8];
+#pragma unroll
+        for (int h = 0; h < H; h++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) acc[h][e] = 0.f;
+        const int kk = live ? k : 0;
+        for (int e0 = 0; e0 < deg; e0 += 8) {
+            Raw8<T> xv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) xv[u] = load8_raw<T>(x + (size_t)cs[min(e0 + u, CH - 1)] * ldx + kk);
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                if (e0 + u < deg) {                                    // (uniform)
+                    float x8[8];
+                    unpack8(xv[u], x8);
+#pragma unroll
+                    for (int h = 0; h < H; h++) {
+                        const float a = al[e0 + u][h];
+#pragma unroll
+                        for (int q = 0; q < 8; q++) acc[h][q] = fmaf(a, x8[q], acc[h][q]);
+                    }
+                }
+            }
+        }
+        if (live)
+#pragma unroll
+            for (int h = 0; h < H; h++) store8<T>(A + ((size_t)h * n_tgt + i) * K + k, acc[h]);
+        return;
+    }
     // softmax statistics: wave wid takes heads wid, wid + 4, ...
     for (int hd = wid; hd < H; hd += 4) {
         const float sd = s[(size_t)i * Q + 2 * hd + 1];

@@ -1770,18 +1770,24 @@ __global__ __launch_bounds__(256) void k_latent_head_fwd(const float *__restrict
     const int D = Ls + Lg;
     const int c = threadIdx.x & 31, i = blockIdx.x * 8 + (threadIdx.x >> 5);
     float val = 0.f, klt = 0.f, e = 0.f;
-    if (i < b && c < D) {
-        if (rng) { e = counter_randn(rng[0], rng[1], (unsigned long long)i * D + c); eps[(size_t)i * D + c] = e; }
-        else e = eps[(size_t)i * D + c];
-    }
-    if (i < b && c < Ls) {
-        val = (float)(p_m[(size_t)i * Ls + c] + (double)e * sqrt(p_v[(size_t)i * Ls + c]));
-    } else if (i < b && c < D) {
-        const int l = c - Ls;
-        const float mu = zg[(size_t)i * 2 * Lg + l], lv = zg[(size_t)i * 2 * Lg + Lg + l];
-        const float var = expf(lv);
-        val = mu + e * sqrtf(var);
-        klt = 1.f + logf(var) - mu * mu - var;
+    {
+        // every operand in ONE round trip: unconditional loads from clamped positions (both branches' operands), selected afterwards
+        const int ic = min(i, b - 1), cs = min(c, Ls - 1), lg = min(max(c - Ls, 0), Lg - 1), cd = min(c, D - 1);
+        const unsigned long long r0 = rng ? rng[0] : 0ull, r1 = rng ? rng[1] : 0ull;
+        const float e_in = eps[(size_t)ic * D + cd];
+        const double pm = p_m[(size_t)ic * Ls + cs], pv = p_v[(size_t)ic * Ls + cs];
+        const float mu = zg[(size_t)ic * 2 * Lg + lg], lv = zg[(size_t)ic * 2 * Lg + Lg + lg];
+        if (i < b && c < D) {
+            if (rng) { e = counter_randn(r0, r1, (unsigned long long)i * D + c); eps[(size_t)i * D + c] = e; }
+            else e = e_in;
+        }
+        if (i < b && c < Ls) {
+            val = (float)(pm + (double)e * sqrt(pv));
+        } else if (i < b && c < D) {
+            const float var = expf(lv);
+            val = mu + e * sqrtf(var);
+            klt = 1.f + logf(var) - mu * mu - var;
+        }
     }
     if (i < b && c < D) latent[(size_t)i * D + c] = val;
     const float ns = half_wave_sum(c < Ls ? val * val : 0.f), ng = half_wave_sum(c >= Ls && c < D ? val * val : 0.f);

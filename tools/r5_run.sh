@@ -47,6 +47,9 @@ abq)
     SPADOT_WGRAD_Q=$q SPADOT_STAMPS=1 timeout -k 10 300 python tools/stage_stamps.py > $O/stage_stamps_wgrad_$q.txt 2> $O/stamps.err || tail -5 $O/stamps.err
     echo "== $q"; head -14 $O/stage_stamps_wgrad_$q.txt | tail -9
   done ;;
+t7)
+  timeout -k 10 900 python -m pytest tests/test_gat_tail_gpu.py tests/test_model_gpu.py tests/test_train_gpu.py tests/test_step_parity_gpu.py -x -q -k "tail or latent or head or glue or staged or deferred or cfg3" > $O/t7.txt 2>&1 || { grep -B2 -A14 "^>" $O/t7.txt | head -60; tail -5 $O/t7.txt; exit 1; }
+  tail -3 $O/t7.txt ;;
 t6)
   timeout -k 10 900 python -m pytest tests/test_gemm_gpu.py tests/test_model_gpu.py tests/test_gat_mfma_gpu.py tests/test_train_gpu.py -x -q -k "wgrad or colsum or gat or staged or deferred or cluster" > $O/t6.txt 2>&1 || { grep -B2 -A14 "^>" $O/t6.txt | head -60; tail -5 $O/t6.txt; exit 1; }
   tail -3 $O/t6.txt ;;
