@@ -733,11 +733,15 @@ class _FirstMapSeeds(torch.autograd.Function):
         lib = model_lib()
         gb = g.contiguous().to(torch.bfloat16)
         out = ctx.wgrad if (ctx.wgrad is not None and _DIRECT_GRAD[0]) else torch.empty((N, K), dtype=torch.float32, device=g.device)
-        need = int(lib.spadot_gemm_wgrad_bf16_workspace(M, N, K, 8))
+        # ONE slice: N / 256 x G / 256 workgroups walk all b rows and write dW themselves.  (Eight slices -- until round 5 -- were
+        # 96 workgroups of one 64-row chunk each plus a 25 MB sum of partials: 80 + 39 us in the step for 0.8 GFLOP; one slice
+        # shortens the SVGP backward stage by 70 us, profiles/r05/ab_first_map_slices.txt.)
+        S_ = 1
+        need = int(lib.spadot_gemm_wgrad_bf16_workspace(M, N, K, S_))
         rc = -22
         if need >= 0:
             ws = torch.empty(max(need, 4), dtype=torch.float32, device=g.device)
-            rc = lib.spadot_gemm_wgrad_bf16(gb.data_ptr(), N, xbf.data_ptr(), xbf.shape[1], out.data_ptr(), K, M, N, K, 8,
+            rc = lib.spadot_gemm_wgrad_bf16(gb.data_ptr(), N, xbf.data_ptr(), xbf.shape[1], out.data_ptr(), K, M, N, K, S_,
                                             ws.data_ptr(), _zero_row(g.device).data_ptr(), _stream())
         if rc == -22:                                   # (a shape the kernel refuses: the library's fp32 product)
             return None, torch.mm(g.t(), x32[:, :K]), None

@@ -40,6 +40,19 @@ ablib)
   done
   SPADOT_STAMPS=1 timeout -k 10 300 python tools/stage_stamps.py > $O/stage_stamps_unpred.txt 2> $O/stamps.err || tail -5 $O/stamps.err
   head -14 $O/stage_stamps_unpred.txt | tail -11 ;;
+abfm)
+  timeout -k 10 300 python -m pytest tests/test_gemm_gpu.py tests/test_model_gpu.py -x -q -k "wgrad or first_map" 2>&1 | tail -2
+  bash tools/ab_step.sh "SPADOT_FM_SLICES=8" "SPADOT_FM_SLICES=2" "SPADOT_FM_SLICES=1" 2>&1 | tee $O/ab_first_map_slices.txt
+  for q in 1; do
+    SPADOT_FM_SLICES=$q SPADOT_STAMPS=1 timeout -k 10 300 python tools/stage_stamps.py > $O/stage_stamps_fm_$q.txt 2> $O/stamps.err || tail -5 $O/stamps.err
+    echo "== $q"; head -14 $O/stage_stamps_fm_$q.txt | tail -9
+  done ;;
+ablate)
+  bash tools/ab_step.sh "SPADOT_LATE_ORDER=heavy" "SPADOT_LATE_ORDER=fifo" 2>&1 | tee $O/ab_late_order.txt
+  for q in heavy fifo; do
+    SPADOT_LATE_ORDER=$q SPADOT_STAMPS=1 timeout -k 10 300 python tools/stage_stamps.py > $O/stage_stamps_late_$q.txt 2> $O/stamps.err || tail -5 $O/stamps.err
+    echo "== $q"; head -14 $O/stage_stamps_late_$q.txt | tail -9
+  done ;;
 abq)
   timeout -k 10 300 python -m pytest tests/test_mlp_chain_gpu.py -x -q -k "recon" 2>&1 | tail -2
   bash tools/ab_step.sh "SPADOT_WGRAD_Q=late" "SPADOT_WGRAD_Q=post" "SPADOT_WGRAD_Q=inline" 2>&1 | tee $O/ab_wgrad_queue.txt
