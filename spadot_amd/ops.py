@@ -711,7 +711,7 @@ class _DenseCD(torch.autograd.Function):
 class _FirstMapSeeds(torch.autograd.Function):
     """h = x32 W^T for the SVGP encoder's G-sized first map on the b seeds (encoder.py:7-34), forward in fp32 from the cached
     fp32 seed rows as before; the WEIGHT GRADIENT g^T x [N x G] is taken on the matrix cores (csrc/gemm_wgrad_bf16.hip:
-    N / 256 x G / 256 tiles x 8 slices of the b rows) from the bf16 image of the same rows that the GAT branch reads.
+    N / 256 x G / 256 tiles, each walking all b rows) from the bf16 image of the same rows that the GAT branch reads.
     The library ran this fp32 product on 12-47 workgroups: 41 us alone, 130-160 us at the end of the SVGP backward beside
     the first GAT layer's weight-gradient GEMM -- the optimizer waited for it.  Only in the bf16 compute dtype (the
     operands are rounded to bf16 like every other large product of that mode; fp32 compute keeps the library GEMM)."""
