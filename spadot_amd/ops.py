@@ -2107,6 +2107,34 @@ class FlatAdamW:
                                                   self.max_norm, _p(self.sumsq), _p(self.step_dev), _p(self.grad_scale), tab,
                                                   _stream()), "spadot_adamw_range_dev")
 
+    def step_sharded(self, group=None):
+        """step() for P data-parallel replicas that each own 1/P of the flat buffers (parallel.sharded_update: reduce-scatter of
+        the gradient, the clip norm from one scalar all-reduce, this rank's slice updated by the same kernel as step(), all-gather
+        of the parameters).  flat_grad holds THIS replica's gradient on entry.  The bf16 weight images are refreshed from the
+        gathered parameters (the update kernel keeps only the rows inside this rank's slice current)."""
+        from . import parallel as _par
+        assert self.count % 4 == 0
+        self.t += 1
+
+        def local_sumsq(lo, hi):
+            # (also advances the device step count: every rank calls this exactly once per step)
+            if hi <= lo:                               # more ranks than slices: nothing to sum, the count still advances
+                self.sumsq.zero_()
+                self.step_dev += 1
+                return self.sumsq
+            _check(model_lib().spadot_grad_norm_step_dev(self.flat_grad[lo:hi].data_ptr(), hi - lo, _p(self.scratch), _p(self.sumsq),
+                                                         _p(self.step_dev), _stream()), "spadot_grad_norm_step_dev")
+            return self.sumsq
+
+        def update_range(lo, hi, sumsq):
+            if sumsq.data_ptr() != self.sumsq.data_ptr():
+                self.sumsq.copy_(sumsq)
+            self._update_range(lo, hi)
+
+        _par.sharded_update(self.flat_grad, self.flat_param, local_sumsq, update_range, group=group)
+        if self._images:
+            self.refresh_images()
+
     def step_head(self):
         """First part of step() in two parts: gradient norm + step count, then the update of the `first` group alone.
         step_rest() must follow.  Together they leave the bits step() leaves (same arithmetic per element)."""

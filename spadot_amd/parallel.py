@@ -158,6 +158,55 @@ def make_grad_sync(opt):
     return sync, sync_async
 
 
+def shard_range(count, rank, P):
+    """[lo, hi) of rank's slice of a flat buffer of `count` elements cut into P equal slices of `per` elements (a multiple of 4:
+    the update kernels work on 16-byte pieces); the last slices may be short or empty.  Returns (lo, hi, per)."""
+    per = (-(-count // P) + 3) // 4 * 4
+    lo = min(rank * per, count)
+    return lo, min(lo + per, count), per
+
+
+def sharded_update(flat_grad, flat_param, local_sumsq, update_range, group=None):
+    """One optimizer step of P replicas with the flat buffers SHARDED over the ranks (opt-in,
+    model_config['sharded_update']): instead of all-reducing the whole gradient (every rank receives and then updates all
+    of it) the gradient is REDUCE-SCATTERED -- rank r receives only the sum of slice r -- each rank clips and updates its own
+    slice, and the new parameters are ALL-GATHERED.  The same bytes cross the wire as in a ring all-reduce, but every rank
+    runs the update (and keeps the two moment buffers current) for 1/P of the parameters; on the point-to-point xGMI
+    topology the two halves are direct exchanges.
+        local_sumsq(lo, hi)         -> 1-element tensor: squared norm of flat_grad[lo:hi] (after the reduce-scatter; zero for
+                                       an empty slice, same dtype on every rank)
+        update_range(lo, hi, sumsq) -> clip (by the GLOBAL squared norm `sumsq`, a 1-element tensor) + AdamW on [lo, hi)
+    The clip norm is the one scalar all-reduce.  Backends without reduce_scatter_tensor / all_gather_into_tensor (gloo: the
+    CPU tests and the one-GPU rehearsal) and buffers that do not divide into equal slices take all-reduce + list all-gather:
+    the same values everywhere, only more traffic.  Every rank ends with identical parameters (the gathered ones)."""
+    rank, P = world()
+    n = flat_grad.numel()
+    lo, hi, per = shard_range(n, rank, P)
+    if P == 1:
+        update_range(0, n, local_sumsq(0, n))
+        return
+    direct = dist.get_backend(group) == "nccl" and per * P == n
+    if direct:
+        dist.reduce_scatter_tensor(flat_grad[lo:hi], flat_grad, op=dist.ReduceOp.SUM, group=group)
+    else:
+        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
+    sq = local_sumsq(lo, hi)                       # (an empty slice -- more ranks than pieces -- contributes zero)
+    dist.all_reduce(sq, op=dist.ReduceOp.SUM, group=group)
+    if hi > lo:
+        update_range(lo, hi, sq)
+    if direct:
+        dist.all_gather_into_tensor(flat_param, flat_param[lo:hi].clone(), group=group)
+    else:
+        mine = torch.zeros(per, dtype=flat_param.dtype, device=flat_param.device)
+        mine[:hi - lo] = flat_param[lo:hi]
+        parts = [torch.empty_like(mine) for _ in range(P)]
+        dist.all_gather(parts, mine, group=group)
+        for r, part in enumerate(parts):
+            a, b, _ = shard_range(n, r, P)
+            if b > a and r != rank:
+                flat_param[a:b] = part[:b - a]
+
+
 def average_buffers(module, weight=1.0):
     """BatchNorm running_mean / running_var averaged over ranks, each replica weighted by `weight` = the number of
     training steps it ran since the last call (each replica saw different batches; a rank that ran none -- more
@@ -326,16 +375,27 @@ def train_SpaDOT_parallel(dataloader_dict, model_config, verbose=False):
     n_terms = len(tu.LOSS_NAMES)
     # replayed hipGraphs, as in the single-replica trainer: one forward+backward graph per (time point, batch),
     # the all-reduce of the flat gradient between replays (not captured), one clip + AdamW graph
+    sharded = bool(model_config.get("sharded_update", False)) and P > 1
     stepper = (tu.GraphedStepper(model, opt, model_config, dataloader_dict, grad_sync=sync,
-                                 grad_sync_async=sync_async if P > 1 else None)
+                                 grad_sync_async=sync_async if (P > 1 and not sharded) else None)
                if model_config.get("use_hip_graphs", True) else None)
 
     def exchange(did_work):
+        if sharded:                                        # the exchange IS the update (reduce-scatter .. all-gather)
+            return
         if stepper is not None and stepper.overlap:        # bucketed: a rank with a batch has exchanged inside fb()
             if not did_work:
                 stepper.exchange_idle()
         else:
             sync(opt.flat_grad)
+
+    def apply_update():
+        if sharded:            # (eager launches between the replayed steps: the step's chain to the update's first part is not used)
+            opt.step_sharded()
+        elif stepper is not None:
+            stepper.update()
+        else:
+            opt.step()
 
     for epoch in range(model_config["maxiter"]):
         beta1 = float(beta1s[epoch])
@@ -354,8 +414,7 @@ def train_SpaDOT_parallel(dataloader_dict, model_config, verbose=False):
 
         with (stepper.chained() if stepper is not None else contextlib.nullcontext()):
             _, n_mine = run_epoch(plan, batches_per_tp, order, compute_grad, opt.zero_grad, opt.flat_grad,
-                                  stepper.update if stepper is not None else opt.step, exchange=exchange,
-                                  set_grad_scale=lambda x: opt.grad_scale.fill_(x))
+                                  apply_update, exchange=exchange, set_grad_scale=lambda x: opt.grad_scale.fill_(x))
         rec = reduce_epoch_losses(sums, counts, plan).cpu().tolist()
         loss_dict[epoch] = OrderedDict(zip(tu.LOSS_NAMES, rec))
         average_buffers(model, weight=n_mine)

@@ -307,3 +307,65 @@ def test_epoch_loss_record_is_the_reference_quantity_whatever_the_rank_count(wor
         assert rec.shape == (7,)
         np.testing.assert_array_equal(rec, res[0][1])                          # the same record on every rank
         np.testing.assert_allclose(rec, one.numpy(), rtol=1e-6)               # ... and the P = 1 record
+
+
+# ---------------------------------------------------------------- sharded update (reduce-scatter .. all-gather)
+
+def _cpu_clip_adamw(p, g, m, v, lo, hi, sumsq, t, lr=3e-4, b1=0.9, b2=0.999, eps=1e-8, wd=1e-2, max_norm=0.3):
+    """clip_grad_norm_(max_norm) + AdamW (_train_utils.py:214-217) on the slice [lo, hi) of flat CPU buffers, clipped by the
+    GLOBAL squared norm `sumsq` -- the arithmetic the device kernel applies per element."""
+    coef = min(1.0, max_norm / (float(sumsq) ** 0.5 + 1e-6))
+    gs = g[lo:hi] * coef
+    m[lo:hi] = b1 * m[lo:hi] + (1 - b1) * gs
+    v[lo:hi] = b2 * v[lo:hi] + (1 - b2) * gs * gs
+    p[lo:hi] *= 1 - lr * wd
+    p[lo:hi] -= lr * (m[lo:hi] / (1 - b1 ** t)) / ((v[lo:hi] / (1 - b2 ** t)).sqrt() + eps)
+
+
+def _local_grad(rank, step, n):
+    return torch.randn(n, generator=torch.Generator().manual_seed(1000 * step + rank), dtype=torch.float64)
+
+
+def _sharded_worker(rank, world, port, q, n, steps):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        p = torch.linspace(-1.0, 1.0, n, dtype=torch.float64)
+        m, v = torch.zeros_like(p), torch.zeros_like(p)
+        for t in range(1, steps + 1):
+            g = _local_grad(rank, t, n)
+            par.sharded_update(g, p, lambda lo, hi: (g[lo:hi] ** 2).sum().reshape(1),
+                               lambda lo, hi, sq: _cpu_clip_adamw(p, g, m, v, lo, hi, sq, t))
+        lo, hi, _ = par.shard_range(n, rank, world)
+        q.put((rank, p.numpy().copy(), m[lo:hi].numpy().copy(), (lo, hi)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, 4096), (4, 4100), (4, 12)])
+def test_sharded_update_leaves_identical_replicas_and_the_unsharded_parameters(world, n):
+    """parallel.sharded_update: every rank reduce-scatters its gradient, clips by the all-reduced squared
+    norm, updates ITS slice and all-gathers the parameters.  All ranks end with the same parameters, and they are what ONE
+    process computes from the summed gradients with the unsharded update -- also when the buffer does not divide evenly
+    (4100 over 4 ranks) and when there are more ranks than 4-element pieces (12 over 4: slices of 4, 4, 4, 0)."""
+    steps = 3
+    p = torch.linspace(-1.0, 1.0, n, dtype=torch.float64)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for t in range(1, steps + 1):
+        g = sum(_local_grad(r, t, n) for r in range(world))
+        _cpu_clip_adamw(p, g, m, v, 0, n, (g ** 2).sum(), t)
+    assert [par.shard_range(12, r, 4)[:2] for r in range(4)] == [(0, 4), (4, 8), (8, 12), (12, 12)]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, q, n, steps)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda r: r[0])
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    for _, pp, mm, (lo, hi) in res:
+        np.testing.assert_array_equal(pp, res[0][1])                                    # identical replicas
+        np.testing.assert_allclose(pp, p.numpy(), rtol=1e-12, atol=1e-14)               # = the unsharded update
+        np.testing.assert_allclose(mm, m[lo:hi].numpy(), rtol=1e-12, atol=1e-14)        # each rank keeps ITS slice's moments

@@ -441,7 +441,7 @@ def test_bucketed_exchange_hands_over_final_buckets_without_changing_the_gradien
     assert [(o_, n_) for o_, n_, _ in seen] == [(0, cut), (4 * cut, opt.count - cut)]
 
 
-def _dp_worker(rank, world, port, q, staged=None, granularity="batch"):
+def _dp_worker(rank, world, port, q, staged=None, granularity="batch", sharded=False):
     """One data-parallel rank on cuda:0 (both ranks share the one GPU of the test box; gloo carries the
     collectives, on a real node the backend is nccl = RCCL)."""
     import os
@@ -456,6 +456,8 @@ def _dp_worker(rank, world, port, q, staged=None, granularity="batch"):
         cfg.update(maxiter=2, input_dim=40, timepoints=[0, 1, 2], device=torch.device(DEV), shard_granularity=granularity)
         if staged is not None:
             cfg["staged_graphs"] = staged
+        if sharded:
+            cfg["sharded_update"] = True
         data = make_dataset(3, 1200, 40, seed=11)
         plan = par.configure_shard(data, cfg, world, rank)
         if granularity == "batch":      # 5 batches per time point, 15 units: rank 0 owns the even canonical indices
@@ -498,6 +500,34 @@ def test_data_parallel_training_two_ranks_one_gpu(staged, granularity):
     assert np.isfinite(l0).all() and l0.shape == (7,)
     np.testing.assert_array_equal(l0, l1)              # the epoch's loss record is the reduced one: the same on every rank
     assert l0[6] > 0                                   # OT term live (ot_epoch = 1)
+
+
+def test_sharded_update_two_ranks_one_gpu_matches_the_all_reduced_update():
+    """model_config['sharded_update'] (FlatAdamW.step_sharded / parallel.sharded_update): two ranks, each
+    updating half of the flat buffers between a reduce-scatter of the gradient and an all-gather of the parameters (gloo here:
+    all-reduce + list all-gather carry the same values), the clip norm from one scalar all-reduce, the bf16 weight images
+    refreshed from the gathered parameters.  Replicas identical; and the run ends where the all-reduce + full-update run of
+    the same two ranks ends, up to the rounding of the squared norm (summed per slice, then over the ranks)."""
+    import socket
+    import torch.multiprocessing as mp
+    out = {}
+    for sharded in (False, True):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q, None, "batch", sharded)) for r in range(2)]
+        for p in procs:
+            p.start()
+        res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda r: r[0])
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+        np.testing.assert_array_equal(res[0][1], res[1][1])            # replicas identical
+        np.testing.assert_array_equal(res[0][4], res[1][4])
+        out[sharded] = res[0]
+    scale = np.abs(out[False][1]).max()
+    np.testing.assert_allclose(out[True][1], out[False][1], rtol=0, atol=2e-4 * scale)
+    np.testing.assert_allclose(out[True][4], out[False][4], rtol=2e-3)
 
 
 def test_device_kmeans_vs_sklearn():
